@@ -1,0 +1,199 @@
+/*
+ * orbx.h — C ABI of the MI355X-native ORB front-end + Hamming matchers.
+ *
+ * This is the drop-in boundary for ONE hot path of kimwin2/ORB_SLAM2v2-1:
+ *   ORBextractor::operator()            reference: src/ORBextractor.cc:1043-1105
+ *   Frame::ComputeStereoMatches         reference: src/Frame.cc:481-655
+ *   ORBmatcher::SearchForInitialization reference: src/ORBmatcher.cc:405-520
+ *   ORBmatcher::SearchByProjection x2   reference: src/ORBmatcher.cc:45-129, 1330-1472
+ *   ORBmatcher::DescriptorDistance      reference: src/ORBmatcher.cc:1649-1665
+ * Plain pointers and sizes only; POD structs; the caller allocates every output.
+ * All functions return 0 on success or a negative orbx_status; nothing throws.
+ * The implementation is HIP for gfx950 only — there is NO CPU fallback: every entry
+ * point that needs the GPU fails with ORBX_ERR_NO_DEVICE when none is usable.
+ *
+ * Pointers named d_* are DEVICE pointers (e.g. torch tensor .data_ptr()); `stream`
+ * is a hipStream_t passed as void* (NULL = the handle's own stream).
+ */
+#ifndef ORBX_H
+#define ORBX_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ORBX_OK = 0,
+    ORBX_ERR_ARG = -1,         /* bad argument (NULL, non-positive size, level too small, ...) */
+    ORBX_ERR_NO_DEVICE = -2,   /* no usable HIP device / kernel image for this GPU */
+    ORBX_ERR_HIP = -3,         /* a HIP runtime call failed (see orbx_last_error) */
+    ORBX_ERR_CAPACITY = -4,    /* caller-provided capacity too small */
+    ORBX_ERR_UNSUPPORTED = -5  /* configuration outside the implemented range */
+} orbx_status;
+
+/* cv::KeyPoint layout the reference serialises (include/BoostArchiver.h:47-57): 28 bytes */
+typedef struct {
+    float x, y;       /* pt, in level-0 pixel units (pt *= mvScaleFactor[octave], :1095-1101) */
+    float size;       /* (int)(31 * mvScaleFactor[octave]) */
+    float angle;      /* IC_Angle, degrees [0,360) */
+    float response;   /* FAST score */
+    int32_t octave;
+    int32_t class_id; /* -1 */
+} orbx_keypoint_t;
+
+typedef struct orbx_extractor orbx_extractor_t;
+
+/* ---- extractor: replaces class ORBextractor (include/ORBextractor.h:45-111) ---------- */
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * (src/ORBextractor.cc:410-470).  device = HIP device ordinal. */
+int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
+                int device, orbx_extractor_t **out);
+int orbx_destroy(orbx_extractor_t *h);
+
+/* GetLevels / GetScaleFactor(s) / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (include/ORBextractor.h:62-83); arrays of nlevels floats,
+ * any may be NULL.  features_per_level / umax expose mnFeaturesPerLevel and umax[16]. */
+int orbx_get_levels(const orbx_extractor_t *h);
+float orbx_get_scale_factor(const orbx_extractor_t *h);
+int orbx_get_tables(const orbx_extractor_t *h, float *scale_factors, float *inv_scale_factors,
+                    float *level_sigma2, float *inv_level_sigma2, int32_t *features_per_level,
+                    int32_t *umax16);
+/* upper bound of keypoints one image can produce (nfeatures + 3 per level) */
+int orbx_max_keypoints(const orbx_extractor_t *h);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors) for one host image
+ * (src/ORBextractor.cc:1043-1105).  img: 8-bit gray, `stride` bytes per row.  Writes up
+ * to `cap` keypoints (28 B each) and descriptors (32 B each, row-major N x 32) into host
+ * buffers and *n_out.  Empty image (w==0||h==0||img==NULL): returns ORBX_OK with
+ * *n_out = 0 and outputs untouched (reference :1046-1047).  Synchronous. */
+int orbx_extract(orbx_extractor_t *h, const uint8_t *img, int w, int hgt, int stride,
+                 orbx_keypoint_t *kps, uint8_t *desc, int cap, int *n_out);
+
+/* Batched many-frame mode on host buffers: B images of identical size.  imgs[b] points
+ * at image b.  kps: B*cap entries, desc: B*cap*32 bytes, n_out: B counts.  Synchronous. */
+int orbx_extract_batch(orbx_extractor_t *h, const uint8_t *const *imgs, int B, int w, int hgt,
+                       int stride, orbx_keypoint_t *kps, uint8_t *desc, int cap, int *n_out);
+
+/* Batched mode on DEVICE buffers (inputs already resident in HBM), asynchronous on
+ * `stream`.  d_imgs: B images, image b at d_imgs + b*image_stride_bytes, rows `stride`
+ * bytes apart.  d_kps [B][cap], d_desc [B][cap][32], d_counts [B] int32 are device
+ * outputs; per-image layout is level-major exactly as the reference concatenates
+ * (:1076-1104).  If a frame produces more than cap keypoints its count is clamped to cap
+ * (cap >= orbx_max_keypoints() never clamps). */
+int orbx_extract_batch_device(orbx_extractor_t *h, const uint8_t *d_imgs, int B, int w, int hgt,
+                              int stride, size_t image_stride_bytes, orbx_keypoint_t *d_kps,
+                              uint8_t *d_desc, int32_t *d_counts, int cap, void *stream);
+
+/* mvImagePyramid[level] of image `b` of the last call (include/ORBextractor.h:85): copies
+ * the inner level (padded=0) or the whole bordered buffer (padded=1, 19 px border,
+ * BORDER_REFLECT_101) into dst (dst_stride bytes per row) and reports its size. dst may
+ * be NULL to query the size only.  Synchronises the handle's last stream. */
+int orbx_pyramid_host(orbx_extractor_t *h, int b, int level, int padded, uint8_t *dst, int dst_stride,
+                      int *w, int *hgt);
+/* Device view of the same level: pointer to the inner ROI's first pixel and its row stride. */
+int orbx_pyramid_device(orbx_extractor_t *h, int b, int level, const uint8_t **d_ptr, int *w, int *hgt,
+                        int *stride);
+
+/* Stage introspection for parity tests (not part of the reference API):
+ * stage 0 = FAST candidates before the quad-tree (vToDistributeKeys order),
+ * stage 1 = keypoints kept by DistributeOctTree (list order).
+ * out: triples (x, y, score) int32, coordinates relative to minBorder (16,16). */
+int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, int stage, int32_t *out_xys, int cap,
+                            int *n_out);
+
+/* Per-stage GPU time of the last batch call in ms (HIP events on the launch stream), when
+ * enabled: [0] pyramid [1] FAST cells [2] quad-tree [3] orientation+blur+descriptor
+ * [4] whole call.  Recording the events costs a few microseconds per batch. */
+#define ORBX_NUM_STAGES 5
+int orbx_set_profiling(orbx_extractor_t *h, int enabled);
+int orbx_get_stage_ms(orbx_extractor_t *h, float *ms5);
+
+/* ---- matchers: replace the hot ORBmatcher / Frame routines --------------------------- */
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1649-1665): host, pure. */
+int orbm_hamming(const uint8_t *a32, const uint8_t *b32);
+
+/* All-pairs 256-bit Hamming distances on device: d_out[i*nb + j] (uint16) =
+ * distance(d_a[i], d_b[j]).  Building block + bandwidth probe of the matchers. */
+int orbm_hamming_matrix_device(const uint8_t *d_a, int na, const uint8_t *d_b, int nb,
+                               uint16_t *d_out, void *stream);
+
+/* Frame::ComputeStereoMatches (src/Frame.cc:481-655) for B stereo frames.  Left/right
+ * keypoints + descriptors + counts are the DEVICE outputs of two extractors (hl, hr) whose
+ * pyramids of the same batch are still resident.  d_uright / d_depth: [B][cap] float
+ * (mvuRight / mvDepth, -1 = no match).  mbf = baseline*fx, mb = mbf/fx (Frame.cc:114).
+ * d_nmatch [B] (may be NULL) = number of surviving matches. Asynchronous on stream. */
+int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *hr, int B,
+                             const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
+                             const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
+                             int cap, float mbf, float mb, float *d_uright, float *d_depth,
+                             int32_t *d_nmatch, void *stream);
+/* Host-buffer convenience for one frame (synchronous); pyramids come from hl / hr, which
+ * must have just extracted the left / right image (image slot 0). */
+int orbm_stereo(orbx_extractor_t *hl, orbx_extractor_t *hr,
+                const orbx_keypoint_t *kl, const uint8_t *dl, int nl,
+                const orbx_keypoint_t *kr, const uint8_t *dr, int nr,
+                float mbf, float mb, float *uright, float *depth, int *nmatch);
+
+/* Frame lookup grid geometry (src/Frame.cc:90-105, 397-407; include/Frame.h:37-38) */
+typedef struct {
+    float min_x, min_y, max_x, max_y; /* mnMinX, mnMinY, mnMaxX, mnMaxY */
+    float inv_w, inv_h;               /* mfGridElementWidthInv, mfGridElementHeightInv */
+} orbm_grid_geom_t;
+
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
+ * (src/ORBmatcher.cc:405-520) on host arrays (undistorted keypoints).  prev_matched
+ * [2*n1] (x,y) is updated in place; matches12[n1] out; *nmatches out. */
+int orbm_search_for_initialization(const orbx_keypoint_t *k1, const uint8_t *d1, int n1,
+                                   const orbx_keypoint_t *k2, const uint8_t *d2, int n2,
+                                   const orbm_grid_geom_t *g2, float *prev_matched, int32_t *matches12,
+                                   int window, float nnratio, int check_orientation, int device,
+                                   int *nmatches);
+
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)
+ * (src/ORBmatcher.cc:45-129), map points gathered into flat arrays by the C++ wrapper. */
+typedef struct {
+    int32_t in_view;          /* mbTrackInView && !isBad() */
+    float proj_x, proj_y, proj_xr; /* mTrackProjX/Y/XR */
+    int32_t level;            /* mnTrackScaleLevel */
+    float view_cos;           /* mTrackViewCos */
+    int32_t observations;     /* Observations() */
+} orbm_mappoint_t;
+/* frame_mp[n] in/out: index of the list's map point held by keypoint i, -1 none,
+ * -2 = held by a map point outside the list whose Observations() is ext_obs[i]. */
+int orbm_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                                 const orbm_grid_geom_t *g, const float *scale_factors, int nlevels,
+                                 const orbm_mappoint_t *mps, const uint8_t *mp_desc, int m,
+                                 int32_t *frame_mp, const int32_t *ext_obs, float th, float nnratio,
+                                 int device, int *nmatches);
+
+/* ORBmatcher::SearchByProjection(Frame &cur, const Frame &last, th, bMono)
+ * (src/ORBmatcher.cc:1330-1472). */
+typedef struct {
+    int32_t has_mp;        /* mvpMapPoints[i] && !mvbOutlier[i] */
+    float wx, wy, wz;      /* GetWorldPos() */
+    int32_t observations;  /* Observations() */
+    int32_t octave;        /* LastFrame.mvKeys[i].octave */
+    float angle;           /* LastFrame.mvKeysUn[i].angle */
+} orbm_lastpoint_t;
+typedef struct { float fx, fy, cx, cy, mbf, mb; } orbm_camera_t;
+/* cur_mp[n] in/out: index i of the last-frame keypoint whose map point keypoint j holds. */
+int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright,
+                                    int n, const orbm_grid_geom_t *g, const float *scale_factors,
+                                    int nlevels, const orbm_camera_t *cam, const float *Tcw_cur16,
+                                    const float *Tcw_last16, const orbm_lastpoint_t *last,
+                                    const uint8_t *last_desc, int nlast, int32_t *cur_mp,
+                                    const int32_t *ext_obs, float th, int mono, int check_orientation,
+                                    int device, int *nmatches);
+
+/* ---- misc ---------------------------------------------------------------------------- */
+const char *orbx_last_error(void);      /* thread-local description of the last failure */
+const char *orbx_version(void);
+int orbx_device_count(void);            /* number of HIP devices visible (0 if none) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

@@ -1,0 +1,148 @@
+/*
+ * orb_oracle.h — CPU ORACLE for the ORB front-end + Hamming matchers.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference
+ * algorithm (kimwin2/ORB_SLAM2v2-1: src/ORBextractor.cc, src/ORBmatcher.cc,
+ * src/Frame.cc) plus the OpenCV 2.4.11/3.2 primitives it calls (cv::FAST,
+ * cv::resize INTER_LINEAR, cv::GaussianBlur, cv::fastAtan2, cvRound), which are
+ * NOT in the reference tree.  Nothing under orb_slam2v2-1_amd/ (the product) may
+ * include, link or call this; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py do, as the checker.
+ *
+ * PARITY UNPINNED: the reference ships no tests / golden vectors and cannot be
+ * compiled here (OpenCV absent), so this oracle is pinned only by analytically
+ * derived known-answer tables and hand-built images.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cv::KeyPoint field order (reference: include/BoostArchiver.h:47-57); 28 bytes */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} oracle_kp_t;
+
+/* FAST candidate before the quad-tree: coordinates relative to minBorder (16,16) */
+typedef struct { int32_t x, y, score; } oracle_cand_t;
+
+typedef struct orb_oracle orb_oracle_t;
+
+orb_oracle_t *oracle_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th);
+void oracle_destroy(orb_oracle_t *o);
+
+/* ctor tables (src/ORBextractor.cc:410-470) */
+const float *oracle_scale_factors(const orb_oracle_t *o);
+const float *oracle_inv_scale_factors(const orb_oracle_t *o);
+const float *oracle_level_sigma2(const orb_oracle_t *o);
+const float *oracle_inv_level_sigma2(const orb_oracle_t *o);
+const int32_t *oracle_features_per_level(const orb_oracle_t *o);
+const int32_t *oracle_umax(const orb_oracle_t *o);
+
+/* ORBextractor::operator() (src/ORBextractor.cc:1043-1105). Returns keypoint count
+ * (<= cap, or -needed if cap is too small), -1000 on bad arguments. */
+int oracle_extract(orb_oracle_t *o, const uint8_t *img, int w, int h, int stride,
+                   oracle_kp_t *kps, uint8_t *desc, int cap);
+
+/* stage introspection after oracle_extract (for staged parity tests) */
+int oracle_pyramid_level(const orb_oracle_t *o, int level, const uint8_t **padded, int *w, int *h,
+                         int *padded_stride); /* padded points at the (w+38)x(h+38) buffer */
+int oracle_level_candidates(const orb_oracle_t *o, int level, const oracle_cand_t **c);
+int oracle_level_keypoints(const orb_oracle_t *o, int level, const oracle_cand_t **c);
+const uint8_t *oracle_blurred_level(const orb_oracle_t *o, int level); /* w*h, stride w */
+/* per-stage wall time of the last oracle_extract, seconds:
+ * [0] pyramid [1] FAST cells [2] quad-tree [3] orientation [4] blur [5] descriptors */
+const double *oracle_stage_seconds(const orb_oracle_t *o);
+
+/* primitives exposed for unit tests */
+float oracle_fast_atan2(float y, float x);
+int oracle_cv_round(double v);
+int oracle_fast_score(const uint8_t *p, int stride, int threshold); /* cornerScore<16>; p = centre */
+int oracle_fast_is_corner(const uint8_t *p, int stride, int threshold);
+/* cv::FAST(img, thr, nms=true) on a w x h sub-image; writes up to cap (x,y,score), returns n */
+int oracle_fast_detect(const uint8_t *img, int stride, int w, int h, int threshold,
+                       oracle_cand_t *out, int cap);
+void oracle_resize_linear(const uint8_t *src, int sw, int sh, int sstride,
+                          uint8_t *dst, int dw, int dh, int dstride);
+void oracle_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride);
+/* DistributeOctTree on a candidate list (coords relative to minBorder); region size
+ * width x height = (maxX-minX) x (maxY-minY). Returns number of selected, in list order. */
+int oracle_distribute_octtree(const oracle_cand_t *cands, int n, int width, int height, int N,
+                              oracle_cand_t *out, int cap);
+
+/* ---- matchers ---- */
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1649-1665) */
+int oracle_hamming(const uint8_t *a, const uint8_t *b);
+
+/* Frame::ComputeStereoMatches (src/Frame.cc:481-655). pyramids given as arrays of
+ * inner-ROI pointers/strides per level. Outputs uright[N], depth[N] (-1 = none).
+ * Returns number of surviving matches. */
+typedef struct {
+    const uint8_t *ptr; int32_t w, h, stride;
+} oracle_img_t;
+int oracle_stereo_match(const oracle_kp_t *kl, const uint8_t *dl, int nl,
+                        const oracle_kp_t *kr, const uint8_t *dr, int nr,
+                        const oracle_img_t *pyr_l, const oracle_img_t *pyr_r, int nlevels,
+                        const float *scale_factors, const float *inv_scale_factors,
+                        float mbf, float mb, float *uright, float *depth);
+
+/* Frame lookup grid (src/Frame.cc:230-245, 342-407; include/Frame.h:37-38) */
+typedef struct {
+    float min_x, min_y, max_x, max_y;          /* mnMinX.. */
+    float inv_w, inv_h;                         /* mfGridElementWidthInv/HeightInv */
+} oracle_grid_geom_t;
+typedef struct oracle_grid oracle_grid_t;
+oracle_grid_t *oracle_grid_build(const oracle_kp_t *kps, int n, const oracle_grid_geom_t *g);
+void oracle_grid_free(oracle_grid_t *g);
+int oracle_grid_query(const oracle_grid_t *g, float x, float y, float r, int min_level, int max_level,
+                      int32_t *out, int cap);
+
+/* ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1603-1644) on bin sizes */
+void oracle_three_maxima(const int32_t *sizes, int L, int *i1, int *i2, int *i3);
+
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520).
+ * prev_matched[2*n1] is updated in place; matches12[n1] out. Returns nmatches. */
+int oracle_search_for_initialization(const oracle_kp_t *k1, const uint8_t *d1, int n1,
+                                     const oracle_kp_t *k2, const uint8_t *d2, int n2,
+                                     const oracle_grid_geom_t *g2, float *prev_matched,
+                                     int32_t *matches12, int window, float nnratio, int check_ori);
+
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)
+ * (src/ORBmatcher.cc:45-129) on gathered map-point arrays.
+ * mp_*: per map point: in_view flag (mbTrackInView && !isBad), proj x/y/xr, level, viewcos,
+ * 32-byte descriptor, observations (>0 means a frame slot holding it blocks).
+ * frame_mp[n]: index of the map point currently held by keypoint i (-1 none) — in/out.
+ * frame_mp_obs[n]: Observations() of a pre-existing holder not in the mp list (only >0 matters)
+ *                  for entries where frame_mp[i] == -2 (external holder). */
+typedef struct {
+    int32_t in_view; float proj_x, proj_y, proj_xr; int32_t level; float view_cos; int32_t observations;
+} oracle_mp_t;
+int oracle_search_by_projection_mp(const oracle_kp_t *kun, const uint8_t *desc, const float *uright, int n,
+                                   const oracle_grid_geom_t *g, const float *scale_factors,
+                                   const oracle_mp_t *mps, const uint8_t *mp_desc, int m,
+                                   int32_t *frame_mp, const int32_t *frame_ext_obs,
+                                   float th, float nnratio);
+
+/* ORBmatcher::SearchByProjection(Frame& cur, const Frame& last, th, bMono)
+ * (src/ORBmatcher.cc:1330-1472). last_*: per last-frame keypoint: has_mp (non-null &&
+ * !outlier), world pos, descriptor of the map point, observations, octave + angle of
+ * last keypoint. Tcw_cur / Tcw_last are row-major 4x4 float. cur_mp[n] in/out holds the
+ * index i of the last-frame keypoint whose map point is assigned (-1 none, -2 external holder). */
+typedef struct {
+    int32_t has_mp; float wx, wy, wz; int32_t observations; int32_t octave; float angle;
+} oracle_lastpt_t;
+typedef struct { float fx, fy, cx, cy, mbf, mb; } oracle_cam_t;
+int oracle_search_by_projection_frame(const oracle_kp_t *kun, const uint8_t *desc, const float *uright, int n,
+                                      const oracle_grid_geom_t *g, const float *scale_factors,
+                                      const oracle_cam_t *cam, const float *Tcw_cur, const float *Tcw_last,
+                                      const oracle_lastpt_t *last, const uint8_t *last_desc, int nlast,
+                                      int32_t *cur_mp, const int32_t *cur_ext_obs,
+                                      float th, int mono, int check_ori);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,331 @@
+"""orb_slam2v2-1_amd — MI355X-native ORB front-end + Hamming matchers (HIP, gfx950).
+
+Python-side binding of the C ABI in include/orbx.h (ctypes; no torch types cross the
+boundary).  The classes mirror the reference's operator interface for this path:
+
+  ORBextractor  <- include/ORBextractor.h:45-111   (ctor args, operator(), getters,
+                                                     mvImagePyramid)
+  ORBmatcher    <- include/ORBmatcher.h:37-102     (TH_LOW/TH_HIGH/HISTO_LENGTH,
+                                                     DescriptorDistance, the hot Search*)
+  compute_stereo_matches <- Frame::ComputeStereoMatches (src/Frame.cc:481-655)
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is usable the calls
+raise OrbxError.  (The CPU oracle lives in /oracle and is test infrastructure only.)
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liborbx_hip.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+MP_DTYPE = np.dtype([("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"),
+                     ("level", "<i4"), ("view_cos", "<f4"), ("observations", "<i4")])
+LASTPT_DTYPE = np.dtype([("has_mp", "<i4"), ("wx", "<f4"), ("wy", "<f4"), ("wz", "<f4"),
+                         ("observations", "<i4"), ("octave", "<i4"), ("angle", "<f4")])
+
+ORBX_OK, ORBX_ERR_ARG, ORBX_ERR_NO_DEVICE, ORBX_ERR_HIP, ORBX_ERR_CAPACITY, ORBX_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+NUM_STAGES = 5
+
+# every symbol include/orbx.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_tables",
+    "orbx_max_keypoints", "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_device",
+    "orbx_pyramid_host", "orbx_pyramid_device", "orbx_debug_level_points", "orbx_set_profiling",
+    "orbx_get_stage_ms", "orbm_hamming", "orbm_hamming_matrix_device", "orbm_stereo_batch_device",
+    "orbm_stereo", "orbm_search_for_initialization", "orbm_search_by_projection_mp",
+    "orbm_search_by_projection_frame", "orbx_last_error", "orbx_version", "orbx_device_count",
+]
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("orbx status %d: %s" % (status, msg))
+        self.status = status
+
+
+class GridGeom(C.Structure):
+    """orbm_grid_geom_t (src/Frame.cc:90-105)."""
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+                ("inv_w", C.c_float), ("inv_h", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("mbf", C.c_float), ("mb", C.c_float)]
+
+
+def grid_geom(w, h):
+    """Grid of an undistorted camera: mnMinX=0, mnMaxX=cols (src/Frame.cc:469-478)."""
+    g = GridGeom()
+    g.min_x, g.min_y, g.max_x, g.max_y = 0.0, 0.0, float(w), float(h)
+    g.inv_w = np.float32(64) / np.float32(w)
+    g.inv_h = np.float32(48) / np.float32(h)
+    return g
+
+
+_lib = None
+
+
+def build(force=False):
+    from . import build as _b
+    return _b.build(force=force)
+
+
+def lib():
+    """Load the HIP library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrbxError(ORBX_ERR_NO_DEVICE, "HIP library %s is missing: run `python __graft_entry__.py` "
+                                            "(build()) first; there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.orbx_create.restype = i32
+    L.orbx_create.argtypes = [i32, f32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.orbx_destroy.argtypes = [vp]
+    L.orbx_get_levels.argtypes = [vp]
+    L.orbx_get_scale_factor.restype = f32
+    L.orbx_get_scale_factor.argtypes = [vp]
+    L.orbx_get_tables.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.orbx_max_keypoints.argtypes = [vp]
+    L.orbx_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
+    L.orbx_extract_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
+    L.orbx_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, sz, vp, vp, vp, i32, vp]
+    L.orbx_pyramid_host.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.orbx_pyramid_device.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.orbx_debug_level_points.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
+    L.orbx_set_profiling.argtypes = [vp, i32]
+    L.orbx_get_stage_ms.argtypes = [vp, vp]
+    L.orbm_hamming.argtypes = [vp, vp]
+    L.orbm_hamming_matrix_device.argtypes = [vp, i32, vp, i32, vp, vp]
+    L.orbm_stereo_batch_device.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp]
+    L.orbm_stereo.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
+    L.orbm_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, C.POINTER(GridGeom), vp, vp, i32, f32,
+                                                 i32, i32, C.POINTER(i32)]
+    L.orbm_search_by_projection_mp.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp, i32, vp, vp, i32, vp, vp,
+                                               f32, f32, i32, C.POINTER(i32)]
+    L.orbm_search_by_projection_frame.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp, i32, C.POINTER(Camera),
+                                                  vp, vp, vp, vp, i32, vp, vp, f32, i32, i32, i32, C.POINTER(i32)]
+    L.orbx_last_error.restype = C.c_char_p
+    L.orbx_version.restype = C.c_char_p
+    for name in EXPORTS:
+        if getattr(L, name).restype is C.c_int:
+            pass
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise OrbxError(rc, lib().orbx_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_count():
+    return lib().orbx_device_count()
+
+
+class ORBextractor:
+    """Mirror of ORB_SLAM2::ORBextractor (reference: include/ORBextractor.h:45-111).
+
+    ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST); calling the object
+    on an 8-bit gray image returns (keypoints[KP_DTYPE], descriptors[N,32] uint8); the mask
+    argument of the reference is ignored there (src/ORBextractor.cc:1043) and absent here.
+    """
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device=0):
+        self._L = lib()
+        h = C.c_void_p()
+        _check(self._L.orbx_create(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST),
+                                   int(minThFAST), int(device), C.byref(h)))
+        self._h = h
+        self.nfeatures, self.nlevels, self.device = int(nfeatures), int(nlevels), int(device)
+        self._shape = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orbx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- getters (include/ORBextractor.h:62-83)
+    def GetLevels(self):
+        return self._L.orbx_get_levels(self._h)
+
+    def GetScaleFactor(self):
+        return self._L.orbx_get_scale_factor(self._h)
+
+    def _tables(self):
+        n = self.nlevels
+        t = [np.zeros(n, np.float32) for _ in range(4)] + [np.zeros(n, np.int32), np.zeros(16, np.int32)]
+        _check(self._L.orbx_get_tables(self._h, *[_p(a) for a in t]))
+        return t
+
+    def GetScaleFactors(self): return self._tables()[0]
+    def GetInverseScaleFactors(self): return self._tables()[1]
+    def GetScaleSigmaSquares(self): return self._tables()[2]
+    def GetInverseScaleSigmaSquares(self): return self._tables()[3]
+    @property
+    def mnFeaturesPerLevel(self): return self._tables()[4]
+    @property
+    def umax(self): return self._tables()[5]
+
+    def max_keypoints(self):
+        return self._L.orbx_max_keypoints(self._h)
+
+    # -- operator()
+    def __call__(self, image):
+        image = np.asarray(image)
+        if image.size == 0:  # empty image: silent return (src/ORBextractor.cc:1046-1047)
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 expected (:1050)"
+        image = np.ascontiguousarray(image)
+        h, w = image.shape
+        cap = max(self.nfeatures + 8 * self.nlevels, 64) + 260
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        _check(self._L.orbx_extract(self._h, _p(image), w, h, image.strides[0], _p(kps), _p(desc), cap, C.byref(n)))
+        self._shape = (h, w)
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, images):
+        """Batched many-frame mode on host arrays [B,h,w]: list of (keypoints, descriptors)."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        B, h, w = images.shape
+        cap = max(self.nfeatures + 8 * self.nlevels, 64) + 260
+        kps = np.zeros((B, cap), KP_DTYPE)
+        desc = np.zeros((B, cap, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        ptrs = (C.c_void_p * B)(*[images[b].ctypes.data for b in range(B)])
+        _check(self._L.orbx_extract_batch(self._h, C.cast(ptrs, C.c_void_p), B, w, h, w, _p(kps), _p(desc), cap, _p(n)))
+        self._shape = (h, w)
+        return [(kps[b, :n[b]].copy(), desc[b, :n[b]].copy()) for b in range(B)]
+
+    def extract_batch_device(self, d_imgs, B, w, h, stride, image_stride, d_kps, d_desc, d_counts, cap, stream=0):
+        """Device-resident batched mode; all d_* are raw device pointers (ints)."""
+        _check(self._L.orbx_extract_batch_device(self._h, d_imgs, B, w, h, stride, image_stride, d_kps, d_desc,
+                                                 d_counts, cap, stream))
+        self._shape = (h, w)
+
+    # -- mvImagePyramid (include/ORBextractor.h:85)
+    def pyramid_level(self, level, b=0, padded=False):
+        w, h = C.c_int(), C.c_int()
+        _check(self._L.orbx_pyramid_host(self._h, b, level, int(padded), None, 0, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        _check(self._L.orbx_pyramid_host(self._h, b, level, int(padded), _p(out), w.value, C.byref(w), C.byref(h)))
+        return out
+
+    @property
+    def mvImagePyramid(self):
+        return [self.pyramid_level(l) for l in range(self.nlevels)]
+
+    def pyramid_device(self, level, b=0):
+        ptr, w, h, s = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+        _check(self._L.orbx_pyramid_device(self._h, b, level, C.byref(ptr), C.byref(w), C.byref(h), C.byref(s)))
+        return ptr.value, w.value, h.value, s.value
+
+    # -- test / profiling hooks
+    def debug_level_points(self, level, stage, b=0):
+        n = C.c_int()
+        _check(self._L.orbx_debug_level_points(self._h, b, level, stage, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), np.int32)
+        if n.value:
+            _check(self._L.orbx_debug_level_points(self._h, b, level, stage, _p(out), n.value, C.byref(n)))
+        return out[:n.value]
+
+    def set_profiling(self, on=True):
+        _check(self._L.orbx_set_profiling(self._h, int(on)))
+
+    def stage_ms(self):
+        ms = np.zeros(NUM_STAGES, np.float32)
+        _check(self._L.orbx_get_stage_ms(self._h, _p(ms)))
+        return ms
+
+
+def compute_stereo_matches(ex_left, ex_right, kl, dl, kr, dr, mbf, mb):
+    """Frame::ComputeStereoMatches (src/Frame.cc:481-655) -> (mvuRight, mvDepth, nmatches).
+
+    ex_left / ex_right must have just extracted the left / right image (their pyramids are
+    read on the device)."""
+    L = lib()
+    kl = np.ascontiguousarray(kl, KP_DTYPE); kr = np.ascontiguousarray(kr, KP_DTYPE)
+    dl = np.ascontiguousarray(dl, np.uint8); dr = np.ascontiguousarray(dr, np.uint8)
+    ur = np.full(len(kl), -1, np.float32); dp = np.full(len(kl), -1, np.float32)
+    n = C.c_int(0)
+    _check(L.orbm_stereo(ex_left._h, ex_right._h, _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr),
+                         float(mbf), float(mb), _p(ur), _p(dp), C.byref(n)))
+    return ur, dp, n.value
+
+
+class ORBmatcher:
+    """Mirror of ORB_SLAM2::ORBmatcher for the hot routines (include/ORBmatcher.h:37-102)."""
+    TH_LOW = 50
+    TH_HIGH = 100
+    HISTO_LENGTH = 30  # src/ORBmatcher.cc:37-39
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        self.device = int(device)
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+        assert a.size == 32 and b.size == 32
+        return lib().orbm_hamming(_p(a), _p(b))
+
+    def SearchForInitialization(self, k1, d1, k2, d2, geom2, vbPrevMatched, windowSize=10):
+        """(src/ORBmatcher.cc:405-520) -> (nmatches, vnMatches12, vbPrevMatched')"""
+        k1 = np.ascontiguousarray(k1, KP_DTYPE); k2 = np.ascontiguousarray(k2, KP_DTYPE)
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        prev = np.ascontiguousarray(vbPrevMatched, np.float32).copy()
+        m12 = np.full(len(k1), -1, np.int32)
+        n = C.c_int(0)
+        _check(lib().orbm_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), C.byref(geom2),
+                                                    _p(prev), _p(m12), int(windowSize), self.mfNNratio,
+                                                    int(self.mbCheckOrientation), self.device, C.byref(n)))
+        return n.value, m12, prev
+
+    def SearchByProjection(self, kun, desc, uright, geom, scale_factors, mps, mp_desc, frame_mp, ext_obs=None, th=1.0):
+        """SearchByProjection(Frame&, vector<MapPoint*>&, th) (src/ORBmatcher.cc:45-129)
+        -> (nmatches, frame_mp')"""
+        kun = np.ascontiguousarray(kun, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+        uright = np.ascontiguousarray(uright, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+        mps = np.ascontiguousarray(mps, MP_DTYPE); mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+        fm = np.ascontiguousarray(frame_mp, np.int32).copy()
+        eo = None if ext_obs is None else np.ascontiguousarray(ext_obs, np.int32)
+        n = C.c_int(0)
+        _check(lib().orbm_search_by_projection_mp(_p(kun), _p(desc), _p(uright), len(kun), C.byref(geom), _p(sf),
+                                                  len(sf), _p(mps), _p(mp_desc), len(mps), _p(fm), _p(eo), float(th),
+                                                  self.mfNNratio, self.device, C.byref(n)))
+        return n.value, fm
+
+    def SearchByProjectionFrame(self, kun, desc, uright, geom, scale_factors, cam, Tcw_cur, Tcw_last, last, last_desc,
+                                cur_mp, ext_obs=None, th=7.0, bMono=False):
+        """SearchByProjection(Frame &cur, const Frame &last, th, bMono) (src/ORBmatcher.cc:1330-1472)
+        -> (nmatches, cur_mp')"""
+        kun = np.ascontiguousarray(kun, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+        uright = np.ascontiguousarray(uright, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+        last = np.ascontiguousarray(last, LASTPT_DTYPE); last_desc = np.ascontiguousarray(last_desc, np.uint8)
+        Tc = np.ascontiguousarray(Tcw_cur, np.float32); Tl = np.ascontiguousarray(Tcw_last, np.float32)
+        cm = np.ascontiguousarray(cur_mp, np.int32).copy()
+        eo = None if ext_obs is None else np.ascontiguousarray(ext_obs, np.int32)
+        n = C.c_int(0)
+        _check(lib().orbm_search_by_projection_frame(_p(kun), _p(desc), _p(uright), len(kun), C.byref(geom), _p(sf),
+                                                     len(sf), C.byref(cam), _p(Tc), _p(Tl), _p(last), _p(last_desc),
+                                                     len(last), _p(cm), _p(eo), float(th), int(bMono),
+                                                     int(self.mbCheckOrientation), self.device, C.byref(n)))
+        return n.value, cm

@@ -1,0 +1,1276 @@
+// orbx_extract.hip — MI355X (gfx950) ORB front-end: hand-written HIP kernels + C ABI.
+//
+// Replaces ORBextractor::operator() of kimwin2/ORB_SLAM2v2-1 (reference:
+// src/ORBextractor.cc:1043-1105) for batches of equally sized frames:
+//   K1 k_pyr_level0 / k_pyr_resize   ComputePyramid                 (:1107-1132)
+//   K2 k_fast_cells                  per-cell cv::FAST + fallback   (:789-829)
+//   K3 k_octree                      DistributeOctTree              (:539-763)
+//   K4 k_describe                    IC_Angle + GaussianBlur + rBRIEF (:77-147, :1085-1090)
+// Integer / bitwise work: no MFMA.  Build with -ffp-contract=off (the float expressions of
+// the reference are evaluated operation by operation).
+#include "orbx_internal.h"
+#include <math.h>
+#include <float.h>
+#include <stdarg.h>
+#include <algorithm>
+
+// ------------------------------------------------------------------------------------
+// error string
+static thread_local char g_err[512] = "";
+void orbx_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *orbx_last_error(void) { return g_err; }
+extern "C" const char *orbx_version(void) { return "orbx 0.1 (gfx950)"; }
+extern "C" int orbx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------
+// constant tables
+__constant__ int8_t c_pattern[1024] = {
+#include "../../include/orb_pattern_31.inc"
+};
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// 7x7 sigma=2 Gaussian in 8-bit fixed point (cvRound(k*256)), sum 257
+__constant__ int c_gauss[7] = {18, 34, 49, 55, 49, 34, 18};
+
+// wave-synchronous LDS hand-off: all 64 lanes of a wave run in lock-step; drain the LDS
+// queue and forbid the compiler from moving LDS accesses across this point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {  // valid for -n < i < 2n-1
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+// ------------------------------------------------------------------------------------
+// K1a: level 0 = input + 19 px BORDER_REFLECT_101 (copyMakeBorder, :1127-1128)
+// one thread = 4 consecutive bytes of a padded row (one dword store)
+__global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t *__restrict__ src, int sstride,
+                                                    size_t simg, uint8_t *__restrict__ pyr,
+                                                    size_t pyrImgBytes, const LevelGeom *__restrict__ geom) {
+    const LevelGeom g = geom[0];
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x4 >= g.pstride) return;
+    const int iy = reflect101(y - ORBX_EDGE, g.h);
+    const uint8_t *srow = src + (size_t)b * simg + (size_t)iy * sstride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int px = x4 + i;
+        uint32_t v = 0;
+        if (px < g.w + 2 * ORBX_EDGE) v = srow[reflect101(px - ORBX_EDGE, g.w)];
+        out |= v << (8 * i);
+    }
+    *(uint32_t *)(pyr + (size_t)b * pyrImgBytes + g.poff + (size_t)y * g.pstride + x4) = out;
+}
+
+// K1b: level l = cv::resize(level l-1, INTER_LINEAR) + border (:1120-1123).
+// 8UC1 fixed-point bilinear of OpenCV <=3.3: coefficients cvRound(w*2048) (tables built on the
+// host in double/float exactly as resize() does), horizontal pass to int32, vertical
+// ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2 >> 2.
+__global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, size_t pyrImgBytes,
+                                                    const LevelGeom *__restrict__ geom, int level,
+                                                    const int32_t *__restrict__ tab) {
+    const LevelGeom g = geom[level];
+    const LevelGeom gp = geom[level - 1];
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x4 >= g.pstride) return;
+    uint8_t *base = pyr + (size_t)b * pyrImgBytes;
+    const uint8_t *S = base + gp.poff + (size_t)ORBX_EDGE * gp.pstride + ORBX_EDGE;  // inner ROI of l-1
+    const int iy = reflect101(y - ORBX_EDGE, g.h);
+    const int sy0 = tab[g.yofsOff + iy];
+    const int bb = tab[g.ybetaOff + iy];
+    const int b0 = (int16_t)(bb & 0xFFFF), b1 = (int16_t)(bb >> 16);
+    const int r0 = min(max(sy0, 0), gp.h - 1), r1 = min(max(sy0 + 1, 0), gp.h - 1);
+    const uint8_t *S0 = S + (size_t)r0 * gp.pstride, *S1 = S + (size_t)r1 * gp.pstride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int px = x4 + i;
+        uint32_t v = 0;
+        if (px < g.w + 2 * ORBX_EDGE) {
+            const int ix = reflect101(px - ORBX_EDGE, g.w);
+            const int sx = tab[g.xofsOff + ix];
+            const int aa = tab[g.xalphaOff + ix];
+            const int a0 = (int16_t)(aa & 0xFFFF), a1 = (int16_t)(aa >> 16);
+            // sx+1 may touch the first border column of level l-1 when a1 == 0: in bounds
+            const int h0 = S0[sx] * a0 + S0[sx + 1] * a1;
+            const int h1 = S1[sx] * a0 + S1[sx + 1] * a1;
+            v = (uint32_t)(((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xFF);
+        }
+        out |= v << (8 * i);
+    }
+    *(uint32_t *)(base + g.poff + (size_t)y * g.pstride + x4) = out;
+}
+
+// ------------------------------------------------------------------------------------
+// K2: one wave per 30-px cell (:789-829).  The cell window (cell + 6 px) is staged in LDS;
+// FAST-9/16 score S at t_lo = min(iniTh, minTh) for every pixel of the evaluated area
+// (window minus its 3-px frame, exactly cv::FAST's loop bounds), 3x3 strict-max NMS that
+// sees zeros outside the evaluated area (cv::FAST never scores them), then the per-cell
+// threshold fallback: {S >= iniTh} if non-empty else {S >= minTh}.  This equals running
+// cv::FAST(iniTh) and, if empty, cv::FAST(minTh): the score is threshold-independent
+// (max over 9-arcs of the min |diff|, minus 1) and a pixel is a corner at t iff S >= t.
+// Output: row-major ordered candidates (x | y<<12 | score<<24, relative to minBorder) in
+// the cell's slot block + count.
+#define FAST_WAVES 4
+
+__device__ __forceinline__ bool has9(uint32_t m16) {
+    uint32_t m = m16 | (m16 << 16);
+    uint32_t x = m & (m >> 1);
+    x &= x >> 2;
+    x &= x >> 4;
+    x &= m >> 8;
+    return (x & 0xFFFFu) != 0;
+}
+
+__global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
+    const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
+    int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ slots, size_t slotsPerImg,
+    int iniTh, int minTh, int TS, int SS, int tileRows, int ldsPerWave) {
+    extern __shared__ uint8_t smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int gc = blockIdx.x * FAST_WAVES + wave, b = blockIdx.y;
+    if (gc >= totalCells) return;  // wave-uniform; the kernel uses no block barrier
+    int l = 0;
+    while (l + 1 < nlevels && gc >= geom[l + 1].cellBase) l++;
+    const LevelGeom g = geom[l];
+    const int c = gc - g.cellBase;
+    const int ci = c / g.nCols, cj = c - ci * g.nCols;
+    const int maxBX = g.w - ORBX_MINB, maxBY = g.h - ORBX_MINB;
+    const int iniY = ORBX_MINB + ci * g.hCell, iniX = ORBX_MINB + cj * g.wCell;
+    int maxY = iniY + g.hCell + 6, maxX = iniX + g.wCell + 6;
+    uint32_t *cnt = cellCnt + (size_t)b * totalCells + gc;
+    if (iniY >= maxBY - 3 || iniX >= maxBX - 6) {  // skipped rows / columns (:794-795,803-804)
+        if (lane == 0) *cnt = 0;
+        return;
+    }
+    if (maxY > maxBY) maxY = maxBY;
+    if (maxX > maxBX) maxX = maxBX;
+    const int tw = maxX - iniX, th = maxY - iniY;  // FAST sub-image
+    const int cw = tw - 6, ch = th - 6;            // evaluated area (rows/cols 3 .. dim-4)
+    if (cw <= 0 || ch <= 0) {
+        if (lane == 0) *cnt = 0;
+        return;
+    }
+    uint8_t *T = smem + (size_t)wave * ldsPerWave;  // window tile [th][TS], th <= tileRows
+    uint8_t *Sc = T + (size_t)TS * tileRows;        // score tile [ch+2][SS] with a zero 1-px halo
+    uint8_t *Fl = Sc + (size_t)SS * (tileRows - 4); // NMS flags [ch*cw]
+
+    const uint8_t *src = pyr + (size_t)b * pyrImgBytes + g.poff + (size_t)(ORBX_EDGE + iniY) * g.pstride +
+                         ORBX_EDGE + iniX;
+    {   // stage window; zero the score tile (incl. its 1-px halo)
+        int r = 0, cc = lane;
+        while (cc >= tw) { cc -= tw; r++; }
+        while (r < th) {
+            T[r * TS + cc] = src[(size_t)r * g.pstride + cc];
+            cc += 64;
+            while (cc >= tw) { cc -= tw; r++; }
+        }
+        const int nz = (ch + 2) * SS;
+        for (int i = lane; i < nz; i += 64) Sc[i] = 0;
+    }
+    wave_sync();
+
+    const int tlo = min(iniTh, minTh) < 0 ? 0 : min(min(iniTh, minTh), 255);
+    const int npx = cw * ch;
+    {   // scores
+        int py = 0, px = lane;
+        while (px >= cw) { px -= cw; py++; }
+        for (int p = lane; p < npx; p += 64) {
+            const uint8_t *q = T + (py + 3) * TS + px + 3;
+            const int v = q[0];
+            int r[16];
+            r[0] = q[3 * TS];      r[1] = q[3 * TS + 1];   r[2] = q[2 * TS + 2];   r[3] = q[TS + 3];
+            r[4] = q[3];           r[5] = q[-TS + 3];      r[6] = q[-2 * TS + 2];  r[7] = q[-3 * TS + 1];
+            r[8] = q[-3 * TS];     r[9] = q[-3 * TS - 1];  r[10] = q[-2 * TS - 2]; r[11] = q[-TS - 3];
+            r[12] = q[-3];         r[13] = q[TS - 3];      r[14] = q[2 * TS - 2];  r[15] = q[3 * TS - 1];
+            const int lo = v - tlo, hi = v + tlo;
+            uint32_t D = 0, Br = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                D |= (uint32_t)(r[k] < lo) << k;
+                Br |= (uint32_t)(r[k] > hi) << k;
+            }
+            const bool dark = has9(D), bright = has9(Br);
+            if (dark || bright) {
+                int d[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) d[k] = dark ? v - r[k] : r[k] - v;
+                int m1[16], m2[16], m4[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) m1[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+                for (int k = 0; k < 16; k++) m2[k] = min(m1[k], m1[(k + 2) & 15]);
+#pragma unroll
+                for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 4) & 15]);
+                int best = -256;
+#pragma unroll
+                for (int k = 0; k < 16; k++) best = max(best, min(m4[k], d[(k + 8) & 15]));
+                Sc[(py + 1) * SS + px + 1] = (uint8_t)(best - 1);
+            }
+            px += 64;
+            while (px >= cw) { px -= cw; py++; }
+        }
+    }
+    wave_sync();
+
+    bool anyIni = false;
+    {   // NMS flags
+        int py = 0, px = lane;
+        while (px >= cw) { px -= cw; py++; }
+        for (int base = 0; base < npx; base += 64) {
+            const int p = base + lane;
+            bool keep = false, ini = false;
+            if (p < npx) {
+                const uint8_t *s = Sc + (py + 1) * SS + px + 1;
+                const int v = s[0];
+                keep = v > s[-1] && v > s[1] && v > s[-SS - 1] && v > s[-SS] && v > s[-SS + 1] &&
+                       v > s[SS - 1] && v > s[SS] && v > s[SS + 1];
+                ini = keep && v >= iniTh;
+                Fl[p] = keep ? 1 : 0;
+            }
+            anyIni |= (__ballot(ini) != 0ull);
+            px += 64;
+            while (px >= cw) { px -= cw; py++; }
+        }
+    }
+    wave_sync();
+
+    const int thr = anyIni ? iniTh : minTh;
+    uint32_t *out = slots + (size_t)b * slotsPerImg + g.slotOff + (size_t)c * g.capc;
+    int total = 0;
+    {   // ordered (row-major) compaction
+        int py = 0, px = lane;
+        while (px >= cw) { px -= cw; py++; }
+        for (int base = 0; base < npx; base += 64) {
+            const int p = base + lane;
+            bool emit = false;
+            int v = 0;
+            if (p < npx) {
+                v = Sc[(py + 1) * SS + px + 1];
+                emit = Fl[p] && v >= thr;
+            }
+            const unsigned long long m = __ballot(emit);
+            if (emit) {
+                const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+                if (pos < g.capc)
+                    out[pos] = (uint32_t)(px + 3 + cj * g.wCell) | ((uint32_t)(py + 3 + ci * g.hCell) << 12) |
+                               ((uint32_t)v << 24);
+            }
+            total += __popcll(m);
+            px += 64;
+            while (px >= cw) { px -= cw; py++; }
+        }
+    }
+    if (lane == 0) *cnt = (uint32_t)min(total, g.capc);
+}
+
+// ------------------------------------------------------------------------------------
+// K3: DistributeOctTree (:539-763), one workgroup per (level, image).
+//
+// Parallel restatement of the reference's std::list surgery (validated against the literal
+// CPU oracle).  Facts it relies on:
+//  * every insertion is push_front, so the list is always ordered by DESCENDING creation
+//    time; the node array here IS the list (index 0 = front);
+//  * a pass visits expandable nodes (created in the previous pass, >1 key) in an order O,
+//    creates the non-empty children n1..n4 of each and erases the parent:
+//       new list = reverse(created sequence) ++ (old list minus the split parents);
+//  * phase 1 (:594-665): O = list order, all expandable nodes are split;
+//    phase 2 (:673-737): O = sort by (size desc, tie), split until size >= N.
+//    Tie-break of equal sizes: the reference compares heap pointers (:684); this build
+//    fixes "later-created first" == smaller list index first.
+//  * a key's child is a pure function of (x, y, parent box): keys never move in memory,
+//    only their 16-bit node index is rewritten.
+#define OCT_T 512
+
+struct OctLds {
+    short4 *box[2];
+    uint32_t *cnt[2];   // bit31 = fresh (created in the previous pass)
+    uint32_t *hist;     // [4*cap] children key counts, also scratch
+    uint16_t *childIdx; // [4*cap]
+    uint16_t *survIdx;  // [cap]
+    uint16_t *xlist;    // [cap] expandable nodes in visiting order
+    int *pn, *pg;       // [cap] inclusive prefix of created children / gain by rank
+    uint8_t *split;     // [cap]
+    unsigned long long *skey;  // [pow2(cap)]
+};
+
+__device__ __forceinline__ int child_of(int x, int y, short4 bx) {
+    const int mx = bx.x + ((bx.y - bx.x + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)   (:483)
+    const int my = bx.z + ((bx.w - bx.z + 1) >> 1);  // UL.y + ceil((BR.y-UL.y)/2)   (:484)
+    return (x < mx ? 0 : 1) | (y < my ? 0 : 2);      // n1,n2,n3,n4                   (:513-525)
+}
+__device__ __forceinline__ short4 child_box(short4 bx, int q) {
+    const short mx = (short)(bx.x + ((bx.y - bx.x + 1) >> 1));
+    const short my = (short)(bx.z + ((bx.w - bx.z + 1) >> 1));
+    short4 r;
+    r.x = (q & 1) ? mx : bx.x;
+    r.y = (q & 1) ? bx.y : mx;
+    r.z = (q & 2) ? my : bx.z;
+    r.w = (q & 2) ? bx.w : my;
+    return r;
+}
+
+// exclusive scan of one int per thread across the block; returns the exclusive prefix and
+// writes the block total to *total (all threads).  wsum: LDS int[OCT_T/64 + 1].
+__device__ __forceinline__ int block_scan_excl(int v, int *wsum, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();  // protect wsum reuse
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < OCT_T / 64; w++) {
+        const int s = wsum[w];
+        if (w < wave) woff += s;
+        tot += s;
+    }
+    *total = tot;
+    return woff + inc - v;
+}
+
+// in-place exclusive scan of an LDS int array a[0..m) (m arbitrary); returns total
+__device__ int array_scan_excl(int *a, int m, int *wsum) {
+    const int chunk = (m + OCT_T - 1) / OCT_T;
+    const int beg = min((int)threadIdx.x * chunk, m), end = min(beg + chunk, m);
+    int s = 0;
+    for (int i = beg; i < end; i++) s += a[i];
+    int total;
+    int off = block_scan_excl(s, wsum, &total);
+    for (int i = beg; i < end; i++) {
+        const int t = a[i];
+        a[i] = off;
+        off += t;
+    }
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(OCT_T, 2) void k_octree(
+    const LevelGeom *__restrict__ geom, int nlevels, int totalCells, const uint32_t *__restrict__ cellCnt,
+    const uint32_t *__restrict__ slots, size_t slotsPerImg, uint32_t *__restrict__ cand,
+    uint16_t *__restrict__ nodeOf, size_t keysPerImg, int32_t *__restrict__ candCnt,
+    uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
+    const int32_t *__restrict__ tab, int capMax, int pow2cap, int scratchInts) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom g = geom[l];
+    // ---- carve LDS
+    uint8_t *sp = smem;
+    OctLds S;
+    S.skey = (unsigned long long *)sp; sp += sizeof(unsigned long long) * pow2cap;
+    S.box[0] = (short4 *)sp; sp += sizeof(short4) * capMax;
+    S.box[1] = (short4 *)sp; sp += sizeof(short4) * capMax;
+    S.cnt[0] = (uint32_t *)sp; sp += 4 * capMax;
+    S.cnt[1] = (uint32_t *)sp; sp += 4 * capMax;
+    S.hist = (uint32_t *)sp; sp += 4 * (size_t)scratchInts;  // >= max(4*cap, ncells+1)
+    S.pn = (int *)sp; sp += 4 * capMax;
+    S.pg = (int *)sp; sp += 4 * capMax;
+    S.childIdx = (uint16_t *)sp; sp += 2 * 4 * capMax;
+    S.survIdx = (uint16_t *)sp; sp += 2 * capMax;
+    S.xlist = (uint16_t *)sp; sp += 2 * capMax;
+    S.split = sp; sp += capMax;
+    __shared__ int wsum[OCT_T / 64 + 1];
+    __shared__ int sh_i[8];  // scalars: 0 S(plit count) 1 nToExpand
+    __shared__ int rootCnt[ORBX_MAX_ROOTS], rootMap[ORBX_MAX_ROOTS];
+
+    const uint32_t *ccnt = cellCnt + (size_t)b * totalCells + g.cellBase;
+    const uint32_t *cslots = slots + (size_t)b * slotsPerImg + g.slotOff;
+    uint32_t *keys = cand + (size_t)b * keysPerImg + g.keyOff;
+    uint16_t *nof = nodeOf + (size_t)b * keysPerImg + g.keyOff;
+
+    // ---- A. ordered concatenation of the cell lists (vToDistributeKeys order, :789-828)
+    int *coff = (int *)S.hist;
+    for (int c = tid; c < g.ncells; c += OCT_T) coff[c] = (int)ccnt[c];
+    __syncthreads();
+    const int n = array_scan_excl(coff, g.ncells, wsum);
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int c = wave; c < g.ncells; c += OCT_T / 64) {
+            const int cn = (int)ccnt[c], o = coff[c];
+            for (int j = lane; j < cn; j += 64) keys[o + j] = cslots[(size_t)c * g.capc + j];
+        }
+    }
+    if (tid == 0) candCnt[b * nlevels + l] = n;
+    if (tid < ORBX_MAX_ROOTS) rootCnt[tid] = 0;
+    __syncthreads();
+
+    // ---- B. root nodes (:543-592)
+    const uint8_t *rootOf = (const uint8_t *)tab + g.rootTabOff;
+    for (int i = tid; i < n; i += OCT_T) {
+        const int r = rootOf[keys[i] & 0xFFF];  // (int)(kp.pt.x / hX), tabulated on the host
+        nof[i] = (uint16_t)r;
+        atomicAdd(&rootCnt[r], 1);
+    }
+    __syncthreads();
+    __shared__ int sh_L;
+    if (tid == 0) {
+        int L = 0;
+        for (int r = 0; r < g.nIni; r++) {
+            if (rootCnt[r] > 0) {
+                short4 bx;
+                bx.x = (short)tab[g.rootBoxOff + r];
+                bx.y = (short)tab[g.rootBoxOff + r + 1];
+                bx.z = 0;
+                bx.w = (short)g.regH;
+                S.box[0][L] = bx;
+                S.cnt[0][L] = (uint32_t)rootCnt[r] | 0x80000000u;
+                rootMap[r] = L++;
+            }
+        }
+        sh_L = L;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += OCT_T) nof[i] = (uint16_t)rootMap[nof[i]];
+    int L = sh_L;
+    int cur = 0, phase = 1;
+    const int N = g.N;
+    bool finish = false;
+
+    // ---- C. passes
+    while (!finish) {
+        short4 *box = S.box[cur], *nbox = S.box[cur ^ 1];
+        uint32_t *cnt = S.cnt[cur], *ncnt = S.cnt[cur ^ 1];
+        // 1. children histograms of the expandable (fresh, >1 key) nodes
+        for (int i = tid; i < 4 * L; i += OCT_T) S.hist[i] = 0;
+        if (tid < 2) sh_i[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += OCT_T) {
+            const int k = nof[i];
+            const uint32_t cv = cnt[k];
+            if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) {
+                const uint32_t key = keys[i];
+                atomicAdd(&S.hist[4 * k + child_of(key & 0xFFF, (key >> 12) & 0xFFF, box[k])], 1u);
+            }
+        }
+        __syncthreads();
+        // 2. visiting order
+        int E;
+        if (phase == 1) {
+            int *flag = S.pn;
+            for (int k = tid; k < L; k += OCT_T) {
+                const uint32_t cv = cnt[k];
+                flag[k] = ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) ? 1 : 0;
+            }
+            __syncthreads();
+            // compaction in list order
+            const int chunk = (L + OCT_T - 1) / OCT_T;
+            const int beg = min(tid * chunk, L), end = min(beg + chunk, L);
+            int s = 0;
+            for (int k = beg; k < end; k++) s += flag[k];
+            int off = block_scan_excl(s, wsum, &E);
+            for (int k = beg; k < end; k++)
+                if (flag[k]) S.xlist[off++] = (uint16_t)k;
+            __syncthreads();
+        } else {
+            int P = 1;
+            while (P < L) P <<= 1;
+            for (int k = tid; k < P; k += OCT_T) {
+                unsigned long long key = ~0ull;
+                if (k < L) {
+                    const uint32_t cv = cnt[k];
+                    if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1)
+                        key = ((unsigned long long)(0x7FFFFFFFu - (cv & 0x7FFFFFFFu)) << 32) | (unsigned)k;
+                }
+                S.skey[k] = key;
+            }
+            __syncthreads();
+            for (int kk = 2; kk <= P; kk <<= 1)
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < P; i += OCT_T) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const unsigned long long a = S.skey[i], c2 = S.skey[ixj];
+                            const bool asc = (i & kk) == 0;
+                            if ((a > c2) == asc) { S.skey[i] = c2; S.skey[ixj] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            int e = 0;
+            for (int k = tid; k < L; k += OCT_T)
+                if (S.skey[k] != ~0ull) { S.xlist[k] = (uint16_t)(S.skey[k] & 0xFFFFu); e++; }
+            int dummy = block_scan_excl(e, wsum, &E);
+            (void)dummy;
+            __syncthreads();
+        }
+        // 3. per-rank created children (nz) and gain (nz-1), inclusive prefixes
+        for (int r = tid; r < E; r += OCT_T) {
+            const int k = S.xlist[r];
+            const int nz = (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) +
+                           (S.hist[4 * k + 3] > 0);
+            S.pn[r] = nz;
+        }
+        __syncthreads();
+        array_scan_excl(S.pn, E, wsum);  // exclusive prefix of nz by rank
+        // gain prefix: incl_gain[r] = excl_nz[r] + nz[r] - (r+1)
+        // 4. number of parents split
+        if (tid == 0) sh_i[0] = E;
+        __syncthreads();
+        if (phase == 2) {
+            for (int r = tid; r < E; r += OCT_T) {
+                const int k = S.xlist[r];
+                const int nz = (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) +
+                               (S.hist[4 * k + 3] > 0);
+                const int after = L + S.pn[r] + nz - (r + 1);   // list size after splitting rank r
+                const int before = L + S.pn[r] - r;             // ... before it
+                if (after >= N && before < N) sh_i[0] = r + 1;  // the break at :730-731
+            }
+            __syncthreads();
+        }
+        const int Sp = sh_i[0];
+        // total created
+        __shared__ int sh_C;
+        if (tid == 0) {
+            int C = 0;
+            if (Sp > 0) {
+                const int k = S.xlist[Sp - 1];
+                const int nz = (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) +
+                               (S.hist[4 * k + 3] > 0);
+                C = S.pn[Sp - 1] + nz;
+            }
+            sh_C = C;
+        }
+        for (int k = tid; k < L; k += OCT_T) S.split[k] = 0;
+        __syncthreads();
+        const int C = sh_C;
+        const int Lnew = L - Sp + C;
+        // 5. create children: sequence s -> new index C-1-s
+        int nexp = 0;
+        for (int r = tid; r < Sp; r += OCT_T) {
+            const int k = S.xlist[r];
+            S.split[k] = 1;
+            int s = S.pn[r];
+            const short4 pb = box[k];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t hc = S.hist[4 * k + q];
+                if (hc > 0) {
+                    const int ni = C - 1 - s;
+                    nbox[ni] = child_box(pb, q);
+                    ncnt[ni] = hc | 0x80000000u;
+                    S.childIdx[4 * k + q] = (uint16_t)ni;
+                    if (hc > 1) nexp++;
+                    s++;
+                }
+            }
+        }
+        if (nexp) atomicAdd(&sh_i[1], nexp);
+        __syncthreads();
+        // survivors keep their relative order behind the new nodes
+        {
+            const int chunk = (L + OCT_T - 1) / OCT_T;
+            const int beg = min(tid * chunk, L), end = min(beg + chunk, L);
+            int s = 0;
+            for (int k = beg; k < end; k++) s += S.split[k] ? 0 : 1;
+            int tot;
+            int off = block_scan_excl(s, wsum, &tot);
+            for (int k = beg; k < end; k++)
+                if (!S.split[k]) {
+                    const int ni = C + off++;
+                    nbox[ni] = box[k];
+                    ncnt[ni] = cnt[k] & 0x7FFFFFFFu;  // no longer fresh
+                    S.survIdx[k] = (uint16_t)ni;
+                }
+        }
+        __syncthreads();
+        // 6. re-index the keys
+        for (int i = tid; i < n; i += OCT_T) {
+            const int k = nof[i];
+            if (S.split[k]) {
+                const uint32_t key = keys[i];
+                nof[i] = S.childIdx[4 * k + child_of(key & 0xFFF, (key >> 12) & 0xFFF, box[k])];
+            } else
+                nof[i] = S.survIdx[k];
+        }
+        const int nToExpand = sh_i[1];
+        // 7. termination (:669-672, :733-734)
+        if (Lnew >= N || Lnew == L) finish = true;
+        else if (phase == 1 && Lnew + 3 * nToExpand > N) phase = 2;
+        L = Lnew;
+        cur ^= 1;
+        __syncthreads();
+    }
+
+    // ---- D. best key of every node, first maximum wins (:744-760); output in list order
+    uint32_t *best = S.hist;
+    for (int k = tid; k < L; k += OCT_T) best[k] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += OCT_T)
+        atomicMax(&best[nof[i]], ((keys[i] >> 24) << 20) | (0xFFFFFu - (uint32_t)i));
+    __syncthreads();
+    uint32_t *okp = lvlKp + (size_t)b * lvlKpCap + g.lvlKpOff;
+    const int Lout = min(L, g.nodeCap);
+    for (int k = tid; k < Lout; k += OCT_T) okp[k] = keys[0xFFFFFu - (best[k] & 0xFFFFFu)];
+    if (tid == 0) lvlCnt[b * nlevels + l] = Lout;
+}
+
+// ------------------------------------------------------------------------------------
+// K4: one wave per kept keypoint: IC_Angle (:77-104) on the un-blurred level, 7x7 sigma=2
+// Gaussian (8-bit fixed point [18 34 49 55 49 34 18], (sum+2^15)>>16) of the 37x37
+// neighbourhood the 256 rotated test pairs can touch (|tap| <= 18), then the steered BRIEF
+// bits (:108-147) packed with one ballot per 64 pairs.  The blurred level is never written
+// to memory: blur is a pure function of the 43x43 source patch, which is staged in LDS from
+// the padded (BORDER_REFLECT_101) level, so border handling is identical to cv::GaussianBlur.
+#define DESC_WAVES 4
+#define PR 21                    // source patch radius = 18 + 3
+#define PROWS (2 * PR + 1)       // 43
+#define PSTRIDE 48               // 12 dwords per patch row
+#define TROWS PROWS
+#define TCOLS (2 * ORBX_DESC_R + 1)  // 37
+#define TSTRIDE 38               // uint16
+#define BSTRIDE 40
+#define DESC_LDS_PER_WAVE (PROWS * PSTRIDE + TROWS * TSTRIDE * 2 + TCOLS * BSTRIDE)
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    // cv::fastAtan2 of OpenCV 2.4.11 / 3.2 (scalar path)
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
+    const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
+    const uint32_t *__restrict__ lvlKp, int lvlKpCap, const int32_t *__restrict__ lvlCnt,
+    orbx_keypoint_t *__restrict__ kps, uint8_t *__restrict__ desc, int32_t *__restrict__ counts, int cap) {
+    __shared__ __align__(16) uint8_t smem[DESC_WAVES * DESC_LDS_PER_WAVE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o = blockIdx.x * DESC_WAVES + wave, b = blockIdx.y;
+    // locate (level, k) of output ordinal o: level-major concatenation (:1076-1104)
+    int l = 0, base = 0, total = 0;
+    {
+        int acc = 0;
+        bool found = false;
+        for (int i = 0; i < nlevels; i++) {
+            const int c = lvlCnt[b * nlevels + i];
+            if (!found && o < acc + c) { l = i; base = acc; found = true; }
+            acc += c;
+        }
+        total = acc;
+        if (blockIdx.x == 0 && threadIdx.x == 0) counts[b] = min(total, cap);
+        if (!found || o >= cap) return;  // wave-uniform
+    }
+    const LevelGeom g = geom[l];
+    const uint32_t key = lvlKp[(size_t)b * lvlKpCap + g.lvlKpOff + (o - base)];
+    const int cx = (int)(key & 0xFFF) + ORBX_MINB, cy = (int)((key >> 12) & 0xFFF) + ORBX_MINB;
+    const int score = (int)(key >> 24);
+
+    uint8_t *P = smem + wave * DESC_LDS_PER_WAVE;           // source patch [43][48]
+    uint16_t *Tm = (uint16_t *)(P + PROWS * PSTRIDE);       // horizontal pass [43][38]
+    uint8_t *Bl = (uint8_t *)(Tm + TROWS * TSTRIDE);        // blurred [37][40]
+
+    // ---- stage the 43x43 patch with aligned dword loads (pstride is a multiple of 64)
+    const uint8_t *lvl = pyr + (size_t)b * pyrImgBytes + g.poff;
+    const size_t a = (size_t)(cy + ORBX_EDGE - PR) * g.pstride + (size_t)(cx + ORBX_EDGE - PR);
+    const int sh = (int)(a & 3);
+    const uint32_t *src = (const uint32_t *)(lvl + (a - sh));
+    const int pstr4 = g.pstride >> 2;
+    for (int i = lane; i < PROWS * 12; i += 64) {
+        const int r = i / 12, c = i - r * 12;
+        ((uint32_t *)P)[r * 12 + c] = src[(size_t)r * pstr4 + c];
+    }
+    wave_sync();
+    const uint8_t *Pc = P + sh;  // Pc[r*48 + c], r,c in [0,43): pixel (cx-21+c, cy-21+r)
+
+    // ---- IC_Angle: lanes 0..30 own one row v = lane-15 of the radius-15 disc
+    int m10 = 0, m01 = 0;
+    if (lane < 31) {
+        const int v = lane - 15;
+        const int d = c_umax[v < 0 ? -v : v];
+        const uint8_t *row = Pc + (PR + v) * PSTRIDE + PR;
+        int s0 = 0, s1 = 0;
+        for (int u = -d; u <= d; ++u) {
+            const int val = row[u];
+            s0 += val;
+            s1 += u * val;
+        }
+        m10 = s1;
+        m01 = v * s0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m10 += __shfl_xor(m10, off);
+        m01 += __shfl_xor(m01, off);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- separable 7-tap blur in 8-bit fixed point
+    for (int i = lane; i < TROWS * TCOLS; i += 64) {
+        const int r = i / TCOLS, c = i - r * TCOLS;
+        const uint8_t *p = Pc + r * PSTRIDE + c;
+        const int acc = c_gauss[0] * (p[0] + p[6]) + c_gauss[1] * (p[1] + p[5]) + c_gauss[2] * (p[2] + p[4]) +
+                        c_gauss[3] * p[3];
+        Tm[r * TSTRIDE + c] = (uint16_t)acc;  // <= 255*257 = 65535
+    }
+    wave_sync();
+    for (int i = lane; i < TCOLS * TCOLS; i += 64) {
+        const int r = i / TCOLS, c = i - r * TCOLS;
+        const uint16_t *p = Tm + r * TSTRIDE + c;
+        int acc = c_gauss[0] * ((int)p[0] + p[6 * TSTRIDE]) + c_gauss[1] * ((int)p[TSTRIDE] + p[5 * TSTRIDE]) +
+                  c_gauss[2] * ((int)p[2 * TSTRIDE] + p[4 * TSTRIDE]) + c_gauss[3] * (int)p[3 * TSTRIDE];
+        acc = (acc + (1 << 15)) >> 16;
+        Bl[r * BSTRIDE + c] = (uint8_t)min(acc, 255);
+    }
+    wave_sync();
+
+    // ---- steered BRIEF: 4 rounds x 64 pairs, one ballot = 8 descriptor bytes
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float ang = angle * factorPI;
+    const float ca = (float)cos((double)ang), sa = (float)sin((double)ang);
+    const uint8_t *Bc = Bl + ORBX_DESC_R * BSTRIDE + ORBX_DESC_R;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int pair = r * 64 + lane;
+        const int8_t *q = c_pattern + 4 * pair;
+        const float x0 = (float)q[0], y0 = (float)q[1], x1 = (float)q[2], y1 = (float)q[3];
+        const int t0 = Bc[__float2int_rn(x0 * sa + y0 * ca) * BSTRIDE + __float2int_rn(x0 * ca - y0 * sa)];
+        const int t1 = Bc[__float2int_rn(x1 * sa + y1 * ca) * BSTRIDE + __float2int_rn(x1 * ca - y1 * sa)];
+        bits[r] = __ballot(t0 < t1);
+    }
+    const size_t oi = (size_t)b * cap + o;
+    if (lane < 4) ((unsigned long long *)(desc + oi * 32))[lane] = bits[lane];
+    if (lane == 0) {
+        orbx_keypoint_t kp;
+        kp.x = (float)cx;
+        kp.y = (float)cy;
+        if (l != 0) { kp.x *= g.scale; kp.y *= g.scale; }  // pt *= mvScaleFactor[level]  (:1095-1101)
+        kp.size = g.size;
+        kp.angle = angle;
+        kp.response = (float)score;
+        kp.octave = l;
+        kp.class_id = -1;
+        kps[oi] = kp;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+static int cv_round(double v) { return (int)lrint(v); }
+static int cv_floor(double v) { int i = (int)v; return i - (v < i); }
+static int cv_ceil(double v) { int i = (int)v; return i + (v > i); }
+static short sat_short_round(float v) {
+    int i = cv_round(v);
+    return (short)(i < -32768 ? -32768 : i > 32767 ? 32767 : i);
+}
+
+extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th,
+                           int device, orbx_extractor_t **out) {
+    if (!out) { orbx_set_error("orbx_create: out is NULL"); return ORBX_ERR_ARG; }
+    *out = nullptr;
+    if (nfeatures < 1 || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || !(scale_factor > 1.0f) || ini_th < 0 ||
+        min_th < 0 || ini_th > 255 || min_th > 255) {
+        orbx_set_error("orbx_create: bad arguments (nfeatures=%d scale=%f nlevels=%d ini=%d min=%d)", nfeatures,
+                       scale_factor, nlevels, ini_th, min_th);
+        return ORBX_ERR_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0 || device < 0 || device >= ndev) {
+        orbx_set_error("orbx_create: no usable HIP device (count=%d, requested %d): %s", ndev, device,
+                       e == hipSuccess ? "ok" : hipGetErrorString(e));
+        return ORBX_ERR_NO_DEVICE;
+    }
+    ORBX_HIP(hipSetDevice(device));
+    orbx_extractor *h = new orbx_extractor();
+    memset(h, 0, sizeof(*h));
+    h->nfeatures = nfeatures; h->nlevels = nlevels; h->ini_th = ini_th; h->min_th = min_th;
+    h->device = device; h->scale_factor = scale_factor;
+    // scale tables (:415-431)
+    h->sf[0] = 1.0f; h->sig2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) {
+        h->sf[i] = (float)(h->sf[i - 1] * h->scale_factor);
+        h->sig2[i] = h->sf[i] * h->sf[i];
+    }
+    for (int i = 0; i < nlevels; i++) { h->isf[i] = 1.0f / h->sf[i]; h->isig2[i] = 1.0f / h->sig2[i]; }
+    // features per level (:435-446)
+    float factor = (float)(1.0f / h->scale_factor);
+    float nDesired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int level = 0; level < nlevels - 1; level++) {
+        h->nfeat[level] = cv_round(nDesired);
+        sum += h->nfeat[level];
+        nDesired *= factor;
+    }
+    h->nfeat[nlevels - 1] = std::max(nfeatures - sum, 0);
+    // umax (:454-469)
+    {
+        int v, v0, vmax = cv_floor(ORBX_HALF_PATCH * sqrtf(2.f) / 2 + 1);
+        int vmin = cv_ceil(ORBX_HALF_PATCH * sqrtf(2.f) / 2);
+        const double hp2 = ORBX_HALF_PATCH * ORBX_HALF_PATCH;
+        for (v = 0; v <= vmax; ++v) h->umax[v] = cv_round(sqrt(hp2 - v * v));
+        for (v = ORBX_HALF_PATCH, v0 = 0; v >= vmin; --v) {
+            while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
+            h->umax[v] = v0;
+            ++v0;
+        }
+    }
+    h->max_kp = 0;
+    ORBX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i <= ORBX_NUM_STAGES; i++) ORBX_HIP(hipEventCreate(&h->ev[i]));
+    *out = h;
+    return ORBX_OK;
+}
+
+static void free_plan(orbx_extractor *h) {
+    hipFree(h->d_geom); hipFree(h->d_tab); hipFree(h->d_pyr); hipFree(h->d_cellCnt); hipFree(h->d_slots);
+    hipFree(h->d_cand); hipFree(h->d_lvlKp); hipFree(h->d_nodeOf); hipFree(h->d_candCnt); hipFree(h->d_lvlCnt);
+    h->d_geom = nullptr; h->d_tab = nullptr; h->d_pyr = nullptr; h->d_cellCnt = nullptr; h->d_slots = nullptr;
+    h->d_cand = nullptr; h->d_lvlKp = nullptr; h->d_nodeOf = nullptr; h->d_candCnt = nullptr; h->d_lvlCnt = nullptr;
+    h->pw = h->ph = h->pB = 0;
+}
+
+extern "C" int orbx_destroy(orbx_extractor_t *h) {
+    if (!h) return ORBX_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    if (h->last_stream) hipStreamSynchronize(h->last_stream);
+    free_plan(h);
+    hipFree(h->d_in); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts);
+    for (int i = 0; i <= ORBX_NUM_STAGES; i++) hipEventDestroy(h->ev[i]);
+    hipStreamDestroy(h->stream);
+    delete h;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_get_levels(const orbx_extractor_t *h) { return h ? h->nlevels : ORBX_ERR_ARG; }
+extern "C" float orbx_get_scale_factor(const orbx_extractor_t *h) { return h ? (float)h->scale_factor : 0.f; }
+extern "C" int orbx_get_tables(const orbx_extractor_t *h, float *sf, float *isf, float *s2, float *is2,
+                               int32_t *nf, int32_t *umax16) {
+    if (!h) return ORBX_ERR_ARG;
+    for (int i = 0; i < h->nlevels; i++) {
+        if (sf) sf[i] = h->sf[i];
+        if (isf) isf[i] = h->isf[i];
+        if (s2) s2[i] = h->sig2[i];
+        if (is2) is2[i] = h->isig2[i];
+        if (nf) nf[i] = h->nfeat[i];
+    }
+    if (umax16) memcpy(umax16, h->umax, sizeof(int32_t) * 16);
+    return ORBX_OK;
+}
+extern "C" int orbx_max_keypoints(const orbx_extractor_t *h) {
+    if (!h) return ORBX_ERR_ARG;
+    // every level returns at most max(N+2, 4*nIni) nodes; nIni is image dependent (<= 64)
+    return h->max_kp > 0 ? h->max_kp : h->nfeatures + 3 * h->nlevels;
+}
+
+// Build the size-dependent plan: level geometry (:773-787, :1111-1112), resize coefficient
+// tables (cv::resize), quad-tree root tables (:543-569), buffer sizes.
+static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
+    if (h->pw == w && h->ph == hgt && h->pB >= B) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(h->device));
+    if (h->last_stream) ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    const int keepB = (h->pw == w && h->ph == hgt) ? h->pB : 0;
+    free_plan(h);
+    B = std::max(B, keepB);
+    std::vector<int32_t> tab;
+    size_t poff = 0, slotOff = 0, keyOff = 0;
+    int cellBase = 0, lvlKpOff = 0, maxNodeCap = 0, maxCells = 0;
+    int maxTw = 0, maxTh = 0;
+    int kpBound = 0;
+    for (int l = 0; l < h->nlevels; l++) {
+        LevelGeom &g = h->geom[l];
+        memset(&g, 0, sizeof(g));
+        const float scale = h->isf[l];
+        g.w = cv_round((float)w * scale);
+        g.h = cv_round((float)hgt * scale);
+        g.regW = g.w - 2 * ORBX_MINB;
+        g.regH = g.h - 2 * ORBX_MINB;
+        if (g.regW < 30 || g.regH < 30) {
+            orbx_set_error("level %d is %dx%d: the reference needs (w-32)>=30 and (h-32)>=30 at every level "
+                           "(nCols/nRows would be 0, src/ORBextractor.cc:784-787)", l, g.w, g.h);
+            return ORBX_ERR_ARG;
+        }
+        if (g.w > 4095 || g.h > 4095) {
+            orbx_set_error("image %dx%d too large: candidate coordinates are packed in 12 bits", w, hgt);
+            return ORBX_ERR_UNSUPPORTED;
+        }
+        g.pstride = (g.w + 2 * ORBX_EDGE + 63) & ~63;
+        g.prows = g.h + 2 * ORBX_EDGE;
+        g.poff = poff;
+        poff += (size_t)g.pstride * g.prows;
+        const float W = 30;
+        const float width = (float)g.regW, height = (float)g.regH;
+        g.nCols = (int)(width / W);
+        g.nRows = (int)(height / W);
+        g.wCell = (int)ceilf(width / g.nCols);
+        g.hCell = (int)ceilf(height / g.nRows);
+        g.ncells = g.nCols * g.nRows;
+        g.cellBase = cellBase;
+        cellBase += g.ncells;
+        g.capc = ((g.wCell + 1) / 2) * ((g.hCell + 1) / 2);
+        g.slotOff = slotOff;
+        slotOff += (size_t)g.ncells * g.capc;
+        g.keyOff = keyOff;
+        g.keyCap = g.ncells * g.capc;
+        if (g.keyCap > 0xFFFFF) {
+            orbx_set_error("level %d can hold %d FAST candidates (> 2^20): unsupported", l, g.keyCap);
+            return ORBX_ERR_UNSUPPORTED;
+        }
+        keyOff += (size_t)g.keyCap;
+        g.N = h->nfeat[l];
+        g.nIni = (int)roundf((float)g.regW / g.regH);
+        if (g.nIni < 1 || g.nIni > ORBX_MAX_ROOTS) {
+            orbx_set_error("aspect ratio gives %d quad-tree roots at level %d (reference divides by zero "
+                           "below 1; supported up to %d)", g.nIni, l, ORBX_MAX_ROOTS);
+            return g.nIni < 1 ? ORBX_ERR_ARG : ORBX_ERR_UNSUPPORTED;
+        }
+        g.nodeCap = std::max(g.N + 3, 4 * g.nIni) + 4 * g.nIni + 1;
+        kpBound += std::max(g.N + 2, 4 * g.nIni);
+        maxNodeCap = std::max(maxNodeCap, g.nodeCap);
+        maxCells = std::max(maxCells, g.ncells);
+        g.lvlKpOff = lvlKpOff;
+        lvlKpOff += g.nodeCap;
+        g.scale = h->sf[l];
+        g.size = (float)(int)(31 * h->sf[l]);
+        maxTw = std::max(maxTw, g.wCell + 6);
+        maxTh = std::max(maxTh, g.hCell + 6);
+        // resize tables of cv::resize(INTER_LINEAR, 8UC1) from level l-1
+        if (l > 0) {
+            const int sw = h->geom[l - 1].w, shh = h->geom[l - 1].h;
+            const double inv_scale_x = (double)g.w / sw, inv_scale_y = (double)g.h / shh;
+            const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+            g.xofsOff = (int)tab.size();
+            tab.resize(tab.size() + g.w);
+            g.xalphaOff = (int)tab.size();
+            tab.resize(tab.size() + g.w);
+            for (int dx = 0; dx < g.w; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = cv_floor(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx + 1 >= sw) {
+                    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+                }
+                const short a0 = sat_short_round((1.f - fx) * 2048), a1 = sat_short_round(fx * 2048);
+                tab[g.xofsOff + dx] = sx;
+                tab[g.xalphaOff + dx] = (int32_t)((uint32_t)(uint16_t)a0 | ((uint32_t)(uint16_t)a1 << 16));
+            }
+            g.yofsOff = (int)tab.size();
+            tab.resize(tab.size() + g.h);
+            g.ybetaOff = (int)tab.size();
+            tab.resize(tab.size() + g.h);
+            for (int dy = 0; dy < g.h; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = cv_floor(fy);
+                fy -= sy;
+                const short b0 = sat_short_round((1.f - fy) * 2048), b1 = sat_short_round(fy * 2048);
+                tab[g.yofsOff + dy] = sy;
+                tab[g.ybetaOff + dy] = (int32_t)((uint32_t)(uint16_t)b0 | ((uint32_t)(uint16_t)b1 << 16));
+            }
+        }
+        // quad-tree roots (:543-569): boxes and the key -> root map, tabulated in host float
+        {
+            const float hX = (float)g.regW / g.nIni;
+            g.rootBoxOff = (int)tab.size();
+            for (int i = 0; i <= g.nIni; i++) tab.push_back((int)(hX * (float)i));
+            const int words = (g.regW + 3) / 4;
+            g.rootTabOff = (int)(tab.size() * 4);
+            size_t base = tab.size();
+            tab.resize(tab.size() + words, 0);
+            uint8_t *rt = (uint8_t *)&tab[base];
+            for (int x = 0; x < g.regW; x++) {
+                size_t r = (size_t)((float)x / hX);
+                if (r >= (size_t)g.nIni) r = g.nIni - 1;
+                rt[x] = (uint8_t)r;
+            }
+        }
+    }
+    if (maxTw > 65 || maxTh > 65) { orbx_set_error("cell window %dx%d exceeds 65", maxTw, maxTh); return ORBX_ERR_UNSUPPORTED; }
+    h->max_kp = kpBound;
+    h->totalCells = cellBase;
+    h->maxNodeCap = maxNodeCap;
+    h->lvlKpCap = lvlKpOff;
+    h->pyrImgBytes = (poff + 255) & ~(size_t)255;
+    h->slotsPerImg = slotOff;
+    h->keysPerImg = (keyOff + 1) & ~(size_t)1;
+    h->fastTileStride = (maxTw + 3) & ~3;
+    h->fastScoreStride = (maxTw - 6 + 2 + 3) & ~3;
+    h->fastTileRows = maxTh;
+    h->fastLdsPerWave = (h->fastTileStride * maxTh + h->fastScoreStride * (maxTh - 4) +
+                         (maxTw - 6) * (maxTh - 6) + 15) & ~15;
+    {   // octree LDS
+        int pow2 = 1;
+        while (pow2 < maxNodeCap) pow2 <<= 1;
+        const int scratch = std::max(4 * maxNodeCap, maxCells + 1);
+        size_t bytes = sizeof(unsigned long long) * pow2 + (size_t)maxNodeCap * (8 * 2 + 4 * 2 + 4 * 2 + 2 * 4 + 2 + 2 + 1) +
+                       4 * (size_t)scratch + 64;
+        h->octLdsBytes = bytes;
+        if (bytes > 150 * 1024) {
+            orbx_set_error("quad-tree needs %zu B of LDS (features per level %d): unsupported", bytes, maxNodeCap);
+            return ORBX_ERR_UNSUPPORTED;
+        }
+    }
+    const size_t Bz = (size_t)B;
+    ORBX_HIP(hipMalloc(&h->d_geom, sizeof(LevelGeom) * ORBX_MAX_LEVELS));
+    ORBX_HIP(hipMalloc(&h->d_tab, sizeof(int32_t) * std::max<size_t>(tab.size(), 1)));
+    ORBX_HIP(hipMalloc(&h->d_pyr, h->pyrImgBytes * Bz));
+    ORBX_HIP(hipMalloc(&h->d_cellCnt, sizeof(uint32_t) * h->totalCells * Bz));
+    ORBX_HIP(hipMalloc(&h->d_slots, sizeof(uint32_t) * h->slotsPerImg * Bz));
+    ORBX_HIP(hipMalloc(&h->d_cand, sizeof(uint32_t) * h->keysPerImg * Bz));
+    ORBX_HIP(hipMalloc(&h->d_nodeOf, sizeof(uint16_t) * h->keysPerImg * Bz));
+    ORBX_HIP(hipMalloc(&h->d_candCnt, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
+    ORBX_HIP(hipMalloc(&h->d_lvlCnt, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
+    ORBX_HIP(hipMalloc(&h->d_lvlKp, sizeof(uint32_t) * (size_t)h->lvlKpCap * Bz));
+    ORBX_HIP(hipMemcpy(h->d_geom, h->geom, sizeof(LevelGeom) * ORBX_MAX_LEVELS, hipMemcpyHostToDevice));
+    if (!tab.empty()) ORBX_HIP(hipMemcpy(h->d_tab, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice));
+    h->pw = w; h->ph = hgt; h->pB = B;
+    return ORBX_OK;
+}
+
+static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int w, int hgt, int stride,
+                           size_t img_stride, orbx_keypoint_t *d_kps, uint8_t *d_desc, int32_t *d_counts,
+                           int cap, hipStream_t st) {
+    const int nl = h->nlevels;
+    const bool prof = h->profiling != 0;
+    if (prof) ORBX_HIP(hipEventRecord(h->ev[0], st));
+    {   // K1
+        const LevelGeom &g0 = h->geom[0];
+        dim3 grid((g0.pstride / 4 + 255) / 256, g0.prows, B);
+        hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, st, d_imgs, stride, img_stride, h->d_pyr,
+                           h->pyrImgBytes, h->d_geom);
+        for (int l = 1; l < nl; l++) {
+            const LevelGeom &g = h->geom[l];
+            dim3 gr((g.pstride / 4 + 255) / 256, g.prows, B);
+            hipLaunchKernelGGL(k_pyr_resize, gr, dim3(256), 0, st, h->d_pyr, h->pyrImgBytes, h->d_geom, l, h->d_tab);
+        }
+    }
+    if (prof) ORBX_HIP(hipEventRecord(h->ev[1], st));
+    {   // K2
+        dim3 grid((h->totalCells + FAST_WAVES - 1) / FAST_WAVES, B);
+        hipLaunchKernelGGL(k_fast_cells, grid, dim3(64 * FAST_WAVES), (size_t)h->fastLdsPerWave * FAST_WAVES, st,
+                           h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_slots,
+                           h->slotsPerImg, h->ini_th, h->min_th, h->fastTileStride, h->fastScoreStride,
+                           h->fastTileRows, h->fastLdsPerWave);
+    }
+    if (prof) ORBX_HIP(hipEventRecord(h->ev[2], st));
+    {   // K3
+        int pow2 = 1;
+        while (pow2 < h->maxNodeCap) pow2 <<= 1;
+        int maxCells = 0;
+        for (int l = 0; l < nl; l++) maxCells = std::max(maxCells, h->geom[l].ncells);
+        const int scratch = std::max(4 * h->maxNodeCap, maxCells + 1);
+        ORBX_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)h->octLdsBytes));
+        hipLaunchKernelGGL(k_octree, dim3(nl, B), dim3(OCT_T), h->octLdsBytes, st, h->d_geom, nl, h->totalCells,
+                           h->d_cellCnt, h->d_slots, h->slotsPerImg, h->d_cand, h->d_nodeOf, h->keysPerImg,
+                           h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2,
+                           scratch);
+    }
+    if (prof) ORBX_HIP(hipEventRecord(h->ev[3], st));
+    {   // K4
+        const int maxo = std::min(cap, h->max_kp);
+        dim3 grid((maxo + DESC_WAVES - 1) / DESC_WAVES, B);
+        hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, st, h->d_pyr, h->pyrImgBytes, h->d_geom, nl,
+                           h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, d_kps, d_desc, d_counts, cap);
+    }
+    if (prof) { ORBX_HIP(hipEventRecord(h->ev[4], st)); h->ev_valid = 1; }
+    ORBX_HIP(hipGetLastError());
+    h->last_stream = st;
+    h->lastB = B;
+    (void)w; (void)hgt;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch_device(orbx_extractor_t *h, const uint8_t *d_imgs, int B, int w, int hgt,
+                                         int stride, size_t image_stride_bytes, orbx_keypoint_t *d_kps,
+                                         uint8_t *d_desc, int32_t *d_counts, int cap, void *stream) {
+    if (!h || !d_imgs || !d_kps || !d_desc || !d_counts || B < 1 || w < 1 || hgt < 1 || stride < w || cap < 1) {
+        orbx_set_error("orbx_extract_batch_device: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP(hipSetDevice(h->device));
+    int rc = ensure_plan(h, w, hgt, B);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    return launch_pipeline(h, d_imgs, B, w, hgt, stride, image_stride_bytes, d_kps, d_desc, d_counts, cap, st);
+}
+
+static int ensure_staging(orbx_extractor *h, size_t in_bytes, int B, int cap) {
+    if (h->d_in_bytes < in_bytes) {
+        hipFree(h->d_in); h->d_in = nullptr; h->d_in_bytes = 0;
+        ORBX_HIP(hipMalloc(&h->d_in, in_bytes));
+        h->d_in_bytes = in_bytes;
+    }
+    if (h->out_cap < cap || h->out_B < B) {
+        hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts);
+        h->d_kps = nullptr; h->d_desc = nullptr; h->d_counts = nullptr;
+        const int nb = std::max(B, h->out_B), nc = std::max(cap, h->out_cap);
+        ORBX_HIP(hipMalloc(&h->d_kps, sizeof(orbx_keypoint_t) * (size_t)nb * nc));
+        ORBX_HIP(hipMalloc(&h->d_desc, (size_t)32 * nb * nc));
+        ORBX_HIP(hipMalloc(&h->d_counts, sizeof(int32_t) * nb));
+        h->out_cap = nc; h->out_B = nb;
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch(orbx_extractor_t *h, const uint8_t *const *imgs, int B, int w, int hgt,
+                                  int stride, orbx_keypoint_t *kps, uint8_t *desc, int cap, int *n_out) {
+    if (!h || !imgs || !kps || !desc || !n_out || B < 1 || cap < 1) {
+        orbx_set_error("orbx_extract_batch: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    if (w <= 0 || hgt <= 0) {  // empty image: silent return (:1046-1047)
+        for (int b = 0; b < B; b++) n_out[b] = 0;
+        return ORBX_OK;
+    }
+    if (stride < w) { orbx_set_error("stride < width"); return ORBX_ERR_ARG; }
+    ORBX_HIP(hipSetDevice(h->device));
+    int rc = ensure_plan(h, w, hgt, B);
+    if (rc) return rc;
+    const size_t img_bytes = ((size_t)w * hgt + 255) & ~(size_t)255;
+    rc = ensure_staging(h, img_bytes * B, B, cap);
+    if (rc) return rc;
+    const int dcap = h->out_cap;
+    for (int b = 0; b < B; b++) {
+        if (!imgs[b]) { orbx_set_error("imgs[%d] is NULL", b); return ORBX_ERR_ARG; }
+        ORBX_HIP(hipMemcpy2DAsync(h->d_in + img_bytes * b, w, imgs[b], stride, w, hgt, hipMemcpyHostToDevice, h->stream));
+    }
+    rc = launch_pipeline(h, h->d_in, B, w, hgt, w, img_bytes, h->d_kps, h->d_desc, h->d_counts, dcap, h->stream);
+    if (rc) return rc;
+    std::vector<int32_t> cnt(B);
+    ORBX_HIP(hipMemcpyAsync(cnt.data(), h->d_counts, sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->stream));
+    ORBX_HIP(hipStreamSynchronize(h->stream));
+    int status = ORBX_OK;
+    for (int b = 0; b < B; b++) {
+        int n = cnt[b];
+        if (n > cap) { n = cap; status = ORBX_ERR_CAPACITY; orbx_set_error("frame %d produced %d keypoints, cap %d", b, cnt[b], cap); }
+        n_out[b] = n;
+        if (n > 0) {
+            ORBX_HIP(hipMemcpyAsync(kps + (size_t)b * cap, h->d_kps + (size_t)b * dcap, sizeof(orbx_keypoint_t) * n,
+                                    hipMemcpyDeviceToHost, h->stream));
+            ORBX_HIP(hipMemcpyAsync(desc + (size_t)b * cap * 32, h->d_desc + (size_t)b * dcap * 32, (size_t)32 * n,
+                                    hipMemcpyDeviceToHost, h->stream));
+        }
+    }
+    ORBX_HIP(hipStreamSynchronize(h->stream));
+    return status;
+}
+
+extern "C" int orbx_extract(orbx_extractor_t *h, const uint8_t *img, int w, int hgt, int stride,
+                            orbx_keypoint_t *kps, uint8_t *desc, int cap, int *n_out) {
+    if (!h || !n_out) { orbx_set_error("orbx_extract: bad arguments"); return ORBX_ERR_ARG; }
+    if (!img || w <= 0 || hgt <= 0) { *n_out = 0; return ORBX_OK; }  // empty image (:1046-1047)
+    const uint8_t *imgs[1] = {img};
+    return orbx_extract_batch(h, imgs, 1, w, hgt, stride, kps, desc, cap, n_out);
+}
+
+int orbx_internal_level(const orbx_extractor *h, int level, int *w, int *hgt, int *pstride,
+                        unsigned long long *poff) {
+    if (!h || level < 0 || level >= h->nlevels || h->pw == 0) return ORBX_ERR_ARG;
+    const LevelGeom &g = h->geom[level];
+    *w = g.w; *hgt = g.h; *pstride = g.pstride; *poff = g.poff;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_pyramid_device(orbx_extractor_t *h, int b, int level, const uint8_t **d_ptr, int *w, int *hgt,
+                                   int *stride) {
+    if (!h || !d_ptr || level < 0 || level >= h->nlevels || h->pw == 0 || b < 0 || b >= h->pB) {
+        orbx_set_error("orbx_pyramid_device: bad arguments or no frame extracted yet");
+        return ORBX_ERR_ARG;
+    }
+    const LevelGeom &g = h->geom[level];
+    *d_ptr = h->d_pyr + (size_t)b * h->pyrImgBytes + g.poff + (size_t)ORBX_EDGE * g.pstride + ORBX_EDGE;
+    if (w) *w = g.w;
+    if (hgt) *hgt = g.h;
+    if (stride) *stride = g.pstride;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_pyramid_host(orbx_extractor_t *h, int b, int level, int padded, uint8_t *dst, int dst_stride,
+                                 int *w, int *hgt) {
+    if (!h || level < 0 || level >= h->nlevels || h->pw == 0 || b < 0 || b >= h->pB) {
+        orbx_set_error("orbx_pyramid_host: bad arguments or no frame extracted yet");
+        return ORBX_ERR_ARG;
+    }
+    const LevelGeom &g = h->geom[level];
+    const int ow = padded ? g.w + 2 * ORBX_EDGE : g.w, oh = padded ? g.h + 2 * ORBX_EDGE : g.h;
+    if (w) *w = ow;
+    if (hgt) *hgt = oh;
+    if (!dst) return ORBX_OK;
+    if (dst_stride < ow) { orbx_set_error("dst_stride < width"); return ORBX_ERR_ARG; }
+    ORBX_HIP(hipSetDevice(h->device));
+    if (h->last_stream) ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    const uint8_t *src = h->d_pyr + (size_t)b * h->pyrImgBytes + g.poff +
+                         (padded ? 0 : (size_t)ORBX_EDGE * g.pstride + ORBX_EDGE);
+    ORBX_HIP(hipMemcpy2D(dst, dst_stride, src, g.pstride, ow, oh, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, int stage, int32_t *out, int cap,
+                                       int *n_out) {
+    if (!h || !n_out || level < 0 || level >= h->nlevels || h->pw == 0 || b < 0 || b >= h->pB || stage < 0 || stage > 1) {
+        orbx_set_error("orbx_debug_level_points: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    ORBX_HIP(hipSetDevice(h->device));
+    if (h->last_stream) ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    const LevelGeom &g = h->geom[level];
+    int32_t n = 0;
+    const int32_t *cntp = (stage == 0 ? h->d_candCnt : h->d_lvlCnt) + b * h->nlevels + level;
+    ORBX_HIP(hipMemcpy(&n, cntp, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (!out || n == 0) return ORBX_OK;
+    const int m = std::min(n, cap);
+    std::vector<uint32_t> tmp(m);
+    const uint32_t *src = stage == 0 ? h->d_cand + (size_t)b * h->keysPerImg + g.keyOff
+                                     : h->d_lvlKp + (size_t)b * h->lvlKpCap + g.lvlKpOff;
+    ORBX_HIP(hipMemcpy(tmp.data(), src, sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m; i++) {
+        out[3 * i] = (int32_t)(tmp[i] & 0xFFF);
+        out[3 * i + 1] = (int32_t)((tmp[i] >> 12) & 0xFFF);
+        out[3 * i + 2] = (int32_t)(tmp[i] >> 24);
+    }
+    return n > cap ? ORBX_ERR_CAPACITY : ORBX_OK;
+}
+
+extern "C" int orbx_set_profiling(orbx_extractor_t *h, int enabled) {
+    if (!h) return ORBX_ERR_ARG;
+    h->profiling = enabled;
+    h->ev_valid = 0;
+    return ORBX_OK;
+}
+extern "C" int orbx_get_stage_ms(orbx_extractor_t *h, float *ms) {
+    if (!h || !ms) return ORBX_ERR_ARG;
+    if (!h->ev_valid) { orbx_set_error("no profiled batch recorded"); return ORBX_ERR_ARG; }
+    ORBX_HIP(hipSetDevice(h->device));
+    ORBX_HIP(hipEventSynchronize(h->ev[4]));
+    for (int i = 0; i < 4; i++) ORBX_HIP(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    ORBX_HIP(hipEventElapsedTime(&ms[4], h->ev[0], h->ev[4]));
+    return ORBX_OK;
+}

@@ -1,0 +1,90 @@
+// orbx_internal.h — shared declarations of the HIP implementation (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "orbx.h"
+
+#define ORBX_MAX_LEVELS 16
+#define ORBX_EDGE 19        // EDGE_THRESHOLD            (reference: src/ORBextractor.cc:74)
+#define ORBX_MINB 16        // minBorderX = EDGE-3       (reference: src/ORBextractor.cc:773)
+#define ORBX_HALF_PATCH 15  // HALF_PATCH_SIZE           (reference: src/ORBextractor.cc:73)
+#define ORBX_DESC_R 18      // max |rotated tap| : pattern radius^2 = 338 -> cvRound <= 18
+#define ORBX_MAX_ROOTS 64
+
+void orbx_set_error(const char *fmt, ...);
+
+#define ORBX_HIP(call)                                                                      \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            orbx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                           __LINE__);                                                       \
+            return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ||                \
+                    e_ == hipErrorNoBinaryForGpu || e_ == hipErrorInsufficientDriver)       \
+                       ? ORBX_ERR_NO_DEVICE                                                 \
+                       : ORBX_ERR_HIP;                                                      \
+        }                                                                                   \
+    } while (0)
+
+// Per-level geometry, built on the host (exactly the reference's arithmetic) and read by
+// every kernel from device memory.
+struct LevelGeom {
+    int w, h;            // inner level size: cvRound(cols*inv), cvRound(rows*inv)   (:1111-1112)
+    int pstride, prows;  // padded buffer: row stride in bytes (multiple of 64), rows = h+38
+    unsigned long long poff;  // byte offset of the padded level inside one image's pyramid block
+    int regW, regH;      // maxBorderX-minBorderX, maxBorderY-minBorderY                 (:773-781)
+    int nCols, nRows, wCell, hCell;  //                                                  (:784-787)
+    int cellBase, ncells;            // global cell numbering across levels
+    int capc;                        // candidate slots per cell = ceil(wCell/2)*ceil(hCell/2)
+    unsigned long long slotOff;      // uint32 offset of this level's slots inside one image's slot block
+    int N;                           // mnFeaturesPerLevel[level]
+    int nIni;                        // round(regW/regH)                                  (:543)
+    int nodeCap;                     // quad-tree list capacity N + 3 + 4*nIni
+    unsigned long long keyOff;       // element offset of this level's keys inside one image's key block
+    int keyCap;                      // ncells*capc
+    int lvlKpOff;                    // offset of this level's kept keypoints in the per-image list
+    int xofsOff, xalphaOff, yofsOff, ybetaOff;  // resize tables (int32 units into d_tab), levels >= 1
+    int rootTabOff, rootBoxOff;      // byte offset (uint8 rootOf[x]) / int32 offset (root x bounds)
+    float scale;                     // mvScaleFactor[level]
+    float size;                      // (float)(int)(31*scale)                            (:837,846)
+};
+
+struct orbx_extractor {
+    int nfeatures, nlevels, ini_th, min_th, device;
+    double scale_factor;
+    float sf[ORBX_MAX_LEVELS], isf[ORBX_MAX_LEVELS], sig2[ORBX_MAX_LEVELS], isig2[ORBX_MAX_LEVELS];
+    int32_t nfeat[ORBX_MAX_LEVELS];
+    int32_t umax[16];
+    int max_kp;  // nfeatures + 3*nlevels (+ roots) upper bound per image
+
+    // plan (depends on image size / batch capacity)
+    int pw, ph, pB;  // planned image size and batch capacity (0 = none)
+    LevelGeom geom[ORBX_MAX_LEVELS];
+    int totalCells, maxNodeCap, lvlKpCap;
+    size_t pyrImgBytes, slotsPerImg, keysPerImg;
+    int fastTileStride, fastScoreStride, fastTileRows, fastLdsPerWave;
+    size_t octLdsBytes;
+    // device buffers
+    LevelGeom *d_geom;
+    int32_t *d_tab;
+    uint8_t *d_pyr;
+    uint32_t *d_cellCnt, *d_slots, *d_cand, *d_lvlKp;
+    uint16_t *d_nodeOf;
+    int32_t *d_candCnt, *d_lvlCnt;
+    // staging for the host API
+    uint8_t *d_in; size_t d_in_bytes;
+    orbx_keypoint_t *d_kps; uint8_t *d_desc; int32_t *d_counts; int out_cap, out_B;
+    hipStream_t stream;      // own stream
+    hipStream_t last_stream; // stream of the last batch call
+    int lastB;
+    int profiling;
+    hipEvent_t ev[ORBX_NUM_STAGES + 1];
+    int ev_valid;
+};
+
+// extractor internals used by the matcher side
+int orbx_internal_level(const orbx_extractor *h, int level, int *w, int *hgt, int *pstride,
+                        unsigned long long *poff);

@@ -1,0 +1,828 @@
+// orbx_match.hip — MI355X (gfx950) Hamming matchers: hand-written HIP kernels + C ABI.
+//
+//   orbm_hamming                     ORBmatcher::DescriptorDistance         (src/ORBmatcher.cc:1649-1665)
+//   k_hamming_matrix                 all-pairs 256-bit distances (building block / bandwidth probe)
+//   k_stereo_match + k_stereo_median Frame::ComputeStereoMatches            (src/Frame.cc:481-655)
+//   k_search_init                    ORBmatcher::SearchForInitialization    (src/ORBmatcher.cc:405-520)
+//   k_search_proj_mp                 ORBmatcher::SearchByProjection(F,MPs)  (src/ORBmatcher.cc:45-129)
+//   k_search_proj_frame              ORBmatcher::SearchByProjection(F,F)    (src/ORBmatcher.cc:1330-1472)
+//
+// Descriptor distance = 4 x popcount64 of the XOR; argmin / top-2 reductions run on packed
+// 64-bit keys (distance | scan-order | index) with wavefront shuffles, so the result is the
+// same element the reference's sequential "first strictly smaller wins" scan selects.
+#include "orbx_internal.h"
+#include <math.h>
+#include <limits.h>
+#include <algorithm>
+
+#define TH_HIGH 100
+#define TH_LOW 50
+#define HISTO_LENGTH 30
+#define GRID_COLS 64
+#define GRID_ROWS 48
+
+typedef unsigned long long u64;
+
+extern "C" int orbm_hamming(const uint8_t *a, const uint8_t *b) {
+    if (!a || !b) return ORBX_ERR_ARG;
+    int d = 0;
+    for (int i = 0; i < 4; i++) {
+        u64 x, y;
+        memcpy(&x, a + 8 * i, 8);
+        memcpy(&y, b + 8 * i, 8);
+        d += __builtin_popcountll(x ^ y);
+    }
+    return d;
+}
+
+struct Desc256 { u64 w[4]; };
+__device__ __forceinline__ Desc256 load_desc(const uint8_t *p) {
+    Desc256 d;
+    const uint4 a = ((const uint4 *)p)[0], b = ((const uint4 *)p)[1];
+    d.w[0] = (u64)a.x | ((u64)a.y << 32); d.w[1] = (u64)a.z | ((u64)a.w << 32);
+    d.w[2] = (u64)b.x | ((u64)b.y << 32); d.w[3] = (u64)b.z | ((u64)b.w << 32);
+    return d;
+}
+__device__ __forceinline__ int ham(const Desc256 &a, const Desc256 &b) {
+    return __popcll(a.w[0] ^ b.w[0]) + __popcll(a.w[1] ^ b.w[1]) + __popcll(a.w[2] ^ b.w[2]) +
+           __popcll(a.w[3] ^ b.w[3]);
+}
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)v, m), hi = __shfl_xor((unsigned)(v >> 32), m);
+    return (u64)lo | ((u64)hi << 32);
+}
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 t = shfl_xor_u64(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------
+// all-pairs Hamming: thread j keeps descriptor b_j in registers; 64 a-rows per block are
+// staged in LDS and broadcast; uint16 outputs are written row-coalesced.
+#define HM_ROWS 64
+__global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t *__restrict__ A, int na,
+                                                        const uint8_t *__restrict__ Bm, int nb,
+                                                        uint16_t *__restrict__ out) {
+    __shared__ u64 sa[HM_ROWS * 4];
+    const int j = blockIdx.x * 256 + threadIdx.x, i0 = blockIdx.y * HM_ROWS;
+    const int rows = min(HM_ROWS, na - i0);
+    if (threadIdx.x < rows * 4) sa[threadIdx.x] = ((const u64 *)(A + (size_t)i0 * 32))[threadIdx.x];
+    __syncthreads();
+    if (j >= nb) return;
+    const Desc256 b = load_desc(Bm + (size_t)j * 32);
+    for (int i = 0; i < rows; i++) {
+        const int d = __popcll(sa[4 * i] ^ b.w[0]) + __popcll(sa[4 * i + 1] ^ b.w[1]) +
+                      __popcll(sa[4 * i + 2] ^ b.w[2]) + __popcll(sa[4 * i + 3] ^ b.w[3]);
+        out[(size_t)(i0 + i) * nb + j] = (uint16_t)d;
+    }
+}
+
+extern "C" int orbm_hamming_matrix_device(const uint8_t *d_a, int na, const uint8_t *d_b, int nb,
+                                          uint16_t *d_out, void *stream) {
+    if (!d_a || !d_b || !d_out || na < 1 || nb < 1) { orbx_set_error("orbm_hamming_matrix_device: bad arguments"); return ORBX_ERR_ARG; }
+    dim3 grid((nb + 255) / 256, (na + HM_ROWS - 1) / HM_ROWS);
+    hipLaunchKernelGGL(k_hamming_matrix, grid, dim3(256), 0, (hipStream_t)stream, d_a, na, d_b, nb, d_out);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches (src/Frame.cc:481-655)
+struct StereoLevels {
+    int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], pstrideL[ORBX_MAX_LEVELS], pstrideR[ORBX_MAX_LEVELS];
+    unsigned long long poffL[ORBX_MAX_LEVELS], poffR[ORBX_MAX_LEVELS];
+    float sf[ORBX_MAX_LEVELS], isf[ORBX_MAX_LEVELS];
+    int nlevels, nRows;
+};
+
+#define ST_WAVES 4
+// one wave per left keypoint: row-band candidate test (:498-508, :535), level and
+// disparity-range tests (:548-553), Hamming argmin (first minimum in iR order, :558-562),
+// then the 11x11 SAD over 11 shifts (:577-607), parabola (:613-620), disparity (:623-636).
+__global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
+    StereoLevels lv, const uint8_t *__restrict__ pyrL, size_t pyrImgL, const uint8_t *__restrict__ pyrR,
+    size_t pyrImgR, const orbx_keypoint_t *__restrict__ kl, const uint8_t *__restrict__ dl,
+    const int32_t *__restrict__ nl, const orbx_keypoint_t *__restrict__ kr, const uint8_t *__restrict__ dr,
+    const int32_t *__restrict__ nr, int cap, float mbf, float mb, float *__restrict__ uright,
+    float *__restrict__ depth, int32_t *__restrict__ sad) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * ST_WAVES + wave, b = blockIdx.y;
+    const int N = min(nl[b], cap), Nr = min(nr[b], cap);
+    if (iL >= cap) return;
+    const size_t o = (size_t)b * cap + iL;
+    if (iL >= N) {
+        if (lane == 0) { uright[o] = -1.0f; depth[o] = -1.0f; sad[o] = -1; }
+        return;
+    }
+    float out_u = -1.0f, out_d = -1.0f;
+    int out_s = -1;
+    const orbx_keypoint_t kpL = kl[o];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    const int row = (int)vL;
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    const float minU = uL - maxD, maxU = uL - minD;
+    bool ok = row >= 0 && row < lv.nRows && !(maxU < 0);
+    if (ok) {
+        const Desc256 dL = load_desc(dl + o * 32);
+        u64 best = ~0ull;
+        const orbx_keypoint_t *krb = kr + (size_t)b * cap;
+        const uint8_t *drb = dr + (size_t)b * cap * 32;
+        for (int iR = lane; iR < Nr; iR += 64) {
+            const orbx_keypoint_t kpR = krb[iR];
+            const float r = 2.0f * lv.sf[kpR.octave];
+            const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
+            if (row < minr || row > maxr) continue;
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = ham(dL, load_desc(drb + (size_t)iR * 32));
+                if (dist < TH_HIGH) {
+                    const u64 key = ((u64)dist << 32) | (unsigned)iR;
+                    best = key < best ? key : best;
+                }
+            }
+        }
+        best = wave_min_u64(best);
+        const int bestDist = best == ~0ull ? TH_HIGH : (int)(best >> 32);
+        const int bestIdxR = best == ~0ull ? 0 : (int)(best & 0xFFFFFFFFu);
+        const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+        if (bestDist < thOrbDist) {
+            const float uR0 = krb[bestIdxR].x;
+            const float scaleFactor = lv.isf[levelL];
+            const float scaleduL = roundf(kpL.x * scaleFactor);
+            const float scaledvL = roundf(kpL.y * scaleFactor);
+            const float scaleduR0 = roundf(uR0 * scaleFactor);
+            const int w = 5, L = 5;
+            const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+            if (!(iniu < 0 || endu >= lv.w[levelL])) {
+                const uint8_t *IL = pyrL + (size_t)b * pyrImgL + lv.poffL[levelL] +
+                                    (size_t)ORBX_EDGE * lv.pstrideL[levelL] + ORBX_EDGE;
+                const uint8_t *IR = pyrR + (size_t)b * pyrImgR + lv.poffR[levelL] +
+                                    (size_t)ORBX_EDGE * lv.pstrideR[levelL] + ORBX_EDGE;
+                const int sL = lv.pstrideL[levelL], sR = lv.pstrideR[levelL];
+                const int cy = (int)scaledvL, cxl = (int)scaleduL, cxr0 = (int)scaleduR0;
+                const int cL = IL[(size_t)cy * sL + cxl];
+                // this lane's two pixels of the 11x11 window (p = lane, lane + 64 < 121)
+                const int p0 = lane, p1 = lane + 64;
+                const bool has1 = p1 < 121;
+                const int ay0 = p0 / 11 - w, ax0 = p0 % 11 - w;
+                const int ay1 = has1 ? p1 / 11 - w : 0, ax1 = has1 ? p1 % 11 - w : 0;
+                const int av0 = (int)IL[(size_t)(cy + ay0) * sL + cxl + ax0] - cL;
+                const int av1 = (int)IL[(size_t)(cy + ay1) * sL + cxl + ax1] - cL;
+                float vDists[11];
+                int bestDistS = INT_MAX, bestincR = 0;
+#pragma unroll
+                for (int incR = -L; incR <= L; incR++) {
+                    const int cxr = cxr0 + incR;
+                    const int cR = IR[(size_t)cy * sR + cxr];
+                    const int bv0 = (int)IR[(size_t)(cy + ay0) * sR + cxr + ax0] - cR;
+                    const int bv1 = (int)IR[(size_t)(cy + ay1) * sR + cxr + ax1] - cR;
+                    const int df0 = av0 - bv0, df1 = av1 - bv1;
+                    int s = (df0 < 0 ? -df0 : df0) + (has1 ? (df1 < 0 ? -df1 : df1) : 0);
+                    s = wave_sum_i32(s);
+                    const float dist = (float)s;
+                    if (dist < (float)bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+                    vDists[L + incR] = dist;
+                }
+                if (!(bestincR == -L || bestincR == L)) {
+                    float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+                    for (int k = 1; k < 10; k++)
+                        if (k == L + bestincR) { dist1 = vDists[k - 1]; dist2 = vDists[k]; dist3 = vDists[k + 1]; }
+                    const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+                    if (!(deltaR < -1 || deltaR > 1)) {
+                        float bestuR = lv.sf[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
+                        float disparity = (uL - bestuR);
+                        if (disparity >= minD && disparity < maxD) {
+                            if (disparity <= 0) { disparity = (float)0.01; bestuR = (float)((double)uL - 0.01); }
+                            out_d = mbf / disparity;
+                            out_u = bestuR;
+                            out_s = bestDistS;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { uright[o] = out_u; depth[o] = out_d; sad[o] = out_s; }
+}
+
+// one workgroup per frame: median of the SAD distances of the accepted matches
+// (sort + vDistIdx[size/2], :641-642) by rank counting on (dist, iL) pairs, then drop
+// every match with dist >= 1.5*1.4*median (:643-654).
+#define SM_T 256
+__global__ __launch_bounds__(SM_T) void k_stereo_median(const int32_t *__restrict__ nl, int cap,
+                                                        float *__restrict__ uright, float *__restrict__ depth,
+                                                        const int32_t *__restrict__ sad,
+                                                        int32_t *__restrict__ nmatch) {
+    extern __shared__ int32_t sd[];  // [cap] sad (or -1)
+    __shared__ int sh_nd, sh_med, sh_keep;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = min(nl[b], cap);
+    const size_t o = (size_t)b * cap;
+    if (tid == 0) { sh_nd = 0; sh_med = -1; sh_keep = 0; }
+    __syncthreads();
+    int c = 0;
+    for (int i = tid; i < N; i += SM_T) {
+        const int s = sad[o + i];
+        sd[i] = s;
+        c += s >= 0;
+    }
+    if (c) atomicAdd(&sh_nd, c);
+    __syncthreads();
+    const int nd = sh_nd;
+    if (nd == 0) {  // reference: UB on the empty vector (:642); defined here as "no matches"
+        if (nmatch && tid == 0) nmatch[b] = 0;
+        return;
+    }
+    const int target = nd / 2;
+    for (int i = tid; i < N; i += SM_T) {
+        const int s = sd[i];
+        if (s < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < N; j++) {
+            const int t = sd[j];
+            rank += (t >= 0) && (t < s || (t == s && j < i));
+        }
+        if (rank == target) sh_med = s;
+    }
+    __syncthreads();
+    const float median = (float)sh_med;
+    const float thDist = 1.5f * 1.4f * median;
+    int keep = 0;
+    for (int i = tid; i < N; i += SM_T) {
+        const int s = sd[i];
+        if (s < 0) continue;
+        if ((float)s < thDist) keep++;
+        else { uright[o + i] = -1; depth[o + i] = -1; }
+    }
+    if (keep) atomicAdd(&sh_keep, keep);
+    __syncthreads();
+    if (nmatch && tid == 0) nmatch[b] = sh_keep;
+}
+
+static int fill_stereo_levels(orbx_extractor *hl, orbx_extractor *hr, StereoLevels *lv) {
+    if (hl->nlevels != hr->nlevels || hl->pw != hr->pw || hl->ph != hr->ph || hl->pw == 0) {
+        orbx_set_error("stereo: left/right extractors must have extracted images of the same size and levels");
+        return ORBX_ERR_ARG;
+    }
+    memset(lv, 0, sizeof(*lv));
+    lv->nlevels = hl->nlevels;
+    for (int l = 0; l < hl->nlevels; l++) {
+        lv->w[l] = hl->geom[l].w; lv->h[l] = hl->geom[l].h;
+        lv->pstrideL[l] = hl->geom[l].pstride; lv->pstrideR[l] = hr->geom[l].pstride;
+        lv->poffL[l] = hl->geom[l].poff; lv->poffR[l] = hr->geom[l].poff;
+        lv->sf[l] = hl->sf[l]; lv->isf[l] = hl->isf[l];
+    }
+    lv->nRows = hl->geom[0].h;
+    return ORBX_OK;
+}
+
+// scratch for the SAD distances, grown on demand (per left extractor handle)
+struct StereoScratch { int32_t *d_sad; size_t n; int device; };
+static thread_local StereoScratch g_ss = {nullptr, 0, -1};
+
+extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *hr, int B,
+                                        const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
+                                        const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
+                                        int cap, float mbf, float mb, float *d_uright, float *d_depth,
+                                        int32_t *d_nmatch, void *stream) {
+    if (!hl || !hr || !d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_uright || !d_depth || B < 1 ||
+        cap < 1 || B > hl->pB || B > hr->pB) {
+        orbx_set_error("orbm_stereo_batch_device: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    StereoLevels lv;
+    int rc = fill_stereo_levels(hl, hr, &lv);
+    if (rc) return rc;
+    ORBX_HIP(hipSetDevice(hl->device));
+    const size_t need = (size_t)B * cap;
+    if (g_ss.n < need || g_ss.device != hl->device) {
+        if (g_ss.d_sad) hipFree(g_ss.d_sad);
+        g_ss.d_sad = nullptr; g_ss.n = 0;
+        ORBX_HIP(hipMalloc(&g_ss.d_sad, sizeof(int32_t) * need));
+        g_ss.n = need; g_ss.device = hl->device;
+    }
+    hipStream_t st = stream ? (hipStream_t)stream : hl->stream;
+    dim3 grid((cap + ST_WAVES - 1) / ST_WAVES, B);
+    hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), 0, st, lv, hl->d_pyr, hl->pyrImgBytes, hr->d_pyr,
+                       hr->pyrImgBytes, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
+                       g_ss.d_sad);
+    hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(SM_T), sizeof(int32_t) * cap, st, d_nl, cap, d_uright,
+                       d_depth, g_ss.d_sad, d_nmatch);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+// tiny RAII helper for the host-array entry points
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t n) { return hipMalloc(&p, n ? n : 1) == hipSuccess ? 0 : -1; }
+};
+#define DEV_ALLOC(buf, bytes) do { if ((buf).alloc(bytes)) { orbx_set_error("hipMalloc(%zu) failed", (size_t)(bytes)); return ORBX_ERR_HIP; } } while (0)
+#define H2D(buf, src, bytes) ORBX_HIP(hipMemcpy((buf).p, (src), (bytes), hipMemcpyHostToDevice))
+
+extern "C" int orbm_stereo(orbx_extractor_t *hl, orbx_extractor_t *hr, const orbx_keypoint_t *kl,
+                           const uint8_t *dl, int nl, const orbx_keypoint_t *kr, const uint8_t *dr, int nr,
+                           float mbf, float mb, float *uright, float *depth, int *nmatch) {
+    if (!hl || !hr || nl < 0 || nr < 0 || (nl > 0 && (!kl || !dl || !uright || !depth)) || (nr > 0 && (!kr || !dr))) {
+        orbx_set_error("orbm_stereo: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    if (nmatch) *nmatch = 0;
+    if (nl == 0) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(hl->device));
+    const int cap = std::max(std::max(nl, nr), 1);
+    DevBuf bkl, bdl, bkr, bdr, bn, bu, bd, bm;
+    DEV_ALLOC(bkl, sizeof(orbx_keypoint_t) * cap); DEV_ALLOC(bdl, (size_t)32 * cap);
+    DEV_ALLOC(bkr, sizeof(orbx_keypoint_t) * cap); DEV_ALLOC(bdr, (size_t)32 * cap);
+    DEV_ALLOC(bn, sizeof(int32_t) * 3); DEV_ALLOC(bu, sizeof(float) * cap); DEV_ALLOC(bd, sizeof(float) * cap);
+    H2D(bkl, kl, sizeof(orbx_keypoint_t) * nl); H2D(bdl, dl, (size_t)32 * nl);
+    if (nr) { H2D(bkr, kr, sizeof(orbx_keypoint_t) * nr); H2D(bdr, dr, (size_t)32 * nr); }
+    int32_t cnt[3] = {nl, nr, 0};
+    H2D(bn, cnt, sizeof(cnt));
+    int32_t *dn = (int32_t *)bn.p;
+    int rc = orbm_stereo_batch_device(hl, hr, 1, (orbx_keypoint_t *)bkl.p, (uint8_t *)bdl.p, dn,
+                                      (orbx_keypoint_t *)bkr.p, (uint8_t *)bdr.p, dn + 1, cap, mbf, mb,
+                                      (float *)bu.p, (float *)bd.p, dn + 2, hl->stream);
+    if (rc) return rc;
+    ORBX_HIP(hipStreamSynchronize(hl->stream));
+    ORBX_HIP(hipMemcpy(uright, bu.p, sizeof(float) * nl, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpy(depth, bd.p, sizeof(float) * nl, hipMemcpyDeviceToHost));
+    int32_t nm = 0;
+    ORBX_HIP(hipMemcpy(&nm, dn + 2, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (nmatch) *nmatch = nm;
+    return ORBX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// guided searches.  Frame::GetFeaturesInArea (src/Frame.cc:342-395) is restated as a
+// predicate: keypoint j is returned iff its grid cell (PosInGrid, :397-407) lies inside the
+// query's cell rectangle, its octave passes the level test and |dx|<r && |dy|<r; the
+// returned ORDER is column-major over cells, insertion (= index) order inside a cell, so the
+// scan position of j is the tuple (cellx, celly, j).  Sequential "first strictly smaller
+// wins" scans (:102-114, :441-457, :1414-1426) therefore select the minimum of the packed key
+//     dist << 28 | cellx << 22 | celly << 16 | j
+// and the runner-up is the second smallest key (stable top-2).
+#define SQ_T 256
+struct Top2 { u64 k1, k2; };
+__device__ __forceinline__ void top2_insert(Top2 &t, u64 k) {
+    if (k < t.k1) { t.k2 = t.k1; t.k1 = k; }
+    else if (k < t.k2) t.k2 = k;
+}
+__device__ __forceinline__ Top2 top2_merge(const Top2 &a, const Top2 &b) {
+    Top2 r;
+    r.k1 = a.k1 < b.k1 ? a.k1 : b.k1;
+    const u64 hi = a.k1 < b.k1 ? b.k1 : a.k1, lo2 = a.k2 < b.k2 ? a.k2 : b.k2;
+    r.k2 = hi < lo2 ? hi : lo2;
+    return r;
+}
+// block-wide top-2 (all threads get the result); sh: u64[2 * SQ_T/64]
+__device__ Top2 block_top2(Top2 t, u64 *sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Top2 u;
+        u.k1 = shfl_xor_u64(t.k1, o);
+        u.k2 = shfl_xor_u64(t.k2, o);
+        t = top2_merge(t, u);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) { sh[2 * wave] = t.k1; sh[2 * wave + 1] = t.k2; }
+    __syncthreads();
+    Top2 r;
+    r.k1 = sh[0]; r.k2 = sh[1];
+#pragma unroll
+    for (int w = 1; w < SQ_T / 64; w++) {
+        Top2 u;
+        u.k1 = sh[2 * w]; u.k2 = sh[2 * w + 1];
+        r = top2_merge(r, u);
+    }
+    return r;
+}
+
+struct AreaQuery { int x0, x1, y0, y1; bool empty; bool checkLevels; int minLevel, maxLevel; float x, y, r; };
+__device__ __forceinline__ AreaQuery make_query(const orbm_grid_geom_t &g, float x, float y, float r, int minLevel,
+                                                int maxLevel) {
+    AreaQuery q;
+    q.x = x; q.y = y; q.r = r; q.minLevel = minLevel; q.maxLevel = maxLevel;
+    q.empty = false;
+    q.x0 = max(0, (int)floorf((x - g.min_x - r) * g.inv_w));
+    if (q.x0 >= GRID_COLS) q.empty = true;
+    q.x1 = min(GRID_COLS - 1, (int)ceilf((x - g.min_x + r) * g.inv_w));
+    if (q.x1 < 0) q.empty = true;
+    q.y0 = max(0, (int)floorf((y - g.min_y - r) * g.inv_h));
+    if (q.y0 >= GRID_ROWS) q.empty = true;
+    q.y1 = min(GRID_ROWS - 1, (int)ceilf((y - g.min_y + r) * g.inv_h));
+    if (q.y1 < 0) q.empty = true;
+    q.checkLevels = (minLevel > 0) || (maxLevel >= 0);
+    return q;
+}
+// cell code of a keypoint: cellx<<8 | celly, 0xFFFF when PosInGrid fails
+__device__ __forceinline__ unsigned cell_code(const orbm_grid_geom_t &g, const orbx_keypoint_t &kp) {
+    const int px = (int)roundf((kp.x - g.min_x) * g.inv_w), py = (int)roundf((kp.y - g.min_y) * g.inv_h);
+    if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) return 0xFFFFu;
+    return (unsigned)(px << 8 | py);
+}
+__device__ __forceinline__ bool in_area(const AreaQuery &q, unsigned code, const orbx_keypoint_t &kp) {
+    if (code == 0xFFFFu) return false;
+    const int cx = (int)(code >> 8), cy = (int)(code & 0xFF);
+    if (cx < q.x0 || cx > q.x1 || cy < q.y0 || cy > q.y1) return false;
+    if (q.checkLevels) {
+        if (kp.octave < q.minLevel) return false;
+        if (q.maxLevel >= 0 && kp.octave > q.maxLevel) return false;
+    }
+    const float distx = kp.x - q.x, disty = kp.y - q.y;
+    return fabsf(distx) < q.r && fabsf(disty) < q.r;
+}
+__device__ __forceinline__ u64 scan_key(int dist, unsigned code, int j) {
+    return ((u64)dist << 28) | ((u64)(code >> 8) << 22) | ((u64)(code & 0xFF) << 16) | (u64)j;
+}
+
+// ORBmatcher::ComputeThreeMaxima (:1603-1644)
+__device__ void three_maxima(const int *histo, int L, int &ind1, int &ind2, int &ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// ---- SearchForInitialization: one workgroup, F1 keypoints in order (the steal / gate on
+// vMatchedDistance makes iteration i1 depend on all earlier ones)
+__global__ __launch_bounds__(SQ_T) void k_search_init(
+    const orbx_keypoint_t *__restrict__ k1, const uint8_t *__restrict__ d1, int n1,
+    const orbx_keypoint_t *__restrict__ k2, const uint8_t *__restrict__ d2, int n2, orbm_grid_geom_t g,
+    float *__restrict__ prev, int32_t *__restrict__ m12, int32_t *__restrict__ m21, int32_t *__restrict__ vmd,
+    uint16_t *__restrict__ code2, int32_t *__restrict__ bin1, int window, float nnratio, int check_ori,
+    int32_t *__restrict__ nmatches_out) {
+    __shared__ u64 sh[2 * SQ_T / 64];
+    __shared__ int hn[HISTO_LENGTH];
+    __shared__ int sh_nm;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < n2; j += SQ_T) { code2[j] = (uint16_t)cell_code(g, k2[j]); vmd[j] = INT_MAX; m21[j] = -1; }
+    for (int i = tid; i < n1; i += SQ_T) { m12[i] = -1; bin1[i] = -1; }
+    if (tid < HISTO_LENGTH) hn[tid] = 0;
+    if (tid == 0) sh_nm = 0;
+    __syncthreads();
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const orbx_keypoint_t kp1 = k1[i1];
+        const int level1 = kp1.octave;
+        if (level1 > 0) continue;
+        const AreaQuery q = make_query(g, prev[2 * i1], prev[2 * i1 + 1], (float)window, level1, level1);
+        if (q.empty) continue;
+        const Desc256 da = load_desc(d1 + (size_t)i1 * 32);
+        Top2 t;
+        t.k1 = t.k2 = ~0ull;
+        for (int j = tid; j < n2; j += SQ_T) {
+            const unsigned code = code2[j];
+            if (!in_area(q, code, k2[j])) continue;
+            const int dist = ham(da, load_desc(d2 + (size_t)j * 32));
+            if (vmd[j] <= dist) continue;
+            top2_insert(t, scan_key(dist, code, j));
+        }
+        t = block_top2(t, sh);
+        if (tid == 0 && t.k1 != ~0ull) {
+            const int bestDist = (int)(t.k1 >> 28), bestIdx2 = (int)(t.k1 & 0xFFFF);
+            const int bestDist2 = t.k2 == ~0ull ? INT_MAX : (int)(t.k2 >> 28);
+            if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * nnratio) {
+                if (m21[bestIdx2] >= 0) { m12[m21[bestIdx2]] = -1; sh_nm--; }
+                m12[i1] = bestIdx2; m21[bestIdx2] = i1; vmd[bestIdx2] = bestDist; sh_nm++;
+                if (check_ori) {
+                    float rot = kp1.angle - k2[bestIdx2].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    bin1[i1] = bin;
+                    hn[bin]++;
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    __shared__ int ind[3];
+    if (tid == 0 && check_ori) three_maxima(hn, HISTO_LENGTH, ind[0], ind[1], ind[2]);
+    __syncthreads();
+    if (check_ori) {
+        int dec = 0;
+        for (int i = tid; i < n1; i += SQ_T) {
+            const int bn = bin1[i];
+            if (bn >= 0 && bn != ind[0] && bn != ind[1] && bn != ind[2] && m12[i] >= 0) { m12[i] = -1; dec++; }
+        }
+        if (dec) atomicSub(&sh_nm, dec);
+    }
+    __syncthreads();
+    for (int i = tid; i < n1; i += SQ_T)
+        if (m12[i] >= 0) { prev[2 * i] = k2[m12[i]].x; prev[2 * i + 1] = k2[m12[i]].y; }
+    if (tid == 0) *nmatches_out = sh_nm;
+}
+
+extern "C" int orbm_search_for_initialization(const orbx_keypoint_t *k1, const uint8_t *d1, int n1,
+                                              const orbx_keypoint_t *k2, const uint8_t *d2, int n2,
+                                              const orbm_grid_geom_t *g2, float *prev_matched, int32_t *matches12,
+                                              int window, float nnratio, int check_orientation, int device,
+                                              int *nmatches) {
+    if (n1 < 0 || n2 < 0 || !g2 || !nmatches || (n1 > 0 && (!k1 || !d1 || !prev_matched || !matches12)) ||
+        (n2 > 0 && (!k2 || !d2)) || n2 > 65535) {
+        orbx_set_error("orbm_search_for_initialization: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    *nmatches = 0;
+    if (n1 == 0) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(device));
+    DevBuf bk1, bd1, bk2, bd2, bprev, bm12, bm21, bvmd, bcode, bbin, bnm;
+    DEV_ALLOC(bk1, sizeof(orbx_keypoint_t) * n1); DEV_ALLOC(bd1, (size_t)32 * n1);
+    DEV_ALLOC(bk2, sizeof(orbx_keypoint_t) * n2); DEV_ALLOC(bd2, (size_t)32 * n2);
+    DEV_ALLOC(bprev, sizeof(float) * 2 * n1); DEV_ALLOC(bm12, 4 * (size_t)n1); DEV_ALLOC(bm21, 4 * (size_t)n2);
+    DEV_ALLOC(bvmd, 4 * (size_t)n2); DEV_ALLOC(bcode, 2 * (size_t)n2); DEV_ALLOC(bbin, 4 * (size_t)n1);
+    DEV_ALLOC(bnm, 4);
+    H2D(bk1, k1, sizeof(orbx_keypoint_t) * n1); H2D(bd1, d1, (size_t)32 * n1);
+    if (n2) { H2D(bk2, k2, sizeof(orbx_keypoint_t) * n2); H2D(bd2, d2, (size_t)32 * n2); }
+    H2D(bprev, prev_matched, sizeof(float) * 2 * n1);
+    hipLaunchKernelGGL(k_search_init, dim3(1), dim3(SQ_T), 0, 0, (orbx_keypoint_t *)bk1.p, (uint8_t *)bd1.p, n1,
+                       (orbx_keypoint_t *)bk2.p, (uint8_t *)bd2.p, n2, *g2, (float *)bprev.p, (int32_t *)bm12.p,
+                       (int32_t *)bm21.p, (int32_t *)bvmd.p, (uint16_t *)bcode.p, (int32_t *)bbin.p, window,
+                       nnratio, check_orientation, (int32_t *)bnm.p);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpy(prev_matched, bprev.p, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpy(matches12, bm12.p, 4 * (size_t)n1, hipMemcpyDeviceToHost));
+    int32_t nm = 0;
+    ORBX_HIP(hipMemcpy(&nm, bnm.p, 4, hipMemcpyDeviceToHost));
+    *nmatches = nm;
+    return ORBX_OK;
+}
+
+// ---- SearchByProjection(Frame, MapPoints)
+__device__ __forceinline__ bool slot_blocked_mp(const int32_t *holder, const int32_t *ext_obs, int idx,
+                                                const orbm_mappoint_t *mps) {
+    const int hm = holder[idx];
+    if (hm == -1) return false;
+    if (hm == -2) return ext_obs && ext_obs[idx] > 0;
+    return mps[hm].observations > 0;
+}
+__global__ __launch_bounds__(SQ_T) void k_search_proj_mp(
+    const orbx_keypoint_t *__restrict__ kun, const uint8_t *__restrict__ desc, const float *__restrict__ uright,
+    int n, orbm_grid_geom_t g, const float *__restrict__ sf, const orbm_mappoint_t *__restrict__ mps,
+    const uint8_t *__restrict__ mp_desc, int m, int32_t *__restrict__ frame_mp, const int32_t *__restrict__ ext_obs,
+    uint16_t *__restrict__ code, float th, float nnratio, int32_t *__restrict__ nmatches_out) {
+    __shared__ u64 sh[2 * SQ_T / 64];
+    const int tid = threadIdx.x;
+    for (int j = tid; j < n; j += SQ_T) code[j] = (uint16_t)cell_code(g, kun[j]);
+    __syncthreads();
+    const bool bFactor = th != 1.0;
+    int nm = 0;
+    for (int iMP = 0; iMP < m; iMP++) {
+        const orbm_mappoint_t p = mps[iMP];
+        if (!p.in_view) continue;
+        const int lvl = p.level;
+        float r = p.view_cos > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (:131-137)
+        if (bFactor) r *= th;
+        const float rs = r * sf[lvl];
+        const AreaQuery q = make_query(g, p.proj_x, p.proj_y, rs, lvl - 1, lvl);
+        if (q.empty) continue;
+        const Desc256 da = load_desc(mp_desc + (size_t)iMP * 32);
+        Top2 t;
+        t.k1 = t.k2 = ~0ull;
+        for (int j = tid; j < n; j += SQ_T) {
+            const unsigned c = code[j];
+            if (!in_area(q, c, kun[j])) continue;
+            if (slot_blocked_mp(frame_mp, ext_obs, j, mps)) continue;
+            if (uright[j] > 0) {
+                const float er = fabsf(p.proj_xr - uright[j]);
+                if (er > rs) continue;
+            }
+            top2_insert(t, scan_key(ham(da, load_desc(desc + (size_t)j * 32)), c, j));
+        }
+        t = block_top2(t, sh);
+        if (t.k1 != ~0ull) {
+            const int bestDist = (int)(t.k1 >> 28), bestIdx = (int)(t.k1 & 0xFFFF);
+            const int bestLevel = kun[bestIdx].octave;
+            int bestDist2 = 256, bestLevel2 = -1;
+            if (t.k2 != ~0ull) { bestDist2 = (int)(t.k2 >> 28); bestLevel2 = kun[(int)(t.k2 & 0xFFFF)].octave; }
+            if (bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)) {
+                if (tid == 0) frame_mp[bestIdx] = iMP;
+                nm++;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) *nmatches_out = nm;
+}
+
+extern "C" int orbm_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright,
+                                            int n, const orbm_grid_geom_t *g, const float *scale_factors,
+                                            int nlevels, const orbm_mappoint_t *mps, const uint8_t *mp_desc, int m,
+                                            int32_t *frame_mp, const int32_t *ext_obs, float th, float nnratio,
+                                            int device, int *nmatches) {
+    if (n < 0 || m < 0 || !g || !scale_factors || nlevels < 1 || !nmatches ||
+        (n > 0 && (!kun || !desc || !uright || !frame_mp)) || (m > 0 && (!mps || !mp_desc)) || n > 65535) {
+        orbx_set_error("orbm_search_by_projection_mp: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    *nmatches = 0;
+    if (n == 0 || m == 0) return ORBX_OK;
+    for (int i = 0; i < m; i++)
+        if (mps[i].in_view && (mps[i].level < 0 || mps[i].level >= nlevels)) {
+            orbx_set_error("map point %d: level %d out of range", i, mps[i].level);
+            return ORBX_ERR_ARG;
+        }
+    ORBX_HIP(hipSetDevice(device));
+    DevBuf bk, bd, bu, bsf, bmp, bmd, bfm, beo, bcode, bnm;
+    DEV_ALLOC(bk, sizeof(orbx_keypoint_t) * n); DEV_ALLOC(bd, (size_t)32 * n); DEV_ALLOC(bu, 4 * (size_t)n);
+    DEV_ALLOC(bsf, 4 * (size_t)nlevels); DEV_ALLOC(bmp, sizeof(orbm_mappoint_t) * m); DEV_ALLOC(bmd, (size_t)32 * m);
+    DEV_ALLOC(bfm, 4 * (size_t)n); DEV_ALLOC(bcode, 2 * (size_t)n); DEV_ALLOC(bnm, 4);
+    H2D(bk, kun, sizeof(orbx_keypoint_t) * n); H2D(bd, desc, (size_t)32 * n); H2D(bu, uright, 4 * (size_t)n);
+    H2D(bsf, scale_factors, 4 * (size_t)nlevels); H2D(bmp, mps, sizeof(orbm_mappoint_t) * m);
+    H2D(bmd, mp_desc, (size_t)32 * m); H2D(bfm, frame_mp, 4 * (size_t)n);
+    if (ext_obs) { DEV_ALLOC(beo, 4 * (size_t)n); H2D(beo, ext_obs, 4 * (size_t)n); }
+    hipLaunchKernelGGL(k_search_proj_mp, dim3(1), dim3(SQ_T), 0, 0, (orbx_keypoint_t *)bk.p, (uint8_t *)bd.p,
+                       (float *)bu.p, n, *g, (float *)bsf.p, (orbm_mappoint_t *)bmp.p, (uint8_t *)bmd.p, m,
+                       (int32_t *)bfm.p, (int32_t *)beo.p, (uint16_t *)bcode.p, th, nnratio, (int32_t *)bnm.p);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpy(frame_mp, bfm.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    int32_t nm = 0;
+    ORBX_HIP(hipMemcpy(&nm, bnm.p, 4, hipMemcpyDeviceToHost));
+    *nmatches = nm;
+    return ORBX_OK;
+}
+
+// ---- SearchByProjection(cur Frame, last Frame)
+__global__ __launch_bounds__(SQ_T) void k_search_proj_frame(
+    const orbx_keypoint_t *__restrict__ kun, const uint8_t *__restrict__ desc, const float *__restrict__ uright,
+    int n, orbm_grid_geom_t g, const float *__restrict__ sf, orbm_camera_t cam, const float *__restrict__ Tc,
+    const float *__restrict__ Tl, const orbm_lastpoint_t *__restrict__ last, const uint8_t *__restrict__ last_desc,
+    int nlast, int32_t *__restrict__ cur_mp, const int32_t *__restrict__ ext_obs, uint16_t *__restrict__ code,
+    int32_t *__restrict__ hist_idx, int32_t *__restrict__ hist_bin, float th, int mono, int check_ori,
+    int32_t *__restrict__ nmatches_out) {
+    __shared__ u64 sh[2 * SQ_T / 64];
+    __shared__ int hn[HISTO_LENGTH];
+    const int tid = threadIdx.x;
+    for (int j = tid; j < n; j += SQ_T) code[j] = (uint16_t)cell_code(g, kun[j]);
+    if (tid < HISTO_LENGTH) hn[tid] = 0;
+    __syncthreads();
+    const float factor = 1.0f / HISTO_LENGTH;
+    // twc = -Rcw^T tcw; tlc = Rlw twc + tlw (:1343-1351): cv::gemm on CV_32F accumulates in double
+    float twc[3], tlc[3];
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Tc[k * 4 + i] * (double)Tc[k * 4 + 3];
+        twc[i] = (float)(s * -1.0);
+    }
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Tl[i * 4 + k] * (double)twc[k];
+        tlc[i] = (float)(s + (double)Tl[i * 4 + 3]);
+    }
+    const bool bForward = tlc[2] > cam.mb && !mono;
+    const bool bBackward = -tlc[2] > cam.mb && !mono;
+    int nm = 0, nh = 0;
+    for (int i = 0; i < nlast; i++) {
+        const orbm_lastpoint_t p = last[i];
+        if (!p.has_mp) continue;
+        float x3[3];
+        for (int r = 0; r < 3; r++) {
+            double s = 0;
+            s += (double)Tc[r * 4 + 0] * (double)p.wx;
+            s += (double)Tc[r * 4 + 1] * (double)p.wy;
+            s += (double)Tc[r * 4 + 2] * (double)p.wz;
+            x3[r] = (float)(s + (double)Tc[r * 4 + 3]);
+        }
+        const float xc = x3[0], yc = x3[1];
+        const float invzc = (float)(1.0 / (double)x3[2]);
+        if (invzc < 0) continue;
+        const float u = cam.fx * xc * invzc + cam.cx;
+        const float v = cam.fy * yc * invzc + cam.cy;
+        if (u < g.min_x || u > g.max_x) continue;
+        if (v < g.min_y || v > g.max_y) continue;
+        const int nLastOctave = p.octave;
+        const float radius = th * sf[nLastOctave];
+        AreaQuery q;
+        if (bForward) q = make_query(g, u, v, radius, nLastOctave, -1);
+        else if (bBackward) q = make_query(g, u, v, radius, 0, nLastOctave);
+        else q = make_query(g, u, v, radius, nLastOctave - 1, nLastOctave + 1);
+        if (q.empty) continue;
+        const Desc256 da = load_desc(last_desc + (size_t)i * 32);
+        Top2 t;
+        t.k1 = t.k2 = ~0ull;
+        for (int j = tid; j < n; j += SQ_T) {
+            const unsigned c = code[j];
+            if (!in_area(q, c, kun[j])) continue;
+            {
+                const int hm = cur_mp[j];
+                if (hm == -2) { if (ext_obs && ext_obs[j] > 0) continue; }
+                else if (hm >= 0 && last[hm].observations > 0) continue;
+            }
+            if (uright[j] > 0) {
+                const float ur = u - cam.mbf * invzc;
+                const float er = fabsf(ur - uright[j]);
+                if (er > radius) continue;
+            }
+            top2_insert(t, scan_key(ham(da, load_desc(desc + (size_t)j * 32)), c, j));
+        }
+        t = block_top2(t, sh);
+        if (t.k1 != ~0ull) {
+            const int bestDist = (int)(t.k1 >> 28), bestIdx2 = (int)(t.k1 & 0xFFFF);
+            if (bestDist <= TH_HIGH) {
+                nm++;
+                if (tid == 0) {
+                    cur_mp[bestIdx2] = i;
+                    if (check_ori) {
+                        float rot = p.angle - kun[bestIdx2].angle;
+                        if (rot < 0.0f) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        hist_idx[nh] = bestIdx2;
+                        hist_bin[nh] = bin;
+                        hn[bin]++;
+                    }
+                }
+                nh++;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (check_ori) {
+        __shared__ int ind[3];
+        __shared__ int sh_dec;
+        if (tid == 0) { three_maxima(hn, HISTO_LENGTH, ind[0], ind[1], ind[2]); sh_dec = 0; }
+        __syncthreads();
+        int dec = 0;
+        for (int k = tid; k < nh; k += SQ_T) {
+            const int bn = hist_bin[k];
+            if (bn != ind[0] && bn != ind[1] && bn != ind[2]) { cur_mp[hist_idx[k]] = -1; dec++; }  // :1463-1464
+        }
+        if (dec) atomicAdd(&sh_dec, dec);
+        __syncthreads();
+        nm -= sh_dec;
+    }
+    if (tid == 0) *nmatches_out = nm;
+}
+
+extern "C" int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright,
+                                               int n, const orbm_grid_geom_t *g, const float *scale_factors,
+                                               int nlevels, const orbm_camera_t *cam, const float *Tcw_cur16,
+                                               const float *Tcw_last16, const orbm_lastpoint_t *last,
+                                               const uint8_t *last_desc, int nlast, int32_t *cur_mp,
+                                               const int32_t *ext_obs, float th, int mono, int check_orientation,
+                                               int device, int *nmatches) {
+    if (n < 0 || nlast < 0 || !g || !scale_factors || nlevels < 1 || !cam || !Tcw_cur16 || !Tcw_last16 || !nmatches ||
+        (n > 0 && (!kun || !desc || !uright || !cur_mp)) || (nlast > 0 && (!last || !last_desc)) || n > 65535) {
+        orbx_set_error("orbm_search_by_projection_frame: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    *nmatches = 0;
+    if (n == 0 || nlast == 0) return ORBX_OK;
+    for (int i = 0; i < nlast; i++)
+        if (last[i].has_mp && (last[i].octave < 0 || last[i].octave >= nlevels)) {
+            orbx_set_error("last point %d: octave %d out of range", i, last[i].octave);
+            return ORBX_ERR_ARG;
+        }
+    ORBX_HIP(hipSetDevice(device));
+    DevBuf bk, bd, bu, bsf, bT, bl, bld, bcm, beo, bcode, bhi, bhb, bnm;
+    DEV_ALLOC(bk, sizeof(orbx_keypoint_t) * n); DEV_ALLOC(bd, (size_t)32 * n); DEV_ALLOC(bu, 4 * (size_t)n);
+    DEV_ALLOC(bsf, 4 * (size_t)nlevels); DEV_ALLOC(bT, 4 * 32); DEV_ALLOC(bl, sizeof(orbm_lastpoint_t) * nlast);
+    DEV_ALLOC(bld, (size_t)32 * nlast); DEV_ALLOC(bcm, 4 * (size_t)n); DEV_ALLOC(bcode, 2 * (size_t)n);
+    DEV_ALLOC(bhi, 4 * (size_t)nlast); DEV_ALLOC(bhb, 4 * (size_t)nlast); DEV_ALLOC(bnm, 4);
+    H2D(bk, kun, sizeof(orbx_keypoint_t) * n); H2D(bd, desc, (size_t)32 * n); H2D(bu, uright, 4 * (size_t)n);
+    H2D(bsf, scale_factors, 4 * (size_t)nlevels);
+    float T2[32];
+    memcpy(T2, Tcw_cur16, 64); memcpy(T2 + 16, Tcw_last16, 64);
+    H2D(bT, T2, sizeof(T2));
+    H2D(bl, last, sizeof(orbm_lastpoint_t) * nlast); H2D(bld, last_desc, (size_t)32 * nlast);
+    H2D(bcm, cur_mp, 4 * (size_t)n);
+    if (ext_obs) { DEV_ALLOC(beo, 4 * (size_t)n); H2D(beo, ext_obs, 4 * (size_t)n); }
+    hipLaunchKernelGGL(k_search_proj_frame, dim3(1), dim3(SQ_T), 0, 0, (orbx_keypoint_t *)bk.p, (uint8_t *)bd.p,
+                       (float *)bu.p, n, *g, (float *)bsf.p, *cam, (float *)bT.p, (float *)bT.p + 16,
+                       (orbm_lastpoint_t *)bl.p, (uint8_t *)bld.p, nlast, (int32_t *)bcm.p, (int32_t *)beo.p,
+                       (uint16_t *)bcode.p, (int32_t *)bhi.p, (int32_t *)bhb.p, th, mono, check_orientation,
+                       (int32_t *)bnm.p);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpy(cur_mp, bcm.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    int32_t nm = 0;
+    ORBX_HIP(hipMemcpy(&nm, bnm.p, 4, hipMemcpyDeviceToHost));
+    *nmatches = nm;
+    return ORBX_OK;
+}
