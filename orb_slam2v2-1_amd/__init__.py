@@ -74,6 +74,29 @@ def build(force=False):
     return _b.build(force=force)
 
 
+def _preload_shared_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so and
+    request it by the un-versioned name, so if our library pulled in /opt/rocm's copy first, a
+    later `import torch` would start a SECOND runtime (whose device init then fails and whose
+    pointers/streams are foreign to ours).  When torch is installed, load its copy first; our
+    library's NEEDED libamdhip64.so.7 then binds to it by soname, whatever the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib():
     """Load the HIP library; fails loudly when it has not been built."""
     global _lib
@@ -82,6 +105,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise OrbxError(ORBX_ERR_NO_DEVICE, "HIP library %s is missing: run `python __graft_entry__.py` "
                                             "(build()) first; there is no CPU fallback" % LIB_PATH)
+    _preload_shared_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     L.orbx_create.restype = i32

@@ -1058,6 +1058,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
                            int cap, hipStream_t st) {
     const int nl = h->nlevels;
     const bool prof = h->profiling != 0;
+    (void)hipGetLastError();  // drop stale errors of other HIP users in this process
     if (prof) ORBX_HIP(hipEventRecord(h->ev[0], st));
     {   // K1
         const LevelGeom &g0 = h->geom[0];

@@ -90,6 +90,7 @@ extern "C" int orbm_hamming_matrix_device(const uint8_t *d_a, int na, const uint
                                           uint16_t *d_out, void *stream) {
     if (!d_a || !d_b || !d_out || na < 1 || nb < 1) { orbx_set_error("orbm_hamming_matrix_device: bad arguments"); return ORBX_ERR_ARG; }
     dim3 grid((nb + 255) / 256, (na + HM_ROWS - 1) / HM_ROWS);
+    (void)hipGetLastError();  // drop stale errors of other HIP users in this process
     hipLaunchKernelGGL(k_hamming_matrix, grid, dim3(256), 0, (hipStream_t)stream, d_a, na, d_b, nb, d_out);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
@@ -315,6 +316,7 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
     }
     hipStream_t st = stream ? (hipStream_t)stream : hl->stream;
     dim3 grid((cap + ST_WAVES - 1) / ST_WAVES, B);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), 0, st, lv, hl->d_pyr, hl->pyrImgBytes, hr->d_pyr,
                        hr->pyrImgBytes, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
                        g_ss.d_sad);
@@ -557,6 +559,7 @@ extern "C" int orbm_search_for_initialization(const orbx_keypoint_t *k1, const u
     H2D(bk1, k1, sizeof(orbx_keypoint_t) * n1); H2D(bd1, d1, (size_t)32 * n1);
     if (n2) { H2D(bk2, k2, sizeof(orbx_keypoint_t) * n2); H2D(bd2, d2, (size_t)32 * n2); }
     H2D(bprev, prev_matched, sizeof(float) * 2 * n1);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_search_init, dim3(1), dim3(SQ_T), 0, 0, (orbx_keypoint_t *)bk1.p, (uint8_t *)bd1.p, n1,
                        (orbx_keypoint_t *)bk2.p, (uint8_t *)bd2.p, n2, *g2, (float *)bprev.p, (int32_t *)bm12.p,
                        (int32_t *)bm21.p, (int32_t *)bvmd.p, (uint16_t *)bcode.p, (int32_t *)bbin.p, window,
@@ -655,6 +658,7 @@ extern "C" int orbm_search_by_projection_mp(const orbx_keypoint_t *kun, const ui
     H2D(bsf, scale_factors, 4 * (size_t)nlevels); H2D(bmp, mps, sizeof(orbm_mappoint_t) * m);
     H2D(bmd, mp_desc, (size_t)32 * m); H2D(bfm, frame_mp, 4 * (size_t)n);
     if (ext_obs) { DEV_ALLOC(beo, 4 * (size_t)n); H2D(beo, ext_obs, 4 * (size_t)n); }
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_search_proj_mp, dim3(1), dim3(SQ_T), 0, 0, (orbx_keypoint_t *)bk.p, (uint8_t *)bd.p,
                        (float *)bu.p, n, *g, (float *)bsf.p, (orbm_mappoint_t *)bmp.p, (uint8_t *)bmd.p, m,
                        (int32_t *)bfm.p, (int32_t *)beo.p, (uint16_t *)bcode.p, th, nnratio, (int32_t *)bnm.p);
@@ -813,6 +817,7 @@ extern "C" int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const
     H2D(bl, last, sizeof(orbm_lastpoint_t) * nlast); H2D(bld, last_desc, (size_t)32 * nlast);
     H2D(bcm, cur_mp, 4 * (size_t)n);
     if (ext_obs) { DEV_ALLOC(beo, 4 * (size_t)n); H2D(beo, ext_obs, 4 * (size_t)n); }
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_search_proj_frame, dim3(1), dim3(SQ_T), 0, 0, (orbx_keypoint_t *)bk.p, (uint8_t *)bd.p,
                        (float *)bu.p, n, *g, (float *)bsf.p, *cam, (float *)bT.p, (float *)bT.p + 16,
                        (orbm_lastpoint_t *)bl.p, (uint8_t *)bld.p, nlast, (int32_t *)bcm.p, (int32_t *)beo.p,

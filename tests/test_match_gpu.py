@@ -1,0 +1,171 @@
+"""GPU parity of the HIP matchers against the CPU oracle through the C ABI (bit-exact indices,
+counts and Hamming distances; float outputs compared exactly — same float operations)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _features(oracle, img, nf=1000):
+    orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    k, d = orc.extract(img)
+    return orc, k, d
+
+
+def test_hamming_host(pkg, oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a = rng.integers(0, 256, 32, dtype=np.uint8)
+        b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert pkg.ORBmatcher.DescriptorDistance(a, b) == oracle.hamming(a, b) == int(np.unpackbits(a ^ b).sum())
+    z = np.zeros(32, np.uint8)
+    assert pkg.ORBmatcher.DescriptorDistance(z, ~z) == 256
+    assert pkg.ORBmatcher.DescriptorDistance(z, z) == 0
+
+
+def test_hamming_matrix(pkg):
+    import torch
+    rng = np.random.default_rng(1)
+    for na, nb in [(1, 1), (63, 257), (1000, 1003), (130, 64)]:
+        a = rng.integers(0, 256, (na, 32), dtype=np.uint8)
+        b = rng.integers(0, 256, (nb, 32), dtype=np.uint8)
+        ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        out = torch.zeros((na, nb), dtype=torch.int16, device="cuda")
+        rc = pkg.lib().orbm_hamming_matrix_device(ta.data_ptr(), na, tb.data_ptr(), nb, out.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, pkg.lib().orbx_last_error()
+        torch.cuda.synchronize()
+        ref = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+        np.testing.assert_array_equal(out.cpu().numpy().astype(np.int32), ref)
+
+
+@pytest.mark.parametrize("w,h,nf,k", [(1241, 376, 2000, 0), (752, 480, 1000, 1), (640, 480, 1000, 2)])
+def test_stereo_parity(pkg, oracle, synth, w, h, nf, k):
+    left, right = synth.stereo_pair_blocky(w, h, k)
+    exl, exr = pkg.ORBextractor(nf, 1.2, 8, 20, 7), pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    kl, dl = exl(left)
+    kr, dr = exr(right)
+    orl, okl, odl = _features(oracle, left, nf)
+    orr, okr, odr = _features(oracle, right, nf)
+    np.testing.assert_array_equal(dl, odl)
+    np.testing.assert_array_equal(dr, odr)
+    fx = 718.856 if w == 1241 else 435.2
+    mbf = 386.1448 if w == 1241 else 47.9
+    mb = np.float32(mbf) / np.float32(fx)
+    ur, dp, n = pkg.compute_stereo_matches(exl, exr, kl, dl, kr, dr, mbf, mb)
+    pl = [orl.pyramid_level(l) for l in range(8)]
+    pr = [orr.pyramid_level(l) for l in range(8)]
+    on, our, odp = oracle.stereo_match(okl, odl, okr, odr, pl, pr, orl.scale_factors, orl.inv_scale_factors, mbf, mb)
+    assert on > 20, "synthetic pair should yield stereo matches (got %d)" % on
+    assert n == on
+    np.testing.assert_array_equal(ur, our)
+    np.testing.assert_array_equal(dp, odp)
+
+
+def test_stereo_edge_cases(pkg, oracle, synth):
+    # no right keypoints / no matches surviving: everything stays -1, count 0 (reference: UB on
+    # the empty vector, src/Frame.cc:642 — defined here as "no matches")
+    w, h = 640, 480
+    left, _ = synth.stereo_pair_blocky(w, h, 5)
+    exl, exr = pkg.ORBextractor(500, 1.2, 8, 20, 7), pkg.ORBextractor(500, 1.2, 8, 20, 7)
+    kl, dl = exl(left)
+    flat = np.full((h, w), 100, np.uint8)
+    kr, dr = exr(flat)
+    assert len(kr) == 0
+    ur, dp, n = pkg.compute_stereo_matches(exl, exr, kl, dl, kr, dr, 40.0, 0.1)
+    assert n == 0 and (ur == -1).all() and (dp == -1).all()
+
+
+def test_search_for_initialization(pkg, oracle, synth):
+    w, h = 640, 480
+    img1 = synth.frame(w, h, 7)
+    img2 = np.roll(img1, (3, 5), axis=(0, 1))  # small camera motion
+    rng = np.random.default_rng(5)
+    img2 = np.clip(img2.astype(np.int16) + rng.integers(-3, 4, img2.shape), 0, 255).astype(np.uint8)
+    _, k1, d1 = _features(oracle, img1, 2000)
+    _, k2, d2 = _features(oracle, img2, 2000)
+    geom_o, geom_g = oracle.grid_geom(w, h), pkg.grid_geom(w, h)
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    for ratio, ori, win in [(0.9, True, 100), (0.9, False, 100), (0.6, True, 30)]:
+        on, om12, oprev = oracle.search_for_initialization(k1, d1, k2, d2, geom_o, prev, win, ratio, ori)
+        m = pkg.ORBmatcher(ratio, ori)
+        gn, gm12, gprev = m.SearchForInitialization(k1, d1, k2, d2, geom_g, prev, win)
+        assert on > 30
+        assert gn == on
+        np.testing.assert_array_equal(gm12, om12)
+        np.testing.assert_array_equal(gprev, oprev)
+
+
+def _mappoints_from(oracle, k, d, rng, m):
+    idx = rng.choice(len(k), size=m, replace=len(k) < m)
+    mps = np.zeros(m, oracle.MP_DTYPE)
+    mps["in_view"] = rng.random(m) > 0.1
+    mps["proj_x"] = k["x"][idx] + rng.normal(0, 1.5, m)
+    mps["proj_y"] = k["y"][idx] + rng.normal(0, 1.5, m)
+    mps["proj_xr"] = mps["proj_x"] - rng.uniform(1, 30, m)
+    mps["level"] = np.clip(k["octave"][idx] + rng.integers(-1, 2, m), 0, 7)
+    mps["view_cos"] = rng.uniform(0.99, 1.0, m)
+    mps["observations"] = rng.integers(0, 4, m)
+    md = d[idx].copy()
+    flip = rng.integers(0, 256, md.shape, dtype=np.uint8) & rng.integers(0, 256, md.shape, dtype=np.uint8) & \
+        rng.integers(0, 256, md.shape, dtype=np.uint8) & rng.integers(0, 256, md.shape, dtype=np.uint8)
+    return mps, md ^ flip
+
+
+def test_search_by_projection_mappoints(pkg, oracle, synth):
+    w, h = 1241, 376
+    _, k, d = _features(oracle, synth.frame(w, h, 11), 1000)
+    rng = np.random.default_rng(9)
+    sf = oracle.Extractor(1000, 1.2, 8, 20, 7).scale_factors
+    for th, ratio in [(1.0, 0.8), (3.0, 0.8), (5.0, 0.6)]:
+        mps, md = _mappoints_from(oracle, k, d, rng, 1500)
+        uright = np.where(rng.random(len(k)) < 0.5, k["x"] - rng.uniform(1, 30, len(k)), -1).astype(np.float32)
+        frame_mp = np.full(len(k), -1, np.int32)
+        ext = np.zeros(len(k), np.int32)
+        pre = rng.choice(len(k), 50, replace=False)
+        frame_mp[pre] = -2
+        ext[pre] = rng.integers(0, 2, 50)
+        on, ofm = oracle.search_by_projection_mp(k, d, uright, oracle.grid_geom(w, h), sf, mps, md, frame_mp, ext, th, ratio)
+        gn, gfm = pkg.ORBmatcher(ratio, True).SearchByProjection(k, d, uright, pkg.grid_geom(w, h), sf, mps, md,
+                                                                 frame_mp, ext, th)
+        assert on > 100
+        assert gn == on
+        np.testing.assert_array_equal(gfm, ofm)
+
+
+def test_search_by_projection_frame(pkg, oracle, synth):
+    w, h = 1241, 376
+    _, k, d = _features(oracle, synth.frame(w, h, 12), 1000)
+    rng = np.random.default_rng(10)
+    sf = oracle.Extractor(1000, 1.2, 8, 20, 7).scale_factors
+    fx, fy, cx, cy, mbf = 718.856, 718.856, 607.19, 185.2, 386.1448
+    cam_o, cam_g = oracle.Cam(fx, fy, cx, cy, mbf, np.float32(mbf) / np.float32(fx)), None
+    cam_g = pkg.Camera(fx, fy, cx, cy, mbf, np.float32(mbf) / np.float32(fx))
+    n = len(k)
+    for mono, dz in [(False, 0.0), (False, 1.5), (False, -1.5), (True, 0.3)]:
+        # last frame = same keypoints seen from a camera shifted by (0.05, 0, dz)
+        z = rng.uniform(4, 40, n).astype(np.float32)
+        last = np.zeros(n, oracle.LASTPT_DTYPE)
+        last["has_mp"] = rng.random(n) > 0.2
+        last["wx"] = (k["x"] - cx) / fx * z
+        last["wy"] = (k["y"] - cy) / fy * z
+        last["wz"] = z
+        last["observations"] = rng.integers(0, 3, n)
+        last["octave"] = k["octave"]
+        last["angle"] = (k["angle"] + rng.normal(0, 4, n)) % 360
+        ld = d.copy()
+        ld ^= (rng.integers(0, 256, ld.shape, dtype=np.uint8) & rng.integers(0, 256, ld.shape, dtype=np.uint8) &
+               rng.integers(0, 256, ld.shape, dtype=np.uint8))
+        Tc = np.eye(4, dtype=np.float32)
+        Tc[0, 3] = 0.02
+        Tl = np.eye(4, dtype=np.float32)
+        Tl[2, 3] = dz
+        uright = np.where(rng.random(n) < 0.5, k["x"] - mbf / z, -1).astype(np.float32)
+        cur = np.full(n, -1, np.int32)
+        on, ocm = oracle.search_by_projection_frame(k, d, uright, oracle.grid_geom(w, h), sf, cam_o, Tc, Tl, last, ld,
+                                                    cur, None, 7.0, mono, True)
+        gn, gcm = pkg.ORBmatcher(0.9, True).SearchByProjectionFrame(k, d, uright, pkg.grid_geom(w, h), sf, cam_g, Tc,
+                                                                    Tl, last, ld, cur, None, 7.0, mono)
+        assert on > 100, on
+        assert gn == on
+        np.testing.assert_array_equal(gcm, ocm)

@@ -1,0 +1,35 @@
+"""Ad-hoc GPU sanity + timing probe (not a test): python tools/quick_gpu.py [B]"""
+import sys, time, importlib, ctypes as C
+sys.path.insert(0, ".")
+import numpy as np
+pkg = importlib.import_module("orb_slam2v2-1_amd")
+synth = importlib.import_module("orb_slam2v2-1_amd.synth")
+import torch
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+w, h, nf = 1241, 376, 1000
+imgs = synth.batch(w, h, 8, 0)
+imgs = np.concatenate([imgs] * ((B + 7) // 8))[:B]
+ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+k, d = ex(imgs[0])
+print("single:", len(k), k[:3], d[0][:8])
+dev = torch.device("cuda:0")
+timg = torch.from_numpy(imgs).to(dev)
+cap = ex.max_keypoints()
+print("cap", cap)
+kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+ex.set_profiling(True)
+for it in range(3):
+    ex.extract_batch_device(timg.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)
+torch.cuda.synchronize()
+t0 = time.time()
+K = 10
+for it in range(K):
+    ex.extract_batch_device(timg.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)
+torch.cuda.synchronize()
+dt = (time.time() - t0) / K
+print("B=%d  %.3f ms/batch  %.1f us/img  %.0f img/s" % (B, dt * 1e3, dt * 1e6 / B, B / dt))
+print("stage ms [pyr, fast, octree, describe, total]:", ex.stage_ms())
+print("counts", cnt[:8].tolist())
