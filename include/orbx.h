@@ -13,7 +13,8 @@
  * point that needs the GPU fails with ORBX_ERR_NO_DEVICE when none is usable.
  *
  * Pointers named d_* are DEVICE pointers (e.g. torch tensor .data_ptr()); `stream`
- * is a hipStream_t passed as void* (NULL = the handle's own stream).
+ * is a hipStream_t passed as void* (NULL = the HIP default stream, as in every HIP API; this
+ * is also what torch.cuda.current_stream().cuda_stream is for torch's default stream).
  */
 #ifndef ORBX_H
 #define ORBX_H
@@ -103,12 +104,15 @@ int orbx_pyramid_device(orbx_extractor_t *h, int b, int level, const uint8_t **d
 int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, int stage, int32_t *out_xys, int cap,
                             int *n_out);
 
-/* Per-stage GPU time of the last batch call in ms (HIP events on the launch stream), when
- * enabled: [0] pyramid [1] FAST cells [2] quad-tree [3] orientation+blur+descriptor
- * [4] whole call.  Recording the events costs a few microseconds per batch. */
+/* Per-stage GPU time in ms, measured with HIP events recorded on the launch stream around
+ * each stage of every batch call while profiling is enabled (a ring of event sets, so no
+ * call ever waits for the GPU): [0] pyramid (k_pyr_*) [1] FAST cells (k_fast_cells)
+ * [2] quad-tree (k_octree) [3] orientation+blur+descriptor (k_describe) [4] whole call.
+ * orbx_get_stage_ms returns the AVERAGE per call since orbx_set_profiling(h,1) and the number
+ * of calls averaged (ncalls may be NULL). */
 #define ORBX_NUM_STAGES 5
 int orbx_set_profiling(orbx_extractor_t *h, int enabled);
-int orbx_get_stage_ms(orbx_extractor_t *h, float *ms5);
+int orbx_get_stage_ms(orbx_extractor_t *h, float *ms5, int *ncalls);
 
 /* ---- matchers: replace the hot ORBmatcher / Frame routines --------------------------- */
 
@@ -124,8 +128,12 @@ int orbm_hamming_matrix_device(const uint8_t *d_a, int na, const uint8_t *d_b, i
  * keypoints + descriptors + counts are the DEVICE outputs of two extractors (hl, hr) whose
  * pyramids of the same batch are still resident.  d_uright / d_depth: [B][cap] float
  * (mvuRight / mvDepth, -1 = no match).  mbf = baseline*fx, mb = mbf/fx (Frame.cc:114).
- * d_nmatch [B] (may be NULL) = number of surviving matches. Asynchronous on stream. */
+ * d_nmatch [B] (may be NULL) = number of surviving matches. Asynchronous on stream.
+ * Frame b reads the pyramid of image slot left_slot0+b of hl and right_slot0+b of hr; hl and
+ * hr may be the SAME handle when one extractor processed left and right images in one batch
+ * (e.g. slots [0,B) left, [B,2B) right). */
 int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *hr, int B,
+                             int left_slot0, int right_slot0,
                              const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
                              const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
                              int cap, float mbf, float mb, float *d_uright, float *d_depth,

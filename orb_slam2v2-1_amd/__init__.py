@@ -123,10 +123,10 @@ def lib():
     L.orbx_pyramid_device.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.orbx_debug_level_points.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
     L.orbx_set_profiling.argtypes = [vp, i32]
-    L.orbx_get_stage_ms.argtypes = [vp, vp]
+    L.orbx_get_stage_ms.argtypes = [vp, vp, C.POINTER(i32)]
     L.orbm_hamming.argtypes = [vp, vp]
     L.orbm_hamming_matrix_device.argtypes = [vp, i32, vp, i32, vp, vp]
-    L.orbm_stereo_batch_device.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp]
+    L.orbm_stereo_batch_device.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp]
     L.orbm_stereo.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
     L.orbm_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, C.POINTER(GridGeom), vp, vp, i32, f32,
                                                  i32, i32, C.POINTER(i32)]
@@ -274,9 +274,19 @@ class ORBextractor:
         _check(self._L.orbx_set_profiling(self._h, int(on)))
 
     def stage_ms(self):
+        """(average ms per call [pyramid, FAST, quad-tree, describe, total], calls averaged)"""
         ms = np.zeros(NUM_STAGES, np.float32)
-        _check(self._L.orbx_get_stage_ms(self._h, _p(ms)))
-        return ms
+        n = C.c_int(0)
+        _check(self._L.orbx_get_stage_ms(self._h, _p(ms), C.byref(n)))
+        return ms, n.value
+
+
+def stereo_batch_device(ex_left, ex_right, B, left_slot0, right_slot0, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap,
+                        mbf, mb, d_uright, d_depth, d_nmatch, stream=0):
+    """Device-resident Frame::ComputeStereoMatches for B frames (raw device pointers)."""
+    _check(lib().orbm_stereo_batch_device(ex_left._h, ex_right._h, B, left_slot0, right_slot0, d_kl, d_dl, d_nl,
+                                          d_kr, d_dr, d_nr, cap, float(mbf), float(mb), d_uright, d_depth,
+                                          d_nmatch, stream))
 
 
 def compute_stereo_matches(ex_left, ex_right, kl, dl, kr, dr, mbf, mb):

@@ -842,7 +842,8 @@ extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int i
     }
     h->max_kp = 0;
     ORBX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (int i = 0; i <= ORBX_NUM_STAGES; i++) ORBX_HIP(hipEventCreate(&h->ev[i]));
+    for (int r = 0; r < ORBX_EV_RING; r++)
+        for (int i = 0; i < ORBX_NUM_STAGES; i++) ORBX_HIP(hipEventCreate(&h->ev[r][i]));
     *out = h;
     return ORBX_OK;
 }
@@ -862,7 +863,8 @@ extern "C" int orbx_destroy(orbx_extractor_t *h) {
     if (h->last_stream) hipStreamSynchronize(h->last_stream);
     free_plan(h);
     hipFree(h->d_in); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts);
-    for (int i = 0; i <= ORBX_NUM_STAGES; i++) hipEventDestroy(h->ev[i]);
+    for (int r = 0; r < ORBX_EV_RING; r++)
+        for (int i = 0; i < ORBX_NUM_STAGES; i++) hipEventDestroy(h->ev[r][i]);
     hipStreamDestroy(h->stream);
     delete h;
     return ORBX_OK;
@@ -1053,13 +1055,36 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     return ORBX_OK;
 }
 
+// add the finished event set `slot` to the per-stage accumulators
+static int harvest_events(orbx_extractor *h, int slot) {
+    hipEvent_t *ev = h->ev[slot];
+    ORBX_HIP(hipEventSynchronize(ev[4]));
+    for (int i = 0; i < 4; i++) {
+        float ms = 0;
+        ORBX_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        h->acc_ms[i] += ms;
+    }
+    float tot = 0;
+    ORBX_HIP(hipEventElapsedTime(&tot, ev[0], ev[4]));
+    h->acc_ms[4] += tot;
+    h->acc_n++;
+    h->ev_pending[slot] = 0;
+    return ORBX_OK;
+}
+
 static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int w, int hgt, int stride,
                            size_t img_stride, orbx_keypoint_t *d_kps, uint8_t *d_desc, int32_t *d_counts,
                            int cap, hipStream_t st) {
     const int nl = h->nlevels;
     const bool prof = h->profiling != 0;
     (void)hipGetLastError();  // drop stale errors of other HIP users in this process
-    if (prof) ORBX_HIP(hipEventRecord(h->ev[0], st));
+    hipEvent_t *ev = nullptr;
+    if (prof) {
+        const int slot = h->ev_head % ORBX_EV_RING;
+        if (h->ev_pending[slot]) { int rc = harvest_events(h, slot); if (rc) return rc; }
+        ev = h->ev[slot];
+        ORBX_HIP(hipEventRecord(ev[0], st));
+    }
     {   // K1
         const LevelGeom &g0 = h->geom[0];
         dim3 grid((g0.pstride / 4 + 255) / 256, g0.prows, B);
@@ -1071,7 +1096,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
             hipLaunchKernelGGL(k_pyr_resize, gr, dim3(256), 0, st, h->d_pyr, h->pyrImgBytes, h->d_geom, l, h->d_tab);
         }
     }
-    if (prof) ORBX_HIP(hipEventRecord(h->ev[1], st));
+    if (prof) ORBX_HIP(hipEventRecord(ev[1], st));
     {   // K2
         dim3 grid((h->totalCells + FAST_WAVES - 1) / FAST_WAVES, B);
         hipLaunchKernelGGL(k_fast_cells, grid, dim3(64 * FAST_WAVES), (size_t)h->fastLdsPerWave * FAST_WAVES, st,
@@ -1079,7 +1104,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
                            h->slotsPerImg, h->ini_th, h->min_th, h->fastTileStride, h->fastScoreStride,
                            h->fastTileRows, h->fastLdsPerWave);
     }
-    if (prof) ORBX_HIP(hipEventRecord(h->ev[2], st));
+    if (prof) ORBX_HIP(hipEventRecord(ev[2], st));
     {   // K3
         int pow2 = 1;
         while (pow2 < h->maxNodeCap) pow2 <<= 1;
@@ -1093,14 +1118,14 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
                            h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2,
                            scratch);
     }
-    if (prof) ORBX_HIP(hipEventRecord(h->ev[3], st));
+    if (prof) ORBX_HIP(hipEventRecord(ev[3], st));
     {   // K4
         const int maxo = std::min(cap, h->max_kp);
         dim3 grid((maxo + DESC_WAVES - 1) / DESC_WAVES, B);
         hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, st, h->d_pyr, h->pyrImgBytes, h->d_geom, nl,
                            h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, d_kps, d_desc, d_counts, cap);
     }
-    if (prof) { ORBX_HIP(hipEventRecord(h->ev[4], st)); h->ev_valid = 1; }
+    if (prof) { ORBX_HIP(hipEventRecord(ev[4], st)); h->ev_pending[h->ev_head % ORBX_EV_RING] = 1; h->ev_head++; }
     ORBX_HIP(hipGetLastError());
     h->last_stream = st;
     h->lastB = B;
@@ -1118,7 +1143,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor_t *h, const uint8_t *d_i
     ORBX_HIP(hipSetDevice(h->device));
     int rc = ensure_plan(h, w, hgt, B);
     if (rc) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream, as in every HIP API
     return launch_pipeline(h, d_imgs, B, w, hgt, stride, image_stride_bytes, d_kps, d_desc, d_counts, cap, st);
 }
 
@@ -1262,16 +1287,22 @@ extern "C" int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, in
 
 extern "C" int orbx_set_profiling(orbx_extractor_t *h, int enabled) {
     if (!h) return ORBX_ERR_ARG;
+    ORBX_HIP(hipSetDevice(h->device));
+    for (int r = 0; r < ORBX_EV_RING; r++)
+        if (h->ev_pending[r]) { ORBX_HIP(hipEventSynchronize(h->ev[r][4])); h->ev_pending[r] = 0; }
     h->profiling = enabled;
-    h->ev_valid = 0;
+    h->ev_head = 0;
+    h->acc_n = 0;
+    for (int i = 0; i < ORBX_NUM_STAGES; i++) h->acc_ms[i] = 0;
     return ORBX_OK;
 }
-extern "C" int orbx_get_stage_ms(orbx_extractor_t *h, float *ms) {
+extern "C" int orbx_get_stage_ms(orbx_extractor_t *h, float *ms, int *ncalls) {
     if (!h || !ms) return ORBX_ERR_ARG;
-    if (!h->ev_valid) { orbx_set_error("no profiled batch recorded"); return ORBX_ERR_ARG; }
     ORBX_HIP(hipSetDevice(h->device));
-    ORBX_HIP(hipEventSynchronize(h->ev[4]));
-    for (int i = 0; i < 4; i++) ORBX_HIP(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
-    ORBX_HIP(hipEventElapsedTime(&ms[4], h->ev[0], h->ev[4]));
+    for (int r = 0; r < ORBX_EV_RING; r++)
+        if (h->ev_pending[r]) { int rc = harvest_events(h, r); if (rc) return rc; }
+    if (h->acc_n == 0) { orbx_set_error("no profiled batch recorded"); return ORBX_ERR_ARG; }
+    for (int i = 0; i < ORBX_NUM_STAGES; i++) ms[i] = (float)(h->acc_ms[i] / (double)h->acc_n);
+    if (ncalls) *ncalls = (int)h->acc_n;
     return ORBX_OK;
 }

@@ -13,6 +13,7 @@
 #define ORBX_HALF_PATCH 15  // HALF_PATCH_SIZE           (reference: src/ORBextractor.cc:73)
 #define ORBX_DESC_R 18      // max |rotated tap| : pattern radius^2 = 338 -> cvRound <= 18
 #define ORBX_MAX_ROOTS 64
+#define ORBX_EV_RING 32
 
 void orbx_set_error(const char *fmt, ...);
 
@@ -80,9 +81,13 @@ struct orbx_extractor {
     hipStream_t stream;      // own stream
     hipStream_t last_stream; // stream of the last batch call
     int lastB;
+    // per-stage HIP-event timing: a ring of event sets so that timing never forces a sync
     int profiling;
-    hipEvent_t ev[ORBX_NUM_STAGES + 1];
-    int ev_valid;
+    hipEvent_t ev[ORBX_EV_RING][ORBX_NUM_STAGES];
+    unsigned char ev_pending[ORBX_EV_RING];
+    int ev_head;
+    double acc_ms[ORBX_NUM_STAGES];
+    long acc_n;
 };
 
 // extractor internals used by the matcher side

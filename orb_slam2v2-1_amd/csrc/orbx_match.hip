@@ -293,13 +293,13 @@ static int fill_stereo_levels(orbx_extractor *hl, orbx_extractor *hr, StereoLeve
 struct StereoScratch { int32_t *d_sad; size_t n; int device; };
 static thread_local StereoScratch g_ss = {nullptr, 0, -1};
 
-extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *hr, int B,
-                                        const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
+extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, int left_slot0,
+                                        int right_slot0, const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
                                         const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
                                         int cap, float mbf, float mb, float *d_uright, float *d_depth,
                                         int32_t *d_nmatch, void *stream) {
     if (!hl || !hr || !d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_uright || !d_depth || B < 1 ||
-        cap < 1 || B > hl->pB || B > hr->pB) {
+        cap < 1 || left_slot0 < 0 || right_slot0 < 0 || left_slot0 + B > hl->pB || right_slot0 + B > hr->pB) {
         orbx_set_error("orbm_stereo_batch_device: bad arguments");
         return ORBX_ERR_ARG;
     }
@@ -314,11 +314,11 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
         ORBX_HIP(hipMalloc(&g_ss.d_sad, sizeof(int32_t) * need));
         g_ss.n = need; g_ss.device = hl->device;
     }
-    hipStream_t st = stream ? (hipStream_t)stream : hl->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream
     dim3 grid((cap + ST_WAVES - 1) / ST_WAVES, B);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), 0, st, lv, hl->d_pyr, hl->pyrImgBytes, hr->d_pyr,
-                       hr->pyrImgBytes, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
+    hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), 0, st, lv, hl->d_pyr + (size_t)left_slot0 * hl->pyrImgBytes, hl->pyrImgBytes,
+                       hr->d_pyr + (size_t)right_slot0 * hr->pyrImgBytes, hr->pyrImgBytes, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
                        g_ss.d_sad);
     hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(SM_T), sizeof(int32_t) * cap, st, d_nl, cap, d_uright,
                        d_depth, g_ss.d_sad, d_nmatch);
@@ -355,7 +355,7 @@ extern "C" int orbm_stereo(orbx_extractor_t *hl, orbx_extractor_t *hr, const orb
     int32_t cnt[3] = {nl, nr, 0};
     H2D(bn, cnt, sizeof(cnt));
     int32_t *dn = (int32_t *)bn.p;
-    int rc = orbm_stereo_batch_device(hl, hr, 1, (orbx_keypoint_t *)bkl.p, (uint8_t *)bdl.p, dn,
+    int rc = orbm_stereo_batch_device(hl, hr, 1, 0, 0, (orbx_keypoint_t *)bkl.p, (uint8_t *)bdl.p, dn,
                                       (orbx_keypoint_t *)bkr.p, (uint8_t *)bdr.p, dn + 1, cap, mbf, mb,
                                       (float *)bu.p, (float *)bd.p, dn + 2, hl->stream);
     if (rc) return rc;
