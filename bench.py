@@ -157,6 +157,7 @@ def main():
         cpu = cpu_baseline(w, h, nf, stereo)
 
     pkg = importlib.import_module("orb_slam2v2-1_amd")
+    batching = importlib.import_module("orb_slam2v2-1_amd.batching")
     pkg.lib()  # fails loudly if the HIP library is missing
     import torch
     import torch.distributed as dist
@@ -186,7 +187,7 @@ def main():
     gather = world > 1 and not args.no_gather
     if gather:
         # one packed record per frame so that a step is ONE all-gather: kps | desc | uright | depth | count
-        rec_bytes = cap * (28 + 32 + 4 + 4) + 16
+        rec_bytes = batching.record_bytes(cap)
         pack = [torch.zeros((B, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         gath = [torch.zeros((world * B, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         works = [None] * nbuf
@@ -212,13 +213,8 @@ def main():
             if timed_idx is not None:
                 ev_m1[timed_idx].record(stream)
         if gather:
-            p = pack[j]
-            o = 0
-            for t, nb in ((kps[j][:B], cap * 28), (desc[j][:B], cap * 32), (ur[j], cap * 4), (dp[j], cap * 4)):
-                p[:, o:o + nb] = t.reshape(B, -1).view(torch.uint8)
-                o += nb
-            p[:, o:o + 4] = cnt[j][:B].reshape(B, 1).view(torch.uint8)
-            works[j] = dist.all_gather_into_tensor(gath[j], p, async_op=True)
+            batching.pack_records(kps[j][:B], desc[j][:B], ur[j], dp[j], cnt[j][:B], out=pack[j])
+            _, works[j] = batching.all_gather_records(pack[j], gath[j], async_op=True)
 
     def drain():
         if gather:

@@ -1,0 +1,70 @@
+"""Batched many-frame mode across GPUs: frame sharding + the result all-gather.
+
+Frames are independent (ORBextractor::operator() reads only its image and ctor constants;
+a stereo pair stays on one GPU because Frame::ComputeStereoMatches needs both images), so a
+batch of F frames is cut into contiguous blocks of F/G frames per GPU.
+There is no data-path collective during compute; ONE all-gather per step gives every rank the
+features of all frames.  Variable keypoint counts travel through the fixed-shape collective as
+one fixed-capacity record per frame:
+
+    [ cap x 28 B keypoints | cap x 32 B descriptors | cap x 4 B mvuRight | cap x 4 B mvDepth
+      | int32 count | 12 B pad ]
+
+Works on any torch device/backend (RCCL on GPUs, gloo on CPU for the tests).
+"""
+import torch
+
+KP_BYTES, DESC_BYTES = 28, 32
+TAIL_BYTES = 16
+
+
+def shard_range(nframes, rank, world):
+    """Contiguous block of frames owned by `rank`: sizes differ by at most one."""
+    base, rem = divmod(nframes, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def record_bytes(cap):
+    return cap * (KP_BYTES + DESC_BYTES + 4 + 4) + TAIL_BYTES
+
+
+def pack_records(kps, desc, uright, depth, counts, out=None):
+    """kps [B,cap,7] f32 (bit pattern of orbx_keypoint_t), desc [B,cap,32] u8, uright/depth
+    [B,cap] f32, counts [B] i32 -> uint8 [B, record_bytes(cap)]."""
+    B, cap = kps.shape[0], kps.shape[1]
+    rb = record_bytes(cap)
+    if out is None:
+        out = torch.zeros((B, rb), dtype=torch.uint8, device=kps.device)
+    o = 0
+    for t, nb in ((kps, cap * KP_BYTES), (desc, cap * DESC_BYTES), (uright, cap * 4), (depth, cap * 4)):
+        out[:, o:o + nb] = t.contiguous().reshape(B, -1).view(torch.uint8)
+        o += nb
+    out[:, o:o + 4] = counts.to(torch.int32).contiguous().reshape(B, 1).view(torch.uint8)
+    return out
+
+
+def unpack_records(rec, cap):
+    """Inverse of pack_records -> dict(kps, desc, uright, depth, counts)."""
+    F = rec.shape[0]
+    o = 0
+    res = {}
+    for name, nb, dt, shape in (("kps", cap * KP_BYTES, torch.float32, (F, cap, 7)),
+                                ("desc", cap * DESC_BYTES, torch.uint8, (F, cap, 32)),
+                                ("uright", cap * 4, torch.float32, (F, cap)),
+                                ("depth", cap * 4, torch.float32, (F, cap))):
+        res[name] = rec[:, o:o + nb].contiguous().view(dt).reshape(shape)
+        o += nb
+    res["counts"] = rec[:, o:o + 4].contiguous().view(torch.int32).reshape(F)
+    return res
+
+
+def all_gather_records(rec, gathered=None, group=None, async_op=False):
+    """One all-gather of the per-frame records of every rank (equal B on every rank).
+    Returns (gathered [world*B, rb], work-or-None); rank r's frames sit at [r*B, (r+1)*B)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if gathered is None:
+        gathered = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=torch.uint8, device=rec.device)
+    work = dist.all_gather_into_tensor(gathered, rec, group=group, async_op=async_op)
+    return gathered, work

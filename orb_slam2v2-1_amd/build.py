@@ -25,8 +25,27 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+HOST = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(HERE, "lib", "liborb_host.so")
+
+
+def build_host(force=False, verbose=False):
+    """C++ host classes (ORB_SLAM2::ORBextractor / ORBmatcher mirrors) over the C ABI: g++ only."""
+    srcs = [os.path.join(HOST, f) for f in ("ORBextractor.cc", "ORBmatcher.cc")]
+    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST)] + [LIB]
+    if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps):
+        return HOST_LIB
+    cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-I" + HOST,
+           "-o", HOST_LIB] + srcs + ["-L" + os.path.dirname(LIB), "-lorbx_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
+        build_host(False, verbose)
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -35,6 +54,7 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_host(True, verbose)
     return LIB
 
 

@@ -1,0 +1,52 @@
+// ORBmatcher.h — the hot routines of the reference's include/ORBmatcher.h:37-102 with the
+// same names, signatures and constants, executed on an MI355X through include/orbx.h.
+// (SearchByBoW / Fuse / SearchBySim3 / SearchForTriangulation / the KeyFrame projections are
+// SURVEY §8(f) "next" and stay on the reference's CPU implementation for now.)
+#ifndef ORBMATCHER_H
+#define ORBMATCHER_H
+
+#include <vector>
+#include "cv_shim.h"
+#include "frame_shim.h"
+#include "orbx.h"
+
+namespace ORB_SLAM2 {
+
+class ORBmatcher {
+public:
+    ORBmatcher(float nnratio = 0.6, bool checkOri = true);
+
+    // Computes the Hamming distance between two ORB descriptors (src/ORBmatcher.cc:1649-1665)
+    static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
+
+    // Search matches between Frame keypoints and projected MapPoints. Returns number of matches.
+    // Used to track the local map (Tracking)                         (src/ORBmatcher.cc:45-129)
+    int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th = 3);
+
+    // Project MapPoints tracked in last frame into the current frame and search matches.
+    // Used to track from previous frame (Tracking)                   (src/ORBmatcher.cc:1330-1472)
+    int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
+
+    // Matching for the Map Initialization (only used in the monocular case) (src/ORBmatcher.cc:405-520)
+    int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched,
+                                std::vector<int> &vnMatches12, int windowSize = 10);
+
+    static const int TH_LOW;
+    static const int TH_HIGH;
+    static const int HISTO_LENGTH;
+
+    // GPU used by the matcher entry points (default: ORBX_DEVICE or 0)
+    static int device;
+
+protected:
+    float mfNNratio;
+    bool mbCheckOrientation;
+};
+
+// Frame::ComputeStereoMatches (src/Frame.cc:481-655): fills F.mvuRight / F.mvDepth from
+// F.mvKeys / mvKeysRight / descriptors and the two extractors' device-resident pyramids.
+// Call it from Frame::ComputeStereoMatches() in place of the CPU body. Returns #matches (<0: error).
+int ComputeStereoMatchesHIP(Frame &F);
+
+}  // namespace ORB_SLAM2
+#endif

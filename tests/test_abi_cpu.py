@@ -1,0 +1,74 @@
+"""CPU: the C-ABI library loads, exports every symbol include/orbx.h declares, and fails
+LOUDLY (never falls back to a CPU path) when no GPU is usable."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "orbx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(orb[xm]_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    b = __import__("importlib").import_module("orb_slam2v2-1_amd.build")
+    b.build()
+    L = pkg.lib()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), "missing export %s" % n
+    assert sorted(pkg.EXPORTS) == names, "EXPORTS list and include/orbx.h disagree"
+
+
+def test_keypoint_struct_is_28_bytes(pkg):
+    assert pkg.KP_DTYPE.itemsize == 28 and pkg.MP_DTYPE.itemsize == 28 and pkg.LASTPT_DTYPE.itemsize == 28
+
+
+def test_hamming_is_host_side(pkg):
+    z = np.zeros(32, np.uint8)
+    assert pkg.ORBmatcher.DescriptorDistance(z, ~z) == 256
+    assert pkg.lib().orbm_hamming(None, None) == pkg.ORBX_ERR_ARG
+    assert pkg.ORBmatcher.TH_LOW == 50 and pkg.ORBmatcher.TH_HIGH == 100 and pkg.ORBmatcher.HISTO_LENGTH == 30
+
+
+def test_no_gpu_fails_loudly(pkg):
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(pkg.OrbxError) as e:
+        pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    assert e.value.status == pkg.ORBX_ERR_NO_DEVICE
+    m = pkg.ORBmatcher(0.9, True)
+    k = np.zeros(4, pkg.KP_DTYPE)
+    with pytest.raises(pkg.OrbxError):
+        m.SearchForInitialization(k, np.zeros((4, 32), np.uint8), k, np.zeros((4, 32), np.uint8),
+                                  pkg.grid_geom(640, 480), np.zeros((4, 2), np.float32), 100)
+
+
+def test_argument_errors(pkg):
+    L = pkg.lib()
+    h = C.c_void_p()
+    assert L.orbx_create(0, 1.2, 8, 20, 7, 0, C.byref(h)) == pkg.ORBX_ERR_ARG
+    assert L.orbx_create(1000, 1.0, 8, 20, 7, 0, C.byref(h)) == pkg.ORBX_ERR_ARG
+    assert L.orbx_create(1000, 1.2, 99, 20, 7, 0, C.byref(h)) == pkg.ORBX_ERR_ARG
+    assert L.orbx_create(1000, 1.2, 8, 20, 7, 0, None) == pkg.ORBX_ERR_ARG
+    assert b"bad" in L.orbx_last_error() or b"NULL" in L.orbx_last_error()
+    assert L.orbx_destroy(None) == 0
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle (or any CPU fallback)."""
+    pk = os.path.join(ROOT, "orb_slam2v2-1_amd")
+    for dirpath, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cc", ".cpp", ".hpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                code = "\n".join(l for l in txt.splitlines() if not l.strip().startswith(("#", "//", "*", "/*", '"""')))
+                assert "import oracle" not in code and "from oracle" not in code and "orb_oracle" not in code, \
+                    "%s references the oracle" % f

@@ -1,0 +1,83 @@
+"""CPU: frame sharding and the packed-record all-gather of the batched multi-GPU mode,
+world_size 2 on gloo (the same code path bench.py drives over RCCL)."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+batching = importlib.import_module("orb_slam2v2-1_amd.batching")
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            r = [batching.shard_range(n, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+    assert batching.shard_range(512, 3, 8) == (192, 256)  # config 4: 512 frames over 8 GPUs
+
+
+def _fake(frame_ids, cap):
+    B = len(frame_ids)
+    g = torch.Generator().manual_seed(1234)
+    kps = torch.zeros((B, cap, 7)); desc = torch.zeros((B, cap, 32), dtype=torch.uint8)
+    ur = torch.zeros((B, cap)); dp = torch.zeros((B, cap)); cnt = torch.zeros(B, dtype=torch.int32)
+    for i, f in enumerate(frame_ids):
+        g.manual_seed(1000 + f)
+        n = int(torch.randint(1, cap + 1, (1,), generator=g))
+        cnt[i] = n
+        kps[i, :n] = torch.rand((n, 7), generator=g) * 1000
+        desc[i, :n] = torch.randint(0, 256, (n, 32), generator=g, dtype=torch.uint8)
+        ur[i, :n] = torch.rand(n, generator=g)
+        dp[i, :n] = torch.rand(n, generator=g)
+    return kps, desc, ur, dp, cnt
+
+
+def test_pack_unpack_roundtrip():
+    cap = 37
+    kps, desc, ur, dp, cnt = _fake([5, 6, 7], cap)
+    rec = batching.pack_records(kps, desc, ur, dp, cnt)
+    assert rec.shape == (3, batching.record_bytes(cap)) and rec.dtype == torch.uint8
+    u = batching.unpack_records(rec, cap)
+    assert torch.equal(u["kps"], kps) and torch.equal(u["desc"], desc) and torch.equal(u["uright"], ur)
+    assert torch.equal(u["depth"], dp) and torch.equal(u["counts"], cnt)
+
+
+def _worker(rank, world, port, total, cap, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s, e = batching.shard_range(total, rank, world)
+        rec = batching.pack_records(*_fake(list(range(s, e)), cap))
+        gathered, work = batching.all_gather_records(rec, async_op=True)
+        work.wait()
+        u = batching.unpack_records(gathered, cap)
+        exp = _fake(list(range(total)), cap)
+        ok = all(torch.equal(a, b) for a, b in zip((u["kps"], u["desc"], u["uright"], u["depth"], u["counts"]), exp))
+        q.put((rank, bool(ok), int(gathered.shape[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgather_world2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, total, cap = 2, 8, 21
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, cap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True, total), (1, True, total)]

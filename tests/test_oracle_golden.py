@@ -1,0 +1,170 @@
+"""CPU: the oracle against the known-answer tables (tests/golden/appendix_c.json, derived
+analytically from the reference's formulas — SURVEY.md Appendix C) and hand-built images.
+The reference ships no tests/golden vectors and cannot be built here, so these are the only
+pins the oracle has ("parity unpinned" against the real binary)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "appendix_c.json")))
+
+
+def test_ctor_tables(oracle):
+    for nf, exp in G["features_per_level"].items():
+        ex = oracle.Extractor(int(nf), 1.2, 8, 20, 7)
+        assert ex.features_per_level.tolist() == exp
+        assert ex.umax.tolist() == G["umax"]
+        np.testing.assert_allclose(ex.scale_factors, G["scale_factors"], rtol=2e-7)
+        np.testing.assert_array_equal(ex.inv_scale_factors, np.float32(1) / ex.scale_factors)
+        np.testing.assert_array_equal(ex.level_sigma2, ex.scale_factors * ex.scale_factors)
+    ex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    assert ex.features_per_level.sum() == 1000  # remainder goes to the last level (:446)
+
+
+@pytest.mark.parametrize("size", sorted(G["pyramid"]))
+def test_pyramid_geometry(oracle, synth, size):
+    w, h = map(int, size.split("x"))
+    exp = G["pyramid"][size]
+    ex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    ex.extract(synth.frame(w, h, 1))
+    dims = [list(ex.pyramid_level(l).shape[::-1]) for l in range(8)]
+    assert dims == exp["dims"]
+    assert sum(a * b for a, b in dims) == exp["P"]
+    assert sum((a + 38) * (b + 38) for a, b in dims) == exp["padded"]
+    for (lw, lh), (nc, nr) in zip(dims, exp["cells"]):
+        assert int(np.float32(lw - 32) / np.float32(30)) == nc and int(np.float32(lh - 32) / np.float32(30)) == nr
+    assert round((dims[0][0] - 32) / (dims[0][1] - 32)) == exp["nIni"]
+
+
+def test_border_is_reflect101(oracle, synth):
+    ex = oracle.Extractor(500, 1.2, 8, 20, 7)
+    ex.extract(synth.frame(320, 240, 2))
+    for l in (0, 3, 7):
+        full = ex.pyramid_level(l, padded=True)
+        inner = full[19:-19, 19:-19]
+        np.testing.assert_array_equal(full, np.pad(inner, 19, mode="reflect"))
+
+
+def test_cv_round_half_even(oracle):
+    L = oracle.lib()
+    assert [L.oracle_cv_round(v) for v in (0.5, 1.5, 2.5, -0.5, -1.5, 2.4999, 2.5001)] == [0, 2, 2, 0, -2, 2, 3]
+
+
+def test_fast_atan2(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        y, x = rng.uniform(-1e5, 1e5, 2)
+        a = L.oracle_fast_atan2(y, x)
+        ref = math.degrees(math.atan2(y, x)) % 360
+        d = abs(a - ref)
+        assert min(d, 360 - d) < 0.35  # polynomial's documented error bound (~0.3 deg)
+    assert L.oracle_fast_atan2(0.0, 1.0) == 0.0
+    assert abs(L.oracle_fast_atan2(1.0, 0.0) - 90) < 1e-4
+    assert abs(L.oracle_fast_atan2(0.0, -1.0) - 180) < 1e-4
+    assert abs(L.oracle_fast_atan2(-1.0, 0.0) - 270) < 1e-4
+
+
+def test_fast_known_answers(oracle):
+    # constant image: nothing
+    assert len(oracle.fast_detect(np.full((40, 40), 90, np.uint8), 7)) == 0
+    # one bright pixel on a dark field: all 16 ring pixels are darker by 150 -> score 149
+    img = np.full((21, 21), 50, np.uint8)
+    img[10, 10] = 200
+    k = oracle.fast_detect(img, 20)
+    assert k.tolist() == [(10, 10, 149)]
+    # a dark pixel: same by symmetry
+    img = np.full((21, 21), 200, np.uint8)
+    img[10, 10] = 50
+    assert oracle.fast_detect(img, 20).tolist() == [(10, 10, 149)]
+    # threshold above the contrast: nothing;   exactly 9 contiguous brighter ring pixels
+    assert len(oracle.fast_detect(img, 150)) == 0
+    img = np.full((21, 21), 100, np.uint8)
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+            (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    for dx, dy in ring[:9]:
+        img[10 + dy, 10 + dx] = 160
+    k = oracle.fast_detect(img, 20)
+    assert (10, 10, 59) in k.tolist()
+    img[10 + ring[8][1], 10 + ring[8][0]] = 100  # only 8 contiguous left: centre is no corner any more
+    assert (10, 10) not in [(a, b) for a, b, _ in oracle.fast_detect(img, 20).tolist()]
+
+
+def test_fast_score_is_threshold_independent(oracle):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    k7 = {(x, y): s for x, y, s in oracle.fast_detect(img, 7).tolist()}
+    k20 = {(x, y): s for x, y, s in oracle.fast_detect(img, 20).tolist()}
+    assert k20, "random image must have corners"
+    # the single-score-map formulation used by the GPU kernel: FAST(ini) == {p in NMS(min): S >= ini}
+    assert k20 == {p: s for p, s in k7.items() if s >= 20}
+
+
+def test_fast_vs_bruteforce_numpy(oracle):
+    rng = np.random.default_rng(4)
+    img = (rng.integers(0, 256, (40, 48)) // 32 * 32).astype(np.uint8)
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+            (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    t = 10
+    S = np.zeros(img.shape, int)
+    for y in range(3, img.shape[0] - 3):
+        for x in range(3, img.shape[1] - 3):
+            v = int(img[y, x])
+            d = [v - int(img[y + dy, x + dx]) for dx, dy in ring]
+            best = max(max(min(d[(s + i) % 16] for i in range(9)) for s in range(16)),
+                       max(min(-d[(s + i) % 16] for i in range(9)) for s in range(16)))
+            if best > t:
+                S[y, x] = best - 1
+    exp = []
+    for y in range(3, img.shape[0] - 3):
+        for x in range(3, img.shape[1] - 3):
+            s = S[y, x]
+            nb = S[y - 1:y + 2, x - 1:x + 2].copy()
+            nb[1, 1] = -1
+            if s > 0 and s > nb.max():
+                exp.append((x, y, s))
+    assert oracle.fast_detect(img, t).tolist() == exp
+
+
+def test_resize_and_blur_properties(oracle):
+    const = np.full((60, 80), 137, np.uint8)
+    assert (oracle.resize_linear(const, 67, 50) == 137).all()
+    # 8-bit fixed-point Gaussian of OpenCV <= 3.3: taps sum to 257, not renormalised
+    assert (oracle.gaussian_blur7(np.full((30, 30), 100, np.uint8)) == (100 * 257 * 257 + 32768) >> 16).all()
+    assert (oracle.gaussian_blur7(np.full((30, 30), 255, np.uint8)) == 255).all()
+    # impulse response = outer product of the taps
+    imp = np.zeros((15, 15), np.uint8)
+    imp[7, 7] = 255
+    taps = np.array(G["gaussian_fixed_point_taps"])
+    exp = (255 * np.outer(taps, taps) + 32768) >> 16
+    np.testing.assert_array_equal(oracle.gaussian_blur7(imp)[4:11, 4:11], exp)
+    # identity resize
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (33, 47), dtype=np.uint8)
+    np.testing.assert_array_equal(oracle.resize_linear(a, 47, 33), a)
+
+
+def test_constant_and_tiny_images(oracle):
+    ex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    k, d = ex.extract(np.full((376, 1241), 77, np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+    with pytest.raises(RuntimeError):
+        ex.extract(np.zeros((100, 100), np.uint8))  # level 7 would have zero cells (reference: UB)
+
+
+def test_octtree_small_cases(oracle):
+    C = oracle.CAND_DTYPE
+    # a single key survives; N=0 still runs one split pass of the roots (:594-672)
+    one = np.array([(10, 10, 50)], C)
+    assert oracle.distribute_octtree(one, 100, 100, 5).tolist() == [(10, 10, 50)]
+    four = np.array([(10, 10, 50), (90, 10, 60), (10, 90, 70), (90, 90, 80)], C)
+    out = oracle.distribute_octtree(four, 100, 100, 4)
+    assert sorted(out.tolist()) == sorted(four.tolist())
+    # list order after one split = reverse creation order n4,n3,n2,n1
+    assert out.tolist() == [(90, 90, 80), (10, 90, 70), (90, 10, 60), (10, 10, 50)]
+    # best response per node, first wins on ties
+    two = np.array([(10, 10, 50), (11, 11, 50), (12, 12, 49)], C)
+    assert oracle.distribute_octtree(two, 100, 100, 1).tolist() == [(10, 10, 50)]
