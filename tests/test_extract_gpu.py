@@ -50,3 +50,91 @@ def test_batch_matches_single(pkg, oracle, synth):
         assert len(gk) == len(ok)
         np.testing.assert_array_equal(gk[["x", "y", "response", "octave"]], ok[["x", "y", "response", "octave"]])
         np.testing.assert_array_equal(gd, od)
+
+
+def _compare(pkg, oracle, img, nf, sf=1.2, nl=8, ini=20, mn=7):
+    ex = pkg.ORBextractor(nf, sf, nl, ini, mn)
+    orc = oracle.Extractor(nf, sf, nl, ini, mn)
+    ok, od = orc.extract(img)
+    gk, gd = ex(img)
+    for l in range(nl):
+        np.testing.assert_array_equal(ex.debug_level_points(l, 0), _cands(orc.level_candidates(l)),
+                                      err_msg="FAST candidates level %d" % l)
+        np.testing.assert_array_equal(ex.debug_level_points(l, 1), _cands(orc.level_keypoints(l)),
+                                      err_msg="quad-tree level %d" % l)
+    assert len(gk) == len(ok)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        np.testing.assert_array_equal(gk[f], ok[f], err_msg=f)
+    np.testing.assert_allclose(gk["angle"], ok["angle"], atol=1e-4, rtol=0)
+    np.testing.assert_array_equal(gd, od)
+    return gk
+
+
+def test_full_hd_4000_features(pkg, oracle, synth):
+    k = _compare(pkg, oracle, synth.frame(1920, 1080, 30), 4000)
+    assert len(k) >= 3900
+
+
+def test_ragged_size_and_small_budget(pkg, oracle, synth):
+    _compare(pkg, oracle, synth.frame(641, 479, 31), 300)
+    _compare(pkg, oracle, synth.frame(333, 257, 32), 50)
+
+
+def test_other_pyramid_parameters(pkg, oracle, synth):
+    _compare(pkg, oracle, synth.frame(640, 480, 33), 800, sf=1.5, nl=4)
+    _compare(pkg, oracle, synth.frame(640, 480, 34), 1000, sf=1.1, nl=12)
+    _compare(pkg, oracle, synth.frame(640, 480, 35), 600, ini=5, mn=12)   # iniTh < minTh
+    _compare(pkg, oracle, synth.frame(640, 480, 36), 600, ini=40, mn=40)
+
+
+def test_sparse_image_fewer_candidates_than_budget(pkg, oracle):
+    # a flat image with a few isolated squares: most cells fall back to minTh and find nothing,
+    # every quad-tree node ends up with one key before N is reached (all bNoMore, :669)
+    rng = np.random.default_rng(7)
+    img = np.full((480, 640), 90, np.uint8)
+    for _ in range(40):
+        x, y = rng.integers(30, 600), rng.integers(30, 440)
+        img[y:y + 9, x:x + 9] = 90 + rng.integers(10, 120)
+    k = _compare(pkg, oracle, img, 1000)
+    assert 0 < len(k) < 600
+
+
+def test_dense_random_texture(pkg, oracle):
+    # uniform noise: FAST fires almost everywhere NMS allows -> stresses slot capacity/order
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (376, 620), dtype=np.uint8)
+    _compare(pkg, oracle, img, 2000)
+
+
+def test_batch_with_empty_and_flat_frames(pkg, oracle, synth):
+    w, h = 640, 480
+    imgs = np.stack([synth.frame(w, h, 40), np.full((h, w), 50, np.uint8), synth.frame(w, h, 41)])
+    ex = pkg.ORBextractor(700, 1.2, 8, 20, 7)
+    res = ex.extract_batch(imgs)
+    orc = oracle.Extractor(700, 1.2, 8, 20, 7)
+    for b in range(3):
+        ok, od = orc.extract(imgs[b])
+        assert len(res[b][0]) == len(ok)
+        np.testing.assert_array_equal(res[b][1], od)
+    assert len(res[1][0]) == 0
+    # empty image: silent, outputs empty (src/ORBextractor.cc:1046-1047)
+    k, d = ex(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+    # too small for the reference's cell grid at the last level: argument error, not a crash
+    with pytest.raises(pkg.OrbxError) as e:
+        ex(np.zeros((100, 100), np.uint8))
+    assert e.value.status == pkg.ORBX_ERR_ARG
+    # the handle still works afterwards and adapts to a new image size
+    k2, _ = ex(synth.frame(752, 480, 42))
+    assert len(k2) > 600
+
+
+def test_determinism_and_batch_size_independence(pkg, synth):
+    w, h = 1241, 376
+    imgs = synth.batch(w, h, 3, k0=50)
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    a = ex.extract_batch(imgs)
+    b = ex.extract_batch(np.concatenate([imgs, imgs[::-1]]))
+    for i in range(3):
+        for j in (i, 5 - i):
+            assert a[i][0].tobytes() == b[j][0].tobytes() and a[i][1].tobytes() == b[j][1].tobytes()
