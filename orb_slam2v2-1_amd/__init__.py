@@ -34,7 +34,7 @@ EXPORTS = [
     "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_tables",
     "orbx_max_keypoints", "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_device",
     "orbx_pyramid_host", "orbx_pyramid_device", "orbx_debug_level_points", "orbx_set_profiling",
-    "orbx_get_stage_ms", "orbm_hamming", "orbm_hamming_matrix_device", "orbm_stereo_batch_device",
+    "orbx_get_stage_ms", "orbx_debug_set", "orbm_hamming", "orbm_hamming_matrix_device", "orbm_stereo_batch_device",
     "orbm_stereo", "orbm_search_for_initialization", "orbm_search_by_projection_mp",
     "orbm_search_by_projection_frame", "orbx_last_error", "orbx_version", "orbx_device_count",
 ]

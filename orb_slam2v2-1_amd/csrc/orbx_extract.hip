@@ -31,6 +31,9 @@ extern "C" int orbx_device_count(void) {
     return n;
 }
 
+int g_debug[8] = {0};
+extern "C" int orbx_debug_set(int key, int value) { if (key < 0 || key >= 8) return ORBX_ERR_ARG; g_debug[key] = value; return ORBX_OK; }
+
 // ------------------------------------------------------------------------------------
 // constant tables
 __constant__ int8_t c_pattern[1024] = {
@@ -117,31 +120,32 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, s
 }
 
 // ------------------------------------------------------------------------------------
-// K2: one wave per 30-px cell (:789-829).  The cell window (cell + 6 px) is staged in LDS;
-// FAST-9/16 score S at t_lo = min(iniTh, minTh) for every pixel of the evaluated area
-// (window minus its 3-px frame, exactly cv::FAST's loop bounds), 3x3 strict-max NMS that
-// sees zeros outside the evaluated area (cv::FAST never scores them), then the per-cell
-// threshold fallback: {S >= iniTh} if non-empty else {S >= minTh}.  This equals running
-// cv::FAST(iniTh) and, if empty, cv::FAST(minTh): the score is threshold-independent
-// (max over 9-arcs of the min |diff|, minus 1) and a pixel is a corner at t iff S >= t.
+// K2: one wave per 30-px cell (:789-829).  The cell window (cell + 6 px) is staged in LDS
+// as one dword per pixel holding the pixel PAIR (p, p+1) in two 16-bit halves, so that the
+// FAST-9/16 score of two horizontally adjacent pixels is computed at once with packed 16-bit
+// VALU ops (v_pk_sub/min/max_i16) from 17 ds_read_b32:
+//     d[k]   = centre - ring[k]                                (signed, both pixels)
+//     dark   = max over the 16 nine-arcs of min d   (log-step sliding minimum, 64+15 ops)
+//     bright = -min over the arcs of max d
+//     S      = max(dark, bright) - 1  if > t_lo = min(iniTh, minTh), else 0
+// which is cornerScore<16> of cv::FAST (threshold independent) and its segment test.  Scores
+// of the evaluated area (window minus its 3-px frame, exactly cv::FAST's loop bounds) go to
+// an LDS tile with a zero halo: the 3x3 strict-max NMS sees zeros outside the evaluated area,
+// as cv::FAST never scores them.  Per-cell threshold fallback: {S >= iniTh} if non-empty
+// else {S >= minTh}; this equals running cv::FAST(iniTh) and, if empty, cv::FAST(minTh).
 // Output: row-major ordered candidates (x | y<<12 | score<<24, relative to minBorder) in
 // the cell's slot block + count.
 #define FAST_WAVES 4
+typedef short short2v __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ bool has9(uint32_t m16) {
-    uint32_t m = m16 | (m16 << 16);
-    uint32_t x = m & (m >> 1);
-    x &= x >> 2;
-    x &= x >> 4;
-    x &= m >> 8;
-    return (x & 0xFFFFu) != 0;
-}
+__device__ __forceinline__ short2v pk_min(short2v a, short2v b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ short2v pk_max(short2v a, short2v b) { return __builtin_elementwise_max(a, b); }
 
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
     int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ slots, size_t slotsPerImg,
-    int iniTh, int minTh, int TS, int SS, int tileRows, int ldsPerWave) {
-    extern __shared__ uint8_t smem[];
+    int iniTh, int minTh, int ES, int SS, int tileRows, int ldsPerWave, int phaseLimit) {
+    extern __shared__ __align__(16) uint8_t smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int gc = blockIdx.x * FAST_WAVES + wave, b = blockIdx.y;
     if (gc >= totalCells) return;  // wave-uniform; the kernel uses no block barrier
@@ -166,67 +170,85 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
         if (lane == 0) *cnt = 0;
         return;
     }
-    uint8_t *T = smem + (size_t)wave * ldsPerWave;  // window tile [th][TS], th <= tileRows
-    uint8_t *Sc = T + (size_t)TS * tileRows;        // score tile [ch+2][SS] with a zero 1-px halo
-    uint8_t *Fl = Sc + (size_t)SS * (tileRows - 4); // NMS flags [ch*cw]
+    uint32_t *E = (uint32_t *)(smem + (size_t)wave * ldsPerWave);  // pair tile [th][ES] dwords
+    uint8_t *Sc = (uint8_t *)(E + (size_t)ES * tileRows);          // score tile [ch+2][SS], pixel (0,0) at +SS+2
+    uint8_t *Fl = (uint8_t *)E;                                    // NMS flags [ch*cw], reuses E after scoring
 
-    const uint8_t *src = pyr + (size_t)b * pyrImgBytes + g.poff + (size_t)(ORBX_EDGE + iniY) * g.pstride +
-                         ORBX_EDGE + iniX;
-    {   // stage window; zero the score tile (incl. its 1-px halo)
-        int r = 0, cc = lane;
-        while (cc >= tw) { cc -= tw; r++; }
-        while (r < th) {
-            T[r * TS + cc] = src[(size_t)r * g.pstride + cc];
-            cc += 64;
-            while (cc >= tw) { cc -= tw; r++; }
+    {   // stage the window: aligned dword loads (pstride % 4 == 0, so every row has the same misalignment)
+        const size_t a = (size_t)(ORBX_EDGE + iniY) * g.pstride + ORBX_EDGE + iniX;
+        const int sh = (int)(a & 3);
+        const uint32_t *src = (const uint32_t *)(pyr + (size_t)b * pyrImgBytes + g.poff + (a - sh));
+        const int nd = (sh + tw + 3) >> 2, pstr4 = g.pstride >> 2, items = nd * th;
+        int r = 0, q = lane;
+        while (q >= nd) { q -= nd; r++; }
+        for (int i = lane; i < items; i += 64) {
+            const uint32_t d0 = src[(size_t)r * pstr4 + q], d1 = src[(size_t)r * pstr4 + q + 1];
+            // bytes b0..b3 of d0 and b4 = first byte of d1 -> pairs (b0,b1) (b1,b2) (b2,b3) (b3,b4)
+            const uint32_t e0 = (d0 & 0xFF) | ((d0 & 0xFF00) << 8);
+            const uint32_t e1 = ((d0 >> 8) & 0xFF) | ((d0 >> 8) & 0xFF00) << 8;
+            const uint32_t e2 = ((d0 >> 16) & 0xFF) | ((d0 >> 16) & 0xFF00) << 8;
+            const uint32_t e3 = (d0 >> 24) | ((d1 & 0xFF) << 16);
+            const int c0 = 4 * q - sh;
+            uint32_t *row = E + r * ES;
+            if (c0 >= 0 && c0 < tw) row[c0] = e0;
+            if (c0 + 1 >= 0 && c0 + 1 < tw) row[c0 + 1] = e1;
+            if (c0 + 2 >= 0 && c0 + 2 < tw) row[c0 + 2] = e2;
+            if (c0 + 3 >= 0 && c0 + 3 < tw) row[c0 + 3] = e3;
+            q += 64;
+            while (q >= nd) { q -= nd; r++; }
         }
-        const int nz = (ch + 2) * SS;
-        for (int i = lane; i < nz; i += 64) Sc[i] = 0;
+        const int nz = ((ch + 2) * SS) >> 2;  // zero the score tile (halo + odd tail columns)
+        for (int i = lane; i < nz; i += 64) ((uint32_t *)Sc)[i] = 0;
     }
     wave_sync();
+    if (phaseLimit == 1) return;
 
-    const int tlo = min(iniTh, minTh) < 0 ? 0 : min(min(iniTh, minTh), 255);
+    const int tlo = max(min(iniTh, minTh), 0);
     const int npx = cw * ch;
-    {   // scores
-        int py = 0, px = lane;
-        while (px >= cw) { px -= cw; py++; }
-        for (int p = lane; p < npx; p += 64) {
-            const uint8_t *q = T + (py + 3) * TS + px + 3;
-            const int v = q[0];
-            int r[16];
-            r[0] = q[3 * TS];      r[1] = q[3 * TS + 1];   r[2] = q[2 * TS + 2];   r[3] = q[TS + 3];
-            r[4] = q[3];           r[5] = q[-TS + 3];      r[6] = q[-2 * TS + 2];  r[7] = q[-3 * TS + 1];
-            r[8] = q[-3 * TS];     r[9] = q[-3 * TS - 1];  r[10] = q[-2 * TS - 2]; r[11] = q[-TS - 3];
-            r[12] = q[-3];         r[13] = q[TS - 3];      r[14] = q[2 * TS - 2];  r[15] = q[3 * TS - 1];
-            const int lo = v - tlo, hi = v + tlo;
-            uint32_t D = 0, Br = 0;
+    {   // scores, two pixels per lane
+        const int pw2 = (cw + 1) >> 1, npairs = pw2 * ch;
+        int py = 0, j = lane;
+        while (j >= pw2) { j -= pw2; py++; }
+        for (int p = lane; p < npairs; p += 64) {
+            const int px = 2 * j;
+            const uint32_t *q = E + (py + 3) * ES + px + 3;
+            const uint32_t *qm3 = q - 3 * ES, *qm2 = q - 2 * ES, *qm1 = q - ES, *qp1 = q + ES, *qp2 = q + 2 * ES,
+                           *qp3 = q + 3 * ES;
+            short2v r[16];
+            const uint32_t vv = q[0];
+            uint32_t rr[16];
+            rr[0] = qp3[0];   rr[1] = qp3[1];   rr[2] = qp2[2];   rr[3] = qp1[3];
+            rr[4] = q[3];     rr[5] = qm1[3];   rr[6] = qm2[2];   rr[7] = qm3[1];
+            rr[8] = qm3[0];   rr[9] = qm3[-1];  rr[10] = qm2[-2]; rr[11] = qm1[-3];
+            rr[12] = q[-3];   rr[13] = qp1[-3]; rr[14] = qp2[-2]; rr[15] = qp3[-1];
+            const short2v v = __builtin_bit_cast(short2v, vv);
+            short2v d[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                D |= (uint32_t)(r[k] < lo) << k;
-                Br |= (uint32_t)(r[k] > hi) << k;
+            for (int k = 0; k < 16; k++) { r[k] = __builtin_bit_cast(short2v, rr[k]); d[k] = v - r[k]; }
+            short2v a1[16], a2[16], a4[16], b1[16], b2[16], b4[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) { a1[k] = pk_min(d[k], d[(k + 1) & 15]); b1[k] = pk_max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+            for (int k = 0; k < 16; k++) { a2[k] = pk_min(a1[k], a1[(k + 2) & 15]); b2[k] = pk_max(b1[k], b1[(k + 2) & 15]); }
+#pragma unroll
+            for (int k = 0; k < 16; k++) { a4[k] = pk_min(a2[k], a2[(k + 4) & 15]); b4[k] = pk_max(b2[k], b2[(k + 4) & 15]); }
+            short2v dark = pk_min(a4[0], d[8]), brt = pk_max(b4[0], d[8]);
+#pragma unroll
+            for (int k = 1; k < 16; k++) {
+                dark = pk_max(dark, pk_min(a4[k], d[(k + 8) & 15]));
+                brt = pk_min(brt, pk_max(b4[k], d[(k + 8) & 15]));
             }
-            const bool dark = has9(D), bright = has9(Br);
-            if (dark || bright) {
-                int d[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) d[k] = dark ? v - r[k] : r[k] - v;
-                int m1[16], m2[16], m4[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) m1[k] = min(d[k], d[(k + 1) & 15]);
-#pragma unroll
-                for (int k = 0; k < 16; k++) m2[k] = min(m1[k], m1[(k + 2) & 15]);
-#pragma unroll
-                for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 4) & 15]);
-                int best = -256;
-#pragma unroll
-                for (int k = 0; k < 16; k++) best = max(best, min(m4[k], d[(k + 8) & 15]));
-                Sc[(py + 1) * SS + px + 1] = (uint8_t)(best - 1);
-            }
-            px += 64;
-            while (px >= cw) { px -= cw; py++; }
+            const short2v best = pk_max(dark, -brt);
+            const int s0 = best.x, s1 = best.y;
+            const uint32_t o0 = s0 > tlo ? (uint32_t)(s0 - 1) : 0u;
+            const uint32_t o1 = (s1 > tlo && px + 1 < cw) ? (uint32_t)(s1 - 1) : 0u;
+            *(uint16_t *)(Sc + (py + 1) * SS + px + 2) = (uint16_t)(o0 | (o1 << 8));
+            j += 64;
+            while (j >= pw2) { j -= pw2; py++; }
         }
     }
     wave_sync();
+    if (phaseLimit == 2) return;
 
     bool anyIni = false;
     {   // NMS flags
@@ -236,7 +258,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
             const int p = base + lane;
             bool keep = false, ini = false;
             if (p < npx) {
-                const uint8_t *s = Sc + (py + 1) * SS + px + 1;
+                const uint8_t *s = Sc + (py + 1) * SS + px + 2;
                 const int v = s[0];
                 keep = v > s[-1] && v > s[1] && v > s[-SS - 1] && v > s[-SS] && v > s[-SS + 1] &&
                        v > s[SS - 1] && v > s[SS] && v > s[SS + 1];
@@ -249,6 +271,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
         }
     }
     wave_sync();
+    if (phaseLimit == 3) return;
 
     const int thr = anyIni ? iniTh : minTh;
     uint32_t *out = slots + (size_t)b * slotsPerImg + g.slotOff + (size_t)c * g.capc;
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
             bool emit = false;
             int v = 0;
             if (p < npx) {
-                v = Sc[(py + 1) * SS + px + 1];
+                v = Sc[(py + 1) * SS + px + 2];
                 emit = Fl[p] && v >= thr;
             }
             const unsigned long long m = __ballot(emit);
@@ -632,15 +655,20 @@ __global__ __launch_bounds__(OCT_T, 2) void k_octree(
 // bits (:108-147) packed with one ballot per 64 pairs.  The blurred level is never written
 // to memory: blur is a pure function of the 43x43 source patch, which is staged in LDS from
 // the padded (BORDER_REFLECT_101) level, so border handling is identical to cv::GaussianBlur.
+// LDS traffic is kept to wide accesses (sub-dword LDS reads were the bottleneck of the first
+// version): the horizontal pass reads one b128 per 4 outputs and uses v_dot4_u32_u8 on
+// byte-aligned windows; the vertical pass slides a 7-row register window down a column pair.
 #define DESC_WAVES 4
 #define PR 21                    // source patch radius = 18 + 3
 #define PROWS (2 * PR + 1)       // 43
-#define PSTRIDE 48               // 12 dwords per patch row
+#define PSTRIDE 48               // 12 dwords per patch row (16-byte aligned rows)
+#define PPAD 16                  // slack behind the patch: the last row's b128 read may run over
 #define TROWS PROWS
 #define TCOLS (2 * ORBX_DESC_R + 1)  // 37
-#define TSTRIDE 38               // uint16
+#define TGROUPS 10               // horizontal pass: 10 groups of 4 outputs per row (cols 0..39)
+#define TSTRIDE4 20              // dwords per row of the u16 intermediate (40 columns)
 #define BSTRIDE 40
-#define DESC_LDS_PER_WAVE (PROWS * PSTRIDE + TROWS * TSTRIDE * 2 + TCOLS * BSTRIDE)
+#define DESC_LDS_PER_WAVE (PROWS * PSTRIDE + PPAD + TROWS * TSTRIDE4 * 4 + TCOLS * BSTRIDE + 8)
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     // cv::fastAtan2 of OpenCV 2.4.11 / 3.2 (scalar path)
@@ -669,7 +697,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     const uint32_t *__restrict__ lvlKp, int lvlKpCap, const int32_t *__restrict__ lvlCnt,
     orbx_keypoint_t *__restrict__ kps, uint8_t *__restrict__ desc, int32_t *__restrict__ counts, int cap) {
     __shared__ __align__(16) uint8_t smem[DESC_WAVES * DESC_LDS_PER_WAVE];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int o = blockIdx.x * DESC_WAVES + wave, b = blockIdx.y;
     // locate (level, k) of output ordinal o: level-major concatenation (:1076-1104)
     int l = 0, base = 0, total = 0;
@@ -685,19 +713,20 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
         if (blockIdx.x == 0 && threadIdx.x == 0) counts[b] = min(total, cap);
         if (!found || o >= cap) return;  // wave-uniform
     }
+    l = __builtin_amdgcn_readfirstlane(l);
     const LevelGeom g = geom[l];
     const uint32_t key = lvlKp[(size_t)b * lvlKpCap + g.lvlKpOff + (o - base)];
     const int cx = (int)(key & 0xFFF) + ORBX_MINB, cy = (int)((key >> 12) & 0xFFF) + ORBX_MINB;
     const int score = (int)(key >> 24);
 
-    uint8_t *P = smem + wave * DESC_LDS_PER_WAVE;           // source patch [43][48]
-    uint16_t *Tm = (uint16_t *)(P + PROWS * PSTRIDE);       // horizontal pass [43][38]
-    uint8_t *Bl = (uint8_t *)(Tm + TROWS * TSTRIDE);        // blurred [37][40]
+    uint8_t *P = smem + wave * DESC_LDS_PER_WAVE;                     // source patch [43][48] (+pad)
+    uint32_t *Tm = (uint32_t *)(P + PROWS * PSTRIDE + PPAD);          // horizontal pass, u16 [43][40]
+    uint8_t *Bl = (uint8_t *)(Tm + TROWS * TSTRIDE4);                 // blurred [37][40]
 
     // ---- stage the 43x43 patch with aligned dword loads (pstride is a multiple of 64)
     const uint8_t *lvl = pyr + (size_t)b * pyrImgBytes + g.poff;
     const size_t a = (size_t)(cy + ORBX_EDGE - PR) * g.pstride + (size_t)(cx + ORBX_EDGE - PR);
-    const int sh = (int)(a & 3);
+    const int sh = __builtin_amdgcn_readfirstlane((int)(a & 3));
     const uint32_t *src = (const uint32_t *)(lvl + (a - sh));
     const int pstr4 = g.pstride >> 2;
     for (int i = lane; i < PROWS * 12; i += 64) {
@@ -705,19 +734,29 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
         ((uint32_t *)P)[r * 12 + c] = src[(size_t)r * pstr4 + c];
     }
     wave_sync();
-    const uint8_t *Pc = P + sh;  // Pc[r*48 + c], r,c in [0,43): pixel (cx-21+c, cy-21+r)
+    // pixel (cx-21+c, cy-21+r) is byte P[r*48 + sh + c], r,c in [0,43)
 
-    // ---- IC_Angle: lanes 0..30 own one row v = lane-15 of the radius-15 disc
+    // ---- IC_Angle: two lanes per row v of the radius-15 disc (u = -15..0 | 1..15)
     int m10 = 0, m01 = 0;
-    if (lane < 31) {
-        const int v = lane - 15;
+    if (lane < 62) {
+        const int v = (lane >> 1) - 15, half = lane & 1;
         const int d = c_umax[v < 0 ? -v : v];
-        const uint8_t *row = Pc + (PR + v) * PSTRIDE + PR;
+        const int o0 = sh + PR - 15 + 16 * half;  // byte offset of u = -15 (half 0) / u = 1 (half 1)
+        const uint32_t *row = (const uint32_t *)(P + (PR + v) * PSTRIDE) + (o0 >> 2);
+        const int sa8 = o0 & 3;
+        uint32_t w[5], wa[4];
+#pragma unroll
+        for (int k = 0; k < 5; k++) w[k] = row[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) wa[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sa8);  // 16 bytes from o0
         int s0 = 0, s1 = 0;
-        for (int u = -d; u <= d; ++u) {
-            const int val = row[u];
-            s0 += val;
-            s1 += u * val;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int val = (int)((wa[k >> 2] >> (8 * (k & 3))) & 0xFF);
+            const int u = half ? k + 1 : k - 15;
+            const bool in = (u < 0 ? -u : u) <= d && u <= 15;
+            s0 += in ? val : 0;
+            s1 += in ? u * val : 0;
         }
         m10 = s1;
         m01 = v * s0;
@@ -729,22 +768,56 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- separable 7-tap blur in 8-bit fixed point
-    for (int i = lane; i < TROWS * TCOLS; i += 64) {
-        const int r = i / TCOLS, c = i - r * TCOLS;
-        const uint8_t *p = Pc + r * PSTRIDE + c;
-        const int acc = c_gauss[0] * (p[0] + p[6]) + c_gauss[1] * (p[1] + p[5]) + c_gauss[2] * (p[2] + p[4]) +
-                        c_gauss[3] * p[3];
-        Tm[r * TSTRIDE + c] = (uint16_t)acc;  // <= 255*257 = 65535
+    // ---- horizontal 7-tap pass: 4 outputs per lane-iteration from one aligned b128 read
+    const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), K1 = 49u | (34u << 8) | (18u << 16);
+    for (int i = lane; i < TROWS * TGROUPS; i += 64) {
+        const int r = i / TGROUPS, cg = i - r * TGROUPS;
+        const uint32_t *pr = (const uint32_t *)(P + r * PSTRIDE) + cg;  // dwords cg .. cg+3 hold bytes 4cg .. 4cg+15
+        const uint32_t d0 = pr[0], d1 = pr[1], d2 = pr[2], d3 = pr[3];
+        // w0..w2 = bytes (sh+4cg) .. +11 : source columns 4cg .. 4cg+11
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+                       w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+        uint32_t oo[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t lo = j ? __builtin_amdgcn_alignbyte(w1, w0, j) : w0;   // bytes j .. j+3
+            const uint32_t hi = j ? __builtin_amdgcn_alignbyte(w2, w1, j) : w1;   // bytes j+4 .. j+7
+            oo[j] = __builtin_amdgcn_udot4(hi, K1, __builtin_amdgcn_udot4(lo, K0, 0u, false), false);  // <= 65535
+        }
+        uint2 st;
+        st.x = oo[0] | (oo[1] << 16);
+        st.y = oo[2] | (oo[3] << 16);
+        *(uint2 *)(Tm + r * TSTRIDE4 + cg * 2) = st;
     }
     wave_sync();
-    for (int i = lane; i < TCOLS * TCOLS; i += 64) {
-        const int r = i / TCOLS, c = i - r * TCOLS;
-        const uint16_t *p = Tm + r * TSTRIDE + c;
-        int acc = c_gauss[0] * ((int)p[0] + p[6 * TSTRIDE]) + c_gauss[1] * ((int)p[TSTRIDE] + p[5 * TSTRIDE]) +
-                  c_gauss[2] * ((int)p[2 * TSTRIDE] + p[4 * TSTRIDE]) + c_gauss[3] * (int)p[3 * TSTRIDE];
-        acc = (acc + (1 << 15)) >> 16;
-        Bl[r * BSTRIDE + c] = (uint8_t)min(acc, 255);
+
+    // ---- vertical pass: lane = (column pair, row segment); 7-row sliding window in registers
+    if (lane < 60) {
+        const int cp = lane % 20, seg = lane / 20;
+        const int r0 = seg * 13, nr = seg == 2 ? 11 : 13;
+        const uint32_t *col = Tm + r0 * TSTRIDE4 + cp;
+        int lo[7], hi[7];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const uint32_t t = col[j * TSTRIDE4];
+            lo[j] = (int)(t & 0xFFFF);
+            hi[j] = (int)(t >> 16);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 13; rr++) {
+            if (rr < nr) {
+                const uint32_t t = col[(rr + 6) * TSTRIDE4];
+                lo[(rr + 6) % 7] = (int)(t & 0xFFFF);
+                hi[(rr + 6) % 7] = (int)(t >> 16);
+                int a0 = 18 * (lo[rr % 7] + lo[(rr + 6) % 7]) + 34 * (lo[(rr + 1) % 7] + lo[(rr + 5) % 7]) +
+                         49 * (lo[(rr + 2) % 7] + lo[(rr + 4) % 7]) + 55 * lo[(rr + 3) % 7];
+                int a1 = 18 * (hi[rr % 7] + hi[(rr + 6) % 7]) + 34 * (hi[(rr + 1) % 7] + hi[(rr + 5) % 7]) +
+                         49 * (hi[(rr + 2) % 7] + hi[(rr + 4) % 7]) + 55 * hi[(rr + 3) % 7];
+                a0 = min((a0 + (1 << 15)) >> 16, 255);
+                a1 = min((a1 + (1 << 15)) >> 16, 255);
+                *(uint16_t *)(Bl + (r0 + rr) * BSTRIDE + 2 * cp) = (uint16_t)(a0 | (a1 << 8));
+            }
+        }
     }
     wave_sync();
 
@@ -1021,11 +1094,10 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     h->pyrImgBytes = (poff + 255) & ~(size_t)255;
     h->slotsPerImg = slotOff;
     h->keysPerImg = (keyOff + 1) & ~(size_t)1;
-    h->fastTileStride = (maxTw + 3) & ~3;
-    h->fastScoreStride = (maxTw - 6 + 2 + 3) & ~3;
+    h->fastTileStride = maxTw;                       // dwords per pair-tile row
+    h->fastScoreStride = (maxTw - 6 + 4 + 3) & ~3;   // bytes per score row: 2-px left halo + >= 2 right
     h->fastTileRows = maxTh;
-    h->fastLdsPerWave = (h->fastTileStride * maxTh + h->fastScoreStride * (maxTh - 4) +
-                         (maxTw - 6) * (maxTh - 6) + 15) & ~15;
+    h->fastLdsPerWave = (4 * h->fastTileStride * maxTh + h->fastScoreStride * (maxTh - 4) + 15) & ~15;
     {   // octree LDS
         int pow2 = 1;
         while (pow2 < maxNodeCap) pow2 <<= 1;
@@ -1102,7 +1174,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
         hipLaunchKernelGGL(k_fast_cells, grid, dim3(64 * FAST_WAVES), (size_t)h->fastLdsPerWave * FAST_WAVES, st,
                            h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_slots,
                            h->slotsPerImg, h->ini_th, h->min_th, h->fastTileStride, h->fastScoreStride,
-                           h->fastTileRows, h->fastLdsPerWave);
+                           h->fastTileRows, h->fastLdsPerWave, g_debug[0]);
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[2], st));
     {   // K3

@@ -1,6 +1,6 @@
 """Ad-hoc GPU sanity + timing probe (not a test): python tools/quick_gpu.py [B]"""
-import sys, time, importlib, ctypes as C
-sys.path.insert(0, ".")
+import sys, os, time, importlib, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 pkg = importlib.import_module("orb_slam2v2-1_amd")
 synth = importlib.import_module("orb_slam2v2-1_amd.synth")
@@ -33,3 +33,12 @@ dt = (time.time() - t0) / K
 print("B=%d  %.3f ms/batch  %.1f us/img  %.0f img/s" % (B, dt * 1e3, dt * 1e6 / B, B / dt))
 print("stage ms [pyr, fast, octree, describe, total]:", ex.stage_ms())
 print("counts", cnt[:8].tolist())
+if len(sys.argv) > 2 and sys.argv[2] == "ablate":
+    for ph in (1, 2, 3, 0):
+        pkg.lib().orbx_debug_set(0, ph)
+        ex.set_profiling(True)
+        for it in range(5):
+            ex.extract_batch_device(timg.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)
+        torch.cuda.synchronize()
+        print("fast phaseLimit", ph, "stage ms", ex.stage_ms()[0])
+
