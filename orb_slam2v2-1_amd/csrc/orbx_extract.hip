@@ -123,9 +123,9 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, s
 // K2: one wave per 30-px cell (:789-829).  The cell window (cell + 6 px) is staged in LDS
 // as one dword per pixel holding the pixel PAIR (p, p+1) in two 16-bit halves, so that the
 // FAST-9/16 score of two horizontally adjacent pixels is computed at once with packed 16-bit
-// VALU ops (v_pk_sub/min/max_i16) from 17 ds_read_b32:
+// VALU ops from 17 ds_read_b32 (the halves are used as f16 denormals, see below):
 //     d[k]   = centre - ring[k]                                (signed, both pixels)
-//     dark   = max over the 16 nine-arcs of min d   (log-step sliding minimum, 64+15 ops)
+//     dark   = max over the 16 nine-arcs of min d   (3-input minima: windows of 3, then of 9)
 //     bright = -min over the arcs of max d
 //     S      = max(dark, bright) - 1  if > t_lo = min(iniTh, minTh), else 0
 // which is cornerScore<16> of cv::FAST (threshold independent) and its segment test.  Scores
@@ -138,8 +138,13 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, s
 #define FAST_WAVES 4
 typedef short short2v __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ short2v pk_min(short2v a, short2v b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ short2v pk_max(short2v a, short2v b) { return __builtin_elementwise_max(a, b); }
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half2v pk_min3(half2v a, half2v b, half2v c) {
+    return __builtin_elementwise_minimum(__builtin_elementwise_minimum(a, b), c);
+}
+__device__ __forceinline__ half2v pk_max3(half2v a, half2v b, half2v c) {
+    return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
+}
 
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
@@ -172,7 +177,6 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     }
     uint32_t *E = (uint32_t *)(smem + (size_t)wave * ldsPerWave);  // pair tile [th][ES] dwords
     uint8_t *Sc = (uint8_t *)(E + (size_t)ES * tileRows);          // score tile [ch+2][SS], pixel (0,0) at +SS+2
-    uint8_t *Fl = (uint8_t *)E;                                    // NMS flags [ch*cw], reuses E after scoring
 
     {   // stage the window: aligned dword loads (pstride % 4 == 0, so every row has the same misalignment)
         const size_t a = (size_t)(ORBX_EDGE + iniY) * g.pstride + ORBX_EDGE + iniX;
@@ -214,31 +218,41 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
             const uint32_t *q = E + (py + 3) * ES + px + 3;
             const uint32_t *qm3 = q - 3 * ES, *qm2 = q - 2 * ES, *qm1 = q - ES, *qp1 = q + ES, *qp2 = q + 2 * ES,
                            *qp3 = q + 3 * ES;
-            short2v r[16];
             const uint32_t vv = q[0];
             uint32_t rr[16];
             rr[0] = qp3[0];   rr[1] = qp3[1];   rr[2] = qp2[2];   rr[3] = qp1[3];
             rr[4] = q[3];     rr[5] = qm1[3];   rr[6] = qm2[2];   rr[7] = qm3[1];
             rr[8] = qm3[0];   rr[9] = qm3[-1];  rr[10] = qm2[-2]; rr[11] = qm1[-3];
             rr[12] = q[-3];   rr[13] = qp1[-3]; rr[14] = qp2[-2]; rr[15] = qp3[-1];
-            const short2v v = __builtin_bit_cast(short2v, vv);
-            short2v d[16];
+            // A 16-bit half holding the integer n in [0,255] IS the f16 denormal n*2^-24, so the
+            // pixel pairs can be fed to the packed f16 pipe unchanged: differences, 3-input
+            // minima/maxima (v_pk_minimum3_f16 / v_pk_maximum3_f16, gfx950) and negation are exact
+            // on these values, and a positive result's bit pattern is again the integer.
+            const half2v v = __builtin_bit_cast(half2v, vv);
+            half2v d[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) { r[k] = __builtin_bit_cast(short2v, rr[k]); d[k] = v - r[k]; }
-            short2v a1[16], a2[16], a4[16], b1[16], b2[16], b4[16];
+            for (int k = 0; k < 16; k++) d[k] = v - __builtin_bit_cast(half2v, rr[k]);
+            half2v a3[16], b3[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) { a1[k] = pk_min(d[k], d[(k + 1) & 15]); b1[k] = pk_max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-            for (int k = 0; k < 16; k++) { a2[k] = pk_min(a1[k], a1[(k + 2) & 15]); b2[k] = pk_max(b1[k], b1[(k + 2) & 15]); }
-#pragma unroll
-            for (int k = 0; k < 16; k++) { a4[k] = pk_min(a2[k], a2[(k + 4) & 15]); b4[k] = pk_max(b2[k], b2[(k + 4) & 15]); }
-            short2v dark = pk_min(a4[0], d[8]), brt = pk_max(b4[0], d[8]);
-#pragma unroll
-            for (int k = 1; k < 16; k++) {
-                dark = pk_max(dark, pk_min(a4[k], d[(k + 8) & 15]));
-                brt = pk_min(brt, pk_max(b4[k], d[(k + 8) & 15]));
+            for (int k = 0; k < 16; k++) {
+                a3[k] = pk_min3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+                b3[k] = pk_max3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
             }
-            const short2v best = pk_max(dark, -brt);
+            half2v a9[16], b9[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {   // nine-arc starting at k
+                a9[k] = pk_min3(a3[k], a3[(k + 3) & 15], a3[(k + 6) & 15]);
+                b9[k] = pk_max3(b3[k], b3[(k + 3) & 15], b3[(k + 6) & 15]);
+            }
+            half2v dk[5], bt[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                dk[k] = pk_max3(a9[3 * k], a9[3 * k + 1], a9[3 * k + 2]);
+                bt[k] = pk_min3(b9[3 * k], b9[3 * k + 1], b9[3 * k + 2]);
+            }
+            const half2v dark = pk_max3(pk_max3(dk[0], dk[1], dk[2]), pk_max3(dk[3], dk[4], a9[15]), a9[15]);
+            const half2v brt = pk_min3(pk_min3(bt[0], bt[1], bt[2]), pk_min3(bt[3], bt[4], b9[15]), b9[15]);
+            const short2v best = __builtin_bit_cast(short2v, __builtin_elementwise_maximum(dark, -brt));
             const int s0 = best.x, s1 = best.y;
             const uint32_t o0 = s0 > tlo ? (uint32_t)(s0 - 1) : 0u;
             const uint32_t o1 = (s1 > tlo && px + 1 < cw) ? (uint32_t)(s1 - 1) : 0u;
@@ -250,54 +264,72 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     wave_sync();
     if (phaseLimit == 2) return;
 
+    // NMS on pixel pairs (same packed-f16 trick: scores are integers 0..254), appending the
+    // survivors in row-major order to an LDS list (px | py<<8 | score<<16); E is free again.
+    uint32_t *Lst = E;
     bool anyIni = false;
-    {   // NMS flags
-        int py = 0, px = lane;
-        while (px >= cw) { px -= cw; py++; }
-        for (int base = 0; base < npx; base += 64) {
+    int nL = 0;
+    {
+        const int pw2 = (cw + 1) >> 1, npairs = pw2 * ch;
+        int py = 0, j = lane;
+        while (j >= pw2) { j -= pw2; py++; }
+        for (int base = 0; base < npairs; base += 64) {
             const int p = base + lane;
-            bool keep = false, ini = false;
-            if (p < npx) {
-                const uint8_t *s = Sc + (py + 1) * SS + px + 2;
-                const int v = s[0];
-                keep = v > s[-1] && v > s[1] && v > s[-SS - 1] && v > s[-SS] && v > s[-SS + 1] &&
-                       v > s[SS - 1] && v > s[SS] && v > s[SS + 1];
-                ini = keep && v >= iniTh;
-                Fl[p] = keep ? 1 : 0;
+            bool k0 = false, k1 = false;
+            int v0 = 0, v1 = 0;
+            const int px = 2 * j;
+            if (p < npairs) {
+                const uint8_t *sc = Sc + (py + 1) * SS + px;  // pixels px-2 .. px+3 are bytes sc[0..5]
+                half2v l3[3], m3[3], r3[3];
+#pragma unroll
+                for (int rw = 0; rw < 3; rw++) {
+                    const uint8_t *q = sc + (rw - 1) * SS;
+                    const uint32_t A = *(const uint16_t *)q, M = *(const uint16_t *)(q + 2), C = *(const uint16_t *)(q + 4);
+                    l3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(M, A, 0x0c040c01u));  // (px-1, px)
+                    m3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(M, M, 0x0c010c00u));  // (px, px+1)
+                    r3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(C, M, 0x0c040c01u));  // (px+1, px+2)
+                }
+                const half2v nb = pk_max3(pk_max3(l3[0], m3[0], r3[0]), pk_max3(l3[2], m3[2], r3[2]),
+                                          __builtin_elementwise_maximum(l3[1], r3[1]));
+                const short2v gt = __builtin_bit_cast(short2v, m3[1] - nb);  // > 0 iff strictly greater
+                const short2v cv = __builtin_bit_cast(short2v, m3[1]);
+                v0 = cv.x; v1 = cv.y;
+                k0 = gt.x > 0;
+                k1 = gt.y > 0 && px + 1 < cw;
             }
-            anyIni |= (__ballot(ini) != 0ull);
-            px += 64;
-            while (px >= cw) { px -= cw; py++; }
+            anyIni |= (__ballot((k0 && v0 >= iniTh) || (k1 && v1 >= iniTh)) != 0ull);
+            const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1), lt = (1ull << lane) - 1ull;
+            int pos = nL + __popcll(m0 & lt) + __popcll(m1 & lt);
+            if (k0) Lst[pos++] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)v0 << 16);
+            if (k1) Lst[pos] = (uint32_t)(px + 1) | ((uint32_t)py << 8) | ((uint32_t)v1 << 16);
+            nL += __popcll(m0) + __popcll(m1);
+            j += 64;
+            while (j >= pw2) { j -= pw2; py++; }
         }
     }
     wave_sync();
     if (phaseLimit == 3) return;
 
+    // per-cell threshold fallback (:809-816) + ordered emission
     const int thr = anyIni ? iniTh : minTh;
     uint32_t *out = slots + (size_t)b * slotsPerImg + g.slotOff + (size_t)c * g.capc;
     int total = 0;
-    {   // ordered (row-major) compaction
-        int py = 0, px = lane;
-        while (px >= cw) { px -= cw; py++; }
-        for (int base = 0; base < npx; base += 64) {
-            const int p = base + lane;
-            bool emit = false;
-            int v = 0;
-            if (p < npx) {
-                v = Sc[(py + 1) * SS + px + 2];
-                emit = Fl[p] && v >= thr;
-            }
-            const unsigned long long m = __ballot(emit);
-            if (emit) {
-                const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
-                if (pos < g.capc)
-                    out[pos] = (uint32_t)(px + 3 + cj * g.wCell) | ((uint32_t)(py + 3 + ci * g.hCell) << 12) |
-                               ((uint32_t)v << 24);
-            }
-            total += __popcll(m);
-            px += 64;
-            while (px >= cw) { px -= cw; py++; }
+    for (int base = 0; base < nL; base += 64) {
+        const int i = base + lane;
+        uint32_t e = 0;
+        bool emit = false;
+        if (i < nL) {
+            e = Lst[i];
+            emit = (int)(e >> 16) >= thr;
         }
+        const unsigned long long m = __ballot(emit);
+        if (emit) {
+            const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < g.capc)
+                out[pos] = (uint32_t)((e & 0xFF) + 3 + cj * g.wCell) | ((uint32_t)(((e >> 8) & 0xFF) + 3 + ci * g.hCell) << 12) |
+                           ((e >> 16) << 24);
+        }
+        total += __popcll(m);
     }
     if (lane == 0) *cnt = (uint32_t)min(total, g.capc);
 }
