@@ -178,26 +178,24 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     uint32_t *E = (uint32_t *)(smem + (size_t)wave * ldsPerWave);  // pair tile [th][ES] dwords
     uint8_t *Sc = (uint8_t *)(E + (size_t)ES * tileRows);          // score tile [ch+2][SS], pixel (0,0) at +SS+2
 
-    {   // stage the window: aligned dword loads (pstride % 4 == 0, so every row has the same misalignment)
-        const size_t a = (size_t)(ORBX_EDGE + iniY) * g.pstride + ORBX_EDGE + iniX;
-        const int sh = (int)(a & 3);
+    // stage the window: aligned dword loads (pstride % 4 == 0, so every row has the same misalignment)
+    const size_t a = (size_t)(ORBX_EDGE + iniY) * g.pstride + ORBX_EDGE + iniX;
+    const int sh = (int)(a & 3);
+    {
         const uint32_t *src = (const uint32_t *)(pyr + (size_t)b * pyrImgBytes + g.poff + (a - sh));
         const int nd = (sh + tw + 3) >> 2, pstr4 = g.pstride >> 2, items = nd * th;
+        // E column index = byte offset inside the aligned row (window column + sh): every item
+        // is one aligned 16-byte LDS write, no bounds checks
         int r = 0, q = lane;
         while (q >= nd) { q -= nd; r++; }
         for (int i = lane; i < items; i += 64) {
             const uint32_t d0 = src[(size_t)r * pstr4 + q], d1 = src[(size_t)r * pstr4 + q + 1];
-            // bytes b0..b3 of d0 and b4 = first byte of d1 -> pairs (b0,b1) (b1,b2) (b2,b3) (b3,b4)
-            const uint32_t e0 = (d0 & 0xFF) | ((d0 & 0xFF00) << 8);
-            const uint32_t e1 = ((d0 >> 8) & 0xFF) | ((d0 >> 8) & 0xFF00) << 8;
-            const uint32_t e2 = ((d0 >> 16) & 0xFF) | ((d0 >> 16) & 0xFF00) << 8;
-            const uint32_t e3 = (d0 >> 24) | ((d1 & 0xFF) << 16);
-            const int c0 = 4 * q - sh;
-            uint32_t *row = E + r * ES;
-            if (c0 >= 0 && c0 < tw) row[c0] = e0;
-            if (c0 + 1 >= 0 && c0 + 1 < tw) row[c0 + 1] = e1;
-            if (c0 + 2 >= 0 && c0 + 2 < tw) row[c0 + 2] = e2;
-            if (c0 + 3 >= 0 && c0 + 3 < tw) row[c0 + 3] = e3;
+            uint4 e;  // bytes b0..b3 of d0 and b4 = first byte of d1 -> pairs (b0,b1) (b1,b2) (b2,b3) (b3,b4)
+            e.x = __builtin_amdgcn_perm(d1, d0, 0x0c010c00u);
+            e.y = __builtin_amdgcn_perm(d1, d0, 0x0c020c01u);
+            e.z = __builtin_amdgcn_perm(d1, d0, 0x0c030c02u);
+            e.w = __builtin_amdgcn_perm(d1, d0, 0x0c040c03u);
+            *(uint4 *)(E + r * ES + 4 * q) = e;
             q += 64;
             while (q >= nd) { q -= nd; r++; }
         }
@@ -208,14 +206,13 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     if (phaseLimit == 1) return;
 
     const int tlo = max(min(iniTh, minTh), 0);
-    const int npx = cw * ch;
     {   // scores, two pixels per lane
         const int pw2 = (cw + 1) >> 1, npairs = pw2 * ch;
         int py = 0, j = lane;
         while (j >= pw2) { j -= pw2; py++; }
         for (int p = lane; p < npairs; p += 64) {
             const int px = 2 * j;
-            const uint32_t *q = E + (py + 3) * ES + px + 3;
+            const uint32_t *q = E + (py + 3) * ES + px + 3 + sh;
             const uint32_t *qm3 = q - 3 * ES, *qm2 = q - 2 * ES, *qm1 = q - ES, *qp1 = q + ES, *qp2 = q + 2 * ES,
                            *qp3 = q + 3 * ES;
             const uint32_t vv = q[0];
@@ -335,6 +332,58 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
 }
 
 // ------------------------------------------------------------------------------------
+// K2b: per (level, image): exclusive scan of the cell counts = offsets of the cell lists in
+// the ordered concatenation (vToDistributeKeys order, :789-828).
+__global__ __launch_bounds__(256) void k_cell_scan(const LevelGeom *__restrict__ geom, int nlevels, int totalCells,
+                                                   const uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ cellOff,
+                                                   int32_t *__restrict__ candCnt) {
+    __shared__ int wsum[4];
+    const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const LevelGeom g = geom[l];
+    const uint32_t *cc = cellCnt + (size_t)b * totalCells + g.cellBase;
+    uint32_t *co = cellOff + (size_t)b * totalCells + g.cellBase;
+    const int chunk = (g.ncells + 255) / 256;
+    const int beg = min(tid * chunk, g.ncells), end = min(beg + chunk, g.ncells);
+    int s = 0;
+    for (int c = beg; c < end; c++) s += (int)cc[c];
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int off = inc - s, tot = 0;
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) off += wsum[w];
+        tot += wsum[w];
+    }
+    for (int c = beg; c < end; c++) {
+        co[c] = (uint32_t)off;
+        off += (int)cc[c];
+    }
+    if (tid == 0) candCnt[b * nlevels + l] = tot;
+}
+
+// K2c: sixteen lanes per cell copy its candidate list to its place in the level's key array.
+#define GATHER_CELLS_PER_BLOCK 16
+__global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ geom, int nlevels, int totalCells,
+                                                const uint32_t *__restrict__ cellCnt, const uint32_t *__restrict__ cellOff,
+                                                const uint32_t *__restrict__ slots, size_t slotsPerImg,
+                                                uint32_t *__restrict__ cand, size_t keysPerImg) {
+    const int sub = threadIdx.x & 15;
+    const int gc = blockIdx.x * GATHER_CELLS_PER_BLOCK + (threadIdx.x >> 4), b = blockIdx.y;
+    if (gc >= totalCells) return;
+    int l = 0;
+    while (l + 1 < nlevels && gc >= geom[l + 1].cellBase) l++;
+    const int c = gc - geom[l].cellBase, capc = geom[l].capc;
+    const int cn = (int)cellCnt[(size_t)b * totalCells + gc], off = (int)cellOff[(size_t)b * totalCells + gc];
+    const uint32_t *src = slots + (size_t)b * slotsPerImg + geom[l].slotOff + (size_t)c * capc;
+    uint32_t *dst = cand + (size_t)b * keysPerImg + geom[l].keyOff + off;
+    for (int j = sub; j < cn; j += 16) dst[j] = src[j];
+}
+
 // K3: DistributeOctTree (:539-763), one workgroup per (level, image).
 //
 // Parallel restatement of the reference's std::list surgery (validated against the literal
@@ -350,7 +399,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
 //    fixes "later-created first" == smaller list index first.
 //  * a key's child is a pure function of (x, y, parent box): keys never move in memory,
 //    only their 16-bit node index is rewritten.
-#define OCT_T 512
+#define OCT_T 1024
 
 struct OctLds {
     short4 *box[2];
@@ -421,14 +470,15 @@ __device__ int array_scan_excl(int *a, int m, int *wsum) {
     return total;
 }
 
-__global__ __launch_bounds__(OCT_T, 2) void k_octree(
+__global__ __launch_bounds__(OCT_T) void k_octree(
     const LevelGeom *__restrict__ geom, int nlevels, int totalCells, const uint32_t *__restrict__ cellCnt,
     const uint32_t *__restrict__ slots, size_t slotsPerImg, uint32_t *__restrict__ cand,
-    uint16_t *__restrict__ nodeOf, size_t keysPerImg, int32_t *__restrict__ candCnt,
+    uint16_t *__restrict__ nodeOf, size_t keysPerImg, const int32_t *__restrict__ candCnt,
     uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
-    const int32_t *__restrict__ tab, int capMax, int pow2cap, int scratchInts) {
+    const int32_t *__restrict__ tab, int capMax, int pow2cap, int scratchInts, int dbgStop) {
     extern __shared__ __align__(16) uint8_t smem[];
-    const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    // level-major block order: the large levels start first and the small ones fill the gaps
+    const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
     const LevelGeom g = geom[l];
     // ---- carve LDS
     uint8_t *sp = smem;
@@ -449,38 +499,30 @@ __global__ __launch_bounds__(OCT_T, 2) void k_octree(
     __shared__ int sh_i[8];  // scalars: 0 S(plit count) 1 nToExpand
     __shared__ int rootCnt[ORBX_MAX_ROOTS], rootMap[ORBX_MAX_ROOTS];
 
-    const uint32_t *ccnt = cellCnt + (size_t)b * totalCells + g.cellBase;
-    const uint32_t *cslots = slots + (size_t)b * slotsPerImg + g.slotOff;
     uint32_t *keys = cand + (size_t)b * keysPerImg + g.keyOff;
     uint16_t *nof = nodeOf + (size_t)b * keysPerImg + g.keyOff;
 
-    // ---- A. ordered concatenation of the cell lists (vToDistributeKeys order, :789-828)
-    int *coff = (int *)S.hist;
-    for (int c = tid; c < g.ncells; c += OCT_T) coff[c] = (int)ccnt[c];
-    __syncthreads();
-    const int n = array_scan_excl(coff, g.ncells, wsum);
-    {
-        const int wave = tid >> 6, lane = tid & 63;
-        for (int c = wave; c < g.ncells; c += OCT_T / 64) {
-            const int cn = (int)ccnt[c], o = coff[c];
-            for (int j = lane; j < cn; j += 64) keys[o + j] = cslots[(size_t)c * g.capc + j];
-        }
-    }
-    if (tid == 0) candCnt[b * nlevels + l] = n;
+    // ---- A/B. keys were gathered in vToDistributeKeys order by k_cell_scan + k_gather
+    const int n = candCnt[b * nlevels + l];
+    const uint8_t *rootOf = (const uint8_t *)tab + g.rootTabOff;
     if (tid < ORBX_MAX_ROOTS) rootCnt[tid] = 0;
     __syncthreads();
-
-    // ---- B. root nodes (:543-592)
-    const uint8_t *rootOf = (const uint8_t *)tab + g.rootTabOff;
-    for (int i = tid; i < n; i += OCT_T) {
-        const int r = rootOf[keys[i] & 0xFFF];  // (int)(kp.pt.x / hX), tabulated on the host
-        nof[i] = (uint16_t)r;
-        atomicAdd(&rootCnt[r], 1);
+    {   // keys per root (:569): per-wave ballot counts, one LDS atomic per wave and root
+        const int lane = tid & 63;
+        for (int i0 = 0; i0 < n; i0 += OCT_T) {
+            const int i = i0 + tid;
+            const int r = i < n ? (int)rootOf[keys[i] & 0xFFF] : -1;
+            for (int q = 0; q < g.nIni; q++) {
+                const unsigned long long m = __ballot(r == q);
+                if (lane == 0 && m) atomicAdd(&rootCnt[q], (int)__popcll(m));
+            }
+        }
     }
     __syncthreads();
+    if (dbgStop == 2) return;
     __shared__ int sh_L;
     if (tid == 0) {
-        int L = 0;
+        int L0 = 0;
         for (int r = 0; r < g.nIni; r++) {
             if (rootCnt[r] > 0) {
                 short4 bx;
@@ -488,38 +530,51 @@ __global__ __launch_bounds__(OCT_T, 2) void k_octree(
                 bx.y = (short)tab[g.rootBoxOff + r + 1];
                 bx.z = 0;
                 bx.w = (short)g.regH;
-                S.box[0][L] = bx;
-                S.cnt[0][L] = (uint32_t)rootCnt[r] | 0x80000000u;
-                rootMap[r] = L++;
+                S.box[0][L0] = bx;
+                S.cnt[0][L0] = (uint32_t)rootCnt[r] | 0x80000000u;
+                rootMap[r] = L0++;
             }
         }
-        sh_L = L;
+        sh_L = L0;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += OCT_T) nof[i] = (uint16_t)rootMap[nof[i]];
     int L = sh_L;
     int cur = 0, phase = 1;
     const int N = g.N;
-    bool finish = false;
-
-    // ---- C. passes
-    while (!finish) {
-        short4 *box = S.box[cur], *nbox = S.box[cur ^ 1];
-        uint32_t *cnt = S.cnt[cur], *ncnt = S.cnt[cur ^ 1];
-        // 1. children histograms of the expandable (fresh, >1 key) nodes
-        for (int i = tid; i < 4 * L; i += OCT_T) S.hist[i] = 0;
-        if (tid < 2) sh_i[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += OCT_T) {
-            const int k = nof[i];
-            const uint32_t cv = cnt[k];
-            if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) {
-                const uint32_t key = keys[i];
-                atomicAdd(&S.hist[4 * k + child_of(key & 0xFFF, (key >> 12) & 0xFFF, box[k])], 1u);
+    for (int i = tid; i < 4 * L; i += OCT_T) S.hist[i] = 0;  // coff is dead from here on
+    __syncthreads();
+    // first sweep: list index of the root + children histogram of the expandable roots
+    for (int i0 = tid; i0 < n; i0 += 4 * OCT_T) {
+        uint32_t key[4];
+        int kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * OCT_T;
+            key[u] = i < n ? keys[i] : 0u;
+            kk[u] = rootOf[key[u] & 0xFFF];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * OCT_T;
+            if (i < n) {
+                const int k = rootMap[kk[u]];
+                nof[i] = (uint16_t)k;
+                const uint32_t cv = S.cnt[0][k];
+                if ((cv & 0x7FFFFFFFu) > 1)
+                    atomicAdd(&S.hist[4 * k + child_of(key[u] & 0xFFF, (key[u] >> 12) & 0xFFF, S.box[0][k])], 1u);
             }
         }
-        __syncthreads();
-        // 2. visiting order
+    }
+    __syncthreads();
+
+    if (dbgStop == 3) return;
+    int npass = 0;
+    // ---- C. passes.  On entry S.hist holds the children key counts of every expandable node.
+    while (true) {
+        short4 *box = S.box[cur], *nbox = S.box[cur ^ 1];
+        uint32_t *cnt = S.cnt[cur], *ncnt = S.cnt[cur ^ 1];
+        if (tid < 2) sh_i[tid] = 0;
+        // 1. visiting order of the expandable (fresh, >1 key) nodes
         int E;
         if (phase == 1) {
             int *flag = S.pn;
@@ -528,8 +583,7 @@ __global__ __launch_bounds__(OCT_T, 2) void k_octree(
                 flag[k] = ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) ? 1 : 0;
             }
             __syncthreads();
-            // compaction in list order
-            const int chunk = (L + OCT_T - 1) / OCT_T;
+            const int chunk = (L + OCT_T - 1) / OCT_T;  // compaction in list order
             const int beg = min(tid * chunk, L), end = min(beg + chunk, L);
             int s = 0;
             for (int k = beg; k < end; k++) s += flag[k];
@@ -550,13 +604,13 @@ __global__ __launch_bounds__(OCT_T, 2) void k_octree(
                 S.skey[k] = key;
             }
             __syncthreads();
-            for (int kk = 2; kk <= P; kk <<= 1)
-                for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int kk2 = 2; kk2 <= P; kk2 <<= 1)
+                for (int j = kk2 >> 1; j > 0; j >>= 1) {
                     for (int i = tid; i < P; i += OCT_T) {
                         const int ixj = i ^ j;
                         if (ixj > i) {
                             const unsigned long long a = S.skey[i], c2 = S.skey[ixj];
-                            const bool asc = (i & kk) == 0;
+                            const bool asc = (i & kk2) == 0;
                             if ((a > c2) == asc) { S.skey[i] = c2; S.skey[ixj] = a; }
                         }
                     }
@@ -565,21 +619,17 @@ __global__ __launch_bounds__(OCT_T, 2) void k_octree(
             int e = 0;
             for (int k = tid; k < L; k += OCT_T)
                 if (S.skey[k] != ~0ull) { S.xlist[k] = (uint16_t)(S.skey[k] & 0xFFFFu); e++; }
-            int dummy = block_scan_excl(e, wsum, &E);
-            (void)dummy;
+            (void)block_scan_excl(e, wsum, &E);
             __syncthreads();
         }
-        // 3. per-rank created children (nz) and gain (nz-1), inclusive prefixes
+        // 2. children created per rank -> exclusive prefix by rank
         for (int r = tid; r < E; r += OCT_T) {
             const int k = S.xlist[r];
-            const int nz = (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) +
-                           (S.hist[4 * k + 3] > 0);
-            S.pn[r] = nz;
+            S.pn[r] = (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) + (S.hist[4 * k + 3] > 0);
         }
         __syncthreads();
-        array_scan_excl(S.pn, E, wsum);  // exclusive prefix of nz by rank
-        // gain prefix: incl_gain[r] = excl_nz[r] + nz[r] - (r+1)
-        // 4. number of parents split
+        array_scan_excl(S.pn, E, wsum);
+        // 3. number of parents split (phase 2 stops at the first rank that reaches N, :730-731)
         if (tid == 0) sh_i[0] = E;
         __syncthreads();
         if (phase == 2) {
@@ -587,22 +637,20 @@ __global__ __launch_bounds__(OCT_T, 2) void k_octree(
                 const int k = S.xlist[r];
                 const int nz = (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) +
                                (S.hist[4 * k + 3] > 0);
-                const int after = L + S.pn[r] + nz - (r + 1);   // list size after splitting rank r
-                const int before = L + S.pn[r] - r;             // ... before it
-                if (after >= N && before < N) sh_i[0] = r + 1;  // the break at :730-731
+                const int after = L + S.pn[r] + nz - (r + 1);  // list size after splitting rank r
+                const int before = L + S.pn[r] - r;            // ... before it
+                if (after >= N && before < N) sh_i[0] = r + 1;
             }
             __syncthreads();
         }
         const int Sp = sh_i[0];
-        // total created
         __shared__ int sh_C;
         if (tid == 0) {
             int C = 0;
             if (Sp > 0) {
                 const int k = S.xlist[Sp - 1];
-                const int nz = (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) +
-                               (S.hist[4 * k + 3] > 0);
-                C = S.pn[Sp - 1] + nz;
+                C = S.pn[Sp - 1] + (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) +
+                    (S.hist[4 * k + 3] > 0);
             }
             sh_C = C;
         }
@@ -610,7 +658,7 @@ __global__ __launch_bounds__(OCT_T, 2) void k_octree(
         __syncthreads();
         const int C = sh_C;
         const int Lnew = L - Sp + C;
-        // 5. create children: sequence s -> new index C-1-s
+        // 4. create children: creation sequence s -> list index C-1-s (every insertion is push_front)
         int nexp = 0;
         for (int r = tid; r < Sp; r += OCT_T) {
             const int k = S.xlist[r];
@@ -632,8 +680,7 @@ __global__ __launch_bounds__(OCT_T, 2) void k_octree(
         }
         if (nexp) atomicAdd(&sh_i[1], nexp);
         __syncthreads();
-        // survivors keep their relative order behind the new nodes
-        {
+        {   // survivors keep their relative order behind the new nodes
             const int chunk = (L + OCT_T - 1) / OCT_T;
             const int beg = min(tid * chunk, L), end = min(beg + chunk, L);
             int s = 0;
@@ -648,32 +695,52 @@ __global__ __launch_bounds__(OCT_T, 2) void k_octree(
                     S.survIdx[k] = (uint16_t)ni;
                 }
         }
-        __syncthreads();
-        // 6. re-index the keys
-        for (int i = tid; i < n; i += OCT_T) {
-            const int k = nof[i];
-            if (S.split[k]) {
-                const uint32_t key = keys[i];
-                nof[i] = S.childIdx[4 * k + child_of(key & 0xFFF, (key >> 12) & 0xFFF, box[k])];
-            } else
-                nof[i] = S.survIdx[k];
-        }
         const int nToExpand = sh_i[1];
-        // 7. termination (:669-672, :733-734)
-        if (Lnew >= N || Lnew == L) finish = true;
-        else if (phase == 1 && Lnew + 3 * nToExpand > N) phase = 2;
+        // 5. termination (:669-672, :733-734)
+        const bool finish = (Lnew >= N || Lnew == L);
+        if (!finish && phase == 1 && Lnew + 3 * nToExpand > N) phase = 2;
+        // 6. one sweep over the keys: new node index + (children histogram of the next pass |
+        //    best key of every node, first maximum wins (:744-760))
+        const int nz = finish ? Lnew : 4 * Lnew;
+        __syncthreads();  // hist / pn consumed
+        for (int i = tid; i < nz; i += OCT_T) S.hist[i] = 0;
+        __syncthreads();
+        for (int i0 = tid; i0 < n; i0 += 4 * OCT_T) {
+            uint32_t key[4];
+            int kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * OCT_T;
+                key[u] = i < n ? keys[i] : 0u;
+                kk[u] = i < n ? (int)nof[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * OCT_T;
+                if (i < n) {
+                    const int ko = kk[u];
+                    const int x = key[u] & 0xFFF, y = (key[u] >> 12) & 0xFFF;
+                    const int k = S.split[ko] ? (int)S.childIdx[4 * ko + child_of(x, y, box[ko])] : (int)S.survIdx[ko];
+                    if (finish) {
+                        atomicMax(&S.hist[k], ((key[u] >> 24) << 20) | (0xFFFFFu - (uint32_t)i));
+                    } else {
+                        nof[i] = (uint16_t)k;
+                        const uint32_t cv = ncnt[k];
+                        if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1)
+                            atomicAdd(&S.hist[4 * k + child_of(x, y, nbox[k])], 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
         L = Lnew;
         cur ^= 1;
-        __syncthreads();
+        if (finish) break;
+        if (dbgStop >= 4 && ++npass >= dbgStop - 3) return;
     }
 
-    // ---- D. best key of every node, first maximum wins (:744-760); output in list order
-    uint32_t *best = S.hist;
-    for (int k = tid; k < L; k += OCT_T) best[k] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += OCT_T)
-        atomicMax(&best[nof[i]], ((keys[i] >> 24) << 20) | (0xFFFFFu - (uint32_t)i));
-    __syncthreads();
+    // ---- D. output in list order
+    const uint32_t *best = S.hist;
     uint32_t *okp = lvlKp + (size_t)b * lvlKpCap + g.lvlKpOff;
     const int Lout = min(L, g.nodeCap);
     for (int k = tid; k < Lout; k += OCT_T) okp[k] = keys[0xFFFFFu - (best[k] & 0xFFFFFu)];
@@ -954,6 +1021,7 @@ extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int i
 }
 
 static void free_plan(orbx_extractor *h) {
+    hipFree(h->d_cellOff); h->d_cellOff = nullptr;
     hipFree(h->d_geom); hipFree(h->d_tab); hipFree(h->d_pyr); hipFree(h->d_cellCnt); hipFree(h->d_slots);
     hipFree(h->d_cand); hipFree(h->d_lvlKp); hipFree(h->d_nodeOf); hipFree(h->d_candCnt); hipFree(h->d_lvlCnt);
     h->d_geom = nullptr; h->d_tab = nullptr; h->d_pyr = nullptr; h->d_cellCnt = nullptr; h->d_slots = nullptr;
@@ -1126,7 +1194,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     h->pyrImgBytes = (poff + 255) & ~(size_t)255;
     h->slotsPerImg = slotOff;
     h->keysPerImg = (keyOff + 1) & ~(size_t)1;
-    h->fastTileStride = maxTw;                       // dwords per pair-tile row
+    h->fastTileStride = (maxTw + 6 + 3) & ~3;        // dwords per pair-tile row (column = byte offset in the aligned row)
     h->fastScoreStride = (maxTw - 6 + 4 + 3) & ~3;   // bytes per score row: 2-px left halo + >= 2 right
     h->fastTileRows = maxTh;
     h->fastLdsPerWave = (4 * h->fastTileStride * maxTh + h->fastScoreStride * (maxTh - 4) + 15) & ~15;
@@ -1147,6 +1215,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     ORBX_HIP(hipMalloc(&h->d_tab, sizeof(int32_t) * std::max<size_t>(tab.size(), 1)));
     ORBX_HIP(hipMalloc(&h->d_pyr, h->pyrImgBytes * Bz));
     ORBX_HIP(hipMalloc(&h->d_cellCnt, sizeof(uint32_t) * h->totalCells * Bz));
+    ORBX_HIP(hipMalloc(&h->d_cellOff, sizeof(uint32_t) * h->totalCells * Bz));
     ORBX_HIP(hipMalloc(&h->d_slots, sizeof(uint32_t) * h->slotsPerImg * Bz));
     ORBX_HIP(hipMalloc(&h->d_cand, sizeof(uint32_t) * h->keysPerImg * Bz));
     ORBX_HIP(hipMalloc(&h->d_nodeOf, sizeof(uint16_t) * h->keysPerImg * Bz));
@@ -1217,10 +1286,15 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
         const int scratch = std::max(4 * h->maxNodeCap, maxCells + 1);
         ORBX_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->octLdsBytes));
-        hipLaunchKernelGGL(k_octree, dim3(nl, B), dim3(OCT_T), h->octLdsBytes, st, h->d_geom, nl, h->totalCells,
+        hipLaunchKernelGGL(k_cell_scan, dim3(nl, B), dim3(256), 0, st, h->d_geom, nl, h->totalCells, h->d_cellCnt,
+                           h->d_cellOff, h->d_candCnt);
+        hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
+                           dim3(256), 0, st, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_cellOff, h->d_slots,
+                           h->slotsPerImg, h->d_cand, h->keysPerImg);
+        hipLaunchKernelGGL(k_octree, dim3(B, nl), dim3(OCT_T), h->octLdsBytes, st, h->d_geom, nl, h->totalCells,
                            h->d_cellCnt, h->d_slots, h->slotsPerImg, h->d_cand, h->d_nodeOf, h->keysPerImg,
-                           h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2,
-                           scratch);
+                           h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2, scratch,
+                           g_debug[1]);
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[3], st));
     {   // K4

@@ -72,7 +72,7 @@ struct orbx_extractor {
     LevelGeom *d_geom;
     int32_t *d_tab;
     uint8_t *d_pyr;
-    uint32_t *d_cellCnt, *d_slots, *d_cand, *d_lvlKp;
+    uint32_t *d_cellCnt, *d_cellOff, *d_slots, *d_cand, *d_lvlKp;
     uint16_t *d_nodeOf;
     int32_t *d_candCnt, *d_lvlCnt;
     // staging for the host API

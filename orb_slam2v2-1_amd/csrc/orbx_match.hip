@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
 }
 
 // one workgroup per frame: median of the SAD distances of the accepted matches
-// (sort + vDistIdx[size/2], :641-642) by rank counting on (dist, iL) pairs, then drop
+// (sort + vDistIdx[size/2], :641-642) by a two-level radix select, then drop
 // every match with dist >= 1.5*1.4*median (:643-654).
 #define SM_T 256
 __global__ __launch_bounds__(SM_T) void k_stereo_median(const int32_t *__restrict__ nl, int cap,
@@ -246,16 +246,30 @@ __global__ __launch_bounds__(SM_T) void k_stereo_median(const int32_t *__restric
         if (nmatch && tid == 0) nmatch[b] = 0;
         return;
     }
+    // median = element of rank nd/2 of the sorted SAD distances (values < 2^16: 121*510 max):
+    // two-level radix select on (high byte, low byte) histograms
+    __shared__ int hist[256];
+    __shared__ int sh_hi, sh_rank;
     const int target = nd / 2;
-    for (int i = tid; i < N; i += SM_T) {
-        const int s = sd[i];
-        if (s < 0) continue;
-        int rank = 0;
-        for (int j = 0; j < N; j++) {
-            const int t = sd[j];
-            rank += (t >= 0) && (t < s || (t == s && j < i));
-        }
-        if (rank == target) sh_med = s;
+    hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += SM_T) { const int s = sd[i]; if (s >= 0) atomicAdd(&hist[(s >> 8) & 0xFF], 1); }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, h = 0;
+        for (; h < 256; h++) { if (acc + hist[h] > target) break; acc += hist[h]; }
+        sh_hi = h; sh_rank = target - acc;
+    }
+    __syncthreads();
+    const int hi8 = sh_hi;
+    hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += SM_T) { const int s = sd[i]; if (s >= 0 && ((s >> 8) & 0xFF) == hi8) atomicAdd(&hist[s & 0xFF], 1); }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, lo = 0;
+        for (; lo < 256; lo++) { if (acc + hist[lo] > sh_rank) break; acc += hist[lo]; }
+        sh_med = (hi8 << 8) | lo;
     }
     __syncthreads();
     const float median = (float)sh_med;

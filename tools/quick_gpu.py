@@ -33,6 +33,14 @@ dt = (time.time() - t0) / K
 print("B=%d  %.3f ms/batch  %.1f us/img  %.0f img/s" % (B, dt * 1e3, dt * 1e6 / B, B / dt))
 print("stage ms [pyr, fast, octree, describe, total]:", ex.stage_ms())
 print("counts", cnt[:8].tolist())
+if len(sys.argv) > 2 and sys.argv[2] == "ablate_oct":
+    for ph in (1, 2, 3, 4, 5, 6, 7, 0):
+        pkg.lib().orbx_debug_set(1, ph)
+        ex.set_profiling(True)
+        for it in range(5):
+            ex.extract_batch_device(timg.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)
+        torch.cuda.synchronize()
+        print("octree dbgStop", ph, "stage ms", ex.stage_ms()[0])
 if len(sys.argv) > 2 and sys.argv[2] == "ablate":
     for ph in (1, 2, 3, 0):
         pkg.lib().orbx_debug_set(0, ph)
