@@ -2,7 +2,7 @@
 //
 // Replaces ORBextractor::operator() of kimwin2/ORB_SLAM2v2-1 (reference:
 // src/ORBextractor.cc:1043-1105) for batches of equally sized frames:
-//   K1 k_pyr_level0 / k_pyr_resize   ComputePyramid                 (:1107-1132)
+//   K1 k_pyramid_fused               ComputePyramid, one launch      (:1107-1132)
 //   K2 k_fast_cells                  per-cell cv::FAST + fallback   (:789-829)
 //   K3 k_octree                      DistributeOctTree              (:539-763)
 //   K4 k_describe                    IC_Angle + GaussianBlur + rBRIEF (:77-147, :1085-1090)
@@ -57,66 +57,123 @@ __device__ __forceinline__ int reflect101(int i, int n) {  // valid for -n < i <
 }
 
 // ------------------------------------------------------------------------------------
-// K1a: level 0 = input + 19 px BORDER_REFLECT_101 (copyMakeBorder, :1127-1128)
-// one thread = 4 consecutive bytes of a padded row (one dword store)
-__global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t *__restrict__ src, int sstride,
-                                                    size_t simg, uint8_t *__restrict__ pyr,
-                                                    size_t pyrImgBytes, const LevelGeom *__restrict__ geom) {
-    const LevelGeom g = geom[0];
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int y = blockIdx.y, b = blockIdx.z;
-    if (x4 >= g.pstride) return;
-    const int iy = reflect101(y - ORBX_EDGE, g.h);
-    const uint8_t *srow = src + (size_t)b * simg + (size_t)iy * sstride;
-    uint32_t out = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int px = x4 + i;
-        uint32_t v = 0;
-        if (px < g.w + 2 * ORBX_EDGE) v = srow[reflect101(px - ORBX_EDGE, g.w)];
-        out |= v << (8 * i);
-    }
-    *(uint32_t *)(pyr + (size_t)b * pyrImgBytes + g.poff + (size_t)y * g.pstride + x4) = out;
-}
+// K1: ComputePyramid (:1107-1132) in ONE launch.  A workgroup owns a tile of the coarsest
+// level and, through the resize source offsets, the corresponding rectangles of every finer
+// level.  It loads its level-0 rectangle from the input once, then computes level after level
+// from the previous one held in LDS (ping-pong), so a level is never read back from memory to
+// build the next.  Rectangles: own_l partitions level l across the tiles; comp_l = own_l plus
+// whatever comp_{l+1} needs (1-2 px of halo per level, recomputed by neighbouring tiles, never
+// written twice).  Arithmetic per pixel is exactly K1b's: 8UC1 fixed-point bilinear of OpenCV
+// <= 3.3 with the host-built coefficient tables; the 19-px BORDER_REFLECT_101 frame
+// (copyMakeBorder, :1122-1128) is written by the owner of the mirrored inner pixel.
+struct PyrSpan { short o0, o1, c0, c1; };  // owned [o0,o1) and computed [c0,c1) range along one axis
 
-// K1b: level l = cv::resize(level l-1, INTER_LINEAR) + border (:1120-1123).
-// 8UC1 fixed-point bilinear of OpenCV <=3.3: coefficients cvRound(w*2048) (tables built on the
-// host in double/float exactly as resize() does), horizontal pass to int32, vertical
-// ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2 >> 2.
-__global__ __launch_bounds__(256) void k_pyr_resize(uint8_t *__restrict__ pyr, size_t pyrImgBytes,
-                                                    const LevelGeom *__restrict__ geom, int level,
-                                                    const int32_t *__restrict__ tab) {
-    const LevelGeom g = geom[level];
-    const LevelGeom gp = geom[level - 1];
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int y = blockIdx.y, b = blockIdx.z;
-    if (x4 >= g.pstride) return;
-    uint8_t *base = pyr + (size_t)b * pyrImgBytes;
-    const uint8_t *S = base + gp.poff + (size_t)ORBX_EDGE * gp.pstride + ORBX_EDGE;  // inner ROI of l-1
-    const int iy = reflect101(y - ORBX_EDGE, g.h);
-    const int sy0 = tab[g.yofsOff + iy];
-    const int bb = tab[g.ybetaOff + iy];
-    const int b0 = (int16_t)(bb & 0xFFFF), b1 = (int16_t)(bb >> 16);
-    const int r0 = min(max(sy0, 0), gp.h - 1), r1 = min(max(sy0 + 1, 0), gp.h - 1);
-    const uint8_t *S0 = S + (size_t)r0 * gp.pstride, *S1 = S + (size_t)r1 * gp.pstride;
-    uint32_t out = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int px = x4 + i;
-        uint32_t v = 0;
-        if (px < g.w + 2 * ORBX_EDGE) {
-            const int ix = reflect101(px - ORBX_EDGE, g.w);
-            const int sx = tab[g.xofsOff + ix];
-            const int aa = tab[g.xalphaOff + ix];
-            const int a0 = (int16_t)(aa & 0xFFFF), a1 = (int16_t)(aa >> 16);
-            // sx+1 may touch the first border column of level l-1 when a1 == 0: in bounds
-            const int h0 = S0[sx] * a0 + S0[sx + 1] * a1;
-            const int h1 = S1[sx] * a0 + S1[sx + 1] * a1;
-            v = (uint32_t)(((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xFF);
+__global__ __launch_bounds__(256) void k_pyramid_fused(
+    const uint8_t *__restrict__ src, int sstride, size_t simg, uint8_t *__restrict__ pyr, size_t pyrImgBytes,
+    const LevelGeom *__restrict__ geom, int nlevels, const int32_t *__restrict__ tab, int xSpanOff, int ySpanOff,
+    int tilesX, int tilesY, int bufBytes, int maxPar) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint8_t *buf[2] = {smem, smem + bufBytes};
+    // per-column {i0 | i1<<16, a0 | a1<<16} and per-row {r0 | r1<<16, b0 | b1<<16} of every level
+    uint2 *xpar = (uint2 *)(smem + 2 * bufBytes), *ypar = xpar + maxPar;
+    __shared__ PyrSpan sX[ORBX_MAX_LEVELS], sY[ORBX_MAX_LEVELS];
+    __shared__ int xo[ORBX_MAX_LEVELS + 1], yo[ORBX_MAX_LEVELS + 1];
+    const int tid = threadIdx.x, tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX, b = blockIdx.y;
+    if (tid < nlevels) sX[tid] = ((const PyrSpan *)(tab + xSpanOff))[tid * tilesX + tx];
+    else if (tid >= 32 && tid < 32 + nlevels) sY[tid - 32] = ((const PyrSpan *)(tab + ySpanOff))[(tid - 32) * tilesY + ty];
+    __syncthreads();
+    if (tid == 0) {
+        int ax = 0, ay = 0;
+        for (int l = 0; l < nlevels; l++) {
+            xo[l] = ax; yo[l] = ay;
+            ax += sX[l].c1 - sX[l].c0; ay += sY[l].c1 - sY[l].c0;
         }
-        out |= v << (8 * i);
+        xo[nlevels] = ax; yo[nlevels] = ay;
     }
-    *(uint32_t *)(base + g.poff + (size_t)y * g.pstride + x4) = out;
+    __syncthreads();
+    {   // ONE round of global loads: the resize parameters of every level + the level-0 rectangle
+        const int nx = xo[nlevels], ny = yo[nlevels];
+        for (int i = tid; i < nx + ny; i += 256) {
+            const bool isx = i < nx;
+            const int j = isx ? i : i - nx;
+            const int *off = isx ? xo : yo;
+            int l = 1;
+            while (l + 1 <= nlevels && j >= off[l + 1]) l++;   // level of entry j (level 0 has no parameters)
+            if (j < off[1]) continue;
+            const LevelGeom *g = geom + l;
+            const PyrSpan cs = isx ? sX[l] : sY[l], ps = isx ? sX[l - 1] : sY[l - 1];
+            const int k = cs.c0 + (j - off[l]);
+            uint2 q;
+            if (isx) {
+                const int sx = tab[g->xofsOff + k], sw = g[-1].w;
+                q.x = (uint32_t)(sx - ps.c0) | ((uint32_t)(min(sx + 1, sw - 1) - ps.c0) << 16);  // clamp acts only where a1 == 0
+                q.y = (uint32_t)tab[g->xalphaOff + k];
+                xpar[j] = q;
+            } else {
+                const int sy = tab[g->yofsOff + k], shh = g[-1].h;
+                q.x = (uint32_t)(min(max(sy, 0), shh - 1) - ps.c0) | ((uint32_t)(min(max(sy + 1, 0), shh - 1) - ps.c0) << 16);
+                q.y = (uint32_t)tab[g->ybetaOff + k];
+                ypar[j] = q;
+            }
+        }
+        const PyrSpan X = sX[0], Y = sY[0];
+        const int cw = X.c1 - X.c0, ch = Y.c1 - Y.c0;
+        const uint8_t *s = src + (size_t)b * simg + (size_t)Y.c0 * sstride + X.c0;
+        const unsigned M = ((1u << 20) + cw - 1) / cw;
+        for (int i = tid; i < cw * ch; i += 256) {
+            const int y = (int)(((unsigned)i * M) >> 20), x = i - y * cw;
+            buf[0][i] = s[(size_t)y * sstride + x];
+        }
+    }
+    __syncthreads();
+    uint8_t *base = pyr + (size_t)b * pyrImgBytes;
+    for (int l = 0; l < nlevels; l++) {
+        const PyrSpan X = sX[l], Y = sY[l];
+        const int cw = X.c1 - X.c0, ch = Y.c1 - Y.c0;
+        uint8_t *cur = buf[l & 1];
+        const LevelGeom *g = geom + l;
+        const int lw = g->w, lh = g->h, pstride = g->pstride;
+        if (l > 0) {
+            const uint8_t *prev = buf[(l & 1) ^ 1];
+            const int pw = sX[l - 1].c1 - sX[l - 1].c0;
+            const uint2 *xp = xpar + xo[l], *yp = ypar + yo[l];
+            const unsigned M = ((1u << 20) + cw - 1) / cw;
+            for (int i = tid; i < cw * ch; i += 256) {
+                const int y = (int)(((unsigned)i * M) >> 20), x = i - y * cw;
+                const uint2 yq = yp[y], xq = xp[x];
+                const uint8_t *S0 = prev + (yq.x & 0xFFFF) * pw, *S1 = prev + (yq.x >> 16) * pw;
+                const int b0 = (int16_t)(yq.y & 0xFFFF), b1 = (int16_t)(yq.y >> 16);
+                const int a0 = (int16_t)(xq.y & 0xFFFF), a1 = (int16_t)(xq.y >> 16);
+                const int i0 = xq.x & 0xFFFF, i1 = xq.x >> 16;
+                const int h0 = S0[i0] * a0 + S0[i1] * a1;
+                const int h1 = S1[i0] * a0 + S1[i1] * a1;
+                cur[i] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+            }
+            __syncthreads();
+        }
+        // write the owned rectangle and its mirror images in the 19-px REFLECT_101 frame
+        uint8_t *dst = base + g->poff;
+        const int ow = X.o1 - X.o0, oh = Y.o1 - Y.o0;
+        const unsigned Mo = ((1u << 20) + ow - 1) / max(ow, 1);
+        for (int i = tid; i < ow * oh; i += 256) {
+            const int iy = (int)(((unsigned)i * Mo) >> 20), ix = i - iy * ow;
+            const int x = X.o0 + ix, y = Y.o0 + iy;
+            const uint8_t v = cur[(y - Y.c0) * cw + (x - X.c0)];
+            const int px = x + ORBX_EDGE, py = y + ORBX_EDGE;
+            const int mx = (x >= 1 && x <= ORBX_EDGE) ? ORBX_EDGE - x
+                           : (x >= lw - 1 - ORBX_EDGE && x <= lw - 2) ? 2 * (lw - 1) - x + ORBX_EDGE : -1;
+            const int my = (y >= 1 && y <= ORBX_EDGE) ? ORBX_EDGE - y
+                           : (y >= lh - 1 - ORBX_EDGE && y <= lh - 2) ? 2 * (lh - 1) - y + ORBX_EDGE : -1;
+            dst[(size_t)py * pstride + px] = v;
+            if (mx >= 0) dst[(size_t)py * pstride + mx] = v;
+            if (my >= 0) {
+                dst[(size_t)my * pstride + px] = v;
+                if (mx >= 0) dst[(size_t)my * pstride + mx] = v;
+            }
+        }
+        // level l+1 writes the other buffer; the barrier after its compute orders this level's
+        // reads of `cur` before `cur` is overwritten by level l+2
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1186,6 +1243,50 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
             }
         }
     }
+    {   // fused-pyramid tile spans, per axis: own_l partitions level l, comp_l = own_l + needs of comp_{l+1}
+        const int Lc = h->nlevels - 1;
+        int T = (int)lrintf(64.0f / h->sf[Lc]);
+        T = std::max(4, std::min(64, (T + 2) & ~3));
+        int maxDim = 0, maxPar = 0;
+        for (int axis = 0; axis < 2; axis++) {
+            auto dim = [&](int l) { return axis == 0 ? h->geom[l].w : h->geom[l].h; };
+            const int nt = (dim(Lc) + T - 1) / T;
+            if (axis == 0) h->pyrTilesX = nt; else h->pyrTilesY = nt;
+            const size_t off = tab.size();
+            tab.resize(off + (size_t)2 * h->nlevels * nt);  // PyrSpan = 4 shorts = 2 int32
+            short *sp = (short *)&tab[off];
+            if (axis == 0) h->pyrXSpanOff = (int)off; else h->pyrYSpanOff = (int)off;
+            for (int t = 0; t < nt; t++) {
+                int c0 = 0, c1 = 0, parSum = 0;
+                for (int l = Lc; l >= 0; l--) {
+                    const int d = dim(l), dc = dim(Lc);
+                    const int b0 = std::min(t * T, dc), b1 = std::min((t + 1) * T, dc);
+                    const int o0 = (int)((long long)b0 * d / dc), o1 = (t == nt - 1) ? d : (int)((long long)b1 * d / dc);
+                    if (l == Lc) { c0 = o0; c1 = o1; }
+                    else {
+                        // rows/cols of level l read by comp_{l+1} = [c0, c1)
+                        const LevelGeom &gn = h->geom[l + 1];
+                        const int ofsOff = axis == 0 ? gn.xofsOff : gn.yofsOff;
+                        int n0 = tab[ofsOff + c0], n1 = tab[ofsOff + c1 - 1] + 1;
+                        n0 = std::min(std::max(n0, 0), d - 1);
+                        n1 = std::min(std::max(n1, 0), d - 1);
+                        c0 = std::min(n0, o0);
+                        c1 = std::max(n1 + 1, o1);
+                    }
+                    short *e = sp + 4 * ((size_t)l * nt + t);
+                    e[0] = (short)o0; e[1] = (short)o1; e[2] = (short)c0; e[3] = (short)c1;
+                    maxDim = std::max(maxDim, c1 - c0);
+                    parSum += c1 - c0;
+                }
+                maxPar = std::max(maxPar, parSum);
+            }
+        }
+        h->pyrMaxDim = (maxDim + 3) & ~3;
+        h->pyrBufBytes = (h->pyrMaxDim * h->pyrMaxDim + 15) & ~15;
+        h->pyrMaxPar = (maxPar + 3) & ~3;
+        h->pyrLdsBytes = 2 * (size_t)h->pyrBufBytes + (size_t)h->pyrMaxPar * 16 + 16;
+        if (h->pyrLdsBytes > 150 * 1024) { orbx_set_error("pyramid tile needs %zu B of LDS", h->pyrLdsBytes); return ORBX_ERR_UNSUPPORTED; }
+    }
     if (maxTw > 65 || maxTh > 65) { orbx_set_error("cell window %dx%d exceeds 65", maxTw, maxTh); return ORBX_ERR_UNSUPPORTED; }
     h->max_kp = kpBound;
     h->totalCells = cellBase;
@@ -1259,15 +1360,9 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
         ORBX_HIP(hipEventRecord(ev[0], st));
     }
     {   // K1
-        const LevelGeom &g0 = h->geom[0];
-        dim3 grid((g0.pstride / 4 + 255) / 256, g0.prows, B);
-        hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, st, d_imgs, stride, img_stride, h->d_pyr,
-                           h->pyrImgBytes, h->d_geom);
-        for (int l = 1; l < nl; l++) {
-            const LevelGeom &g = h->geom[l];
-            dim3 gr((g.pstride / 4 + 255) / 256, g.prows, B);
-            hipLaunchKernelGGL(k_pyr_resize, gr, dim3(256), 0, st, h->d_pyr, h->pyrImgBytes, h->d_geom, l, h->d_tab);
-        }
+        hipLaunchKernelGGL(k_pyramid_fused, dim3(h->pyrTilesX * h->pyrTilesY, B), dim3(256), h->pyrLdsBytes, st, d_imgs,
+                           stride, img_stride, h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->d_tab, h->pyrXSpanOff,
+                           h->pyrYSpanOff, h->pyrTilesX, h->pyrTilesY, h->pyrBufBytes, h->pyrMaxPar);
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[1], st));
     {   // K2

@@ -68,6 +68,8 @@ struct orbx_extractor {
     size_t pyrImgBytes, slotsPerImg, keysPerImg;
     int fastTileStride, fastScoreStride, fastTileRows, fastLdsPerWave;
     size_t octLdsBytes;
+    int pyrTilesX, pyrTilesY, pyrXSpanOff, pyrYSpanOff, pyrBufBytes, pyrMaxDim, pyrMaxPar;
+    size_t pyrLdsBytes;
     // device buffers
     LevelGeom *d_geom;
     int32_t *d_tab;
