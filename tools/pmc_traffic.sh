@@ -1,0 +1,11 @@
+#!/bin/bash
+# HBM traffic of the bench command per kernel launch (run on the GPU box through gpurun):
+# two separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950),
+# each with --kernel-trace only, as MI355X_MICROARCH.md "HBM" prescribes.
+set -e
+out=$GRAFT_REPO_ROOT/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/pmc_write.log 2>&1
+python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write > $out/pmc_traffic.json
+cat $out/pmc_traffic.json
