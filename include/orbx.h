@@ -196,7 +196,8 @@ int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
                                     const int32_t *ext_obs, float th, int mono, int check_orientation,
                                     int device, int *nmatches);
 
-/* Developer knobs for kernel ablation timing (key 0: stop k_fast_cells after phase n; 0 = off).
+/* Developer knobs for kernel ablation timing (key 0: stop k_fast_cells after phase n; 0 = off;
+ * key 1: stop k_octree early; key 2: force the exact one-workgroup matcher kernels).
  * Never set in production: outputs are incomplete while a knob is active. */
 int orbx_debug_set(int key, int value);
 

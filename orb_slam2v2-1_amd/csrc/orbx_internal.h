@@ -95,3 +95,19 @@ struct orbx_extractor {
 // extractor internals used by the matcher side
 int orbx_internal_level(const orbx_extractor *h, int level, int *w, int *hgt, int *pstride,
                         unsigned long long *poff);
+
+// orbx_match_fast.hip: parallel candidate search + speculative resolution.  Return ORBX_OK
+// (results written), 1 (= fall back to the exact one-workgroup kernel) or a negative error.
+int fast_search_for_initialization(const orbx_keypoint_t *k1, const uint8_t *d1, int n1, const orbx_keypoint_t *k2,
+                                   const uint8_t *d2, int n2, const orbm_grid_geom_t *g2, float *prev, int32_t *m12,
+                                   int window, float nnratio, int check_ori, int device, int *nmatches);
+int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                                 const orbm_grid_geom_t *g, const float *sf, int nlevels, const orbm_mappoint_t *mps,
+                                 const uint8_t *mp_desc, int m, int32_t *frame_mp, const int32_t *ext_obs, float th,
+                                 float nnratio, int device, int *nmatches);
+int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                                    const orbm_grid_geom_t *g, const float *sf, int nlevels, const orbm_camera_t *cam,
+                                    const float *Tc16, const float *Tl16, const orbm_lastpoint_t *last,
+                                    const uint8_t *last_desc, int nlast, int32_t *cur_mp, const int32_t *ext_obs,
+                                    float th, int mono, int check_ori, int device, int *nmatches);
+extern int g_debug[8];  // developer knobs (orbx_debug_set); [2] != 0 forces the exact one-workgroup matcher kernels

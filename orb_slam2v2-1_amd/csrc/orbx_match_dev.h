@@ -1,0 +1,100 @@
+// orbx_match_dev.h — device helpers shared by the matcher kernels (orbx_match.hip: exact
+// single-workgroup kernels; orbx_match_fast.hip: parallel candidate search + speculative
+// sequential resolution).
+#pragma once
+#include "orbx_internal.h"
+#include <limits.h>
+
+#define TH_HIGH 100
+#define TH_LOW 50
+#define HISTO_LENGTH 30
+#define GRID_COLS 64
+#define GRID_ROWS 48
+
+typedef unsigned long long u64;
+
+struct Desc256 { u64 w[4]; };
+__device__ __forceinline__ Desc256 load_desc(const uint8_t *p) {
+    Desc256 d;
+    const uint4 a = ((const uint4 *)p)[0], b = ((const uint4 *)p)[1];
+    d.w[0] = (u64)a.x | ((u64)a.y << 32); d.w[1] = (u64)a.z | ((u64)a.w << 32);
+    d.w[2] = (u64)b.x | ((u64)b.y << 32); d.w[3] = (u64)b.z | ((u64)b.w << 32);
+    return d;
+}
+__device__ __forceinline__ int ham(const Desc256 &a, const Desc256 &b) {
+    return __popcll(a.w[0] ^ b.w[0]) + __popcll(a.w[1] ^ b.w[1]) + __popcll(a.w[2] ^ b.w[2]) +
+           __popcll(a.w[3] ^ b.w[3]);
+}
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)v, m), hi = __shfl_xor((unsigned)(v >> 32), m);
+    return (u64)lo | ((u64)hi << 32);
+}
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 t = shfl_xor_u64(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+
+// Frame::GetFeaturesInArea (src/Frame.cc:342-395) as a predicate + scan-order key, see
+// orbx_match.hip "guided searches".
+struct AreaQuery { int x0, x1, y0, y1; bool empty; bool checkLevels; int minLevel, maxLevel; float x, y, r; };
+__device__ __forceinline__ AreaQuery make_query(const orbm_grid_geom_t &g, float x, float y, float r, int minLevel,
+                                                int maxLevel) {
+    AreaQuery q;
+    q.x = x; q.y = y; q.r = r; q.minLevel = minLevel; q.maxLevel = maxLevel;
+    q.empty = false;
+    q.x0 = max(0, (int)floorf((x - g.min_x - r) * g.inv_w));
+    if (q.x0 >= GRID_COLS) q.empty = true;
+    q.x1 = min(GRID_COLS - 1, (int)ceilf((x - g.min_x + r) * g.inv_w));
+    if (q.x1 < 0) q.empty = true;
+    q.y0 = max(0, (int)floorf((y - g.min_y - r) * g.inv_h));
+    if (q.y0 >= GRID_ROWS) q.empty = true;
+    q.y1 = min(GRID_ROWS - 1, (int)ceilf((y - g.min_y + r) * g.inv_h));
+    if (q.y1 < 0) q.empty = true;
+    q.checkLevels = (minLevel > 0) || (maxLevel >= 0);
+    return q;
+}
+// cell code of a keypoint: cellx<<8 | celly, 0xFFFF when PosInGrid fails
+__device__ __forceinline__ unsigned cell_code(const orbm_grid_geom_t &g, const orbx_keypoint_t &kp) {
+    const int px = (int)roundf((kp.x - g.min_x) * g.inv_w), py = (int)roundf((kp.y - g.min_y) * g.inv_h);
+    if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) return 0xFFFFu;
+    return (unsigned)(px << 8 | py);
+}
+__device__ __forceinline__ bool in_area(const AreaQuery &q, unsigned code, const orbx_keypoint_t &kp) {
+    if (code == 0xFFFFu) return false;
+    const int cx = (int)(code >> 8), cy = (int)(code & 0xFF);
+    if (cx < q.x0 || cx > q.x1 || cy < q.y0 || cy > q.y1) return false;
+    if (q.checkLevels) {
+        if (kp.octave < q.minLevel) return false;
+        if (q.maxLevel >= 0 && kp.octave > q.maxLevel) return false;
+    }
+    const float distx = kp.x - q.x, disty = kp.y - q.y;
+    return fabsf(distx) < q.r && fabsf(disty) < q.r;
+}
+__device__ __forceinline__ u64 scan_key(int dist, unsigned code, int j) {
+    return ((u64)dist << 28) | ((u64)(code >> 8) << 22) | ((u64)(code & 0xFF) << 16) | (u64)j;
+}
+
+// ORBmatcher::ComputeThreeMaxima (:1603-1644)
+__device__ inline void three_maxima(const int *histo, int L, int &ind1, int &ind2, int &ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+

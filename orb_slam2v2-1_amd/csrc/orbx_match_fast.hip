@@ -1,0 +1,615 @@
+// orbx_match_fast.hip — guided searches (SearchForInitialization, SearchByProjection x2) as
+// a PARALLEL candidate search followed by a SPECULATIVE sequential resolution.
+//
+// The reference loops over its queries in order and every accepted match changes what later
+// queries may take (mvpMapPoints[idx] already set, :87-89 / :1405-1407; vMatchedDistance gate
+// and steal, :444-445,463-470).  Two observations make this parallel without changing a bit:
+//  A. the expensive part of a query — window test, level test, stereo gate, Hamming distance
+//     of every candidate — does not depend on earlier queries.  k_cand runs it with one wave
+//     per query and keeps the QK best candidates sorted by the reference's scan-order key
+//     (dist | cellx | celly | index), plus the number of candidates found.
+//  B. the state only ever BLOCKS more candidates (a keypoint gets a holder; vMatchedDistance
+//     only decreases), so a query's decision can only change through a keypoint that is its
+//     current best or second-best.  k_resolve_* walks the queries 64 at a time: every lane
+//     decides from the current state, a lane may commit if no EARLIER lane of the chunk claims
+//     one of its two keypoints, the longest conflict-free prefix commits, the rest re-decides.
+// If a query runs out of its QK candidates while more existed, or sizes exceed the LDS plan,
+// the call falls back to the exact one-workgroup kernels of orbx_match.hip (same results).
+#include "orbx_match_dev.h"
+#include <math.h>
+#include <algorithm>
+
+#define QK 8
+#define CAND_CAP 512  // candidates staged per query in LDS before the top-QK selection
+
+struct GQuery {
+    float x, y, r;
+    int32_t minLevel, maxLevel, valid;
+    float ur_c, ur_tol;  // stereo gate: skip j if uright[j] > 0 && |ur_c - uright[j]| > ur_tol (ur_tol < 0: off)
+};
+
+// key = dist << 32 | cellx << 26 | celly << 20 | index << 4 | octave: ordered like the reference's scan
+__device__ __forceinline__ u64 fast_key(int dist, unsigned code, int j, int octave) {
+    return ((u64)dist << 32) | ((u64)(code >> 8) << 26) | ((u64)(code & 0xFF) << 20) | ((u64)j << 4) | (u64)(octave & 15);
+}
+#define KEY_DIST(k) ((int)((k) >> 32))
+#define KEY_IDX(k) ((int)(((k) >> 4) & 0xFFFF))
+#define KEY_OCT(k) ((int)((k) & 15))
+
+__global__ __launch_bounds__(256) void k_cell_codes(const orbx_keypoint_t *__restrict__ kp, int n, orbm_grid_geom_t g,
+                                                    uint16_t *__restrict__ code) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) code[j] = (uint16_t)cell_code(g, kp[j]);
+}
+
+// ---- A. one wave per query: all candidates -> LDS; out: the QK smallest keys (sorted), or with
+// FULL the whole sorted list (stride CAND_CAP) for searches whose runner-up can be deep in the list
+template <bool FULL>
+__global__ __launch_bounds__(256) void k_cand(const GQuery *__restrict__ qs, const uint8_t *__restrict__ qdesc, int m,
+                                              const orbx_keypoint_t *__restrict__ kps, const uint8_t *__restrict__ desc,
+                                              const float *__restrict__ uright, const uint8_t *__restrict__ sblocked,
+                                              const uint16_t *__restrict__ code, int n, orbm_grid_geom_t g,
+                                              u64 *__restrict__ keys, int32_t *__restrict__ ncand) {
+    __shared__ u64 cl[4][CAND_CAP];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + wave;
+    if (qi >= m) return;
+    u64 *L = cl[wave];
+    const GQuery Q = qs[qi];
+    int cnt = 0;
+    if (Q.valid) {
+        const AreaQuery aq = make_query(g, Q.x, Q.y, Q.r, Q.minLevel, Q.maxLevel);
+        if (!aq.empty) {
+            const Desc256 da = load_desc(qdesc + (size_t)qi * 32);
+            for (int j0 = 0; j0 < n; j0 += 64) {
+                const int j = j0 + lane;
+                bool ok = false;
+                u64 key = ~0ull;
+                if (j < n) {
+                    const unsigned c = code[j];
+                    const orbx_keypoint_t kp = kps[j];
+                    ok = in_area(aq, c, kp) && !(sblocked && sblocked[j]);
+                    if (ok && Q.ur_tol >= 0.0f) {
+                        const float u = uright[j];
+                        if (u > 0 && fabsf(Q.ur_c - u) > Q.ur_tol) ok = false;
+                    }
+                    if (ok) key = fast_key(ham(da, load_desc(desc + (size_t)j * 32)), c, j, kp.octave);
+                }
+                const u64 mk = __ballot(ok);
+                if (ok) {
+                    const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
+                    if (pos < CAND_CAP) L[pos] = key;
+                }
+                cnt += __popcll(mk);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int nl = min(cnt, CAND_CAP);
+    if (FULL) {   // bitonic sort of the staged list (wave-synchronous), then copy out
+        int P = 1;
+        while (P < nl) P <<= 1;
+        for (int i = nl + lane; i < P; i += 64) L[i] = ~0ull;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int kk = 2; kk <= P; kk <<= 1)
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int i = lane; i < P; i += 64) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const u64 a = L[i], b = L[ixj];
+                        if ((a > b) == ((i & kk) == 0)) { L[i] = b; L[ixj] = a; }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        for (int i = lane; i < nl; i += 64) keys[(size_t)qi * CAND_CAP + i] = L[i];
+        if (lane == 0) ncand[qi] = cnt;
+        return;
+    }
+    u64 last = 0;
+    bool first = true;
+    u64 mine = ~0ull;
+    for (int r = 0; r < QK; r++) {  // selection of the QK smallest keys (keys are unique)
+        u64 best = ~0ull;
+        for (int i = lane; i < nl; i += 64) {
+            const u64 k = L[i];
+            if ((first || k > last) && k < best) best = k;
+        }
+        best = wave_min_u64(best);
+        if (lane == r) mine = best;
+        last = best;
+        first = false;
+        if (best == ~0ull) break;
+    }
+    if (lane < QK) keys[(size_t)qi * QK + lane] = mine;
+    if (lane == 0) ncand[qi] = cnt;  // cnt > CAND_CAP makes the resolver report an overflow if it matters
+}
+
+// lanes j > i of the chunk whose best / second keypoint equals lane i's claim are in conflict
+__device__ __forceinline__ bool chunk_conflict(int claim, int myBest, int mySecond, u64 pending) {
+    const int lane = threadIdx.x & 63;
+    bool conflict = false;
+    for (int i = 0; i < 63; i++) {
+        if (!((pending >> i) & 1ull)) continue;  // wave-uniform
+        const int ci = __builtin_amdgcn_readlane(claim, i);
+        if (ci >= 0 && lane > i && (ci == myBest || ci == mySecond)) conflict = true;
+    }
+    return conflict;
+}
+
+// ---- B1. SearchByProjection(Frame, MapPoints): resolution  (src/ORBmatcher.cc:98-125)
+__global__ __launch_bounds__(64) void k_resolve_mp(const u64 *__restrict__ keys, const int32_t *__restrict__ ncand,
+                                                   const orbm_mappoint_t *__restrict__ mps, int m, int n,
+                                                   int32_t *__restrict__ frame_mp, float nnratio,
+                                                   int32_t *__restrict__ out /* [0] nmatches [1] overflow */) {
+    extern __shared__ uint8_t blocked[];  // [n] dynamic: keypoint got a holder with Observations() > 0
+    const int lane = threadIdx.x;
+    for (int j = lane; j < n; j += 64) blocked[j] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    int nm = 0;
+    bool overflow = false;
+    for (int c0 = 0; c0 < m; c0 += 64) {
+        const int qi = c0 + lane;
+        u64 k[QK];
+        int nc = 0, obs = 0;
+        if (qi < m) {
+            nc = ncand[qi];
+            obs = mps[qi].observations;
+#pragma unroll
+            for (int r = 0; r < QK; r++) k[r] = keys[(size_t)qi * QK + r];
+        }
+        if (nc > CAND_CAP) overflow = true;  // k_cand dropped candidates: its top-QK is not trustworthy
+        u64 pending = __ballot(qi < m && nc > 0);
+        while (pending) {
+            const bool act = (pending >> lane) & 1ull;
+            int best = -1, second = -1, bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1;
+            bool ranout = false;
+            if (act) {
+                int found = 0;
+#pragma unroll
+                for (int r = 0; r < QK; r++) {
+                    if (found < 2 && k[r] != ~0ull) {
+                        const int idx = KEY_IDX(k[r]);
+                        if (!blocked[idx]) {
+                            if (found == 0) { best = idx; bestDist = KEY_DIST(k[r]); bestLevel = KEY_OCT(k[r]); }
+                            else { second = idx; bestDist2 = KEY_DIST(k[r]); bestLevel2 = KEY_OCT(k[r]); }
+                            found++;
+                        }
+                    }
+                }
+                ranout = found < 2 && nc > QK;  // more candidates existed than were kept
+            }
+            const bool accept = act && best >= 0 && bestDist <= TH_HIGH &&
+                                !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
+            const bool conflict = chunk_conflict(accept ? best : -1, best, second, pending) && act;
+            const u64 cm = __ballot(conflict);
+            const u64 commit = cm ? (pending & ((1ull << __builtin_ctzll(cm)) - 1ull)) : pending;
+            const bool mineCommits = (commit >> lane) & 1ull;
+            if (mineCommits && ranout) overflow = true;
+            if (mineCommits && accept) {
+                frame_mp[best] = qi;       // :122
+                if (obs > 0) blocked[best] = 1;
+                nm++;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            pending &= ~commit;
+        }
+    }
+    nm = wave_sum_i32(nm);
+    const u64 ov = __ballot(overflow);
+    if (lane == 0) { out[0] = nm; out[1] = ov ? 1 : 0; }
+}
+
+// ---- B2. SearchForInitialization: resolution  (src/ORBmatcher.cc:433-512)
+__global__ __launch_bounds__(64) void k_resolve_init(const u64 *__restrict__ keys, const int32_t *__restrict__ ncand,
+                                                     const orbx_keypoint_t *__restrict__ k1, const orbx_keypoint_t *__restrict__ k2,
+                                                     int n1, int n2, float *__restrict__ prev, int32_t *__restrict__ m12,
+                                                     int32_t *__restrict__ bin1, float nnratio, int check_ori,
+                                                     int32_t *__restrict__ out) {
+    extern __shared__ int32_t sm[];  // vmd[n2], m21[n2]
+    int32_t *vmd = sm, *m21 = sm + n2;
+    __shared__ int hn[HISTO_LENGTH];
+    __shared__ int ind[3];
+    const int lane = threadIdx.x;
+    for (int j = lane; j < n2; j += 64) { vmd[j] = INT_MAX; m21[j] = -1; }
+    for (int i = lane; i < n1; i += 64) { m12[i] = -1; bin1[i] = -1; }
+    if (lane < HISTO_LENGTH) hn[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nm = 0;
+    bool overflow = false;
+    for (int c0 = 0; c0 < n1; c0 += 64) {
+        const int qi = c0 + lane;
+        int nc = 0;
+        if (qi < n1) nc = ncand[qi];
+        const u64 *kl = keys + (size_t)(qi < n1 ? qi : 0) * CAND_CAP;  // whole candidate list, sorted
+        if (nc > CAND_CAP) overflow = true;
+        nc = min(nc, CAND_CAP);
+        int resume = 0;  // entries before the current best stay gated for good: re-decisions resume there
+        u64 pending = __ballot(qi < n1 && nc > 0);
+        while (pending) {
+            const bool act = (pending >> lane) & 1ull;
+            int best = -1, second = -1, bestDist = INT_MAX, bestDist2 = INT_MAX;
+            if (act) {
+                int found = 0;
+                for (int p = resume; p < nc && found < 2; p++) {
+                    const u64 key = kl[p];
+                    const int idx = KEY_IDX(key), dist = KEY_DIST(key);
+                    if (!(vmd[idx] <= dist)) {  // :444-445
+                        if (found == 0) { best = idx; bestDist = dist; resume = p; }
+                        else { second = idx; bestDist2 = dist; }
+                        found++;
+                    }
+                }
+            }
+            const bool ranout = false;
+            const bool accept = act && best >= 0 && bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * nnratio;
+            const bool conflict = chunk_conflict(accept ? best : -1, best, second, pending) && act;
+            const u64 cm = __ballot(conflict);
+            const u64 commit = cm ? (pending & ((1ull << __builtin_ctzll(cm)) - 1ull)) : pending;
+            const bool mineCommits = (commit >> lane) & 1ull;
+            if (mineCommits && ranout) overflow = true;
+            if (mineCommits && accept) {
+                const int old = m21[best];
+                if (old >= 0) { m12[old] = -1; nm--; }   // steal (:463-467)
+                m12[qi] = best; m21[best] = qi; vmd[best] = bestDist; nm++;
+                if (check_ori) {
+                    float rot = k1[qi].angle - k2[best].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    bin1[qi] = bin;
+                    atomicAdd(&hn[bin], 1);
+                }
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            pending &= ~commit;
+        }
+    }
+    if (check_ori) {
+        if (lane == 0) three_maxima(hn, HISTO_LENGTH, ind[0], ind[1], ind[2]);
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < n1; i += 64) {
+            const int bn = bin1[i];
+            if (bn >= 0 && bn != ind[0] && bn != ind[1] && bn != ind[2] && m12[i] >= 0) { m12[i] = -1; nm--; }
+        }
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < n1; i += 64)
+        if (m12[i] >= 0) { prev[2 * i] = k2[m12[i]].x; prev[2 * i + 1] = k2[m12[i]].y; }
+    nm = wave_sum_i32(nm);
+    const u64 ov = __ballot(overflow);
+    if (lane == 0) { out[0] = nm; out[1] = ov ? 1 : 0; }
+}
+
+// ---- B3. SearchByProjection(cur, last): resolution  (src/ORBmatcher.cc:1399-1469)
+__global__ __launch_bounds__(64) void k_resolve_frame(const u64 *__restrict__ keys, const int32_t *__restrict__ ncand,
+                                                      const orbm_lastpoint_t *__restrict__ last,
+                                                      const orbx_keypoint_t *__restrict__ kun, int nlast, int n,
+                                                      int32_t *__restrict__ cur_mp, int32_t *__restrict__ hist_idx,
+                                                      int32_t *__restrict__ hist_bin, int check_ori,
+                                                      int32_t *__restrict__ out) {
+    extern __shared__ uint8_t blocked[];
+    __shared__ int hn[HISTO_LENGTH];
+    __shared__ int ind[3];
+    const int lane = threadIdx.x;
+    for (int j = lane; j < n; j += 64) blocked[j] = 0;
+    if (lane < HISTO_LENGTH) hn[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nm = 0, nh = 0;
+    bool overflow = false;
+    for (int c0 = 0; c0 < nlast; c0 += 64) {
+        const int qi = c0 + lane;
+        u64 k[QK];
+        int nc = 0, obs = 0;
+        float ang = 0;
+        if (qi < nlast) {
+            nc = ncand[qi];
+            obs = last[qi].observations;
+            ang = last[qi].angle;
+#pragma unroll
+            for (int r = 0; r < QK; r++) k[r] = keys[(size_t)qi * QK + r];
+        }
+        if (nc > CAND_CAP) overflow = true;
+        u64 pending = __ballot(qi < nlast && nc > 0);
+        while (pending) {
+            const bool act = (pending >> lane) & 1ull;
+            int best = -1, bestDist = 256;
+            bool ranout = false;
+            if (act) {
+#pragma unroll
+                for (int r = 0; r < QK; r++)
+                    if (best < 0 && k[r] != ~0ull && !blocked[KEY_IDX(k[r])]) { best = KEY_IDX(k[r]); bestDist = KEY_DIST(k[r]); }
+                ranout = best < 0 && nc > QK;
+            }
+            const bool accept = act && best >= 0 && bestDist <= TH_HIGH;
+            const bool conflict = chunk_conflict(accept ? best : -1, best, -1, pending) && act;
+            const u64 cm = __ballot(conflict);
+            const u64 commit = cm ? (pending & ((1ull << __builtin_ctzll(cm)) - 1ull)) : pending;
+            const bool mineCommits = (commit >> lane) & 1ull;
+            if (mineCommits && ranout) overflow = true;
+            const bool doit = mineCommits && accept;
+            const u64 dm = __ballot(doit);
+            if (doit) {
+                cur_mp[best] = qi;  // :1430
+                if (obs > 0) blocked[best] = 1;
+                nm++;
+                if (check_ori) {
+                    float rot = ang - kun[best].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    const int pos = nh + __popcll(dm & ((1ull << lane) - 1ull));
+                    hist_idx[pos] = best;
+                    hist_bin[pos] = bin;
+                    atomicAdd(&hn[bin], 1);
+                }
+            }
+            nh += __popcll(dm);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            pending &= ~commit;
+        }
+    }
+    if (check_ori) {
+        if (lane == 0) three_maxima(hn, HISTO_LENGTH, ind[0], ind[1], ind[2]);
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < nh; t += 64) {
+            const int bn = hist_bin[t];
+            if (bn != ind[0] && bn != ind[1] && bn != ind[2]) { cur_mp[hist_idx[t]] = -1; nm--; }  // :1463-1464
+        }
+    }
+    nm = wave_sum_i32(nm);
+    const u64 ov = __ballot(overflow);
+    if (lane == 0) { out[0] = nm; out[1] = ov ? 1 : 0; }
+}
+
+// ---- query builders
+__global__ __launch_bounds__(256) void k_queries_init(const orbx_keypoint_t *__restrict__ k1, const float *__restrict__ prev,
+                                                      int n1, int window, GQuery *__restrict__ q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n1) return;
+    GQuery Q;
+    const int level1 = k1[i].octave;
+    Q.valid = level1 > 0 ? 0 : 1;                      // :421-423
+    Q.x = prev[2 * i]; Q.y = prev[2 * i + 1]; Q.r = (float)window;
+    Q.minLevel = level1; Q.maxLevel = level1;          // :425
+    Q.ur_c = 0; Q.ur_tol = -1.0f;
+    q[i] = Q;
+}
+__global__ __launch_bounds__(256) void k_queries_mp(const orbm_mappoint_t *__restrict__ mps, int m,
+                                                    const float *__restrict__ sf, float th, GQuery *__restrict__ q,
+                                                    const int32_t *__restrict__ frame_mp, const int32_t *__restrict__ ext_obs,
+                                                    int n, uint8_t *__restrict__ sblocked) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {  // holders present before the call (:87-89)
+        const int hm = frame_mp[i];
+        sblocked[i] = hm == -1 ? 0 : hm == -2 ? (ext_obs && ext_obs[i] > 0) : (mps[hm].observations > 0);
+    }
+    if (i >= m) return;
+    const orbm_mappoint_t p = mps[i];
+    GQuery Q;
+    Q.valid = p.in_view ? 1 : 0;
+    float r = p.view_cos > 0.998 ? 2.5f : 4.0f;        // RadiusByViewingCos (:131-137)
+    if (th != 1.0) r *= th;
+    const int lvl = p.in_view ? p.level : 0;
+    const float rs = r * sf[lvl];
+    Q.x = p.proj_x; Q.y = p.proj_y; Q.r = rs;
+    Q.minLevel = lvl - 1; Q.maxLevel = lvl;            // :66
+    Q.ur_c = p.proj_xr; Q.ur_tol = rs;                 // :91-96
+    q[i] = Q;
+}
+__global__ __launch_bounds__(256) void k_queries_frame(const orbm_lastpoint_t *__restrict__ last, int nlast,
+                                                       const float *__restrict__ sf, orbm_camera_t cam,
+                                                       orbm_grid_geom_t g, const float *__restrict__ Tc,
+                                                       const float *__restrict__ Tl, float th, int mono,
+                                                       GQuery *__restrict__ q, const int32_t *__restrict__ cur_mp,
+                                                       const int32_t *__restrict__ ext_obs, int n,
+                                                       uint8_t *__restrict__ sblocked) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int hm = cur_mp[i];
+        sblocked[i] = hm == -1 ? 0 : hm == -2 ? (ext_obs && ext_obs[i] > 0) : (last[hm].observations > 0);
+    }
+    if (i >= nlast) return;
+    // twc = -Rcw^T tcw; tlc = Rlw twc + tlw (:1343-1351): cv::gemm on CV_32F accumulates in double
+    float twc[3], tlc2 = 0;
+    for (int a = 0; a < 3; a++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Tc[k * 4 + a] * (double)Tc[k * 4 + 3];
+        twc[a] = (float)(s * -1.0);
+    }
+    {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Tl[2 * 4 + k] * (double)twc[k];
+        tlc2 = (float)(s + (double)Tl[2 * 4 + 3]);
+    }
+    const bool bForward = tlc2 > cam.mb && !mono, bBackward = -tlc2 > cam.mb && !mono;
+    const orbm_lastpoint_t p = last[i];
+    GQuery Q;
+    Q.valid = 0; Q.x = Q.y = Q.r = 0; Q.minLevel = Q.maxLevel = -1; Q.ur_c = 0; Q.ur_tol = -1.0f;
+    if (p.has_mp) {
+        float x3[3];
+        for (int r = 0; r < 3; r++) {
+            double s = 0;
+            s += (double)Tc[r * 4 + 0] * (double)p.wx;
+            s += (double)Tc[r * 4 + 1] * (double)p.wy;
+            s += (double)Tc[r * 4 + 2] * (double)p.wz;
+            x3[r] = (float)(s + (double)Tc[r * 4 + 3]);
+        }
+        const float invzc = (float)(1.0 / (double)x3[2]);
+        if (!(invzc < 0)) {
+            const float u = cam.fx * x3[0] * invzc + cam.cx, v = cam.fy * x3[1] * invzc + cam.cy;
+            if (!(u < g.min_x || u > g.max_x) && !(v < g.min_y || v > g.max_y)) {
+                const int oct = p.octave;
+                const float radius = th * sf[oct];
+                Q.valid = 1; Q.x = u; Q.y = v; Q.r = radius;
+                if (bForward) { Q.minLevel = oct; Q.maxLevel = -1; }
+                else if (bBackward) { Q.minLevel = 0; Q.maxLevel = oct; }
+                else { Q.minLevel = oct - 1; Q.maxLevel = oct + 1; }
+                Q.ur_c = u - cam.mbf * invzc; Q.ur_tol = radius;   // :1409-1414
+            }
+        }
+    }
+    q[i] = Q;
+}
+
+// ---- host side: one grow-only device arena per host thread (no hipMalloc per call)
+struct Arena {
+    uint8_t *base = nullptr; size_t cap = 0, off = 0; int device = -1; hipStream_t st = nullptr;
+};
+static thread_local Arena g_ar;
+static int arena_begin(int device, size_t need) {
+    ORBX_HIP(hipSetDevice(device));
+    if (g_ar.device != device || g_ar.cap < need) {
+        if (g_ar.base) { hipSetDevice(g_ar.device >= 0 ? g_ar.device : device); hipFree(g_ar.base); hipSetDevice(device); }
+        if (!g_ar.st || g_ar.device != device) {
+            if (g_ar.st) hipStreamDestroy(g_ar.st);
+            ORBX_HIP(hipStreamCreateWithFlags(&g_ar.st, hipStreamNonBlocking));
+        }
+        g_ar.base = nullptr; g_ar.cap = 0;
+        const size_t cap = std::max(need * 2, (size_t)4 << 20);
+        ORBX_HIP(hipMalloc(&g_ar.base, cap));
+        g_ar.cap = cap; g_ar.device = device;
+    }
+    g_ar.off = 0;
+    return ORBX_OK;
+}
+template <typename T> static T *arena_get(size_t count) {
+    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    T *p = (T *)(g_ar.base + g_ar.off);
+    g_ar.off += bytes;
+    return p;
+}
+#define UP(dst, src, count) ORBX_HIP(hipMemcpyAsync((dst), (src), sizeof(*(dst)) * (size_t)(count), hipMemcpyHostToDevice, st))
+#define ORBX_FAST_FALLBACK 1  // positive: not an error, the caller runs the exact legacy kernel
+
+// Returns ORBX_OK (results written), ORBX_FAST_FALLBACK, or a negative error.
+int fast_search_for_initialization(const orbx_keypoint_t *k1, const uint8_t *d1, int n1, const orbx_keypoint_t *k2,
+                                   const uint8_t *d2, int n2, const orbm_grid_geom_t *g2, float *prev, int32_t *m12,
+                                   int window, float nnratio, int check_ori, int device, int *nmatches) {
+    if (n2 > 8000 || n1 > 65535) return ORBX_FAST_FALLBACK;  // LDS plan of k_resolve_init (8 B per F2 keypoint)
+    const size_t need = (size_t)(n1 + n2) * (28 + 32 + 64) + (size_t)n1 * (CAND_CAP * 8 + 64) + 65536;
+    int rc = arena_begin(device, need);
+    if (rc) return rc;
+    hipStream_t st = g_ar.st;
+    orbx_keypoint_t *dk1 = arena_get<orbx_keypoint_t>(n1), *dk2 = arena_get<orbx_keypoint_t>(n2);
+    uint8_t *dd1 = arena_get<uint8_t>((size_t)32 * n1), *dd2 = arena_get<uint8_t>((size_t)32 * n2);
+    float *dprev = arena_get<float>(2 * (size_t)n1);
+    int32_t *dm12 = arena_get<int32_t>(n1), *dbin = arena_get<int32_t>(n1), *dnc = arena_get<int32_t>(n1), *dout = arena_get<int32_t>(4);
+    uint16_t *dcode = arena_get<uint16_t>(n2);
+    GQuery *dq = arena_get<GQuery>(n1);
+    u64 *dkeys = arena_get<u64>((size_t)n1 * CAND_CAP);
+    UP(dk1, k1, n1); UP(dk2, k2, n2); UP(dd1, d1, (size_t)32 * n1); UP(dd2, d2, (size_t)32 * n2); UP(dprev, prev, 2 * (size_t)n1);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_cell_codes, dim3((n2 + 255) / 256), dim3(256), 0, st, dk2, n2, *g2, dcode);
+    hipLaunchKernelGGL(k_queries_init, dim3((n1 + 255) / 256), dim3(256), 0, st, dk1, dprev, n1, window, dq);
+    hipLaunchKernelGGL(k_cand<true>, dim3((n1 + 3) / 4), dim3(256), 0, st, dq, dd1, n1, dk2, dd2, (const float *)nullptr,
+                       (const uint8_t *)nullptr, dcode, n2, *g2, dkeys, dnc);
+    hipLaunchKernelGGL(k_resolve_init, dim3(1), dim3(64), sizeof(int32_t) * 2 * (size_t)n2, st, dkeys, dnc, dk1, dk2, n1, n2,
+                       dprev, dm12, dbin, nnratio, check_ori, dout);
+    ORBX_HIP(hipGetLastError());
+    int32_t out[2] = {0, 0};
+    ORBX_HIP(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    if (out[1]) return ORBX_FAST_FALLBACK;
+    ORBX_HIP(hipMemcpyAsync(prev, dprev, sizeof(float) * 2 * (size_t)n1, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipMemcpyAsync(m12, dm12, sizeof(int32_t) * (size_t)n1, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    *nmatches = out[0];
+    return ORBX_OK;
+}
+
+int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                                 const orbm_grid_geom_t *g, const float *sf, int nlevels, const orbm_mappoint_t *mps,
+                                 const uint8_t *mp_desc, int m, int32_t *frame_mp, const int32_t *ext_obs, float th,
+                                 float nnratio, int device, int *nmatches) {
+    if (n > 60000) return ORBX_FAST_FALLBACK;
+    const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)m * (28 + 32 + QK * 8 + 64) + 65536;
+    int rc = arena_begin(device, need);
+    if (rc) return rc;
+    hipStream_t st = g_ar.st;
+    orbx_keypoint_t *dk = arena_get<orbx_keypoint_t>(n);
+    uint8_t *dd = arena_get<uint8_t>((size_t)32 * n), *dmd = arena_get<uint8_t>((size_t)32 * m), *dsb = arena_get<uint8_t>(n);
+    float *du = arena_get<float>(n), *dsf = arena_get<float>(nlevels);
+    orbm_mappoint_t *dmp = arena_get<orbm_mappoint_t>(m);
+    int32_t *dfm = arena_get<int32_t>(n), *deo = arena_get<int32_t>(n), *dnc = arena_get<int32_t>(m), *dout = arena_get<int32_t>(4);
+    uint16_t *dcode = arena_get<uint16_t>(n);
+    GQuery *dq = arena_get<GQuery>(m);
+    u64 *dkeys = arena_get<u64>((size_t)m * QK);
+    UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(du, uright, n); UP(dsf, sf, nlevels); UP(dmp, mps, m);
+    UP(dmd, mp_desc, (size_t)32 * m); UP(dfm, frame_mp, n);
+    if (ext_obs) UP(deo, ext_obs, n);
+    (void)hipGetLastError();
+    const int mx = std::max(n, m);
+    hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *g, dcode);
+    hipLaunchKernelGGL(k_queries_mp, dim3((mx + 255) / 256), dim3(256), 0, st, dmp, m, dsf, th, dq, dfm,
+                       ext_obs ? deo : (const int32_t *)nullptr, n, dsb);
+    hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dmd, m, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
+    hipLaunchKernelGGL(k_resolve_mp, dim3(1), dim3(64), (size_t)((n + 15) & ~15), st, dkeys, dnc, dmp, m, n, dfm, nnratio, dout);
+    ORBX_HIP(hipGetLastError());
+    int32_t out[2] = {0, 0};
+    ORBX_HIP(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    if (out[1]) return ORBX_FAST_FALLBACK;
+    ORBX_HIP(hipMemcpyAsync(frame_mp, dfm, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    *nmatches = out[0];
+    return ORBX_OK;
+}
+
+int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                                    const orbm_grid_geom_t *g, const float *sf, int nlevels, const orbm_camera_t *cam,
+                                    const float *Tc16, const float *Tl16, const orbm_lastpoint_t *last,
+                                    const uint8_t *last_desc, int nlast, int32_t *cur_mp, const int32_t *ext_obs,
+                                    float th, int mono, int check_ori, int device, int *nmatches) {
+    if (n > 60000) return ORBX_FAST_FALLBACK;
+    const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)nlast * (28 + 32 + QK * 8 + 64) + 65536;
+    int rc = arena_begin(device, need);
+    if (rc) return rc;
+    hipStream_t st = g_ar.st;
+    orbx_keypoint_t *dk = arena_get<orbx_keypoint_t>(n);
+    uint8_t *dd = arena_get<uint8_t>((size_t)32 * n), *dld = arena_get<uint8_t>((size_t)32 * nlast), *dsb = arena_get<uint8_t>(n);
+    float *du = arena_get<float>(n), *dsf = arena_get<float>(nlevels), *dT = arena_get<float>(32);
+    orbm_lastpoint_t *dl = arena_get<orbm_lastpoint_t>(nlast);
+    int32_t *dcm = arena_get<int32_t>(n), *deo = arena_get<int32_t>(n), *dnc = arena_get<int32_t>(nlast), *dout = arena_get<int32_t>(4);
+    int32_t *dhi = arena_get<int32_t>(nlast), *dhb = arena_get<int32_t>(nlast);
+    uint16_t *dcode = arena_get<uint16_t>(n);
+    GQuery *dq = arena_get<GQuery>(nlast);
+    u64 *dkeys = arena_get<u64>((size_t)nlast * QK);
+    float T2[32];
+    memcpy(T2, Tc16, 64); memcpy(T2 + 16, Tl16, 64);
+    UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(du, uright, n); UP(dsf, sf, nlevels); UP(dl, last, nlast);
+    UP(dld, last_desc, (size_t)32 * nlast); UP(dcm, cur_mp, n); UP(dT, T2, 32);
+    if (ext_obs) UP(deo, ext_obs, n);
+    ORBX_HIP(hipStreamSynchronize(st));  // T2 lives on this stack frame
+    (void)hipGetLastError();
+    const int mx = std::max(n, nlast);
+    hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *g, dcode);
+    hipLaunchKernelGGL(k_queries_frame, dim3((mx + 255) / 256), dim3(256), 0, st, dl, nlast, dsf, *cam, *g, dT, dT + 16, th,
+                       mono, dq, dcm, ext_obs ? deo : (const int32_t *)nullptr, n, dsb);
+    hipLaunchKernelGGL(k_cand<false>, dim3((nlast + 3) / 4), dim3(256), 0, st, dq, dld, nlast, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
+    hipLaunchKernelGGL(k_resolve_frame, dim3(1), dim3(64), (size_t)((n + 15) & ~15), st, dkeys, dnc, dl, dk, nlast, n, dcm,
+                       dhi, dhb, check_ori, dout);
+    ORBX_HIP(hipGetLastError());
+    int32_t out[2] = {0, 0};
+    ORBX_HIP(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    if (out[1]) return ORBX_FAST_FALLBACK;
+    ORBX_HIP(hipMemcpyAsync(cur_mp, dcm, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    *nmatches = out[0];
+    return ORBX_OK;
+}

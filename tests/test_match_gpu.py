@@ -76,7 +76,16 @@ def test_stereo_edge_cases(pkg, oracle, synth):
     assert n == 0 and (ur == -1).all() and (dp == -1).all()
 
 
-def test_search_for_initialization(pkg, oracle, synth):
+@pytest.fixture(params=["fast", "exact"])
+def matcher_path(request, pkg):
+    """Both implementations of the guided searches: parallel candidates + speculative
+    resolution (default) and the exact one-workgroup kernels it falls back to."""
+    pkg.lib().orbx_debug_set(2, 1 if request.param == "exact" else 0)
+    yield request.param
+    pkg.lib().orbx_debug_set(2, 0)
+
+
+def test_search_for_initialization(pkg, oracle, synth, matcher_path):
     w, h = 640, 480
     img1 = synth.frame(w, h, 7)
     img2 = np.roll(img1, (3, 5), axis=(0, 1))  # small camera motion
@@ -112,7 +121,7 @@ def _mappoints_from(oracle, k, d, rng, m):
     return mps, md ^ flip
 
 
-def test_search_by_projection_mappoints(pkg, oracle, synth):
+def test_search_by_projection_mappoints(pkg, oracle, synth, matcher_path):
     w, h = 1241, 376
     _, k, d = _features(oracle, synth.frame(w, h, 11), 1000)
     rng = np.random.default_rng(9)
@@ -133,7 +142,7 @@ def test_search_by_projection_mappoints(pkg, oracle, synth):
         np.testing.assert_array_equal(gfm, ofm)
 
 
-def test_search_by_projection_frame(pkg, oracle, synth):
+def test_search_by_projection_frame(pkg, oracle, synth, matcher_path):
     w, h = 1241, 376
     _, k, d = _features(oracle, synth.frame(w, h, 12), 1000)
     rng = np.random.default_rng(10)
@@ -169,3 +178,44 @@ def test_search_by_projection_frame(pkg, oracle, synth):
         assert on > 100, on
         assert gn == on
         np.testing.assert_array_equal(gcm, ocm)
+
+
+def test_guided_search_heavy_contention(pkg, oracle, synth, matcher_path):
+    """Many queries competing for few keypoints: long conflict chains in the speculative
+    resolver, blocked candidates beyond the kept top-8 (forces the exact fallback)."""
+    w, h = 640, 480
+    _, k, d = _features(oracle, synth.frame(w, h, 13), 300)
+    rng = np.random.default_rng(11)
+    sf = oracle.Extractor(300, 1.2, 8, 20, 7).scale_factors
+    m = 3000
+    idx = rng.choice(min(len(k), 40), m, replace=True)  # everything projects onto the first 40 keypoints
+    mps = np.zeros(m, oracle.MP_DTYPE)
+    mps["in_view"] = 1
+    mps["proj_x"] = k["x"][idx] + rng.normal(0, 6, m)
+    mps["proj_y"] = k["y"][idx] + rng.normal(0, 6, m)
+    mps["proj_xr"] = mps["proj_x"]
+    mps["level"] = k["octave"][idx]
+    mps["view_cos"] = 0.9
+    mps["observations"] = rng.integers(0, 2, m)
+    md = d[idx] ^ (rng.integers(0, 256, (m, 32), dtype=np.uint8) & rng.integers(0, 256, (m, 32), dtype=np.uint8) &
+                   rng.integers(0, 256, (m, 32), dtype=np.uint8) & rng.integers(0, 256, (m, 32), dtype=np.uint8))
+    ur = np.full(len(k), -1, np.float32)
+    fm = np.full(len(k), -1, np.int32)
+    on, ofm = oracle.search_by_projection_mp(k, d, ur, oracle.grid_geom(w, h), sf, mps, md, fm, None, 10.0, 0.9)
+    gn, gfm = pkg.ORBmatcher(0.9, True).SearchByProjection(k, d, ur, pkg.grid_geom(w, h), sf, mps, md, fm, None, 10.0)
+    assert gn == on
+    np.testing.assert_array_equal(gfm, ofm)
+    # initialization matcher with a tiny second frame: every F1 keypoint fights for the same few F2 keypoints
+    k2, d2 = k[:25].copy(), d[:25].copy()
+    k1 = np.repeat(k[:25], 40)
+    d1 = np.repeat(d[:25], 40, axis=0) ^ (rng.integers(0, 256, (1000, 32), dtype=np.uint8) &
+                                           rng.integers(0, 256, (1000, 32), dtype=np.uint8) &
+                                           rng.integers(0, 256, (1000, 32), dtype=np.uint8))
+    k1["octave"] = 0
+    k2["octave"] = 0
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    on, om12, oprev = oracle.search_for_initialization(k1, d1, k2, d2, oracle.grid_geom(w, h), prev, 100, 0.9, True)
+    gn, gm12, gprev = pkg.ORBmatcher(0.9, True).SearchForInitialization(k1, d1, k2, d2, pkg.grid_geom(w, h), prev, 100)
+    assert gn == on
+    np.testing.assert_array_equal(gm12, om12)
+    np.testing.assert_array_equal(gprev, oprev)
