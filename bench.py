@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the result all-gather when N > 1")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only to rehearse N > 1 on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -164,13 +166,21 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible — the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        print("bench.py: %d ranks but %d GPU(s): RCCL needs one GPU per rank" % (world, ndev), file=sys.stderr)
+        sys.exit(3)
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     d_imgs = torch.from_numpy(imgs).to(dev)
 
-    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=local_rank)
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=dev_index)
     cap = ex.max_keypoints()
     ex(imgs[0])                     # plan for this image size; cap is now exact
     cap = ex.max_keypoints()
@@ -214,7 +224,11 @@ def main():
                 ev_m1[timed_idx].record(stream)
         if gather:
             batching.pack_records(kps[j][:B], desc[j][:B], ur[j], dp[j], cnt[j][:B], out=pack[j])
-            _, works[j] = batching.all_gather_records(pack[j], gath[j], async_op=True)
+            if args.backend == "nccl":
+                _, works[j] = batching.all_gather_records(pack[j], gath[j], async_op=True)
+            else:  # rehearsal: gloo moves host memory
+                g, _ = batching.all_gather_records(pack[j].cpu())
+                gath[j].copy_(g)
 
     def drain():
         if gather:
@@ -285,7 +299,7 @@ def main():
                        "width": w, "height": h, "nlevels": 8, "scale_factor": 1.2, "nfeatures": nf,
                        "ini_th_fast": 20, "min_th_fast": 7, "frames_per_step_per_gpu": B,
                        "match": "Frame::ComputeStereoMatches" if stereo else "none",
-                       "parallelism": "frames sharded over %d GPU(s)%s" % (world, ", results all-gathered (RCCL)" if gather else ""),
+                       "parallelism": "frames sharded over %d GPU(s)%s" % (world, ", results all-gathered (%s)" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal") if gather else ""),
                        "avg_keypoints_per_image": round(navg, 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0,
                          "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,

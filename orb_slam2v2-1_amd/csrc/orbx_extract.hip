@@ -73,7 +73,6 @@ __global__ __launch_bounds__(256) void k_pyramid_fused(
     const LevelGeom *__restrict__ geom, int nlevels, const int32_t *__restrict__ tab, int xSpanOff, int ySpanOff,
     int tilesX, int tilesY, int bufBytes, int maxPar) {
     extern __shared__ __align__(16) uint8_t smem[];
-    uint8_t *buf[2] = {smem, smem + bufBytes};
     // per-column {i0 | i1<<16, a0 | a1<<16} and per-row {r0 | r1<<16, b0 | b1<<16} of every level
     uint2 *xpar = (uint2 *)(smem + 2 * bufBytes), *ypar = xpar + maxPar;
     __shared__ PyrSpan sX[ORBX_MAX_LEVELS], sY[ORBX_MAX_LEVELS];
@@ -122,7 +121,7 @@ __global__ __launch_bounds__(256) void k_pyramid_fused(
         const unsigned M = ((1u << 20) + cw - 1) / cw;
         for (int i = tid; i < cw * ch; i += 256) {
             const int y = (int)(((unsigned)i * M) >> 20), x = i - y * cw;
-            buf[0][i] = s[(size_t)y * sstride + x];
+            smem[i] = s[(size_t)y * sstride + x];
         }
     }
     __syncthreads();
@@ -130,11 +129,11 @@ __global__ __launch_bounds__(256) void k_pyramid_fused(
     for (int l = 0; l < nlevels; l++) {
         const PyrSpan X = sX[l], Y = sY[l];
         const int cw = X.c1 - X.c0, ch = Y.c1 - Y.c0;
-        uint8_t *cur = buf[l & 1];
+        uint8_t *cur = smem + (l & 1) * bufBytes;  // ping-pong; plain offsets keep the LDS address space
         const LevelGeom *g = geom + l;
         const int lw = g->w, lh = g->h, pstride = g->pstride;
         if (l > 0) {
-            const uint8_t *prev = buf[(l & 1) ^ 1];
+            const uint8_t *prev = smem + ((l & 1) ^ 1) * bufBytes;
             const int pw = sX[l - 1].c1 - sX[l - 1].c0;
             const uint2 *xp = xpar + xo[l], *yp = ypar + yo[l];
             const unsigned M = ((1u << 20) + cw - 1) / cw;
@@ -628,8 +627,9 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
     int npass = 0;
     // ---- C. passes.  On entry S.hist holds the children key counts of every expandable node.
     while (true) {
-        short4 *box = S.box[cur], *nbox = S.box[cur ^ 1];
-        uint32_t *cnt = S.cnt[cur], *ncnt = S.cnt[cur ^ 1];
+        // plain offsets (no runtime-indexed pointer arrays): keeps the accesses in the LDS address space
+        short4 *box = S.box[0] + cur * capMax, *nbox = S.box[0] + (cur ^ 1) * capMax;
+        uint32_t *cnt = S.cnt[0] + cur * capMax, *ncnt = S.cnt[0] + (cur ^ 1) * capMax;
         if (tid < 2) sh_i[tid] = 0;
         // 1. visiting order of the expandable (fresh, >1 key) nodes
         int E;
