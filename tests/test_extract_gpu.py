@@ -138,3 +138,63 @@ def test_determinism_and_batch_size_independence(pkg, synth):
     for i in range(3):
         for j in (i, 5 - i):
             assert a[i][0].tobytes() == b[j][0].tobytes() and a[i][1].tobytes() == b[j][1].tobytes()
+
+
+def test_two_extractors_on_two_host_threads(pkg, oracle, synth):
+    """The reference runs the left and right extractor instances on two std::threads
+    (src/Frame.cc:78-81): two handles must be usable concurrently."""
+    import threading
+    w, h = 752, 480
+    left, right = synth.stereo_pair_blocky(w, h, 60)
+    exs = [pkg.ORBextractor(1000, 1.2, 8, 20, 7) for _ in range(2)]
+    out = [None, None]
+
+    def work(i, img):
+        for _ in range(5):
+            out[i] = exs[i](img)
+
+    ts = [threading.Thread(target=work, args=(i, im)) for i, im in enumerate((left, right))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i, im in enumerate((left, right)):
+        ok, od = oracle.Extractor(1000, 1.2, 8, 20, 7).extract(im)
+        assert len(out[i][0]) == len(ok)
+        np.testing.assert_array_equal(out[i][1], od)
+        np.testing.assert_array_equal(out[i][0]["x"], ok["x"])
+
+
+def test_device_batch_on_a_torch_side_stream(pkg, oracle, synth):
+    """orbx_extract_batch_device on a non-default stream with torch-owned buffers."""
+    import torch
+    w, h, B = 640, 480, 6
+    imgs = synth.batch(w, h, B, k0=70)
+    ex = pkg.ORBextractor(800, 1.2, 8, 20, 7)
+    ex(imgs[0])
+    cap = ex.max_keypoints()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        d = torch.from_numpy(imgs).cuda()
+        kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+        desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+        ex.extract_batch_device(d.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap,
+                                s.cuda_stream)
+    s.synchronize()
+    orc = oracle.Extractor(800, 1.2, 8, 20, 7)
+    for b in range(B):
+        ok, od = orc.extract(imgs[b])
+        n = int(cnt[b])
+        assert n == len(ok)
+        np.testing.assert_array_equal(desc[b, :n].cpu().numpy(), od)
+        got = kps[b, :n].cpu().numpy().view(np.uint8).reshape(n, 28)
+        np.testing.assert_array_equal(got, ok.view(np.uint8).reshape(n, 28))
+    # mvImagePyramid of a batch slot
+    np.testing.assert_array_equal(ex.pyramid_level(5, b=3), _pyr(oracle, imgs[3], 800, 5))
+
+
+def _pyr(oracle, img, nf, level):
+    o = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    o.extract(img)
+    return o.pyramid_level(level)
