@@ -551,8 +551,6 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
     S.survIdx = (uint16_t *)sp; sp += 2 * capMax;
     S.xlist = (uint16_t *)sp; sp += 2 * capMax;
     S.split = sp; sp += capMax;
-    __shared__ int wsum[OCT_T / 64 + 1];
-    __shared__ int sh_i[8];  // scalars: 0 S(plit count) 1 nToExpand
     __shared__ int rootCnt[ORBX_MAX_ROOTS], rootMap[ORBX_MAX_ROOTS];
 
     uint32_t *keys = cand + (size_t)b * keysPerImg + g.keyOff;
@@ -626,140 +624,169 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
     if (dbgStop == 3) return;
     int npass = 0;
     // ---- C. passes.  On entry S.hist holds the children key counts of every expandable node.
+    // The list bookkeeping of a pass touches only O(list size) entries: it is done by wave 0
+    // alone with wave-synchronous LDS hand-offs (no workgroup barriers); the other waves wait.
+    __shared__ int sh_Lnew, sh_finish, sh_phase;
     while (true) {
         // plain offsets (no runtime-indexed pointer arrays): keeps the accesses in the LDS address space
         short4 *box = S.box[0] + cur * capMax, *nbox = S.box[0] + (cur ^ 1) * capMax;
         uint32_t *cnt = S.cnt[0] + cur * capMax, *ncnt = S.cnt[0] + (cur ^ 1) * capMax;
-        if (tid < 2) sh_i[tid] = 0;
-        // 1. visiting order of the expandable (fresh, >1 key) nodes
-        int E;
-        if (phase == 1) {
-            int *flag = S.pn;
-            for (int k = tid; k < L; k += OCT_T) {
-                const uint32_t cv = cnt[k];
-                flag[k] = ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) ? 1 : 0;
-            }
-            __syncthreads();
-            const int chunk = (L + OCT_T - 1) / OCT_T;  // compaction in list order
-            const int beg = min(tid * chunk, L), end = min(beg + chunk, L);
-            int s = 0;
-            for (int k = beg; k < end; k++) s += flag[k];
-            int off = block_scan_excl(s, wsum, &E);
-            for (int k = beg; k < end; k++)
-                if (flag[k]) S.xlist[off++] = (uint16_t)k;
-            __syncthreads();
-        } else {
-            int P = 1;
-            while (P < L) P <<= 1;
-            for (int k = tid; k < P; k += OCT_T) {
-                unsigned long long key = ~0ull;
-                if (k < L) {
+        if (tid < 64) {
+            const int lane = tid;
+            // 1. visiting order of the expandable (fresh, >1 key) nodes
+            int E;
+            if (phase == 1) {   // list order
+                const int chunk = (L + 63) >> 6;
+                const int beg = min(lane * chunk, L), end = min(beg + chunk, L);
+                int s = 0;
+                for (int k = beg; k < end; k++) {
                     const uint32_t cv = cnt[k];
-                    if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1)
-                        key = ((unsigned long long)(0x7FFFFFFFu - (cv & 0x7FFFFFFFu)) << 32) | (unsigned)k;
+                    s += ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) ? 1 : 0;
                 }
-                S.skey[k] = key;
-            }
-            __syncthreads();
-            for (int kk2 = 2; kk2 <= P; kk2 <<= 1)
-                for (int j = kk2 >> 1; j > 0; j >>= 1) {
-                    for (int i = tid; i < P; i += OCT_T) {
-                        const int ixj = i ^ j;
-                        if (ixj > i) {
-                            const unsigned long long a = S.skey[i], c2 = S.skey[ixj];
-                            const bool asc = (i & kk2) == 0;
-                            if ((a > c2) == asc) { S.skey[i] = c2; S.skey[ixj] = a; }
+                int inc = s;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(inc, o);
+                    if (lane >= o) inc += t;
+                }
+                E = __builtin_amdgcn_readlane(inc, 63);
+                int off = inc - s;
+                for (int k = beg; k < end; k++) {
+                    const uint32_t cv = cnt[k];
+                    if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) S.xlist[off++] = (uint16_t)k;
+                }
+            } else {            // (size desc, later-created first): bitonic sort of (~size, list index)
+                int P = 1;
+                while (P < L) P <<= 1;
+                int e = 0;
+                for (int k = lane; k < P; k += 64) {
+                    unsigned long long key = ~0ull;
+                    if (k < L) {
+                        const uint32_t cv = cnt[k];
+                        if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) {
+                            key = ((unsigned long long)(0x7FFFFFFFu - (cv & 0x7FFFFFFFu)) << 32) | (unsigned)k;
+                            e++;
                         }
                     }
-                    __syncthreads();
+                    S.skey[k] = key;
                 }
-            int e = 0;
-            for (int k = tid; k < L; k += OCT_T)
-                if (S.skey[k] != ~0ull) { S.xlist[k] = (uint16_t)(S.skey[k] & 0xFFFFu); e++; }
-            (void)block_scan_excl(e, wsum, &E);
-            __syncthreads();
-        }
-        // 2. children created per rank -> exclusive prefix by rank
-        for (int r = tid; r < E; r += OCT_T) {
-            const int k = S.xlist[r];
-            S.pn[r] = (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) + (S.hist[4 * k + 3] > 0);
-        }
-        __syncthreads();
-        array_scan_excl(S.pn, E, wsum);
-        // 3. number of parents split (phase 2 stops at the first rank that reaches N, :730-731)
-        if (tid == 0) sh_i[0] = E;
-        __syncthreads();
-        if (phase == 2) {
-            for (int r = tid; r < E; r += OCT_T) {
-                const int k = S.xlist[r];
-                const int nz = (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) +
-                               (S.hist[4 * k + 3] > 0);
-                const int after = L + S.pn[r] + nz - (r + 1);  // list size after splitting rank r
-                const int before = L + S.pn[r] - r;            // ... before it
-                if (after >= N && before < N) sh_i[0] = r + 1;
-            }
-            __syncthreads();
-        }
-        const int Sp = sh_i[0];
-        __shared__ int sh_C;
-        if (tid == 0) {
-            int C = 0;
-            if (Sp > 0) {
-                const int k = S.xlist[Sp - 1];
-                C = S.pn[Sp - 1] + (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) +
-                    (S.hist[4 * k + 3] > 0);
-            }
-            sh_C = C;
-        }
-        for (int k = tid; k < L; k += OCT_T) S.split[k] = 0;
-        __syncthreads();
-        const int C = sh_C;
-        const int Lnew = L - Sp + C;
-        // 4. create children: creation sequence s -> list index C-1-s (every insertion is push_front)
-        int nexp = 0;
-        for (int r = tid; r < Sp; r += OCT_T) {
-            const int k = S.xlist[r];
-            S.split[k] = 1;
-            int s = S.pn[r];
-            const short4 pb = box[k];
+                wave_sync();
+                for (int kk2 = 2; kk2 <= P; kk2 <<= 1)
+                    for (int j = kk2 >> 1; j > 0; j >>= 1) {
+                        for (int i = lane; i < P; i += 64) {
+                            const int ixj = i ^ j;
+                            if (ixj > i) {
+                                const unsigned long long a = S.skey[i], c2 = S.skey[ixj];
+                                if ((a > c2) == ((i & kk2) == 0)) { S.skey[i] = c2; S.skey[ixj] = a; }
+                            }
+                        }
+                        wave_sync();
+                    }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t hc = S.hist[4 * k + q];
-                if (hc > 0) {
-                    const int ni = C - 1 - s;
-                    nbox[ni] = child_box(pb, q);
-                    ncnt[ni] = hc | 0x80000000u;
-                    S.childIdx[4 * k + q] = (uint16_t)ni;
-                    if (hc > 1) nexp++;
-                    s++;
+                for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+                E = e;
+                for (int k = lane; k < E; k += 64) S.xlist[k] = (uint16_t)(S.skey[k] & 0xFFFFu);
+            }
+            wave_sync();
+            // 2. children created per rank -> exclusive prefix by rank (in S.pn)
+            int Sp = E, C = 0;
+            {
+                const int chunk = (E + 63) >> 6;
+                const int beg = min(lane * chunk, E), end = min(beg + chunk, E);
+                int s = 0;
+                for (int r = beg; r < end; r++) {
+                    const int k = S.xlist[r];
+                    s += (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) + (S.hist[4 * k + 3] > 0);
+                }
+                int inc = s;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(inc, o);
+                    if (lane >= o) inc += t;
+                }
+                int off = inc - s;
+                // 3. number of parents split: phase 2 stops at the first rank that reaches N (:730-731)
+                int hit = 0x7FFFFFFF;
+                for (int r = beg; r < end; r++) {
+                    const int k = S.xlist[r];
+                    const int nz = (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) + (S.hist[4 * k + 3] > 0);
+                    S.pn[r] = off;
+                    if (phase == 2) {
+                        const int after = L + off + nz - (r + 1), before = L + off - r;
+                        if (after >= N && before < N) hit = r + 1;
+                    }
+                    off += nz;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) hit = min(hit, __shfl_xor(hit, o));
+                if (phase == 2 && hit != 0x7FFFFFFF) Sp = hit;
+                wave_sync();
+                if (Sp > 0) {
+                    const int k = S.xlist[Sp - 1];
+                    C = S.pn[Sp - 1] + (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) + (S.hist[4 * k + 3] > 0);
                 }
             }
-        }
-        if (nexp) atomicAdd(&sh_i[1], nexp);
-        __syncthreads();
-        {   // survivors keep their relative order behind the new nodes
-            const int chunk = (L + OCT_T - 1) / OCT_T;
-            const int beg = min(tid * chunk, L), end = min(beg + chunk, L);
-            int s = 0;
-            for (int k = beg; k < end; k++) s += S.split[k] ? 0 : 1;
-            int tot;
-            int off = block_scan_excl(s, wsum, &tot);
-            for (int k = beg; k < end; k++)
-                if (!S.split[k]) {
-                    const int ni = C + off++;
-                    nbox[ni] = box[k];
-                    ncnt[ni] = cnt[k] & 0x7FFFFFFFu;  // no longer fresh
-                    S.survIdx[k] = (uint16_t)ni;
+            const int Lnew = L - Sp + C;
+            for (int k = lane; k < L; k += 64) S.split[k] = 0;
+            wave_sync();
+            // 4. create children: creation sequence s -> list index C-1-s (every insertion is push_front)
+            int nexp = 0;
+            for (int r = lane; r < Sp; r += 64) {
+                const int k = S.xlist[r];
+                S.split[k] = 1;
+                int s = S.pn[r];
+                const short4 pb = box[k];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t hc = S.hist[4 * k + q];
+                    if (hc > 0) {
+                        const int ni = C - 1 - s;
+                        nbox[ni] = child_box(pb, q);
+                        ncnt[ni] = hc | 0x80000000u;
+                        S.childIdx[4 * k + q] = (uint16_t)ni;
+                        if (hc > 1) nexp++;
+                        s++;
+                    }
                 }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nexp += __shfl_xor(nexp, o);
+            wave_sync();
+            {   // survivors keep their relative order behind the new nodes
+                const int chunk = (L + 63) >> 6;
+                const int beg = min(lane * chunk, L), end = min(beg + chunk, L);
+                int s = 0;
+                for (int k = beg; k < end; k++) s += S.split[k] ? 0 : 1;
+                int inc = s;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(inc, o);
+                    if (lane >= o) inc += t;
+                }
+                int off = inc - s;
+                for (int k = beg; k < end; k++)
+                    if (!S.split[k]) {
+                        const int ni = C + off++;
+                        nbox[ni] = box[k];
+                        ncnt[ni] = cnt[k] & 0x7FFFFFFFu;  // no longer fresh
+                        S.survIdx[k] = (uint16_t)ni;
+                    }
+            }
+            // 5. termination (:669-672, :733-734)
+            const bool fin = (Lnew >= N || Lnew == L);
+            if (lane == 0) {
+                sh_Lnew = Lnew;
+                sh_finish = fin ? 1 : 0;
+                sh_phase = (!fin && phase == 1 && Lnew + 3 * nexp > N) ? 2 : phase;
+            }
         }
-        const int nToExpand = sh_i[1];
-        // 5. termination (:669-672, :733-734)
-        const bool finish = (Lnew >= N || Lnew == L);
-        if (!finish && phase == 1 && Lnew + 3 * nToExpand > N) phase = 2;
+        __syncthreads();
+        const int Lnew = sh_Lnew;
+        const bool finish = sh_finish != 0;
+        phase = sh_phase;
         // 6. one sweep over the keys: new node index + (children histogram of the next pass |
         //    best key of every node, first maximum wins (:744-760))
         const int nz = finish ? Lnew : 4 * Lnew;
-        __syncthreads();  // hist / pn consumed
         for (int i = tid; i < nz; i += OCT_T) S.hist[i] = 0;
         __syncthreads();
         for (int i0 = tid; i0 < n; i0 += 4 * OCT_T) {
