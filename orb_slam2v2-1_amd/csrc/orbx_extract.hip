@@ -154,20 +154,29 @@ __global__ __launch_bounds__(256) void k_pyramid_fused(
         uint8_t *dst = base + g->poff;
         const int ow = X.o1 - X.o0, oh = Y.o1 - Y.o0;
         const unsigned Mo = ((1u << 20) + ow - 1) / max(ow, 1);
-        for (int i = tid; i < ow * oh; i += 256) {
-            const int iy = (int)(((unsigned)i * Mo) >> 20), ix = i - iy * ow;
-            const int x = X.o0 + ix, y = Y.o0 + iy;
-            const uint8_t v = cur[(y - Y.c0) * cw + (x - X.c0)];
-            const int px = x + ORBX_EDGE, py = y + ORBX_EDGE;
-            const int mx = (x >= 1 && x <= ORBX_EDGE) ? ORBX_EDGE - x
-                           : (x >= lw - 1 - ORBX_EDGE && x <= lw - 2) ? 2 * (lw - 1) - x + ORBX_EDGE : -1;
-            const int my = (y >= 1 && y <= ORBX_EDGE) ? ORBX_EDGE - y
-                           : (y >= lh - 1 - ORBX_EDGE && y <= lh - 2) ? 2 * (lh - 1) - y + ORBX_EDGE : -1;
-            dst[(size_t)py * pstride + px] = v;
-            if (mx >= 0) dst[(size_t)py * pstride + mx] = v;
-            if (my >= 0) {
-                dst[(size_t)my * pstride + px] = v;
-                if (mx >= 0) dst[(size_t)my * pstride + mx] = v;
+        // workgroup-uniform: does the owned rectangle touch a band that is mirrored into the frame?
+        const bool edgeX = X.o0 <= ORBX_EDGE || X.o1 >= lw - ORBX_EDGE, edgeY = Y.o0 <= ORBX_EDGE || Y.o1 >= lh - ORBX_EDGE;
+        if (!edgeX && !edgeY) {   // interior tile (the common case): plain copy
+            for (int i = tid; i < ow * oh; i += 256) {
+                const int iy = (int)(((unsigned)i * Mo) >> 20), ix = i - iy * ow;
+                dst[(size_t)(Y.o0 + iy + ORBX_EDGE) * pstride + X.o0 + ix + ORBX_EDGE] = cur[(Y.o0 + iy - Y.c0) * cw + (X.o0 + ix - X.c0)];
+            }
+        } else {
+            for (int i = tid; i < ow * oh; i += 256) {
+                const int iy = (int)(((unsigned)i * Mo) >> 20), ix = i - iy * ow;
+                const int x = X.o0 + ix, y = Y.o0 + iy;
+                const uint8_t v = cur[(y - Y.c0) * cw + (x - X.c0)];
+                const int px = x + ORBX_EDGE, py = y + ORBX_EDGE;
+                const int mx = (x >= 1 && x <= ORBX_EDGE) ? ORBX_EDGE - x
+                               : (x >= lw - 1 - ORBX_EDGE && x <= lw - 2) ? 2 * (lw - 1) - x + ORBX_EDGE : -1;
+                const int my = (y >= 1 && y <= ORBX_EDGE) ? ORBX_EDGE - y
+                               : (y >= lh - 1 - ORBX_EDGE && y <= lh - 2) ? 2 * (lh - 1) - y + ORBX_EDGE : -1;
+                dst[(size_t)py * pstride + px] = v;
+                if (mx >= 0) dst[(size_t)py * pstride + mx] = v;
+                if (my >= 0) {
+                    dst[(size_t)my * pstride + px] = v;
+                    if (mx >= 0) dst[(size_t)my * pstride + mx] = v;
+                }
             }
         }
         // level l+1 writes the other buffer; the barrier after its compute orders this level's
@@ -1272,7 +1281,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     }
     {   // fused-pyramid tile spans, per axis: own_l partitions level l, comp_l = own_l + needs of comp_{l+1}
         const int Lc = h->nlevels - 1;
-        int T = (int)lrintf(64.0f / h->sf[Lc]);
+        int T = (int)lrintf((g_debug[3] > 0 ? (float)g_debug[3] : 64.0f) / h->sf[Lc]);
         T = std::max(4, std::min(64, (T + 2) & ~3));
         int maxDim = 0, maxPar = 0;
         for (int axis = 0; axis < 2; axis++) {

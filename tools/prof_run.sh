@@ -3,7 +3,7 @@
 set -e
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -- python3 $GRAFT_REPO_ROOT/tools/quick_gpu.py "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_$tag; rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -- python3 $GRAFT_REPO_ROOT/tools/quick_gpu.py "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
 python3 - <<PY
 import csv, glob
 for f in glob.glob("$GRAFT_REPO_ROOT/gpurun_out/prof_$tag/**/*kernel_stats.csv", recursive=True):

@@ -9,6 +9,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 w, h, nf = 1241, 376, 1000
 imgs = synth.batch(w, h, 8, 0)
 imgs = np.concatenate([imgs] * ((B + 7) // 8))[:B]
+import os as _os
+if _os.environ.get("PYR_T"): pkg.lib().orbx_debug_set(3, int(_os.environ["PYR_T"]))
 ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
 k, d = ex(imgs[0])
 print("single:", len(k), k[:3], d[0][:8])
