@@ -67,6 +67,22 @@ struct StereoLevels {
 };
 
 #define ST_WAVES 4
+// right keypoints in the compact form the candidate loop needs (8 B, coalesced):
+// x = minr | maxr << 12 | octave << 24 (row band floor(y-r)..ceil(y+r), r = 2*scale, :498-508), y = bits of pt.x
+__global__ __launch_bounds__(256) void k_stereo_prep(StereoLevels lv, const orbx_keypoint_t *__restrict__ kr,
+                                                     const int32_t *__restrict__ nr, int cap, uint2 *__restrict__ rc) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= min(nr[b], cap)) return;
+    const orbx_keypoint_t kp = kr[(size_t)b * cap + i];
+    const float r = 2.0f * lv.sf[kp.octave];
+    int maxr = (int)ceilf(kp.y + r), minr = (int)floorf(kp.y - r);
+    minr = max(minr, 0);
+    maxr = min(maxr, 4095);
+    uint2 o;
+    o.x = maxr < minr ? 0xFFFu : ((uint32_t)minr | ((uint32_t)maxr << 12) | ((uint32_t)kp.octave << 24));  // empty band: min > max
+    o.y = __float_as_uint(kp.x);
+    rc[(size_t)b * cap + i] = o;
+}
 // one wave per left keypoint: row-band candidate test (:498-508, :535), level and
 // disparity-range tests (:548-553), Hamming argmin (first minimum in iR order, :558-562),
 // then the 11x11 SAD over 11 shifts (:577-607), parabola (:613-620), disparity (:623-636).
@@ -75,7 +91,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
     size_t pyrImgR, const orbx_keypoint_t *__restrict__ kl, const uint8_t *__restrict__ dl,
     const int32_t *__restrict__ nl, const orbx_keypoint_t *__restrict__ kr, const uint8_t *__restrict__ dr,
     const int32_t *__restrict__ nr, int cap, float mbf, float mb, float *__restrict__ uright,
-    float *__restrict__ depth, int32_t *__restrict__ sad) {
+    float *__restrict__ depth, int32_t *__restrict__ sad, const uint2 *__restrict__ rc) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int iL = blockIdx.x * ST_WAVES + wave, b = blockIdx.y;
     const int N = min(nl[b], cap), Nr = min(nr[b], cap);
@@ -99,13 +115,13 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
         u64 best = ~0ull;
         const orbx_keypoint_t *krb = kr + (size_t)b * cap;
         const uint8_t *drb = dr + (size_t)b * cap * 32;
+        const uint2 *rcb = rc + (size_t)b * cap;
         for (int iR = lane; iR < Nr; iR += 64) {
-            const orbx_keypoint_t kpR = krb[iR];
-            const float r = 2.0f * lv.sf[kpR.octave];
-            const int maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
+            const uint2 q = rcb[iR];
+            const int minr = (int)(q.x & 0xFFF), maxr = (int)((q.x >> 12) & 0xFFF), octR = (int)(q.x >> 24);
             if (row < minr || row > maxr) continue;
-            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
-            const float uR = kpR.x;
+            if (octR < levelL - 1 || octR > levelL + 1) continue;
+            const float uR = __uint_as_float(q.y);
             if (uR >= minU && uR <= maxU) {
                 const int dist = ham(dL, load_desc(drb + (size_t)iR * 32));
                 if (dist < TH_HIGH) {
@@ -265,8 +281,8 @@ static int fill_stereo_levels(orbx_extractor *hl, orbx_extractor *hr, StereoLeve
 }
 
 // scratch for the SAD distances, grown on demand (per left extractor handle)
-struct StereoScratch { int32_t *d_sad; size_t n; int device; };
-static thread_local StereoScratch g_ss = {nullptr, 0, -1};
+struct StereoScratch { int32_t *d_sad; uint2 *d_rc; size_t n; int device; };
+static thread_local StereoScratch g_ss = {nullptr, nullptr, 0, -1};
 
 extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, int left_slot0,
                                         int right_slot0, const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
@@ -285,16 +301,19 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
     const size_t need = (size_t)B * cap;
     if (g_ss.n < need || g_ss.device != hl->device) {
         if (g_ss.d_sad) hipFree(g_ss.d_sad);
-        g_ss.d_sad = nullptr; g_ss.n = 0;
+        if (g_ss.d_rc) hipFree(g_ss.d_rc);
+        g_ss.d_sad = nullptr; g_ss.d_rc = nullptr; g_ss.n = 0;
         ORBX_HIP(hipMalloc(&g_ss.d_sad, sizeof(int32_t) * need));
+        ORBX_HIP(hipMalloc(&g_ss.d_rc, sizeof(uint2) * need));
         g_ss.n = need; g_ss.device = hl->device;
     }
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream
     dim3 grid((cap + ST_WAVES - 1) / ST_WAVES, B);
     (void)hipGetLastError();
+    hipLaunchKernelGGL(k_stereo_prep, dim3((cap + 255) / 256, B), dim3(256), 0, st, lv, d_kr, d_nr, cap, g_ss.d_rc);
     hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), 0, st, lv, hl->d_pyr + (size_t)left_slot0 * hl->pyrImgBytes, hl->pyrImgBytes,
                        hr->d_pyr + (size_t)right_slot0 * hr->pyrImgBytes, hr->pyrImgBytes, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
-                       g_ss.d_sad);
+                       g_ss.d_sad, g_ss.d_rc);
     hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(SM_T), sizeof(int32_t) * cap, st, d_nl, cap, d_uright,
                        d_depth, g_ss.d_sad, d_nmatch);
     ORBX_HIP(hipGetLastError());
