@@ -211,6 +211,75 @@ __device__ __forceinline__ half2v pk_max3(half2v a, half2v b, half2v c) {
     return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
 }
 
+// FAST-9/16 score of the pixel pair (px, px+1) of row py of the evaluated area -> score tile
+__device__ __forceinline__ void fast_score_pair(const uint32_t *E, int ES, int sh, uint8_t *Sc, int SS, int tlo, int cw,
+                                                int py, int px) {
+    const uint32_t *q = E + (py + 3) * ES + px + 3 + sh;
+    const uint32_t *qm3 = q - 3 * ES, *qm2 = q - 2 * ES, *qm1 = q - ES, *qp1 = q + ES, *qp2 = q + 2 * ES,
+                   *qp3 = q + 3 * ES;
+    const uint32_t vv = q[0];
+    uint32_t rr[16];
+    rr[0] = qp3[0];   rr[1] = qp3[1];   rr[2] = qp2[2];   rr[3] = qp1[3];
+    rr[4] = q[3];     rr[5] = qm1[3];   rr[6] = qm2[2];   rr[7] = qm3[1];
+    rr[8] = qm3[0];   rr[9] = qm3[-1];  rr[10] = qm2[-2]; rr[11] = qm1[-3];
+    rr[12] = q[-3];   rr[13] = qp1[-3]; rr[14] = qp2[-2]; rr[15] = qp3[-1];
+    // A 16-bit half holding the integer n in [0,255] IS the f16 denormal n*2^-24, so the
+    // pixel pairs can be fed to the packed f16 pipe unchanged: differences, 3-input
+    // minima/maxima (v_pk_minimum3_f16 / v_pk_maximum3_f16, gfx950) and negation are exact
+    // on these values, and a positive result's bit pattern is again the integer.
+    const half2v v = __builtin_bit_cast(half2v, vv);
+    half2v d[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = v - __builtin_bit_cast(half2v, rr[k]);
+    half2v a3[16], b3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        a3[k] = pk_min3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        b3[k] = pk_max3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    }
+    half2v a9[16], b9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {   // nine-arc starting at k
+        a9[k] = pk_min3(a3[k], a3[(k + 3) & 15], a3[(k + 6) & 15]);
+        b9[k] = pk_max3(b3[k], b3[(k + 3) & 15], b3[(k + 6) & 15]);
+    }
+    half2v dk[5], bt[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        dk[k] = pk_max3(a9[3 * k], a9[3 * k + 1], a9[3 * k + 2]);
+        bt[k] = pk_min3(b9[3 * k], b9[3 * k + 1], b9[3 * k + 2]);
+    }
+    const half2v dark = pk_max3(pk_max3(dk[0], dk[1], dk[2]), pk_max3(dk[3], dk[4], a9[15]), a9[15]);
+    const half2v brt = pk_min3(pk_min3(bt[0], bt[1], bt[2]), pk_min3(bt[3], bt[4], b9[15]), b9[15]);
+    const short2v best = __builtin_bit_cast(short2v, __builtin_elementwise_maximum(dark, -brt));
+    const int s0 = best.x, s1 = best.y;
+    const uint32_t o0 = s0 > tlo ? (uint32_t)(s0 - 1) : 0u;
+    const uint32_t o1 = (s1 > tlo && px + 1 < cw) ? (uint32_t)(s1 - 1) : 0u;
+    *(uint16_t *)(Sc + (py + 1) * SS + px + 2) = (uint16_t)(o0 | (o1 << 8));
+}
+
+// strict 3x3 maximum test of the pair (px, px+1): scores v0/v1 and keep flags
+__device__ __forceinline__ void fast_nms_pair(const uint8_t *Sc, int SS, int cw, int py, int px, bool &k0, bool &k1,
+                                              int &v0, int &v1) {
+    const uint8_t *sc = Sc + (py + 1) * SS + px;  // pixels px-2 .. px+3 are bytes sc[0..5]
+    half2v l3[3], m3[3], r3[3];
+#pragma unroll
+    for (int rw = 0; rw < 3; rw++) {
+        const uint8_t *q = sc + (rw - 1) * SS;
+        const uint32_t A = *(const uint16_t *)q, M = *(const uint16_t *)(q + 2), C = *(const uint16_t *)(q + 4);
+        l3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(M, A, 0x0c040c01u));  // (px-1, px)
+        m3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(M, M, 0x0c010c00u));  // (px, px+1)
+        r3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(C, M, 0x0c040c01u));  // (px+1, px+2)
+    }
+    const half2v nb = pk_max3(pk_max3(l3[0], m3[0], r3[0]), pk_max3(l3[2], m3[2], r3[2]),
+                              __builtin_elementwise_maximum(l3[1], r3[1]));
+    const short2v gt = __builtin_bit_cast(short2v, m3[1] - nb);  // > 0 iff strictly greater
+    const short2v cv = __builtin_bit_cast(short2v, m3[1]);
+    v0 = cv.x; v1 = cv.y;
+    k0 = gt.x > 0;
+    k1 = gt.y > 0 && px + 1 < cw;
+}
+
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
     int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ slots, size_t slotsPerImg,
@@ -271,54 +340,19 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     if (phaseLimit == 1) return;
 
     const int tlo = max(min(iniTh, minTh), 0);
-    {   // scores, two pixels per lane
-        const int pw2 = (cw + 1) >> 1, npairs = pw2 * ch;
+    const int pw2 = (cw + 1) >> 1;
+    // scores, two pixels per lane.  Cells up to 32 px wide (the rule) use a fixed lane -> (row mod 4,
+    // pair) map: no per-iteration index arithmetic; wider cells walk a flat pair index.
+    if (pw2 <= 16) {
+        const int j = lane & 15, r4 = lane >> 4;
+        if (j < pw2)
+            for (int py = r4; py < ch; py += 4) fast_score_pair(E, ES, sh, Sc, SS, tlo, cw, py, 2 * j);
+    } else {
+        const int npairs = pw2 * ch;
         int py = 0, j = lane;
         while (j >= pw2) { j -= pw2; py++; }
         for (int p = lane; p < npairs; p += 64) {
-            const int px = 2 * j;
-            const uint32_t *q = E + (py + 3) * ES + px + 3 + sh;
-            const uint32_t *qm3 = q - 3 * ES, *qm2 = q - 2 * ES, *qm1 = q - ES, *qp1 = q + ES, *qp2 = q + 2 * ES,
-                           *qp3 = q + 3 * ES;
-            const uint32_t vv = q[0];
-            uint32_t rr[16];
-            rr[0] = qp3[0];   rr[1] = qp3[1];   rr[2] = qp2[2];   rr[3] = qp1[3];
-            rr[4] = q[3];     rr[5] = qm1[3];   rr[6] = qm2[2];   rr[7] = qm3[1];
-            rr[8] = qm3[0];   rr[9] = qm3[-1];  rr[10] = qm2[-2]; rr[11] = qm1[-3];
-            rr[12] = q[-3];   rr[13] = qp1[-3]; rr[14] = qp2[-2]; rr[15] = qp3[-1];
-            // A 16-bit half holding the integer n in [0,255] IS the f16 denormal n*2^-24, so the
-            // pixel pairs can be fed to the packed f16 pipe unchanged: differences, 3-input
-            // minima/maxima (v_pk_minimum3_f16 / v_pk_maximum3_f16, gfx950) and negation are exact
-            // on these values, and a positive result's bit pattern is again the integer.
-            const half2v v = __builtin_bit_cast(half2v, vv);
-            half2v d[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = v - __builtin_bit_cast(half2v, rr[k]);
-            half2v a3[16], b3[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                a3[k] = pk_min3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-                b3[k] = pk_max3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-            }
-            half2v a9[16], b9[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {   // nine-arc starting at k
-                a9[k] = pk_min3(a3[k], a3[(k + 3) & 15], a3[(k + 6) & 15]);
-                b9[k] = pk_max3(b3[k], b3[(k + 3) & 15], b3[(k + 6) & 15]);
-            }
-            half2v dk[5], bt[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                dk[k] = pk_max3(a9[3 * k], a9[3 * k + 1], a9[3 * k + 2]);
-                bt[k] = pk_min3(b9[3 * k], b9[3 * k + 1], b9[3 * k + 2]);
-            }
-            const half2v dark = pk_max3(pk_max3(dk[0], dk[1], dk[2]), pk_max3(dk[3], dk[4], a9[15]), a9[15]);
-            const half2v brt = pk_min3(pk_min3(bt[0], bt[1], bt[2]), pk_min3(bt[3], bt[4], b9[15]), b9[15]);
-            const short2v best = __builtin_bit_cast(short2v, __builtin_elementwise_maximum(dark, -brt));
-            const int s0 = best.x, s1 = best.y;
-            const uint32_t o0 = s0 > tlo ? (uint32_t)(s0 - 1) : 0u;
-            const uint32_t o1 = (s1 > tlo && px + 1 < cw) ? (uint32_t)(s1 - 1) : 0u;
-            *(uint16_t *)(Sc + (py + 1) * SS + px + 2) = (uint16_t)(o0 | (o1 << 8));
+            fast_score_pair(E, ES, sh, Sc, SS, tlo, cw, py, 2 * j);
             j += 64;
             while (j >= pw2) { j -= pw2; py++; }
         }
@@ -332,41 +366,27 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     bool anyIni = false;
     int nL = 0;
     {
-        const int pw2 = (cw + 1) >> 1, npairs = pw2 * ch;
-        int py = 0, j = lane;
-        while (j >= pw2) { j -= pw2; py++; }
+        const bool grid16 = pw2 <= 16;
+        const int npairs = grid16 ? ((ch + 3) & ~3) * 16 : pw2 * ch;
+        int py = grid16 ? (lane >> 4) : 0, j = grid16 ? (lane & 15) : lane;
+        if (!grid16) while (j >= pw2) { j -= pw2; py++; }
         for (int base = 0; base < npairs; base += 64) {
-            const int p = base + lane;
             bool k0 = false, k1 = false;
             int v0 = 0, v1 = 0;
             const int px = 2 * j;
-            if (p < npairs) {
-                const uint8_t *sc = Sc + (py + 1) * SS + px;  // pixels px-2 .. px+3 are bytes sc[0..5]
-                half2v l3[3], m3[3], r3[3];
-#pragma unroll
-                for (int rw = 0; rw < 3; rw++) {
-                    const uint8_t *q = sc + (rw - 1) * SS;
-                    const uint32_t A = *(const uint16_t *)q, M = *(const uint16_t *)(q + 2), C = *(const uint16_t *)(q + 4);
-                    l3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(M, A, 0x0c040c01u));  // (px-1, px)
-                    m3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(M, M, 0x0c010c00u));  // (px, px+1)
-                    r3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(C, M, 0x0c040c01u));  // (px+1, px+2)
-                }
-                const half2v nb = pk_max3(pk_max3(l3[0], m3[0], r3[0]), pk_max3(l3[2], m3[2], r3[2]),
-                                          __builtin_elementwise_maximum(l3[1], r3[1]));
-                const short2v gt = __builtin_bit_cast(short2v, m3[1] - nb);  // > 0 iff strictly greater
-                const short2v cv = __builtin_bit_cast(short2v, m3[1]);
-                v0 = cv.x; v1 = cv.y;
-                k0 = gt.x > 0;
-                k1 = gt.y > 0 && px + 1 < cw;
-            }
+            const bool act = grid16 ? (j < pw2 && py < ch) : (base + lane < npairs);
+            if (act) fast_nms_pair(Sc, SS, cw, py, px, k0, k1, v0, v1);
             anyIni |= (__ballot((k0 && v0 >= iniTh) || (k1 && v1 >= iniTh)) != 0ull);
             const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1), lt = (1ull << lane) - 1ull;
             int pos = nL + __popcll(m0 & lt) + __popcll(m1 & lt);
             if (k0) Lst[pos++] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)v0 << 16);
             if (k1) Lst[pos] = (uint32_t)(px + 1) | ((uint32_t)py << 8) | ((uint32_t)v1 << 16);
             nL += __popcll(m0) + __popcll(m1);
-            j += 64;
-            while (j >= pw2) { j -= pw2; py++; }
+            if (grid16) py += 4;
+            else {
+                j += 64;
+                while (j >= pw2) { j -= pw2; py++; }
+            }
         }
     }
     wave_sync();
