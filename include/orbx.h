@@ -196,6 +196,34 @@ int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
                                     const int32_t *ext_obs, float th, int mono, int check_orientation,
                                     int device, int *nmatches);
 
+/* Generic projected-window matcher: the common core of the reference's SearchByProjection
+ * family once the caller has projected its map points.  For every valid
+ * query, in order: candidates = Frame::GetFeaturesInArea(u, v, radius, min_level, max_level)
+ * (src/Frame.cc:342-395); a candidate is skipped when its slot already has a blocking holder
+ * (and, if ur_tol >= 0, when uright[j] > 0 && |ur_c - uright[j]| > ur_tol); the first minimum
+ * of the Hamming distance wins; if it is <= max_dist, holder[best] = query index, nmatches++,
+ * and with check_orientation the match enters the 30-bin rotation histogram
+ * (query angle - keypoint angle) whose bins outside the three maxima are undone at the end
+ * (holder = -1, nmatches--), exactly as src/ORBmatcher.cc:1549-1597 does.
+ * holder[n] in/out: -1 empty, >= 0 index of the query holding the slot, -2 held from outside
+ * (ext_blocks[j] != 0 says whether that holder blocks; NULL = it blocks).  A query's own
+ * claim blocks later queries iff queries[q].blocks != 0.
+ * ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)
+ * (src/ORBmatcher.cc:1474-1601) = projection + MapPoint::PredictScale on the host
+ * (orb_slam2v2-1_amd/host/ORBmatcher.cc) + this call with blocks = 1, max_dist = ORBdist. */
+typedef struct {
+    int32_t valid;
+    float u, v, radius;
+    int32_t min_level, max_level;
+    float angle;      /* orientation of the query's own keypoint (pKF->mvKeysUn[i].angle) */
+    int32_t blocks;
+    float ur_c, ur_tol;
+} orbm_window_query_t;
+int orbm_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                       const orbm_grid_geom_t *g, const orbm_window_query_t *queries, const uint8_t *query_desc,
+                       int m, int32_t *holder, const int32_t *ext_blocks, int max_dist, int check_orientation,
+                       int device, int *nmatches);
+
 /* Developer knobs for kernel ablation timing (key 0: stop k_fast_cells after phase n; 0 = off;
  * key 1: stop k_octree early; key 2: force the exact one-workgroup matcher kernels).
  * Never set in production: outputs are incomplete while a knob is active. */

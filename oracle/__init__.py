@@ -29,6 +29,10 @@ MP_DTYPE = np.dtype([("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), (
                      ("level", "<i4"), ("view_cos", "<f4"), ("observations", "<i4")])
 LASTPT_DTYPE = np.dtype([("has_mp", "<i4"), ("wx", "<f4"), ("wy", "<f4"), ("wz", "<f4"),
                          ("observations", "<i4"), ("octave", "<i4"), ("angle", "<f4")])
+KFPOINT_DTYPE = np.dtype([("valid", "<i4"), ("wx", "<f4"), ("wy", "<f4"), ("wz", "<f4"), ("max_distance", "<f4"),
+                          ("min_distance", "<f4"), ("angle", "<f4")])
+WINDOW_DTYPE = np.dtype([("valid", "<i4"), ("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("min_level", "<i4"),
+                         ("max_level", "<i4"), ("angle", "<f4"), ("blocks", "<i4"), ("ur_c", "<f4"), ("ur_tol", "<f4")])
 assert KP_DTYPE.itemsize == 28 and MP_DTYPE.itemsize == 28 and LASTPT_DTYPE.itemsize == 28
 
 
@@ -116,6 +120,10 @@ def lib():
         L.oracle_search_by_projection_frame.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp,
                                                         C.POINTER(Cam), vp, vp, vp, vp, i32, vp, vp,
                                                         f32, i32, i32]
+        L.oracle_kf_window_queries.argtypes = [vp, i32, C.POINTER(GridGeom), vp, i32, f32, C.POINTER(Cam), vp, f32, vp]
+        L.oracle_search_by_projection_kf.restype = i32
+        L.oracle_search_by_projection_kf.argtypes = [vp, vp, i32, C.POINTER(GridGeom), vp, i32, f32, C.POINTER(Cam), vp,
+                                                     vp, vp, i32, vp, f32, i32, i32]
         _lib = L
     return _lib
 
@@ -312,4 +320,24 @@ def search_by_projection_frame(kun, desc, uright, geom, sf, cam, Tcw_cur, Tcw_la
                                                 _p(sf), C.byref(cam), _p(Tc), _p(Tl), _p(last),
                                                 _p(last_desc), len(last), _p(cm), _p(eo), th, int(mono),
                                                 int(check_ori))
+    return n, cm
+
+
+def kf_window_queries(kf, geom, sf, log_sf, cam, Tcw_cur, th):
+    kf = np.ascontiguousarray(kf, KFPOINT_DTYPE); sf = np.ascontiguousarray(sf, np.float32)
+    Tc = np.ascontiguousarray(Tcw_cur, np.float32)
+    q = np.zeros(len(kf), WINDOW_DTYPE)
+    lib().oracle_kf_window_queries(_p(kf), len(kf), C.byref(geom), _p(sf), len(sf), float(log_sf), C.byref(cam), _p(Tc),
+                                   float(th), _p(q))
+    return q
+
+
+def search_by_projection_kf(kun, desc, geom, sf, log_sf, cam, Tcw_cur, kf, kf_desc, cur_mp, th, orb_dist, check_ori=True):
+    kun = np.ascontiguousarray(kun, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    sf = np.ascontiguousarray(sf, np.float32); kf = np.ascontiguousarray(kf, KFPOINT_DTYPE)
+    kd = np.ascontiguousarray(kf_desc, np.uint8); Tc = np.ascontiguousarray(Tcw_cur, np.float32)
+    cm = np.ascontiguousarray(cur_mp, np.int32).copy()
+    n = lib().oracle_search_by_projection_kf(_p(kun), _p(desc), len(kun), C.byref(geom), _p(sf), len(sf), float(log_sf),
+                                             C.byref(cam), _p(Tc), _p(kf), _p(kd), len(kf), _p(cm), float(th),
+                                             int(orb_dist), int(check_ori))
     return n, cm

@@ -142,6 +142,28 @@ int oracle_search_by_projection_frame(const oracle_kp_t *kun, const uint8_t *des
                                       int32_t *cur_mp, const int32_t *cur_ext_obs,
                                       float th, int mono, int check_ori);
 
+/* ---- ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)
+ * (src/ORBmatcher.cc:1474-1601), used by Tracking::Relocalization.
+ * kf[i]: map point i of pKF->GetMapPointMatches(): valid = pMP && !isBad() && !sAlreadyFound.count(pMP). */
+typedef struct {
+    int32_t valid; float wx, wy, wz; float max_distance, min_distance; /* mfMaxDistance, mfMinDistance */
+    float angle;                                                        /* pKF->mvKeysUn[i].angle */
+} oracle_kfpoint_t;
+/* window query the projection stage produces for the matcher (same layout as orbm_window_query_t) */
+typedef struct {
+    int32_t valid; float u, v, radius; int32_t min_level, max_level; float angle; int32_t blocks;
+    float ur_c, ur_tol;
+} oracle_window_query_t;
+/* projection + PredictScale (src/MapPoint.cc:414-429) -> one window query per keyframe point */
+void oracle_kf_window_queries(const oracle_kfpoint_t *kf, int m, const oracle_grid_geom_t *g, const float *scale_factors,
+                              int nlevels, float log_scale_factor, const oracle_cam_t *cam, const float *Tcw_cur,
+                              float th, oracle_window_query_t *q);
+/* cur_mp[n] in/out: -1 empty, -2 held by a map point outside the list (blocks), >= 0 index into kf */
+int oracle_search_by_projection_kf(const oracle_kp_t *kun, const uint8_t *desc, int n, const oracle_grid_geom_t *g,
+                                   const float *scale_factors, int nlevels, float log_scale_factor,
+                                   const oracle_cam_t *cam, const float *Tcw_cur, const oracle_kfpoint_t *kf,
+                                   const uint8_t *kf_desc, int m, int32_t *cur_mp, float th, int orb_dist, int check_ori);
+
 #ifdef __cplusplus
 }
 #endif

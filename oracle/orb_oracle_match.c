@@ -425,3 +425,92 @@ int oracle_search_by_projection_frame(const oracle_kp_t *kun, const uint8_t *des
     free(hist); free(idxs); oracle_grid_free(grid);
     return nmatches;
 }
+
+/* ---------------------- SearchByProjection(Frame, KeyFrame, sAlreadyFound, th, ORBdist) */
+void oracle_kf_window_queries(const oracle_kfpoint_t *kf, int m, const oracle_grid_geom_t *g, const float *sf,
+                              int nlevels, float mfLogScaleFactor, const oracle_cam_t *cam, const float *Tc, float th,
+                              oracle_window_query_t *q) {
+    /* Ow = -Rcw^T tcw (:1478-1480), cv::gemm double accumulation */
+    float Ow[3];
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Tc[k * 4 + i] * (double)Tc[k * 4 + 3];
+        Ow[i] = (float)(s * -1.0);
+    }
+    for (int i = 0; i < m; i++) {
+        oracle_window_query_t *o = &q[i];
+        memset(o, 0, sizeof(*o));
+        o->min_level = o->max_level = -1; o->ur_tol = -1.0f; o->blocks = 1; o->angle = kf[i].angle;
+        if (!kf[i].valid) continue;
+        float x3[3];
+        for (int r = 0; r < 3; r++) {
+            double s = 0;
+            s += (double)Tc[r * 4 + 0] * (double)kf[i].wx; s += (double)Tc[r * 4 + 1] * (double)kf[i].wy;
+            s += (double)Tc[r * 4 + 2] * (double)kf[i].wz;
+            x3[r] = (float)(s + (double)Tc[r * 4 + 3]);
+        }
+        const float xc = x3[0], yc = x3[1];
+        const float invzc = (float)(1.0 / x3[2]);
+        const float u = cam->fx * xc * invzc + cam->cx;
+        const float v = cam->fy * yc * invzc + cam->cy;
+        if (u < g->min_x || u > g->max_x) continue;
+        if (v < g->min_y || v > g->max_y) continue;
+        /* PO = x3Dw - Ow; dist3D = cv::norm(PO): L2 of a CV_32F Mat accumulates in double */
+        const float p0 = kf[i].wx - Ow[0], p1 = kf[i].wy - Ow[1], p2 = kf[i].wz - Ow[2];
+        const float dist3D = (float)sqrt((double)p0 * p0 + (double)p1 * p1 + (double)p2 * p2);
+        const float maxDistance = 1.2f * kf[i].max_distance, minDistance = 0.8f * kf[i].min_distance;
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        /* MapPoint::PredictScale(dist3D, &CurrentFrame) (src/MapPoint.cc:414-429) */
+        const float ratio = kf[i].max_distance / dist3D;
+        int nScale = (int)ceilf(logf(ratio) / mfLogScaleFactor);
+        if (nScale < 0) nScale = 0; else if (nScale >= nlevels) nScale = nlevels - 1;
+        o->valid = 1; o->u = u; o->v = v; o->radius = th * sf[nScale];
+        o->min_level = nScale - 1; o->max_level = nScale + 1;
+    }
+}
+
+int oracle_search_by_projection_kf(const oracle_kp_t *kun, const uint8_t *desc, int n, const oracle_grid_geom_t *g,
+                                   const float *sf, int nlevels, float mfLogScaleFactor, const oracle_cam_t *cam,
+                                   const float *Tc, const oracle_kfpoint_t *kf, const uint8_t *kf_desc, int m,
+                                   int32_t *cur_mp, float th, int ORBdist, int check_ori) {
+    int nmatches = 0;
+    oracle_window_query_t *q = (oracle_window_query_t *)malloc(sizeof(*q) * (m > 0 ? m : 1));
+    oracle_kf_window_queries(kf, m, g, sf, nlevels, mfLogScaleFactor, cam, Tc, th, q);
+    int32_t *hist = (int32_t *)malloc(sizeof(int32_t) * HISTO_LENGTH * (size_t)(m > 0 ? m : 1));
+    int32_t hn[HISTO_LENGTH] = {0};
+    const float factor = 1.0f / HISTO_LENGTH;
+    oracle_grid_t *grid = oracle_grid_build(kun, n, g);
+    int32_t *idxs = (int32_t *)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+    for (int i = 0; i < m; i++) {
+        if (!q[i].valid) continue;
+        const int nc = oracle_grid_query(grid, q[i].u, q[i].v, q[i].radius, q[i].min_level, q[i].max_level, idxs, n);
+        if (nc == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = idxs[c];
+            if (cur_mp[i2] != -1) continue;                 /* if(CurrentFrame.mvpMapPoints[i2]) continue;  (:1543) */
+            const int dist = oracle_hamming(kf_desc + 32 * (size_t)i, desc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBdist) {
+            cur_mp[bestIdx2] = i;
+            nmatches++;
+            if (check_ori) {
+                float rot = kf[i].angle - kun[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                hist[(size_t)bin * m + hn[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (check_ori) {
+        int ind1, ind2, ind3;
+        oracle_three_maxima(hn, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < hn[i]; j++) { cur_mp[hist[(size_t)i * m + j]] = -1; nmatches--; }
+    }
+    free(hist); free(idxs); free(q); oracle_grid_free(grid);
+    return nmatches;
+}

@@ -25,6 +25,8 @@ MP_DTYPE = np.dtype([("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), (
                      ("level", "<i4"), ("view_cos", "<f4"), ("observations", "<i4")])
 LASTPT_DTYPE = np.dtype([("has_mp", "<i4"), ("wx", "<f4"), ("wy", "<f4"), ("wz", "<f4"),
                          ("observations", "<i4"), ("octave", "<i4"), ("angle", "<f4")])
+WINDOW_DTYPE = np.dtype([("valid", "<i4"), ("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("min_level", "<i4"),
+                         ("max_level", "<i4"), ("angle", "<f4"), ("blocks", "<i4"), ("ur_c", "<f4"), ("ur_tol", "<f4")])
 
 ORBX_OK, ORBX_ERR_ARG, ORBX_ERR_NO_DEVICE, ORBX_ERR_HIP, ORBX_ERR_CAPACITY, ORBX_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 NUM_STAGES = 5
@@ -36,7 +38,7 @@ EXPORTS = [
     "orbx_pyramid_host", "orbx_pyramid_device", "orbx_debug_level_points", "orbx_set_profiling",
     "orbx_get_stage_ms", "orbx_debug_set", "orbm_hamming", "orbm_hamming_matrix_device", "orbm_stereo_batch_device",
     "orbm_stereo", "orbm_search_for_initialization", "orbm_search_by_projection_mp",
-    "orbm_search_by_projection_frame", "orbx_last_error", "orbx_version", "orbx_device_count",
+    "orbm_search_by_projection_frame", "orbm_match_windows", "orbx_last_error", "orbx_version", "orbx_device_count",
 ]
 
 
@@ -134,6 +136,7 @@ def lib():
                                                f32, f32, i32, C.POINTER(i32)]
     L.orbm_search_by_projection_frame.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp, i32, C.POINTER(Camera),
                                                   vp, vp, vp, vp, i32, vp, vp, f32, i32, i32, i32, C.POINTER(i32)]
+    L.orbm_match_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp, vp, i32, vp, vp, i32, i32, i32, C.POINTER(i32)]
     L.orbx_last_error.restype = C.c_char_p
     L.orbx_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -363,3 +366,18 @@ class ORBmatcher:
                                                      len(last), _p(cm), _p(eo), float(th), int(bMono),
                                                      int(self.mbCheckOrientation), self.device, C.byref(n)))
         return n.value, cm
+
+
+def match_windows(kun, desc, uright, geom, queries, query_desc, holder, ext_blocks=None, max_dist=100,
+                  check_orientation=True, device=0):
+    """orbm_match_windows: the projected-window matcher behind the SearchByProjection family
+    -> (nmatches, holder')"""
+    kun = np.ascontiguousarray(kun, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+    q = np.ascontiguousarray(queries, WINDOW_DTYPE); qd = np.ascontiguousarray(query_desc, np.uint8)
+    h = np.ascontiguousarray(holder, np.int32).copy()
+    eb = None if ext_blocks is None else np.ascontiguousarray(ext_blocks, np.int32)
+    n = C.c_int(0)
+    _check(lib().orbm_match_windows(_p(kun), _p(desc), _p(ur), len(kun), C.byref(geom), _p(q), _p(qd), len(q), _p(h),
+                                    _p(eb), int(max_dist), int(check_orientation), int(device), C.byref(n)))
+    return n.value, h

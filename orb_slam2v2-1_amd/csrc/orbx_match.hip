@@ -789,3 +789,116 @@ extern "C" int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const
     *nmatches = nm;
     return ORBX_OK;
 }
+
+// ---- generic projected-window matcher, exact one-workgroup form (fallback of fast_match_windows)
+__global__ __launch_bounds__(SQ_T) void k_match_windows_exact(
+    const orbx_keypoint_t *__restrict__ kun, const uint8_t *__restrict__ desc, const float *__restrict__ uright, int n,
+    orbm_grid_geom_t g, const orbm_window_query_t *__restrict__ qs, const uint8_t *__restrict__ qdesc, int m,
+    int32_t *__restrict__ holder, const int32_t *__restrict__ ext_blocks, uint16_t *__restrict__ code,
+    int32_t *__restrict__ hist_idx, int32_t *__restrict__ hist_bin, int max_dist, int check_ori,
+    int32_t *__restrict__ nmatches_out) {
+    __shared__ u64 sh[2 * SQ_T / 64];
+    __shared__ int hn[HISTO_LENGTH];
+    const int tid = threadIdx.x;
+    for (int j = tid; j < n; j += SQ_T) code[j] = (uint16_t)cell_code(g, kun[j]);
+    if (tid < HISTO_LENGTH) hn[tid] = 0;
+    __syncthreads();
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nm = 0, nh = 0;
+    for (int i = 0; i < m; i++) {
+        const orbm_window_query_t p = qs[i];
+        if (!p.valid) continue;
+        const AreaQuery q = make_query(g, p.u, p.v, p.radius, p.min_level, p.max_level);
+        if (q.empty) continue;
+        const Desc256 da = load_desc(qdesc + (size_t)i * 32);
+        Top2 t;
+        t.k1 = t.k2 = ~0ull;
+        for (int j = tid; j < n; j += SQ_T) {
+            const unsigned c = code[j];
+            if (!in_area(q, c, kun[j])) continue;
+            const int hm = holder[j];
+            if (hm == -2) { if (!ext_blocks || ext_blocks[j] != 0) continue; }
+            else if (hm >= 0 && qs[hm].blocks != 0) continue;
+            if (p.ur_tol >= 0.0f && uright && uright[j] > 0 && fabsf(p.ur_c - uright[j]) > p.ur_tol) continue;
+            top2_insert(t, scan_key(ham(da, load_desc(desc + (size_t)j * 32)), c, j));
+        }
+        t = block_top2(t, sh);
+        if (t.k1 != ~0ull) {
+            const int bestDist = (int)(t.k1 >> 28), best = (int)(t.k1 & 0xFFFF);
+            if (bestDist <= max_dist) {
+                nm++;
+                if (tid == 0) {
+                    holder[best] = i;
+                    if (check_ori) {
+                        float rot = p.angle - kun[best].angle;
+                        if (rot < 0.0f) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        hist_idx[nh] = best;
+                        hist_bin[nh] = bin;
+                        hn[bin]++;
+                    }
+                }
+                nh++;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (check_ori) {
+        __shared__ int ind[3];
+        __shared__ int sh_dec;
+        if (tid == 0) { three_maxima(hn, HISTO_LENGTH, ind[0], ind[1], ind[2]); sh_dec = 0; }
+        __syncthreads();
+        int dec = 0;
+        for (int k = tid; k < nh; k += SQ_T) {
+            const int bn = hist_bin[k];
+            if (bn != ind[0] && bn != ind[1] && bn != ind[2]) { holder[hist_idx[k]] = -1; dec++; }
+        }
+        if (dec) atomicAdd(&sh_dec, dec);
+        __syncthreads();
+        nm -= sh_dec;
+    }
+    if (tid == 0) *nmatches_out = nm;
+}
+
+extern "C" int orbm_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                                  const orbm_grid_geom_t *g, const orbm_window_query_t *queries, const uint8_t *query_desc,
+                                  int m, int32_t *holder, const int32_t *ext_blocks, int max_dist, int check_orientation,
+                                  int device, int *nmatches) {
+    if (n < 0 || m < 0 || !g || !nmatches || (n > 0 && (!kun || !desc || !holder)) || (m > 0 && (!queries || !query_desc)) ||
+        n > 65535) {
+        orbx_set_error("orbm_match_windows: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    *nmatches = 0;
+    if (n == 0 || m == 0) return ORBX_OK;
+    for (int i = 0; i < n; i++)
+        if (holder[i] < -2 || holder[i] >= m) { orbx_set_error("holder[%d] = %d out of range", i, holder[i]); return ORBX_ERR_ARG; }
+    if (!g_debug[2]) {
+        const int frc = fast_match_windows(kun, desc, uright, n, g, queries, query_desc, m, holder, ext_blocks, max_dist,
+                                           check_orientation, device, nmatches);
+        if (frc <= 0) return frc;
+    }
+    ORBX_HIP(hipSetDevice(device));
+    DevBuf bk, bd, bu, bq, bqd, bh, beb, bcode, bhi, bhb, bnm;
+    DEV_ALLOC(bk, sizeof(orbx_keypoint_t) * n); DEV_ALLOC(bd, (size_t)32 * n); DEV_ALLOC(bq, sizeof(orbm_window_query_t) * m);
+    DEV_ALLOC(bqd, (size_t)32 * m); DEV_ALLOC(bh, 4 * (size_t)n); DEV_ALLOC(bcode, 2 * (size_t)n); DEV_ALLOC(bhi, 4 * (size_t)m);
+    DEV_ALLOC(bhb, 4 * (size_t)m); DEV_ALLOC(bnm, 4);
+    H2D(bk, kun, sizeof(orbx_keypoint_t) * n); H2D(bd, desc, (size_t)32 * n); H2D(bq, queries, sizeof(orbm_window_query_t) * m);
+    H2D(bqd, query_desc, (size_t)32 * m); H2D(bh, holder, 4 * (size_t)n);
+    if (uright) { DEV_ALLOC(bu, 4 * (size_t)n); H2D(bu, uright, 4 * (size_t)n); }
+    if (ext_blocks) { DEV_ALLOC(beb, 4 * (size_t)n); H2D(beb, ext_blocks, 4 * (size_t)n); }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_match_windows_exact, dim3(1), dim3(SQ_T), 0, 0, (orbx_keypoint_t *)bk.p, (uint8_t *)bd.p,
+                       (float *)bu.p, n, *g, (orbm_window_query_t *)bq.p, (uint8_t *)bqd.p, m, (int32_t *)bh.p,
+                       (int32_t *)beb.p, (uint16_t *)bcode.p, (int32_t *)bhi.p, (int32_t *)bhb.p, max_dist,
+                       check_orientation, (int32_t *)bnm.p);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpy(holder, bh.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    int32_t nm = 0;
+    ORBX_HIP(hipMemcpy(&nm, bnm.p, 4, hipMemcpyDeviceToHost));
+    *nmatches = nm;
+    return ORBX_OK;
+}

@@ -376,6 +376,109 @@ __global__ __launch_bounds__(64) void k_resolve_frame(const u64 *__restrict__ ke
     if (lane == 0) { out[0] = nm; out[1] = ov ? 1 : 0; }
 }
 
+// ---- B4. generic projected-window matcher: resolution (top-1, any blocking holder; :1539-1570)
+__global__ __launch_bounds__(64) void k_resolve_windows(const u64 *__restrict__ keys, const int32_t *__restrict__ ncand,
+                                                        const orbm_window_query_t *__restrict__ qs,
+                                                        const orbx_keypoint_t *__restrict__ kun, int m, int n,
+                                                        int32_t *__restrict__ holder, int32_t *__restrict__ hist_idx,
+                                                        int32_t *__restrict__ hist_bin, int max_dist, int check_ori,
+                                                        int32_t *__restrict__ out) {
+    extern __shared__ uint8_t blocked[];
+    __shared__ int hn[HISTO_LENGTH];
+    __shared__ int ind[3];
+    const int lane = threadIdx.x;
+    for (int j = lane; j < n; j += 64) blocked[j] = 0;
+    if (lane < HISTO_LENGTH) hn[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nm = 0, nh = 0;
+    bool overflow = false;
+    for (int c0 = 0; c0 < m; c0 += 64) {
+        const int qi = c0 + lane;
+        u64 k[QK];
+        int nc = 0, blocks = 0;
+        float ang = 0;
+        if (qi < m) {
+            nc = ncand[qi];
+            blocks = qs[qi].blocks;
+            ang = qs[qi].angle;
+#pragma unroll
+            for (int r = 0; r < QK; r++) k[r] = keys[(size_t)qi * QK + r];
+        }
+        if (nc > CAND_CAP) overflow = true;
+        u64 pending = __ballot(qi < m && nc > 0);
+        while (pending) {
+            const bool act = (pending >> lane) & 1ull;
+            int best = -1, bestDist = 256;
+            bool ranout = false;
+            if (act) {
+#pragma unroll
+                for (int r = 0; r < QK; r++)
+                    if (best < 0 && k[r] != ~0ull && !blocked[KEY_IDX(k[r])]) { best = KEY_IDX(k[r]); bestDist = KEY_DIST(k[r]); }
+                ranout = best < 0 && nc > QK;
+            }
+            const bool accept = act && best >= 0 && bestDist <= max_dist;
+            const bool conflict = chunk_conflict(accept ? best : -1, best, -1, pending) && act;
+            const u64 cm = __ballot(conflict);
+            const u64 commit = cm ? (pending & ((1ull << __builtin_ctzll(cm)) - 1ull)) : pending;
+            const bool mineCommits = (commit >> lane) & 1ull;
+            if (mineCommits && ranout) overflow = true;
+            const bool doit = mineCommits && accept;
+            const u64 dm = __ballot(doit);
+            if (doit) {
+                holder[best] = qi;
+                if (blocks) blocked[best] = 1;
+                nm++;
+                if (check_ori) {
+                    float rot = ang - kun[best].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    const int pos = nh + __popcll(dm & ((1ull << lane) - 1ull));
+                    hist_idx[pos] = best;
+                    hist_bin[pos] = bin;
+                    atomicAdd(&hn[bin], 1);
+                }
+            }
+            nh += __popcll(dm);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            pending &= ~commit;
+        }
+    }
+    if (check_ori) {
+        if (lane == 0) three_maxima(hn, HISTO_LENGTH, ind[0], ind[1], ind[2]);
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < nh; t += 64) {
+            const int bn = hist_bin[t];
+            if (bn != ind[0] && bn != ind[1] && bn != ind[2]) { holder[hist_idx[t]] = -1; nm--; }
+        }
+    }
+    nm = wave_sum_i32(nm);
+    const u64 ov = __ballot(overflow);
+    if (lane == 0) { out[0] = nm; out[1] = ov ? 1 : 0; }
+}
+
+__global__ __launch_bounds__(256) void k_queries_windows(const orbm_window_query_t *__restrict__ w, int m,
+                                                         GQuery *__restrict__ q, const int32_t *__restrict__ holder,
+                                                         const int32_t *__restrict__ ext_blocks, int n,
+                                                         uint8_t *__restrict__ sblocked) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int hm = holder[i];
+        sblocked[i] = hm == -1 ? 0 : hm == -2 ? (ext_blocks ? (ext_blocks[i] != 0) : 1) : (w[hm].blocks != 0);
+    }
+    if (i >= m) return;
+    GQuery Q;
+    Q.valid = w[i].valid ? 1 : 0;
+    Q.x = w[i].u; Q.y = w[i].v; Q.r = w[i].radius;
+    Q.minLevel = w[i].min_level; Q.maxLevel = w[i].max_level;
+    Q.ur_c = w[i].ur_c; Q.ur_tol = w[i].ur_tol;
+    q[i] = Q;
+}
+
 // ---- query builders
 __global__ __launch_bounds__(256) void k_queries_init(const orbx_keypoint_t *__restrict__ k1, const float *__restrict__ prev,
                                                       int n1, int window, GQuery *__restrict__ q) {
@@ -609,6 +712,46 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
     ORBX_HIP(hipStreamSynchronize(st));
     if (out[1]) return ORBX_FAST_FALLBACK;
     ORBX_HIP(hipMemcpyAsync(cur_mp, dcm, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    *nmatches = out[0];
+    return ORBX_OK;
+}
+
+int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                       const orbm_grid_geom_t *g, const orbm_window_query_t *q, const uint8_t *qdesc, int m,
+                       int32_t *holder, const int32_t *ext_blocks, int max_dist, int check_ori, int device, int *nmatches) {
+    if (n > 60000) return ORBX_FAST_FALLBACK;
+    const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)m * (40 + 32 + QK * 8 + 96) + 65536;
+    int rc = arena_begin(device, need);
+    if (rc) return rc;
+    hipStream_t st = g_ar.st;
+    orbx_keypoint_t *dk = arena_get<orbx_keypoint_t>(n);
+    uint8_t *dd = arena_get<uint8_t>((size_t)32 * n), *dqd = arena_get<uint8_t>((size_t)32 * m), *dsb = arena_get<uint8_t>(n);
+    float *du = arena_get<float>(n);
+    orbm_window_query_t *dw = arena_get<orbm_window_query_t>(m);
+    int32_t *dh = arena_get<int32_t>(n), *deb = arena_get<int32_t>(n), *dnc = arena_get<int32_t>(m), *dout = arena_get<int32_t>(4);
+    int32_t *dhi = arena_get<int32_t>(m), *dhb = arena_get<int32_t>(m);
+    uint16_t *dcode = arena_get<uint16_t>(n);
+    GQuery *dq = arena_get<GQuery>(m);
+    u64 *dkeys = arena_get<u64>((size_t)m * QK);
+    UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(dw, q, m); UP(dqd, qdesc, (size_t)32 * m); UP(dh, holder, n);
+    if (uright) UP(du, uright, n);
+    else ORBX_HIP(hipMemsetAsync(du, 0, sizeof(float) * (size_t)n, st));  // 0: no stereo coordinate, never gated
+    if (ext_blocks) UP(deb, ext_blocks, n);
+    (void)hipGetLastError();
+    const int mx = std::max(n, m);
+    hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *g, dcode);
+    hipLaunchKernelGGL(k_queries_windows, dim3((mx + 255) / 256), dim3(256), 0, st, dw, m, dq, dh,
+                       ext_blocks ? deb : (const int32_t *)nullptr, n, dsb);
+    hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dqd, m, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
+    hipLaunchKernelGGL(k_resolve_windows, dim3(1), dim3(64), (size_t)((n + 15) & ~15), st, dkeys, dnc, dw, dk, m, n, dh, dhi,
+                       dhb, max_dist, check_ori, dout);
+    ORBX_HIP(hipGetLastError());
+    int32_t out[2] = {0, 0};
+    ORBX_HIP(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    if (out[1]) return ORBX_FAST_FALLBACK;
+    ORBX_HIP(hipMemcpyAsync(holder, dh, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
     ORBX_HIP(hipStreamSynchronize(st));
     *nmatches = out[0];
     return ORBX_OK;

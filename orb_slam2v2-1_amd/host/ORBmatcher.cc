@@ -4,6 +4,7 @@
 #include "ORBmatcher.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 
@@ -127,6 +128,76 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
         if (holder[i] != before[i]) {
             if (holder[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[holder[i]];  // :1430
             else if (holder[i] == -1) CurrentFrame.mvpMapPoints[i] = static_cast<MapPoint *>(NULL);  // :1463
+        }
+    return nmatches;
+}
+
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound,
+                                   const float th, const int ORBdist) {
+    const int n = CurrentFrame.N;
+    const std::vector<MapPoint *> vpMPs = pKF->GetMapPointMatches();
+    const int m = (int)vpMPs.size();
+    if (n == 0 || m == 0) return 0;
+    // projection + scale prediction stay on the host (they are O(m) scalar work and
+    // MapPoint::PredictScale goes through the platform's logf, :1491-1527); the window search,
+    // Hamming argmin and rotation histogram run on the GPU
+    const float *T = CurrentFrame.mTcw.ptr<float>(0);
+    const size_t ts = CurrentFrame.mTcw.step / sizeof(float);
+    float Ow[3];
+    for (int i = 0; i < 3; i++) {  // Ow = -Rcw.t()*tcw: cv::gemm accumulates CV_32F products in double
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)T[k * ts + i] * (double)T[k * ts + 3];
+        Ow[i] = (float)(s * -1.0);
+    }
+    std::vector<orbm_window_query_t> q(m);
+    std::vector<uint8_t> qd((size_t)32 * m);
+    for (int i = 0; i < m; i++) {
+        orbm_window_query_t &o = q[i];
+        std::memset(&o, 0, sizeof(o));
+        o.min_level = o.max_level = -1; o.ur_tol = -1.0f; o.blocks = 1;
+        MapPoint *pMP = vpMPs[i];
+        if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+        o.angle = pKF->mvKeysUn[i].angle;
+        cv::Mat x3Dw = pMP->GetWorldPos();
+        float xw[3] = {x3Dw.at<float>(0), x3Dw.at<float>(1), x3Dw.at<float>(2)}, x3[3];
+        for (int r = 0; r < 3; r++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += (double)T[r * ts + k] * (double)xw[k];
+            x3[r] = (float)(s + (double)T[r * ts + 3]);
+        }
+        const float xc = x3[0], yc = x3[1];
+        const float invzc = 1.0 / x3[2];
+        const float u = Frame::fx * xc * invzc + Frame::cx;
+        const float v = Frame::fy * yc * invzc + Frame::cy;
+        if (u < Frame::mnMinX || u > Frame::mnMaxX) continue;
+        if (v < Frame::mnMinY || v > Frame::mnMaxY) continue;
+        const float p0 = xw[0] - Ow[0], p1 = xw[1] - Ow[1], p2 = xw[2] - Ow[2];
+        float dist3D = (float)std::sqrt((double)p0 * p0 + (double)p1 * p1 + (double)p2 * p2);  // cv::norm(PO)
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
+        o.valid = 1; o.u = u; o.v = v;
+        o.radius = th * CurrentFrame.mvScaleFactors[nPredictedLevel];
+        o.min_level = nPredictedLevel - 1; o.max_level = nPredictedLevel + 1;
+        cv::Mat dMP = pMP->GetDescriptor();
+        std::memcpy(&qd[(size_t)32 * i], dMP.ptr(0), 32);
+    }
+    std::vector<orbx_keypoint_t> kun; gather_keypoints(CurrentFrame.mvKeysUn, kun);
+    std::vector<uint8_t> desc; gather_descriptors(CurrentFrame.mDescriptors, n, desc);
+    std::vector<int32_t> holder(n, -1);
+    for (int i = 0; i < n; i++)
+        if (CurrentFrame.mvpMapPoints[i]) holder[i] = -2;  // any holder blocks (:1543)
+    const std::vector<int32_t> before = holder;
+    const orbm_grid_geom_t g = grid_of(CurrentFrame);
+    int nmatches = 0;
+    if (orbm_match_windows(kun.data(), desc.data(), NULL, n, &g, q.data(), qd.data(), m, holder.data(), NULL, ORBdist,
+                           mbCheckOrientation ? 1 : 0, device, &nmatches) != ORBX_OK)
+        return fail("SearchByProjection");
+    for (int i = 0; i < n; i++)
+        if (holder[i] != before[i]) {
+            if (holder[i] >= 0) CurrentFrame.mvpMapPoints[i] = vpMPs[holder[i]];                   // :1563
+            else if (holder[i] == -1) CurrentFrame.mvpMapPoints[i] = static_cast<MapPoint *>(NULL);  // :1592
         }
     return nmatches;
 }

@@ -5,6 +5,7 @@
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
+#include <set>
 #include <vector>
 #include "cv_shim.h"
 #include "frame_shim.h"
@@ -26,6 +27,11 @@ public:
     // Project MapPoints tracked in last frame into the current frame and search matches.
     // Used to track from previous frame (Tracking)                   (src/ORBmatcher.cc:1330-1472)
     int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
+
+    // Project MapPoints seen in KeyFrame into the Frame and search matches.
+    // Used in relocalisation (Tracking)                              (src/ORBmatcher.cc:1474-1601)
+    int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th,
+                           const int ORBdist);
 
     // Matching for the Map Initialization (only used in the monocular case) (src/ORBmatcher.cc:405-520)
     int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched,

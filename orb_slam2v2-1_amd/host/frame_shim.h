@@ -8,11 +8,15 @@
 #include "Frame.h"
 #include "MapPoint.h"
 #else
+#include <cmath>
+#include <set>
 #include <vector>
 #include "cv_shim.h"
 #include "ORBextractor.h"
 
 namespace ORB_SLAM2 {
+
+class Frame;
 
 class MapPoint {
 public:
@@ -26,8 +30,13 @@ public:
     int Observations() { return nObs; }
     cv::Mat GetDescriptor() { return mDescriptor.clone(); }  // src/MapPoint.cc:319-323
     cv::Mat GetWorldPos() { return mWorldPos.clone(); }
+    // scale-invariance distances (src/MapPoint.cc:385-395) and level prediction (:414-429)
+    float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
+    float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
+    inline int PredictScale(const float &currentDist, Frame *pF);
     bool mbBad;
     int nObs;
+    float mfMinDistance = 0.f, mfMaxDistance = 0.f;
     cv::Mat mDescriptor, mWorldPos;
 };
 
@@ -47,6 +56,24 @@ public:
     cv::Mat mTcw;
     std::vector<float> mvScaleFactors, mvInvScaleFactors;
     static float mnMinX, mnMaxX, mnMinY, mnMaxY;
+    int mnScaleLevels = 0;          // src/Frame.cc:69
+    float mfScaleFactor = 0.f, mfLogScaleFactor = 0.f;  // :70-71
+};
+
+inline int MapPoint::PredictScale(const float &currentDist, Frame *pF) {
+    using namespace std;
+    float ratio = mfMaxDistance / currentDist;
+    int nScale = ceil(log(ratio) / pF->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
+    return nScale;
+}
+
+class KeyFrame {
+public:
+    std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }  // src/KeyFrame.cc
+    std::vector<cv::KeyPoint> mvKeysUn;
+    std::vector<MapPoint *> mvpMapPoints;
 };
 
 }  // namespace ORB_SLAM2

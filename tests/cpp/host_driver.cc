@@ -3,7 +3,9 @@
 // files and compares its outputs with the CPU oracle.
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 #include "ORBextractor.h"
@@ -143,6 +145,50 @@ int main(int argc, char **argv) {
         printf("%d %d\n", F.N, n);
         return 0;
     }
-    fprintf(stderr, "usage: host_driver extract|stereo|init|projmp ...\n");
+    if (mode == "projkf" && argc == 13) {
+        // argv: img w h nf kf.bin(oracle_kfpoint_t[m]) kfdesc.bin th orbdist fx,fy,cx,cy tx tz out
+        const int w = atoi(argv[3]), h = atoi(argv[4]), nf = atoi(argv[5]);
+        const float th = (float)atof(argv[8]);
+        const int orbdist = atoi(argv[9]);
+        float cam[4];
+        sscanf(argv[10], "%f,%f,%f,%f", &cam[0], &cam[1], &cam[2], &cam[3]);
+        const std::string out = argv[12];
+        std::vector<unsigned char> a = slurp(argv[2]), kraw = slurp(argv[6]), draw = slurp(argv[7]);
+        ORBextractor ex(nf, 1.2f, 8, 20, 7);
+        if (!ex.ok()) return 3;
+        Frame F;
+        fill_frame(F, &ex, cv::Mat(h, w, CV_8UC1, a.data()), w, h);
+        Frame::fx = cam[0]; Frame::fy = cam[1]; Frame::cx = cam[2]; Frame::cy = cam[3];
+        F.mnScaleLevels = ex.GetLevels(); F.mfScaleFactor = ex.GetScaleFactor(); F.mfLogScaleFactor = log(F.mfScaleFactor);
+        float tx = 0, tz = 0;
+        sscanf(argv[11], "%f,%f", &tx, &tz);
+        F.mTcw.at<float>(0, 3) = tx; F.mTcw.at<float>(2, 3) = tz;
+        struct KfPt { int valid; float wx, wy, wz, maxd, mind, angle; };
+        const int m = (int)(kraw.size() / sizeof(KfPt));
+        const KfPt *kp = (const KfPt *)kraw.data();
+        std::vector<MapPoint> pts(m);
+        KeyFrame KF;
+        KF.mvKeysUn.resize(m); KF.mvpMapPoints.resize(m);
+        std::set<MapPoint *> already;
+        for (int i = 0; i < m; i++) {
+            pts[i].mWorldPos.at<float>(0) = kp[i].wx; pts[i].mWorldPos.at<float>(1) = kp[i].wy; pts[i].mWorldPos.at<float>(2) = kp[i].wz;
+            pts[i].mfMaxDistance = kp[i].maxd; pts[i].mfMinDistance = kp[i].mind;
+            pts[i].mDescriptor = cv::Mat(1, 32, CV_8U);
+            memcpy(pts[i].mDescriptor.ptr(0), &draw[(size_t)32 * i], 32);
+            KF.mvKeysUn[i].angle = kp[i].angle;
+            KF.mvpMapPoints[i] = &pts[i];
+            // invalid points alternate between the three ways the reference skips a point
+            if (!kp[i].valid) { if (i % 3 == 0) KF.mvpMapPoints[i] = NULL; else if (i % 3 == 1) pts[i].mbBad = true; else already.insert(&pts[i]); }
+        }
+        ORBmatcher matcher(0.9f, true);
+        const int n = matcher.SearchByProjection(F, &KF, already, th, orbdist);
+        std::vector<int> held(F.N, -1);
+        for (int i = 0; i < F.N; i++)
+            if (F.mvpMapPoints[i]) held[i] = (int)(F.mvpMapPoints[i] - &pts[0]);
+        dump(out + ".held", held.data(), held.size() * 4);
+        printf("%d %d\n", F.N, n);
+        return 0;
+    }
+    fprintf(stderr, "usage: host_driver extract|stereo|init|projmp|projkf ...\n");
     return 2;
 }

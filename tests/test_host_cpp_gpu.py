@@ -108,3 +108,41 @@ def test_search_by_projection_through_mappoints(driver, oracle, synth, tmp_path)
                                              orc.scale_factors, mps, md, np.full(len(k), -1, np.int32), None, 3.0, 0.8)
     assert N == len(k) and nm == on > 100
     np.testing.assert_array_equal(np.fromfile(str(tmp_path / "p.held"), np.int32), ofm)
+
+
+def test_search_by_projection_through_keyframe(driver, oracle, synth, tmp_path):
+    """SURVEY §8(f) rank 1 through the C++ class: ORBmatcher::SearchByProjection(Frame&, KeyFrame*,
+    sAlreadyFound, th, ORBdist) — projection + PredictScale on the host, matching on the GPU."""
+    w, h, nf = 1241, 376, 1000
+    img = synth.frame(w, h, 25)
+    img.tofile(tmp_path / "a.raw")
+    orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    k, d = orc.extract(img)
+    sf = orc.scale_factors
+    rng = np.random.default_rng(5)
+    fx, fy, cx, cy = 718.856, 718.856, 607.19, 185.2
+    m = 1300
+    idx = rng.choice(len(k), m, replace=True)
+    z = rng.uniform(4, 40, m).astype(np.float32)
+    kf = np.zeros(m, oracle.KFPOINT_DTYPE)
+    kf["valid"] = rng.random(m) > 0.2
+    kf["wx"] = ((k["x"][idx] + rng.normal(0, 2, m) - cx) / fx * z).astype(np.float32)
+    kf["wy"] = ((k["y"][idx] + rng.normal(0, 2, m) - cy) / fy * z).astype(np.float32)
+    kf["wz"] = z
+    kf["max_distance"] = z * sf[k["octave"][idx]] * rng.uniform(0.85, 1.15, m)
+    kf["min_distance"] = kf["max_distance"] / sf[7] * rng.uniform(0.5, 1.0, m)
+    kf["angle"] = (k["angle"][idx] + rng.normal(0, 5, m)) % 360
+    kd = d[idx] ^ (rng.integers(0, 256, (m, 32), dtype=np.uint8) & rng.integers(0, 256, (m, 32), dtype=np.uint8) &
+                   rng.integers(0, 256, (m, 32), dtype=np.uint8))
+    kf.tofile(tmp_path / "kf.bin"); kd.tofile(tmp_path / "kd.bin")
+    th, orbdist, tx, tz = 10.0, 100, 0.03, 0.2
+    N, nm = _run(driver, "projkf", tmp_path / "a.raw", w, h, nf, tmp_path / "kf.bin", tmp_path / "kd.bin", th, orbdist,
+                 "%r,%r,%r,%r" % (fx, fy, cx, cy), "%r,%r" % (tx, tz), tmp_path / "k")
+    Tc = np.eye(4, dtype=np.float32)
+    Tc[0, 3], Tc[2, 3] = tx, tz
+    cam = oracle.Cam(fx, fy, cx, cy, 0.0, 0.0)
+    log_sf = np.float32(np.log(np.float32(1.2)))
+    on, ocm = oracle.search_by_projection_kf(k, d, oracle.grid_geom(w, h), sf, log_sf, cam, Tc, kf, kd,
+                                             np.full(len(k), -1, np.int32), th, orbdist)
+    assert N == len(k) and nm == on > 100
+    np.testing.assert_array_equal(np.fromfile(str(tmp_path / "k.held"), np.int32), ocm)

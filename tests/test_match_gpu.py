@@ -219,3 +219,79 @@ def test_guided_search_heavy_contention(pkg, oracle, synth, matcher_path):
     assert gn == on
     np.testing.assert_array_equal(gm12, om12)
     np.testing.assert_array_equal(gprev, oprev)
+
+
+def _kf_scene(oracle, synth, rng, n_ext=40):
+    """A keyframe whose map points project near the current frame's keypoints."""
+    w, h = 1241, 376
+    _, k, d = _features(oracle, synth.frame(w, h, 14), 1000)
+    sf = oracle.Extractor(1000, 1.2, 8, 20, 7).scale_factors
+    fx, fy, cx, cy = 718.856, 718.856, 607.19, 185.2
+    cam = oracle.Cam(fx, fy, cx, cy, 386.1448, np.float32(386.1448) / np.float32(fx))
+    n = len(k)
+    m = 1500
+    idx = rng.choice(n, m, replace=True)
+    z = rng.uniform(4, 40, m).astype(np.float32)
+    kf = np.zeros(m, oracle.KFPOINT_DTYPE)
+    kf["valid"] = rng.random(m) > 0.15
+    kf["wx"] = (k["x"][idx] + rng.normal(0, 2, m) - cx) / fx * z
+    kf["wy"] = (k["y"][idx] + rng.normal(0, 2, m) - cy) / fy * z
+    kf["wz"] = z
+    # scale-invariance range such that the predicted level is around the keypoint's octave
+    lvl = k["octave"][idx]
+    kf["max_distance"] = z * sf[lvl] * rng.uniform(0.85, 1.15, m)
+    kf["min_distance"] = kf["max_distance"] / sf[7] * rng.uniform(0.5, 1.0, m)
+    kf["angle"] = (k["angle"][idx] + rng.normal(0, 5, m)) % 360
+    kd = d[idx] ^ (rng.integers(0, 256, (m, 32), dtype=np.uint8) & rng.integers(0, 256, (m, 32), dtype=np.uint8) &
+                   rng.integers(0, 256, (m, 32), dtype=np.uint8))
+    Tc = np.eye(4, dtype=np.float32)
+    Tc[0, 3], Tc[2, 3] = 0.03, 0.2
+    cur = np.full(n, -1, np.int32)
+    cur[rng.choice(n, n_ext, replace=False)] = -2
+    return w, h, k, d, sf, cam, kf, kd, Tc, cur
+
+
+def test_search_by_projection_keyframe(pkg, oracle, synth, matcher_path):
+    """SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)
+    (src/ORBmatcher.cc:1474-1601) = host projection (oracle stage here) + orbm_match_windows."""
+    rng = np.random.default_rng(21)
+    w, h, k, d, sf, cam, kf, kd, Tc, cur = _kf_scene(oracle, synth, rng)
+    log_sf = np.float32(np.log(np.float32(1.2)))
+    for th, orbdist in [(10.0, 100), (3.0, 64)]:
+        on, ocm = oracle.search_by_projection_kf(k, d, oracle.grid_geom(w, h), sf, log_sf, cam, Tc, kf, kd, cur, th, orbdist)
+        q = oracle.kf_window_queries(kf, oracle.grid_geom(w, h), sf, log_sf, cam, Tc, th)
+        assert q["valid"].sum() > 500
+        gn, gcm = pkg.match_windows(k, d, None, pkg.grid_geom(w, h), q, kd, cur, None, orbdist, True)
+        assert on > 100
+        assert gn == on
+        np.testing.assert_array_equal(gcm, ocm)
+
+
+def test_match_windows_generic_paths_agree(pkg, oracle, synth, matcher_path):
+    """Generic matcher with per-query blocking and the stereo gate: the speculative path
+    and the exact one-workgroup path give the same holders."""
+    w, h = 1241, 376
+    _, k, d = _features(oracle, synth.frame(w, h, 15), 1000)
+    rng = np.random.default_rng(22)
+    n = len(k)
+    q = np.zeros(n, pkg.WINDOW_DTYPE)
+    q["valid"] = rng.random(n) > 0.2
+    q["u"] = k["x"] + rng.normal(0, 2, n)
+    q["v"] = k["y"] + rng.normal(0, 2, n)
+    q["radius"] = 7.0 * oracle.Extractor(1000, 1.2, 8, 20, 7).scale_factors[k["octave"]]
+    q["min_level"] = k["octave"] - 1
+    q["max_level"] = k["octave"] + 1
+    q["angle"] = k["angle"]
+    q["blocks"] = rng.integers(0, 2, n)
+    q["ur_c"] = q["u"] - 10
+    q["ur_tol"] = q["radius"]
+    uright = np.where(rng.random(n) < 0.5, k["x"] - rng.uniform(5, 15, n), -1).astype(np.float32)
+    qd = d ^ (rng.integers(0, 256, d.shape, dtype=np.uint8) & rng.integers(0, 256, d.shape, dtype=np.uint8) &
+              rng.integers(0, 256, d.shape, dtype=np.uint8))
+    holder = np.full(n, -1, np.int32)
+    pkg.lib().orbx_debug_set(2, 1)
+    en, eh = pkg.match_windows(k, d, uright, pkg.grid_geom(w, h), q, qd, holder, None, 100, True)
+    pkg.lib().orbx_debug_set(2, 0 if matcher_path == "fast" else 1)
+    gn, gh = pkg.match_windows(k, d, uright, pkg.grid_geom(w, h), q, qd, holder, None, 100, True)
+    assert gn == en > 100
+    np.testing.assert_array_equal(gh, eh)
