@@ -268,13 +268,14 @@ def main():
         counts = cnt[(args.warmup + args.steps - 1) % nbuf].cpu().numpy()
         navg = float(counts.mean())
         bytes_img = 3 * P + 60 * navg
+        ncand_img = sum(len(ex.debug_level_points(l, 0, b=0)) for l in range(8))   # FAST candidates of image 0
         bytes_frame = (2 * bytes_img + 64 * navg) if stereo else bytes_img
         # dominant single kernel of the step (HIP events on the launch stream, averaged over the
         # timed region).  Algorithmic bytes per image: FAST+NMS reads every level once = P;
         # quad-tree reads its candidates; describe reads P + writes 60 N (SURVEY §8(d) split).
         kern = {
             "k_fast_cells": (float(stage_ms[1]), P * nimg),
-            "k_octree": (float(stage_ms[2]), 8.0 * 26000 * nimg),
+            "k_octree": (float(stage_ms[2]), 8.0 * ncand_img * nimg),   # 4 B key + 2 B node index read, 2 B written
             "k_describe": (float(stage_ms[3]), (P + 60 * navg) * nimg),
         }
         dom = max(kern, key=lambda k: kern[k][0])

@@ -514,6 +514,36 @@ __device__ __forceinline__ short4 child_box(short4 bx, int q) {
     return r;
 }
 
+// four consecutive keys / node indices of one thread (16-B / 8-B accesses; the level's key block is 16-B aligned)
+__device__ __forceinline__ void load_keys4(const uint32_t *keys, int i0, int n, uint32_t key[4]) {
+    if (i0 + 3 < n) {
+        const uint4 v = *(const uint4 *)(keys + i0);
+        key[0] = v.x; key[1] = v.y; key[2] = v.z; key[3] = v.w;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) key[u] = i0 + u < n ? keys[i0 + u] : 0u;
+    }
+}
+__device__ __forceinline__ void load_nof4(const uint16_t *nof, int i0, int n, int kk[4]) {
+    if (i0 + 3 < n) {
+        const ushort4 v = *(const ushort4 *)(nof + i0);
+        kk[0] = v.x; kk[1] = v.y; kk[2] = v.z; kk[3] = v.w;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) kk[u] = i0 + u < n ? (int)nof[i0 + u] : 0;
+    }
+}
+__device__ __forceinline__ void store_nof4(uint16_t *nof, int i0, int n, const int kk[4]) {
+    if (i0 + 3 < n) {
+        ushort4 v;
+        v.x = (unsigned short)kk[0]; v.y = (unsigned short)kk[1]; v.z = (unsigned short)kk[2]; v.w = (unsigned short)kk[3];
+        *(ushort4 *)(nof + i0) = v;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (i0 + u < n) nof[i0 + u] = (uint16_t)kk[u];
+    }
+}
+
 // exclusive scan of one int per thread across the block; returns the exclusive prefix and
 // writes the block total to *total (all threads).  wsum: LDS int[OCT_T/64 + 1].
 __device__ __forceinline__ int block_scan_excl(int v, int *wsum, int *total) {
@@ -592,12 +622,17 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
     __syncthreads();
     {   // keys per root (:569): per-wave ballot counts, one LDS atomic per wave and root
         const int lane = tid & 63;
-        for (int i0 = 0; i0 < n; i0 += OCT_T) {
-            const int i = i0 + tid;
-            const int r = i < n ? (int)rootOf[keys[i] & 0xFFF] : -1;
-            for (int q = 0; q < g.nIni; q++) {
-                const unsigned long long m = __ballot(r == q);
-                if (lane == 0 && m) atomicAdd(&rootCnt[q], (int)__popcll(m));
+        for (int b0 = 0; b0 < n; b0 += 4 * OCT_T) {
+            const int i0 = b0 + 4 * tid;
+            uint32_t key[4];
+            load_keys4(keys, i0, n, key);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int r = i0 + u < n ? (int)rootOf[key[u] & 0xFFF] : -1;
+                for (int q = 0; q < g.nIni; q++) {
+                    const unsigned long long m = __ballot(r == q);
+                    if (lane == 0 && m) atomicAdd(&rootCnt[q], (int)__popcll(m));
+                }
             }
         }
     }
@@ -627,26 +662,23 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
     for (int i = tid; i < 4 * L; i += OCT_T) S.hist[i] = 0;  // coff is dead from here on
     __syncthreads();
     // first sweep: list index of the root + children histogram of the expandable roots
-    for (int i0 = tid; i0 < n; i0 += 4 * OCT_T) {
+    for (int b0 = 0; b0 < n; b0 += 4 * OCT_T) {
+        const int i0 = b0 + 4 * tid;
         uint32_t key[4];
         int kk[4];
+        load_keys4(keys, i0, n, key);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int i = i0 + u * OCT_T;
-            key[u] = i < n ? keys[i] : 0u;
-            kk[u] = rootOf[key[u] & 0xFFF];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = i0 + u * OCT_T;
-            if (i < n) {
-                const int k = rootMap[kk[u]];
-                nof[i] = (uint16_t)k;
+            const int k = rootMap[rootOf[key[u] & 0xFFF]];
+            kk[u] = k;
+            int bin = -1;
+            if (i0 + u < n) {
                 const uint32_t cv = S.cnt[0][k];
-                if ((cv & 0x7FFFFFFFu) > 1)
-                    atomicAdd(&S.hist[4 * k + child_of(key[u] & 0xFFF, (key[u] >> 12) & 0xFFF, S.box[0][k])], 1u);
+                if ((cv & 0x7FFFFFFFu) > 1) bin = 4 * k + child_of(key[u] & 0xFFF, (key[u] >> 12) & 0xFFF, S.box[0][k]);
             }
+            if (bin >= 0) atomicAdd(&S.hist[bin], 1u);
         }
+        store_nof4(nof, i0, n, kk);
     }
     __syncthreads();
 
@@ -818,32 +850,31 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
         const int nz = finish ? Lnew : 4 * Lnew;
         for (int i = tid; i < nz; i += OCT_T) S.hist[i] = 0;
         __syncthreads();
-        for (int i0 = tid; i0 < n; i0 += 4 * OCT_T) {
+        for (int b0 = 0; b0 < n; b0 += 4 * OCT_T) {
+            const int i0 = b0 + 4 * tid;
             uint32_t key[4];
             int kk[4];
+            load_keys4(keys, i0, n, key);
+            load_nof4(nof, i0, n, kk);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int i = i0 + u * OCT_T;
-                key[u] = i < n ? keys[i] : 0u;
-                kk[u] = i < n ? (int)nof[i] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = i0 + u * OCT_T;
+                const int i = i0 + u;
+                int bin = -1;
                 if (i < n) {
                     const int ko = kk[u];
                     const int x = key[u] & 0xFFF, y = (key[u] >> 12) & 0xFFF;
                     const int k = S.split[ko] ? (int)S.childIdx[4 * ko + child_of(x, y, box[ko])] : (int)S.survIdx[ko];
+                    kk[u] = k;
                     if (finish) {
                         atomicMax(&S.hist[k], ((key[u] >> 24) << 20) | (0xFFFFFu - (uint32_t)i));
                     } else {
-                        nof[i] = (uint16_t)k;
                         const uint32_t cv = ncnt[k];
-                        if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1)
-                            atomicAdd(&S.hist[4 * k + child_of(x, y, nbox[k])], 1u);
+                        if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) bin = 4 * k + child_of(x, y, nbox[k]);
                     }
                 }
+                if (bin >= 0) atomicAdd(&S.hist[bin], 1u);
             }
+            if (!finish) store_nof4(nof, i0, n, kk);
         }
         __syncthreads();
         L = Lnew;
@@ -1230,7 +1261,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
             orbx_set_error("level %d can hold %d FAST candidates (> 2^20): unsupported", l, g.keyCap);
             return ORBX_ERR_UNSUPPORTED;
         }
-        keyOff += (size_t)g.keyCap;
+        keyOff += ((size_t)g.keyCap + 7) & ~(size_t)7;  // 16-B aligned key blocks (uint4 / ushort4 sweeps)
         g.N = h->nfeat[l];
         g.nIni = (int)roundf((float)g.regW / g.regH);
         if (g.nIni < 1 || g.nIni > ORBX_MAX_ROOTS) {
@@ -1350,7 +1381,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     h->lvlKpCap = lvlKpOff;
     h->pyrImgBytes = (poff + 255) & ~(size_t)255;
     h->slotsPerImg = slotOff;
-    h->keysPerImg = (keyOff + 1) & ~(size_t)1;
+    h->keysPerImg = (keyOff + 7) & ~(size_t)7;
     h->fastTileStride = (maxTw + 6 + 3) & ~3;        // dwords per pair-tile row (column = byte offset in the aligned row)
     h->fastScoreStride = (maxTw - 6 + 4 + 3) & ~3;   // bytes per score row: 2-px left halo + >= 2 right
     h->fastTileRows = maxTh;
