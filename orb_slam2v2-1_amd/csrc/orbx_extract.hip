@@ -585,15 +585,332 @@ __device__ int array_scan_excl(int *a, int m, int *wsum) {
     return total;
 }
 
+// K3 (main path): DistributeOctTree from a COUNT PYRAMID.  A key's path through the quad-tree
+// is a pure function of its coordinates (root by tabulated x/hX, then ceil-halved boxes), so
+// ONE sweep over the keys histograms them at a fixed depth Dm and the key count of every node
+// of every shallower depth follows by summing children.  All the list surgery of the passes
+// (which nodes are split, in which order, where the break falls) then runs on node counts only
+// — no further key sweep — and one final sweep walks every key down to its leaf to elect the
+// best response per node.  Two sweeps over the keys instead of one per pass.  If a pass would
+// need counts deeper than Dm (sparse, clustered candidates) the level is flagged and redone by
+// the sweep-per-pass kernel k_octree below: results never depend on the path taken.
+__device__ __forceinline__ uint32_t pyr_count(const uint32_t *pyr, int nIni, int Dm, int d, uint32_t c) {
+    const uint32_t off = (uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u);
+    if (d == Dm) return (pyr[off + (c >> 1)] >> (16 * (c & 1))) & 0xFFFFu;
+    return pyr[off + c];
+}
+
+__global__ __launch_bounds__(OCT_T) void k_octree_pyr(
+    const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand, size_t keysPerImg,
+    const int32_t *__restrict__ candCnt, uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
+    const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;  // level-major: large levels start first
+    const LevelGeom g = geom[l];
+    const int Dm = g.pyrDepth, nIni = g.nIni, N = g.N;
+    uint8_t *sp = smem;
+    unsigned long long *skey = (unsigned long long *)sp; sp += sizeof(unsigned long long) * pow2cap;
+    uint32_t *cntA = (uint32_t *)sp; sp += 4 * 2 * capMax;   // [2][cap] key count, bit31 = fresh
+    uint32_t *nidA = (uint32_t *)sp; sp += 4 * 2 * capMax;   // [2][cap] depth << 28 | cell
+    uint32_t *hist = (uint32_t *)sp; sp += 4 * 4 * capMax;   // children counts of list node k; later best[]
+    int *pn = (int *)sp; sp += 4 * capMax;
+    uint32_t *pyr = (uint32_t *)sp; sp += 4 * (size_t)pyrWords;
+    uint16_t *xlist = (uint16_t *)sp; sp += 2 * capMax;
+    uint8_t *split = sp; sp += capMax;
+    __shared__ int sh_L, sh_Lnew, sh_finish, sh_phase, sh_abort;
+
+    const uint32_t *keys = cand + (size_t)b * keysPerImg + g.keyOff;
+    const int n = candCnt[b * nlevels + l];
+    const uint8_t *rootOf = (const uint8_t *)tab + g.rootTabOff;
+    const int32_t *rootX = tab + g.rootBoxOff;
+    const uint32_t offDeep = (uint32_t)nIni * (((1u << (2 * Dm)) - 1u) / 3u);
+
+    // ---- 1. histogram of the keys at depth Dm (two 16-bit counters per word)
+    for (int i = tid; i < pyrWords; i += OCT_T) pyr[i] = 0;
+    if (tid == 0) sh_abort = 0;
+    __syncthreads();
+    for (int i0 = 4 * tid; i0 < n; i0 += 4 * OCT_T) {
+        uint32_t key[4];
+        load_keys4(keys, i0, n, key);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + u < n) {
+                const int x = key[u] & 0xFFF, y = (key[u] >> 12) & 0xFFF;
+                const int r = rootOf[x];
+                short4 bx;
+                bx.x = (short)rootX[r]; bx.y = (short)rootX[r + 1]; bx.z = 0; bx.w = (short)g.regH;
+                uint32_t c = (uint32_t)r;
+                for (int d = 0; d < Dm; d++) {
+                    const int q = child_of(x, y, bx);
+                    bx = child_box(bx, q);
+                    c = 4 * c + q;
+                }
+                atomicAdd(&pyr[offDeep + (c >> 1)], 1u << (16 * (c & 1)));
+            }
+    }
+    __syncthreads();
+    // ---- 2. counts of the shallower depths
+    for (int d = Dm - 1; d >= 0; d--) {
+        const uint32_t off = (uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u);
+        const int ne = nIni << (2 * d);
+        for (int e = tid; e < ne; e += OCT_T) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) s += pyr_count(pyr, nIni, Dm, d + 1, 4u * e + q);
+            pyr[off + e] = s;
+        }
+        __syncthreads();
+    }
+    // ---- 3. root nodes (:543-592)
+    if (tid == 0) {
+        int L0 = 0;
+        for (int r = 0; r < nIni; r++) {
+            const uint32_t c = pyr[r];
+            if (c > 0) { cntA[L0] = c | 0x80000000u; nidA[L0] = (uint32_t)r; L0++; }
+        }
+        sh_L = L0;
+    }
+    __syncthreads();
+    int L = sh_L, cur = 0, phase = 1;
+
+    // ---- 4. passes: list bookkeeping on node counts only, by wave 0
+    while (true) {
+        uint32_t *cnt = cntA + cur * capMax, *ncnt = cntA + (cur ^ 1) * capMax;
+        uint32_t *nid = nidA + cur * capMax, *nnid = nidA + (cur ^ 1) * capMax;
+        if (tid < 64) {
+            const int lane = tid;
+            // children counts of every expandable node from the pyramid
+            bool deep = false;
+            for (int k = lane; k < L; k += 64) {
+                const uint32_t cv = cnt[k];
+                if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) {
+                    const int d = (int)(nid[k] >> 28);
+                    const uint32_t c = nid[k] & 0x0FFFFFFFu;
+                    if (d + 1 > Dm) deep = true;
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) hist[4 * k + q] = pyr_count(pyr, nIni, Dm, d + 1, 4u * c + q);
+                    }
+                }
+            }
+            if (__ballot(deep)) { if (lane == 0) sh_abort = 1; }
+            wave_sync();
+            if (!sh_abort) {
+                // visiting order of the expandable (fresh, >1 key) nodes
+                int E;
+                if (phase == 1) {   // list order
+                    const int chunk = (L + 63) >> 6;
+                    const int beg = min(lane * chunk, L), end = min(beg + chunk, L);
+                    int s = 0;
+                    for (int k = beg; k < end; k++) {
+                        const uint32_t cv = cnt[k];
+                        s += ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) ? 1 : 0;
+                    }
+                    int inc = s;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int t = __shfl_up(inc, o);
+                        if (lane >= o) inc += t;
+                    }
+                    E = __builtin_amdgcn_readlane(inc, 63);
+                    int off = inc - s;
+                    for (int k = beg; k < end; k++) {
+                        const uint32_t cv = cnt[k];
+                        if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) xlist[off++] = (uint16_t)k;
+                    }
+                } else {            // (size desc, later-created first): bitonic sort of (~size, list index)
+                    int P = 1;
+                    while (P < L) P <<= 1;
+                    int e = 0;
+                    for (int k = lane; k < P; k += 64) {
+                        unsigned long long key = ~0ull;
+                        if (k < L) {
+                            const uint32_t cv = cnt[k];
+                            if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) {
+                                key = ((unsigned long long)(0x7FFFFFFFu - (cv & 0x7FFFFFFFu)) << 32) | (unsigned)k;
+                                e++;
+                            }
+                        }
+                        skey[k] = key;
+                    }
+                    wave_sync();
+                    for (int kk2 = 2; kk2 <= P; kk2 <<= 1)
+                        for (int j = kk2 >> 1; j > 0; j >>= 1) {
+                            for (int i = lane; i < P; i += 64) {
+                                const int ixj = i ^ j;
+                                if (ixj > i) {
+                                    const unsigned long long a = skey[i], c2 = skey[ixj];
+                                    if ((a > c2) == ((i & kk2) == 0)) { skey[i] = c2; skey[ixj] = a; }
+                                }
+                            }
+                            wave_sync();
+                        }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+                    E = e;
+                    for (int k = lane; k < E; k += 64) xlist[k] = (uint16_t)(skey[k] & 0xFFFFu);
+                }
+                wave_sync();
+                // children created per rank -> exclusive prefix by rank; number of parents split
+                int Sp = E, C = 0;
+                {
+                    const int chunk = (E + 63) >> 6;
+                    const int beg = min(lane * chunk, E), end = min(beg + chunk, E);
+                    int s = 0;
+                    for (int r = beg; r < end; r++) {
+                        const int k = xlist[r];
+                        s += (hist[4 * k] > 0) + (hist[4 * k + 1] > 0) + (hist[4 * k + 2] > 0) + (hist[4 * k + 3] > 0);
+                    }
+                    int inc = s;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int t = __shfl_up(inc, o);
+                        if (lane >= o) inc += t;
+                    }
+                    int off = inc - s;
+                    int hit = 0x7FFFFFFF;
+                    for (int r = beg; r < end; r++) {
+                        const int k = xlist[r];
+                        const int nz = (hist[4 * k] > 0) + (hist[4 * k + 1] > 0) + (hist[4 * k + 2] > 0) + (hist[4 * k + 3] > 0);
+                        pn[r] = off;
+                        if (phase == 2) {
+                            const int after = L + off + nz - (r + 1), before = L + off - r;
+                            if (after >= N && before < N) hit = r + 1;   // the break at :730-731
+                        }
+                        off += nz;
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) hit = min(hit, __shfl_xor(hit, o));
+                    if (phase == 2 && hit != 0x7FFFFFFF) Sp = hit;
+                    wave_sync();
+                    if (Sp > 0) {
+                        const int k = xlist[Sp - 1];
+                        C = pn[Sp - 1] + (hist[4 * k] > 0) + (hist[4 * k + 1] > 0) + (hist[4 * k + 2] > 0) + (hist[4 * k + 3] > 0);
+                    }
+                }
+                const int Lnew = L - Sp + C;
+                for (int k = lane; k < L; k += 64) split[k] = 0;
+                wave_sync();
+                // create children: creation sequence s -> list index C-1-s (every insertion is push_front)
+                int nexp = 0;
+                for (int r = lane; r < Sp; r += 64) {
+                    const int k = xlist[r];
+                    split[k] = 1;
+                    int s = pn[r];
+                    const uint32_t pd = nid[k] >> 28, pc = nid[k] & 0x0FFFFFFFu;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t hc = hist[4 * k + q];
+                        if (hc > 0) {
+                            const int ni = C - 1 - s;
+                            ncnt[ni] = hc | 0x80000000u;
+                            nnid[ni] = ((pd + 1) << 28) | (4u * pc + q);
+                            if (hc > 1) nexp++;
+                            s++;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) nexp += __shfl_xor(nexp, o);
+                wave_sync();
+                {   // survivors keep their relative order behind the new nodes
+                    const int chunk = (L + 63) >> 6;
+                    const int beg = min(lane * chunk, L), end = min(beg + chunk, L);
+                    int s = 0;
+                    for (int k = beg; k < end; k++) s += split[k] ? 0 : 1;
+                    int inc = s;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int t = __shfl_up(inc, o);
+                        if (lane >= o) inc += t;
+                    }
+                    int off = inc - s;
+                    for (int k = beg; k < end; k++)
+                        if (!split[k]) {
+                            const int ni = C + off++;
+                            ncnt[ni] = cnt[k] & 0x7FFFFFFFu;  // no longer fresh
+                            nnid[ni] = nid[k];
+                        }
+                }
+                const bool fin = (Lnew >= N || Lnew == L);   // :669-672, :733-734
+                if (lane == 0) {
+                    sh_Lnew = Lnew;
+                    sh_finish = fin ? 1 : 0;
+                    sh_phase = (!fin && phase == 1 && Lnew + 3 * nexp > N) ? 2 : phase;
+                }
+            }
+        }
+        __syncthreads();
+        if (sh_abort) {   // counts deeper than the pyramid are needed: hand the level to k_octree
+            if (tid == 0) fallback[b * nlevels + l] = 1;
+            return;
+        }
+        L = sh_Lnew;
+        phase = sh_phase;
+        cur ^= 1;
+        if (sh_finish) break;
+        __syncthreads();
+    }
+
+    // ---- 5. leaf map (depth, cell) -> list index, in place of the counts
+    {
+        const uint32_t *nid = nidA + cur * capMax;
+        __syncthreads();
+        for (int i = tid; i < pyrWords; i += OCT_T) pyr[i] = 0xFFFFFFFFu;
+        for (int i = tid; i < L; i += OCT_T) hist[i] = 0;  // best[]
+        __syncthreads();
+        for (int k = tid; k < L; k += OCT_T) {
+            const int d = (int)(nid[k] >> 28);
+            const uint32_t c = nid[k] & 0x0FFFFFFFu;
+            const uint32_t off = (uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u);
+            if (d == Dm) ((uint16_t *)(pyr + off))[c] = (uint16_t)k;
+            else pyr[off + c] = (uint32_t)k;
+        }
+        __syncthreads();
+    }
+    // ---- 6. every key walks down to its leaf; best key of the node, first maximum wins (:744-760)
+    for (int i0 = 4 * tid; i0 < n; i0 += 4 * OCT_T) {
+        uint32_t key[4];
+        load_keys4(keys, i0, n, key);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + u < n) {
+                const int x = key[u] & 0xFFF, y = (key[u] >> 12) & 0xFFF;
+                const int r = rootOf[x];
+                short4 bx;
+                bx.x = (short)rootX[r]; bx.y = (short)rootX[r + 1]; bx.z = 0; bx.w = (short)g.regH;
+                uint32_t c = (uint32_t)r, node = 0xFFFFFFFFu;
+                for (int d = 0; d <= Dm; d++) {
+                    const uint32_t off = (uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u);
+                    const uint32_t v = d == Dm ? (uint32_t)((const uint16_t *)(pyr + off))[c] : pyr[off + c];
+                    if (d == Dm ? (v != 0xFFFFu) : (v != 0xFFFFFFFFu)) { node = v; break; }
+                    const int q = child_of(x, y, bx);
+                    bx = child_box(bx, q);
+                    c = 4 * c + q;
+                }
+                if (node != 0xFFFFFFFFu) atomicMax(&hist[node], ((key[u] >> 24) << 20) | (0xFFFFFu - (uint32_t)(i0 + u)));
+            }
+    }
+    __syncthreads();
+    // ---- 7. output in list order
+    uint32_t *okp = lvlKp + (size_t)b * lvlKpCap + g.lvlKpOff;
+    const int Lout = min(L, g.nodeCap);
+    for (int k = tid; k < Lout; k += OCT_T) okp[k] = keys[0xFFFFFu - (hist[k] & 0xFFFFFu)];
+    if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; fallback[b * nlevels + l] = 0; }
+}
+
+// K3 (fallback): one sweep over the keys per pass; runs only for levels k_octree_pyr flagged
 __global__ __launch_bounds__(OCT_T) void k_octree(
     const LevelGeom *__restrict__ geom, int nlevels, int totalCells, const uint32_t *__restrict__ cellCnt,
     const uint32_t *__restrict__ slots, size_t slotsPerImg, uint32_t *__restrict__ cand,
     uint16_t *__restrict__ nodeOf, size_t keysPerImg, const int32_t *__restrict__ candCnt,
     uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
-    const int32_t *__restrict__ tab, int capMax, int pow2cap, int scratchInts, int dbgStop) {
+    const int32_t *__restrict__ tab, int capMax, int pow2cap, int scratchInts, int dbgStop,
+    const int32_t *__restrict__ fallback) {
     extern __shared__ __align__(16) uint8_t smem[];
     // level-major block order: the large levels start first and the small ones fill the gaps
     const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+    if (fallback && !fallback[b * nlevels + l]) return;  // done by k_octree_pyr
     const LevelGeom g = geom[l];
     // ---- carve LDS
     uint8_t *sp = smem;
@@ -1166,6 +1483,7 @@ extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int i
 
 static void free_plan(orbx_extractor *h) {
     hipFree(h->d_cellOff); h->d_cellOff = nullptr;
+    hipFree(h->d_octFallback); h->d_octFallback = nullptr;
     hipFree(h->d_geom); hipFree(h->d_tab); hipFree(h->d_pyr); hipFree(h->d_cellCnt); hipFree(h->d_slots);
     hipFree(h->d_cand); hipFree(h->d_lvlKp); hipFree(h->d_nodeOf); hipFree(h->d_candCnt); hipFree(h->d_lvlCnt);
     h->d_geom = nullptr; h->d_tab = nullptr; h->d_pyr = nullptr; h->d_cellCnt = nullptr; h->d_slots = nullptr;
@@ -1219,7 +1537,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     B = std::max(B, keepB);
     std::vector<int32_t> tab;
     size_t poff = 0, slotOff = 0, keyOff = 0;
-    int cellBase = 0, lvlKpOff = 0, maxNodeCap = 0, maxCells = 0;
+    int cellBase = 0, lvlKpOff = 0, maxNodeCap = 0, maxCells = 0, maxPyrWords = 0;
     int maxTw = 0, maxTh = 0;
     int kpBound = 0;
     for (int l = 0; l < h->nlevels; l++) {
@@ -1270,6 +1588,14 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
             return g.nIni < 1 ? ORBX_ERR_ARG : ORBX_ERR_UNSUPPORTED;
         }
         g.nodeCap = std::max(g.N + 3, 4 * g.nIni) + 4 * g.nIni + 1;
+        {   // depth of the count pyramid: enough cells for the passes of a dense level, bounded by LDS
+            int d = 1;
+            while ((g.nIni << (2 * d)) < 4 * std::max(g.N, 1) && d < 7) d++;
+            while ((g.nIni << (2 * d)) > 16384 && d > 1) d--;
+            g.pyrDepth = d;
+            const int words = g.nIni * (((1 << (2 * d)) - 1) / 3) + ((g.nIni << (2 * d)) + 1) / 2 + 1;
+            maxPyrWords = std::max(maxPyrWords, words);
+        }
         kpBound += std::max(g.N + 2, 4 * g.nIni);
         maxNodeCap = std::max(maxNodeCap, g.nodeCap);
         maxCells = std::max(maxCells, g.ncells);
@@ -1393,6 +1719,9 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
         size_t bytes = sizeof(unsigned long long) * pow2 + (size_t)maxNodeCap * (8 * 2 + 4 * 2 + 4 * 2 + 2 * 4 + 2 + 2 + 1) +
                        4 * (size_t)scratch + 64;
         h->octLdsBytes = bytes;
+        h->octPyrWords = maxPyrWords;
+        h->octPyrLdsBytes = sizeof(unsigned long long) * pow2 + (size_t)maxNodeCap * (8 + 8 + 16 + 4 + 2 + 1) + 4 * (size_t)maxPyrWords + 64;
+        if (h->octPyrLdsBytes > 150 * 1024) { orbx_set_error("quad-tree pyramid needs %zu B of LDS", h->octPyrLdsBytes); return ORBX_ERR_UNSUPPORTED; }
         if (bytes > 150 * 1024) {
             orbx_set_error("quad-tree needs %zu B of LDS (features per level %d): unsupported", bytes, maxNodeCap);
             return ORBX_ERR_UNSUPPORTED;
@@ -1410,6 +1739,8 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     ORBX_HIP(hipMalloc(&h->d_candCnt, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
     ORBX_HIP(hipMalloc(&h->d_lvlCnt, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
     ORBX_HIP(hipMalloc(&h->d_lvlKp, sizeof(uint32_t) * (size_t)h->lvlKpCap * Bz));
+    ORBX_HIP(hipMalloc(&h->d_octFallback, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
+    ORBX_HIP(hipMemset(h->d_octFallback, 0, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
     ORBX_HIP(hipMemcpy(h->d_geom, h->geom, sizeof(LevelGeom) * ORBX_MAX_LEVELS, hipMemcpyHostToDevice));
     if (!tab.empty()) ORBX_HIP(hipMemcpy(h->d_tab, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice));
     h->pw = w; h->ph = hgt; h->pB = B;
@@ -1473,10 +1804,18 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
         hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
                            dim3(256), 0, st, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_cellOff, h->d_slots,
                            h->slotsPerImg, h->d_cand, h->keysPerImg);
+        const bool usePyr = g_debug[4] == 0;
+        if (usePyr) {
+            ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_pyr, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)h->octPyrLdsBytes));
+            hipLaunchKernelGGL(k_octree_pyr, dim3(B, nl), dim3(OCT_T), h->octPyrLdsBytes, st, h->d_geom, nl, h->d_cand,
+                               h->keysPerImg, h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap,
+                               pow2, h->octPyrWords, h->d_octFallback);
+        }
         hipLaunchKernelGGL(k_octree, dim3(B, nl), dim3(OCT_T), h->octLdsBytes, st, h->d_geom, nl, h->totalCells,
                            h->d_cellCnt, h->d_slots, h->slotsPerImg, h->d_cand, h->d_nodeOf, h->keysPerImg,
                            h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2, scratch,
-                           g_debug[1]);
+                           g_debug[1], usePyr ? h->d_octFallback : (const int32_t *)nullptr);
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[3], st));
     {   // K4

@@ -44,6 +44,7 @@ struct LevelGeom {
     int N;                           // mnFeaturesPerLevel[level]
     int nIni;                        // round(regW/regH)                                  (:543)
     int nodeCap;                     // quad-tree list capacity N + 3 + 4*nIni
+    int pyrDepth;                    // depth Dm of the quad-tree count pyramid (k_octree_pyr)
     unsigned long long keyOff;       // element offset of this level's keys inside one image's key block
     int keyCap;                      // ncells*capc
     int lvlKpOff;                    // offset of this level's kept keypoints in the per-image list
@@ -67,7 +68,9 @@ struct orbx_extractor {
     int totalCells, maxNodeCap, lvlKpCap;
     size_t pyrImgBytes, slotsPerImg, keysPerImg;
     int fastTileStride, fastScoreStride, fastTileRows, fastLdsPerWave;
-    size_t octLdsBytes;
+    size_t octLdsBytes, octPyrLdsBytes;
+    int octPyrWords;
+    int32_t *d_octFallback;
     int pyrTilesX, pyrTilesY, pyrXSpanOff, pyrYSpanOff, pyrBufBytes, pyrMaxDim, pyrMaxPar;
     size_t pyrLdsBytes;
     // device buffers
