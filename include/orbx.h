@@ -225,7 +225,8 @@ int orbm_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const fl
                        int device, int *nmatches);
 
 /* Developer knobs for kernel ablation timing (key 0: stop k_fast_cells after phase n; 0 = off;
- * key 1: stop k_octree early; key 2: force the exact one-workgroup matcher kernels).
+ * key 1: stop k_octree early; key 2: force the exact one-workgroup matcher kernels;
+ * key 3: pyramid tile size; key 4: quad-tree by k_octree alone, without the count pyramid).
  * Never set in production: outputs are incomplete while a knob is active. */
 int orbx_debug_set(int key, int value);
 

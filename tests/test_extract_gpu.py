@@ -198,3 +198,23 @@ def _pyr(oracle, img, nf, level):
     o = oracle.Extractor(nf, 1.2, 8, 20, 7)
     o.extract(img)
     return o.pyramid_level(level)
+
+
+def test_quadtree_sweep_kernel_alone(pkg, oracle, synth):
+    """k_octree (one key sweep per pass) is the exact fallback of k_octree_pyr: run it alone."""
+    pkg.lib().orbx_debug_set(4, 1)
+    try:
+        _compare(pkg, oracle, synth.frame(752, 480, 80), 1000)
+        _compare(pkg, oracle, synth.frame(640, 480, 81), 2000)
+    finally:
+        pkg.lib().orbx_debug_set(4, 0)
+
+
+def test_quadtree_pyramid_overflow_falls_back(pkg, oracle):
+    """Clustered candidates: the tree gets deeper than the count pyramid in a few levels, which
+    are then redone by k_octree; a large budget on a small textured patch forces it."""
+    rng = np.random.default_rng(9)
+    img = np.full((480, 640), 100, np.uint8)
+    img[200:280, 260:380] = rng.integers(0, 256, (80, 120), dtype=np.uint8)   # all corners in 2 % of the image
+    k = _compare(pkg, oracle, img, 3000)
+    assert len(k) > 0  # the reference stops early on clustered input (size == prevSize, :669)
