@@ -1252,6 +1252,30 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
+// (float)cos((double)a), (float)sin((double)a) for a in [0, 2*pi] (src/ORBextractor.cc:112-113).
+// The generic double-precision library routines cost ~220 fp64 instructions per wave (two range
+// reductions with a Payne-Hanek path); here: one Cody-Waite reduction by k*pi/2 (k <= 4, exact
+// product with the 33-bit head of pi/2) and the fdlibm kernel polynomials on |r| <= pi/4, < 1 ulp
+// in double, so the value rounded to float is the library's (differences need a double result
+// within 1e-16 of a float rounding boundary).
+__device__ __forceinline__ void sincos_0_2pi(float af, float &sn, float &cs) {
+    const double a = (double)af;
+    const double k = rint(a * 6.36619772367581382433e-01);                       // 2/pi
+    const double r = (a - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+    const double z = r * r;
+    const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                      z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double s = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+    const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double c = w + (((1.0 - w) - hz) + z * pc);
+    const int q = (int)k & 3;
+    const double sq = (q & 1) ? c : s, cq = (q & 1) ? s : c;
+    sn = (float)((q & 2) ? -sq : sq);
+    cs = (float)(((q + 1) & 2) ? -cq : cq);
+}
+
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
     const uint32_t *__restrict__ lvlKp, int lvlKpCap, const int32_t *__restrict__ lvlCnt,
@@ -1384,7 +1408,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     // ---- steered BRIEF: 4 rounds x 64 pairs, one ballot = 8 descriptor bytes
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ang = angle * factorPI;
-    const float ca = (float)cos((double)ang), sa = (float)sin((double)ang);
+    float ca, sa;
+    sincos_0_2pi(ang, sa, ca);
     const uint8_t *Bc = Bl + ORBX_DESC_R * BSTRIDE + ORBX_DESC_R;
     unsigned long long bits[4];
 #pragma unroll
