@@ -219,10 +219,31 @@ typedef struct {
     int32_t blocks;
     float ur_c, ur_tol;
 } orbm_window_query_t;
+/* g_assign (both calls below): a KeyFrame keeps the cell lists its Frame built with float bounds
+ * (src/KeyFrame.cc:41,53) but queries them with int-truncated bounds (include/KeyFrame.h:199-202,
+ * src/KeyFrame.cc:577-589): pass the Frame's geometry here and the KeyFrame's in g.  NULL = g. */
 int orbm_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
-                       const orbm_grid_geom_t *g, const orbm_window_query_t *queries, const uint8_t *query_desc,
+                       const orbm_grid_geom_t *g, const orbm_grid_geom_t *g_assign,
+                       const orbm_window_query_t *queries, const uint8_t *query_desc,
                        int m, int32_t *holder, const int32_t *ext_blocks, int max_dist, int check_orientation,
                        int device, int *nmatches);
+
+/* Stateless projected-window search: the matching core of ORBmatcher::Fuse (both overloads,
+ * src/ORBmatcher.cc:827-977, 979-1102) and ORBmatcher::SearchBySim3 (:1104-1328), whose queries
+ * never read what an earlier query wrote.  For every valid query: candidates =
+ * KeyFrame::GetFeaturesInArea(u, v, radius) (src/KeyFrame.cc:572-611, same cells and order as
+ * Frame's) with octave in [min_level, max_level] (the callers pass [pred-1, pred]); with
+ * inv_level_sigma2 != NULL each candidate must also pass Fuse's reprojection gate (:916-940):
+ * uright[j] >= 0 ? (ex^2+ey^2+er^2)*inv_level_sigma2[octave] <= 7.8, er = ur_c - uright[j]
+ *               : (ex^2+ey^2)*inv_level_sigma2[octave] <= 5.99      (uright NULL = all mono).
+ * Out: best_idx[m] = first minimum of the Hamming distance in scan order (-1: no candidate),
+ * best_dist[m] (256 when none).  The caller applies its own threshold (TH_LOW / TH_HIGH) and
+ * map-point bookkeeping (orb_slam2v2-1_amd/host/ORBmatcher.cc). angle, blocks, ur_tol unused. */
+int orbm_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                         const orbm_grid_geom_t *g, const orbm_grid_geom_t *g_assign,
+                         const orbm_window_query_t *queries, const uint8_t *query_desc,
+                         int m, const float *inv_level_sigma2, int nlevels, int32_t *best_idx, int32_t *best_dist,
+                         int device);
 
 /* Developer knobs for kernel ablation timing (key 0: stop k_fast_cells after phase n; 0 = off;
  * key 1: stop k_octree early; key 2: force the exact one-workgroup matcher kernels;

@@ -31,6 +31,8 @@ LASTPT_DTYPE = np.dtype([("has_mp", "<i4"), ("wx", "<f4"), ("wy", "<f4"), ("wz",
                          ("observations", "<i4"), ("octave", "<i4"), ("angle", "<f4")])
 KFPOINT_DTYPE = np.dtype([("valid", "<i4"), ("wx", "<f4"), ("wy", "<f4"), ("wz", "<f4"), ("max_distance", "<f4"),
                           ("min_distance", "<f4"), ("angle", "<f4")])
+MP3D_DTYPE = np.dtype([("valid", "<i4"), ("wx", "<f4"), ("wy", "<f4"), ("wz", "<f4"), ("nx", "<f4"), ("ny", "<f4"),
+                       ("nz", "<f4"), ("max_distance", "<f4"), ("min_distance", "<f4")])
 WINDOW_DTYPE = np.dtype([("valid", "<i4"), ("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("min_level", "<i4"),
                          ("max_level", "<i4"), ("angle", "<f4"), ("blocks", "<i4"), ("ur_c", "<f4"), ("ur_tol", "<f4")])
 assert KP_DTYPE.itemsize == 28 and MP_DTYPE.itemsize == 28 and LASTPT_DTYPE.itemsize == 28
@@ -124,6 +126,19 @@ def lib():
         L.oracle_search_by_projection_kf.restype = i32
         L.oracle_search_by_projection_kf.argtypes = [vp, vp, i32, C.POINTER(GridGeom), vp, i32, f32, C.POINTER(Cam), vp,
                                                      vp, vp, i32, vp, f32, i32, i32]
+        G, K = C.POINTER(GridGeom), C.POINTER(Cam)
+        L.oracle_sim3_window_queries.argtypes = [vp, i32, G, vp, i32, f32, K, vp, f32, vp]
+        L.oracle_pose_window_queries.argtypes = [vp, i32, G, vp, i32, f32, K, vp, f32, vp]
+        L.oracle_best_in_windows.argtypes = [vp, vp, vp, i32, G, G, vp, vp, i32, vp, i32, vp, vp]
+        L.oracle_search_by_projection_sim3.restype = i32
+        L.oracle_search_by_projection_sim3.argtypes = [vp, vp, i32, G, G, vp, i32, f32, K, vp, vp, vp, i32, vp, i32]
+        L.oracle_fuse.restype = i32
+        L.oracle_fuse.argtypes = [vp, vp, vp, i32, G, G, vp, vp, i32, f32, K, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp]
+        L.oracle_fuse_sim3.restype = i32
+        L.oracle_fuse_sim3.argtypes = [vp, vp, i32, G, G, vp, i32, f32, K, vp, vp, vp, i32, vp, vp, vp, f32, vp, vp]
+        L.oracle_search_by_sim3.restype = i32
+        L.oracle_search_by_sim3.argtypes = [vp, vp, i32, vp, vp, i32, G, G, vp, i32, f32, K, vp, vp, f32, vp, vp, vp, vp, vp, vp,
+                                            f32, vp]
         _lib = L
     return _lib
 
@@ -341,3 +356,89 @@ def search_by_projection_kf(kun, desc, geom, sf, log_sf, cam, Tcw_cur, kf, kf_de
                                              C.byref(cam), _p(Tc), _p(kf), _p(kd), len(kf), _p(cm), float(th),
                                              int(orb_dist), int(check_ori))
     return n, cm
+
+
+# ---- KeyFrame-side matchers (orb_oracle_kfmatch.c)
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _g(geom):
+    return None if geom is None else C.byref(geom)
+
+
+def sim3_window_queries(pts, geom, sf, log_sf, cam, Scw, th):
+    pts = np.ascontiguousarray(pts, MP3D_DTYPE); sf = _f32(sf); S = _f32(Scw)
+    q = np.zeros(len(pts), WINDOW_DTYPE)
+    lib().oracle_sim3_window_queries(_p(pts), len(pts), C.byref(geom), _p(sf), len(sf), float(log_sf), C.byref(cam),
+                                     _p(S), float(th), _p(q))
+    return q
+
+
+def pose_window_queries(pts, geom, sf, log_sf, cam, Tcw, th):
+    pts = np.ascontiguousarray(pts, MP3D_DTYPE); sf = _f32(sf); T = _f32(Tcw)
+    q = np.zeros(len(pts), WINDOW_DTYPE)
+    lib().oracle_pose_window_queries(_p(pts), len(pts), C.byref(geom), _p(sf), len(sf), float(log_sf), C.byref(cam),
+                                     _p(T), float(th), _p(q))
+    return q
+
+
+def best_in_windows(kun, desc, uright, geom, q, qdesc, inv_sigma2=None, geom_assign=None):
+    kun = np.ascontiguousarray(kun, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    ur = None if uright is None else _f32(uright)
+    q = np.ascontiguousarray(q, WINDOW_DTYPE); qd = np.ascontiguousarray(qdesc, np.uint8)
+    s2 = None if inv_sigma2 is None else _f32(inv_sigma2)
+    bi = np.zeros(len(q), np.int32); bd = np.zeros(len(q), np.int32)
+    lib().oracle_best_in_windows(_p(kun), _p(desc), _p(ur), len(kun), C.byref(geom), _g(geom_assign), _p(q), _p(qd), len(q), _p(s2),
+                                 0 if s2 is None else len(s2), _p(bi), _p(bd))
+    return bi, bd
+
+
+def search_by_projection_sim3(kun, desc, geom, sf, log_sf, cam, Scw, pts, pdesc, matched, th, geom_assign=None):
+    kun = np.ascontiguousarray(kun, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    pts = np.ascontiguousarray(pts, MP3D_DTYPE); pd = np.ascontiguousarray(pdesc, np.uint8)
+    sf = _f32(sf); S = _f32(Scw); mt = np.ascontiguousarray(matched, np.int32).copy()
+    n = lib().oracle_search_by_projection_sim3(_p(kun), _p(desc), len(kun), C.byref(geom), _g(geom_assign), _p(sf), len(sf), float(log_sf),
+                                               C.byref(cam), _p(S), _p(pts), _p(pd), len(pts), _p(mt), int(th))
+    return n, mt
+
+
+def fuse(kun, desc, uright, geom, sf, inv_sigma2, log_sf, cam, Tcw, pts, pdesc, bad, in_kf, obs, slot, ext_obs, ext_bad, th,
+         geom_assign=None):
+    """-> (nFused, best_idx, action, state dict after the call)"""
+    kun = np.ascontiguousarray(kun, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    ur = None if uright is None else _f32(uright)
+    pts = np.ascontiguousarray(pts, MP3D_DTYPE); pd = np.ascontiguousarray(pdesc, np.uint8)
+    sf = _f32(sf); s2 = _f32(inv_sigma2); T = _f32(Tcw)
+    st = {k: np.ascontiguousarray(v, np.int32).copy() for k, v in
+          dict(bad=bad, in_kf=in_kf, obs=obs, slot=slot, ext_obs=ext_obs, ext_bad=ext_bad).items()}
+    bi = np.zeros(len(pts), np.int32); act = np.zeros(len(pts), np.int32)
+    n = lib().oracle_fuse(_p(kun), _p(desc), _p(ur), len(kun), C.byref(geom), _g(geom_assign), _p(sf), _p(s2), len(sf), float(log_sf),
+                          C.byref(cam), _p(T), _p(pts), _p(pd), len(pts), _p(st["bad"]), _p(st["in_kf"]), _p(st["obs"]),
+                          _p(st["slot"]), _p(st["ext_obs"]), _p(st["ext_bad"]), float(th), _p(bi), _p(act))
+    return n, bi, act, st
+
+
+def fuse_sim3(kun, desc, geom, sf, log_sf, cam, Scw, pts, pdesc, bad, slot, ext_bad, th, geom_assign=None):
+    kun = np.ascontiguousarray(kun, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    pts = np.ascontiguousarray(pts, MP3D_DTYPE); pd = np.ascontiguousarray(pdesc, np.uint8)
+    sf = _f32(sf); S = _f32(Scw)
+    bad = np.ascontiguousarray(bad, np.int32); eb = np.ascontiguousarray(ext_bad, np.int32)
+    sl = np.ascontiguousarray(slot, np.int32).copy()
+    bi = np.zeros(len(pts), np.int32); rep = np.zeros(len(pts), np.int32)
+    n = lib().oracle_fuse_sim3(_p(kun), _p(desc), len(kun), C.byref(geom), _g(geom_assign), _p(sf), len(sf), float(log_sf), C.byref(cam),
+                               _p(S), _p(pts), _p(pd), len(pts), _p(bad), _p(sl), _p(eb), float(th), _p(bi), _p(rep))
+    return n, bi, rep, sl
+
+
+def search_by_sim3(k1, d1, k2, d2, geom, sf, log_sf, cam, T1w, T2w, s12, R12, t12, pts1, pd1, pts2, pd2, th, geom_assign=None):
+    k1 = np.ascontiguousarray(k1, KP_DTYPE); d1 = np.ascontiguousarray(d1, np.uint8)
+    k2 = np.ascontiguousarray(k2, KP_DTYPE); d2 = np.ascontiguousarray(d2, np.uint8)
+    pts1 = np.ascontiguousarray(pts1, MP3D_DTYPE); pd1 = np.ascontiguousarray(pd1, np.uint8)
+    pts2 = np.ascontiguousarray(pts2, MP3D_DTYPE); pd2 = np.ascontiguousarray(pd2, np.uint8)
+    sf = _f32(sf); T1 = _f32(T1w); T2 = _f32(T2w); R = _f32(R12); t = _f32(t12)
+    m12 = np.zeros(len(k1), np.int32)
+    n = lib().oracle_search_by_sim3(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), C.byref(geom), _g(geom_assign), _p(sf), len(sf),
+                                    float(log_sf), C.byref(cam), _p(T1), _p(T2), float(s12), _p(R), _p(t), _p(pts1),
+                                    _p(pd1), _p(pts2), _p(pd2), float(th), _p(m12))
+    return n, m12

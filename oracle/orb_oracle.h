@@ -97,6 +97,7 @@ typedef struct {
 typedef struct oracle_grid oracle_grid_t;
 oracle_grid_t *oracle_grid_build(const oracle_kp_t *kps, int n, const oracle_grid_geom_t *g);
 void oracle_grid_free(oracle_grid_t *g);
+void oracle_grid_set_query_geom(oracle_grid_t *g, const oracle_grid_geom_t *query_geom);
 int oracle_grid_query(const oracle_grid_t *g, float x, float y, float r, int min_level, int max_level,
                       int32_t *out, int cap);
 
@@ -163,6 +164,48 @@ int oracle_search_by_projection_kf(const oracle_kp_t *kun, const uint8_t *desc, 
                                    const float *scale_factors, int nlevels, float log_scale_factor,
                                    const oracle_cam_t *cam, const float *Tcw_cur, const oracle_kfpoint_t *kf,
                                    const uint8_t *kf_desc, int m, int32_t *cur_mp, float th, int orb_dist, int check_ori);
+
+/* ---- SURVEY §8(f) rank 1, KeyFrame side (orb_oracle_kfmatch.c): SearchByProjection(KeyFrame*, Scw, ...)
+ * (src/ORBmatcher.cc:290-403), Fuse x2 (:827-1102), SearchBySim3 (:1104-1328). */
+typedef struct {
+    int32_t valid;                       /* the caller's static skip conditions (null / bad / already found) */
+    float wx, wy, wz;                    /* GetWorldPos() */
+    float nx, ny, nz;                    /* GetNormal() */
+    float max_distance, min_distance;    /* mfMaxDistance, mfMinDistance */
+} oracle_mappoint3d_t;
+void oracle_decompose_sim3(const float *Scw16, float *Rcw9, float *tcw3, float *Ow3);
+void oracle_sim3_window_queries(const oracle_mappoint3d_t *pts, int m, const oracle_grid_geom_t *g, const float *sf,
+                                int nlevels, float log_sf, const oracle_cam_t *cam, const float *Scw, float th,
+                                oracle_window_query_t *q);
+void oracle_pose_window_queries(const oracle_mappoint3d_t *pts, int m, const oracle_grid_geom_t *g, const float *sf,
+                                int nlevels, float log_sf, const oracle_cam_t *cam, const float *Tcw, float th,
+                                oracle_window_query_t *q);
+/* g: the KeyFrame's query bounds; ga: the bounds the keypoints were binned with (NULL = g) */
+void oracle_best_in_windows(const oracle_kp_t *kun, const uint8_t *desc, const float *uright, int n,
+                            const oracle_grid_geom_t *g, const oracle_grid_geom_t *ga, const oracle_window_query_t *q, const uint8_t *qdesc, int m,
+                            const float *inv_sigma2, int nlevels, int32_t *best_idx, int32_t *best_dist);
+int oracle_search_by_projection_sim3(const oracle_kp_t *kun, const uint8_t *desc, int n, const oracle_grid_geom_t *g,
+                                     const oracle_grid_geom_t *ga,
+                                     const float *sf, int nlevels, float log_sf, const oracle_cam_t *cam,
+                                     const float *Scw, const oracle_mappoint3d_t *pts, const uint8_t *pdesc, int m,
+                                     int32_t *matched, int th);
+int oracle_fuse(const oracle_kp_t *kun, const uint8_t *desc, const float *uright, int n, const oracle_grid_geom_t *g,
+                const oracle_grid_geom_t *ga,
+                const float *sf, const float *inv_sigma2, int nlevels, float log_sf, const oracle_cam_t *cam,
+                const float *Tcw, const oracle_mappoint3d_t *pts, const uint8_t *pdesc, int m, int32_t *bad,
+                int32_t *in_kf, int32_t *obs, int32_t *slot, const int32_t *ext_obs, int32_t *ext_bad, float th,
+                int32_t *best_idx, int32_t *action);
+int oracle_fuse_sim3(const oracle_kp_t *kun, const uint8_t *desc, int n, const oracle_grid_geom_t *g,
+                     const oracle_grid_geom_t *ga, const float *sf,
+                     int nlevels, float log_sf, const oracle_cam_t *cam, const float *Scw,
+                     const oracle_mappoint3d_t *pts, const uint8_t *pdesc, int m, const int32_t *bad, int32_t *slot,
+                     const int32_t *ext_bad, float th, int32_t *best_idx, int32_t *replace);
+int oracle_search_by_sim3(const oracle_kp_t *k1, const uint8_t *d1, int n1, const oracle_kp_t *k2, const uint8_t *d2,
+                          int n2, const oracle_grid_geom_t *g, const oracle_grid_geom_t *ga, const float *sf, int nlevels,
+                          float log_sf,
+                          const oracle_cam_t *cam, const float *T1w, const float *T2w, float s12, const float *R12,
+                          const float *t12, const oracle_mappoint3d_t *pts1, const uint8_t *pd1,
+                          const oracle_mappoint3d_t *pts2, const uint8_t *pd2, float th, int32_t *match12);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,9 @@ oracle_grid_t *oracle_grid_build(const oracle_kp_t *kps, int n, const oracle_gri
     free(cnt);
     return g;
 }
+/* KeyFrame keeps the Frame's cell lists but queries them with its own int-truncated bounds
+ * (include/KeyFrame.h:199-202 `const int mnMinX..`, src/KeyFrame.cc:41,53,577-589) */
+void oracle_grid_set_query_geom(oracle_grid_t *g, const oracle_grid_geom_t *q) { if (g && q) g->g = *q; }
 void oracle_grid_free(oracle_grid_t *g) { if (g) { free(g->cell_start); free(g->items); free(g); } }
 
 int oracle_grid_query(const oracle_grid_t *gr, float x, float y, float r, int minLevel, int maxLevel,

@@ -38,7 +38,7 @@ EXPORTS = [
     "orbx_pyramid_host", "orbx_pyramid_device", "orbx_debug_level_points", "orbx_set_profiling",
     "orbx_get_stage_ms", "orbx_debug_set", "orbm_hamming", "orbm_hamming_matrix_device", "orbm_stereo_batch_device",
     "orbm_stereo", "orbm_search_for_initialization", "orbm_search_by_projection_mp",
-    "orbm_search_by_projection_frame", "orbm_match_windows", "orbx_last_error", "orbx_version", "orbx_device_count",
+    "orbm_search_by_projection_frame", "orbm_match_windows", "orbm_best_in_windows", "orbx_last_error", "orbx_version", "orbx_device_count",
 ]
 
 
@@ -136,7 +136,8 @@ def lib():
                                                f32, f32, i32, C.POINTER(i32)]
     L.orbm_search_by_projection_frame.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp, i32, C.POINTER(Camera),
                                                   vp, vp, vp, vp, i32, vp, vp, f32, i32, i32, i32, C.POINTER(i32)]
-    L.orbm_match_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp, vp, i32, vp, vp, i32, i32, i32, C.POINTER(i32)]
+    L.orbm_match_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, vp, i32, i32, i32, C.POINTER(i32)]
+    L.orbm_best_in_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, i32, vp, vp, i32]
     L.orbx_last_error.restype = C.c_char_p
     L.orbx_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -369,7 +370,7 @@ class ORBmatcher:
 
 
 def match_windows(kun, desc, uright, geom, queries, query_desc, holder, ext_blocks=None, max_dist=100,
-                  check_orientation=True, device=0):
+                  check_orientation=True, device=0, geom_assign=None):
     """orbm_match_windows: the projected-window matcher behind the SearchByProjection family
     -> (nmatches, holder')"""
     kun = np.ascontiguousarray(kun, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
@@ -378,6 +379,20 @@ def match_windows(kun, desc, uright, geom, queries, query_desc, holder, ext_bloc
     h = np.ascontiguousarray(holder, np.int32).copy()
     eb = None if ext_blocks is None else np.ascontiguousarray(ext_blocks, np.int32)
     n = C.c_int(0)
-    _check(lib().orbm_match_windows(_p(kun), _p(desc), _p(ur), len(kun), C.byref(geom), _p(q), _p(qd), len(q), _p(h),
+    _check(lib().orbm_match_windows(_p(kun), _p(desc), _p(ur), len(kun), C.byref(geom),
+                                    None if geom_assign is None else C.byref(geom_assign), _p(q), _p(qd), len(q), _p(h),
                                     _p(eb), int(max_dist), int(check_orientation), int(device), C.byref(n)))
     return n.value, h
+
+
+def best_in_windows(kun, desc, uright, geom, queries, query_desc, inv_level_sigma2=None, device=0, geom_assign=None):
+    """orbm_best_in_windows: stateless window search behind Fuse / SearchBySim3 -> (best_idx, best_dist)"""
+    kun = np.ascontiguousarray(kun, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+    q = np.ascontiguousarray(queries, WINDOW_DTYPE); qd = np.ascontiguousarray(query_desc, np.uint8)
+    s2 = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+    bi = np.full(len(q), -1, np.int32); bd = np.full(len(q), 256, np.int32)
+    _check(lib().orbm_best_in_windows(_p(kun), _p(desc), _p(ur), len(kun), C.byref(geom),
+                                      None if geom_assign is None else C.byref(geom_assign), _p(q), _p(qd), len(q), _p(s2),
+                                      0 if s2 is None else len(s2), _p(bi), _p(bd), int(device)))
+    return bi, bd

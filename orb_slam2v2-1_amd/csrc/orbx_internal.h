@@ -114,6 +114,11 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
                                     const uint8_t *last_desc, int nlast, int32_t *cur_mp, const int32_t *ext_obs,
                                     float th, int mono, int check_ori, int device, int *nmatches);
 int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
-                       const orbm_grid_geom_t *g, const orbm_window_query_t *q, const uint8_t *qdesc, int m,
+                       const orbm_grid_geom_t *g, const orbm_grid_geom_t *ga, const orbm_window_query_t *q,
+                       const uint8_t *qdesc, int m,
                        int32_t *holder, const int32_t *ext_blocks, int max_dist, int check_ori, int device, int *nmatches);
+int fast_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                         const orbm_grid_geom_t *g, const orbm_grid_geom_t *ga, const orbm_window_query_t *q,
+                         const uint8_t *qdesc, int m, const float *inv_sigma2, int nlevels, int32_t *best_idx,
+                         int32_t *best_dist, int device);
 extern int g_debug[8];  // developer knobs (orbx_debug_set); [2] != 0 forces the exact one-workgroup matcher kernels

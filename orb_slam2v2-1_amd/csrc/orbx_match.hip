@@ -793,14 +793,15 @@ extern "C" int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const
 // ---- generic projected-window matcher, exact one-workgroup form (fallback of fast_match_windows)
 __global__ __launch_bounds__(SQ_T) void k_match_windows_exact(
     const orbx_keypoint_t *__restrict__ kun, const uint8_t *__restrict__ desc, const float *__restrict__ uright, int n,
-    orbm_grid_geom_t g, const orbm_window_query_t *__restrict__ qs, const uint8_t *__restrict__ qdesc, int m,
+    orbm_grid_geom_t g, orbm_grid_geom_t ga, const orbm_window_query_t *__restrict__ qs,
+    const uint8_t *__restrict__ qdesc, int m,
     int32_t *__restrict__ holder, const int32_t *__restrict__ ext_blocks, uint16_t *__restrict__ code,
     int32_t *__restrict__ hist_idx, int32_t *__restrict__ hist_bin, int max_dist, int check_ori,
     int32_t *__restrict__ nmatches_out) {
     __shared__ u64 sh[2 * SQ_T / 64];
     __shared__ int hn[HISTO_LENGTH];
     const int tid = threadIdx.x;
-    for (int j = tid; j < n; j += SQ_T) code[j] = (uint16_t)cell_code(g, kun[j]);
+    for (int j = tid; j < n; j += SQ_T) code[j] = (uint16_t)cell_code(ga, kun[j]);
     if (tid < HISTO_LENGTH) hn[tid] = 0;
     __syncthreads();
     const float factor = 1.0f / HISTO_LENGTH;
@@ -862,8 +863,25 @@ __global__ __launch_bounds__(SQ_T) void k_match_windows_exact(
     if (tid == 0) *nmatches_out = nm;
 }
 
+extern "C" int orbm_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                                    const orbm_grid_geom_t *g, const orbm_grid_geom_t *g_assign,
+                                    const orbm_window_query_t *queries,
+                                    const uint8_t *query_desc, int m, const float *inv_level_sigma2, int nlevels,
+                                    int32_t *best_idx, int32_t *best_dist, int device) {
+    if (n < 0 || m < 0 || !g || (n > 0 && (!kun || !desc)) || (m > 0 && (!queries || !query_desc || !best_idx || !best_dist)) ||
+        n > 65535 || (inv_level_sigma2 && nlevels <= 0)) {
+        orbx_set_error("orbm_best_in_windows: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    for (int i = 0; i < m; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    if (n == 0 || m == 0) return ORBX_OK;
+    return fast_best_in_windows(kun, desc, uright, n, g, g_assign ? g_assign : g, queries, query_desc, m, inv_level_sigma2, nlevels, best_idx,
+                                best_dist, device);
+}
+
 extern "C" int orbm_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
-                                  const orbm_grid_geom_t *g, const orbm_window_query_t *queries, const uint8_t *query_desc,
+                                  const orbm_grid_geom_t *g, const orbm_grid_geom_t *g_assign,
+                                  const orbm_window_query_t *queries, const uint8_t *query_desc,
                                   int m, int32_t *holder, const int32_t *ext_blocks, int max_dist, int check_orientation,
                                   int device, int *nmatches) {
     if (n < 0 || m < 0 || !g || !nmatches || (n > 0 && (!kun || !desc || !holder)) || (m > 0 && (!queries || !query_desc)) ||
@@ -876,7 +894,7 @@ extern "C" int orbm_match_windows(const orbx_keypoint_t *kun, const uint8_t *des
     for (int i = 0; i < n; i++)
         if (holder[i] < -2 || holder[i] >= m) { orbx_set_error("holder[%d] = %d out of range", i, holder[i]); return ORBX_ERR_ARG; }
     if (!g_debug[2]) {
-        const int frc = fast_match_windows(kun, desc, uright, n, g, queries, query_desc, m, holder, ext_blocks, max_dist,
+        const int frc = fast_match_windows(kun, desc, uright, n, g, g_assign ? g_assign : g, queries, query_desc, m, holder, ext_blocks, max_dist,
                                            check_orientation, device, nmatches);
         if (frc <= 0) return frc;
     }
@@ -891,7 +909,7 @@ extern "C" int orbm_match_windows(const orbx_keypoint_t *kun, const uint8_t *des
     if (ext_blocks) { DEV_ALLOC(beb, 4 * (size_t)n); H2D(beb, ext_blocks, 4 * (size_t)n); }
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_match_windows_exact, dim3(1), dim3(SQ_T), 0, 0, (orbx_keypoint_t *)bk.p, (uint8_t *)bd.p,
-                       (float *)bu.p, n, *g, (orbm_window_query_t *)bq.p, (uint8_t *)bqd.p, m, (int32_t *)bh.p,
+                       (float *)bu.p, n, *g, g_assign ? *g_assign : *g, (orbm_window_query_t *)bq.p, (uint8_t *)bqd.p, m, (int32_t *)bh.p,
                        (int32_t *)beb.p, (uint16_t *)bcode.p, (int32_t *)bhi.p, (int32_t *)bhb.p, max_dist,
                        check_orientation, (int32_t *)bnm.p);
     ORBX_HIP(hipGetLastError());

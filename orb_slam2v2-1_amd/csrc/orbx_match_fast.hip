@@ -718,7 +718,8 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
 }
 
 int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
-                       const orbm_grid_geom_t *g, const orbm_window_query_t *q, const uint8_t *qdesc, int m,
+                       const orbm_grid_geom_t *g, const orbm_grid_geom_t *ga, const orbm_window_query_t *q,
+                       const uint8_t *qdesc, int m,
                        int32_t *holder, const int32_t *ext_blocks, int max_dist, int check_ori, int device, int *nmatches) {
     if (n > 60000) return ORBX_FAST_FALLBACK;
     const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)m * (40 + 32 + QK * 8 + 96) + 65536;
@@ -740,7 +741,7 @@ int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const fl
     if (ext_blocks) UP(deb, ext_blocks, n);
     (void)hipGetLastError();
     const int mx = std::max(n, m);
-    hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *g, dcode);
+    hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *ga, dcode);
     hipLaunchKernelGGL(k_queries_windows, dim3((mx + 255) / 256), dim3(256), 0, st, dw, m, dq, dh,
                        ext_blocks ? deb : (const int32_t *)nullptr, n, dsb);
     hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dqd, m, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
@@ -754,5 +755,87 @@ int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const fl
     ORBX_HIP(hipMemcpyAsync(holder, dh, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
     ORBX_HIP(hipStreamSynchronize(st));
     *nmatches = out[0];
+    return ORBX_OK;
+}
+
+// ---- C. stateless window search (Fuse x2, SearchBySim3: src/ORBmatcher.cc:827-1328).  No query
+// reads what an earlier one wrote, so this is k_cand reduced to its minimum: one wave per query,
+// every lane keeps the smallest scan-order key of its keypoints, one wave-min at the end.
+// GATE adds Fuse's per-candidate reprojection test (:916-940).
+template <bool GATE>
+__global__ __launch_bounds__(256) void k_best(const orbm_window_query_t *__restrict__ qs, const uint8_t *__restrict__ qdesc,
+                                              int m, const orbx_keypoint_t *__restrict__ kps,
+                                              const uint8_t *__restrict__ desc, const float *__restrict__ uright,
+                                              const float *__restrict__ inv_sigma2, int nlevels,
+                                              const uint16_t *__restrict__ code, int n, orbm_grid_geom_t g,
+                                              int32_t *__restrict__ best_idx, int32_t *__restrict__ best_dist) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + wave;
+    if (qi >= m) return;
+    const orbm_window_query_t Q = qs[qi];
+    u64 best = ~0ull;
+    if (Q.valid) {
+        const AreaQuery aq = make_query(g, Q.u, Q.v, Q.radius, -1, -1);   // KeyFrame::GetFeaturesInArea: no levels
+        if (!aq.empty) {
+            const Desc256 da = load_desc(qdesc + (size_t)qi * 32);
+            for (int j = lane; j < n; j += 64) {
+                const unsigned c = code[j];
+                const orbx_keypoint_t kp = kps[j];
+                if (!in_area(aq, c, kp)) continue;
+                if (kp.octave < Q.min_level || kp.octave > Q.max_level) continue;  // :913 / :1069 / :1209
+                if (GATE) {
+                    const int lvl = min(max(kp.octave, 0), nlevels - 1);
+                    const float ex = Q.u - kp.x, ey = Q.v - kp.y;
+                    const float kr = uright ? uright[j] : -1.0f;
+                    if (kr >= 0) {                                      // :916-929
+                        const float er = Q.ur_c - kr;
+                        const float e2 = ex * ex + ey * ey + er * er;
+                        if ((double)(e2 * inv_sigma2[lvl]) > 7.8) continue;
+                    } else {                                            // :930-940
+                        const float e2 = ex * ex + ey * ey;
+                        if ((double)(e2 * inv_sigma2[lvl]) > 5.99) continue;
+                    }
+                }
+                const u64 key = fast_key(ham(da, load_desc(desc + (size_t)j * 32)), c, j, kp.octave);
+                best = key < best ? key : best;
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) {
+        best_idx[qi] = best == ~0ull ? -1 : KEY_IDX(best);
+        best_dist[qi] = best == ~0ull ? 256 : KEY_DIST(best);
+    }
+}
+
+int fast_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                         const orbm_grid_geom_t *g, const orbm_grid_geom_t *ga, const orbm_window_query_t *q,
+                         const uint8_t *qdesc, int m,
+                         const float *inv_sigma2, int nlevels, int32_t *best_idx, int32_t *best_dist, int device) {
+    const size_t need = (size_t)n * (28 + 32 + 16) + (size_t)m * (40 + 32 + 16) + 65536;
+    int rc = arena_begin(device, need);
+    if (rc) return rc;
+    hipStream_t st = g_ar.st;
+    orbx_keypoint_t *dk = arena_get<orbx_keypoint_t>(n);
+    uint8_t *dd = arena_get<uint8_t>((size_t)32 * n), *dqd = arena_get<uint8_t>((size_t)32 * m);
+    float *du = arena_get<float>(n), *dis = arena_get<float>(nlevels > 0 ? nlevels : 1);
+    orbm_window_query_t *dw = arena_get<orbm_window_query_t>(m);
+    int32_t *dbi = arena_get<int32_t>(m), *dbd = arena_get<int32_t>(m);
+    uint16_t *dcode = arena_get<uint16_t>(n);
+    UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(dw, q, m); UP(dqd, qdesc, (size_t)32 * m);
+    if (uright) UP(du, uright, n);
+    if (inv_sigma2) UP(dis, inv_sigma2, nlevels);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *ga, dcode);
+    if (inv_sigma2)
+        hipLaunchKernelGGL(k_best<true>, dim3((m + 3) / 4), dim3(256), 0, st, dw, dqd, m, dk, dd,
+                           uright ? du : (const float *)nullptr, dis, nlevels, dcode, n, *g, dbi, dbd);
+    else
+        hipLaunchKernelGGL(k_best<false>, dim3((m + 3) / 4), dim3(256), 0, st, dw, dqd, m, dk, dd, (const float *)nullptr,
+                           (const float *)nullptr, nlevels, dcode, n, *g, dbi, dbd);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(best_idx, dbi, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipMemcpyAsync(best_dist, dbd, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
     return ORBX_OK;
 }

@@ -191,7 +191,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
     const std::vector<int32_t> before = holder;
     const orbm_grid_geom_t g = grid_of(CurrentFrame);
     int nmatches = 0;
-    if (orbm_match_windows(kun.data(), desc.data(), NULL, n, &g, q.data(), qd.data(), m, holder.data(), NULL, ORBdist,
+    if (orbm_match_windows(kun.data(), desc.data(), NULL, n, &g, NULL, q.data(), qd.data(), m, holder.data(), NULL, ORBdist,
                            mbCheckOrientation ? 1 : 0, device, &nmatches) != ORBX_OK)
         return fail("SearchByProjection");
     for (int i = 0; i < n; i++)
@@ -200,6 +200,289 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
             else if (holder[i] == -1) CurrentFrame.mvpMapPoints[i] = static_cast<MapPoint *>(NULL);  // :1592
         }
     return nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------
+// KeyFrame-side projection matchers.  The projection arithmetic below is the
+// reference's cv::Mat expressions written out with OpenCV's evaluation rules: Mat*Mat(+Mat) is a
+// gemm that accumulates in double and rounds once, Mat/scalar and scalar*Mat scale by a FLOAT,
+// Mat::dot and cv::norm accumulate in double.
+struct Pose3 { float R[9], t[3], Ow[3]; };
+
+// :298-303 / :988-992
+static void decompose_sim3(const cv::Mat &Scw, Pose3 &P) {
+    double d = 0;
+    for (int k = 0; k < 3; k++) d += (double)Scw.at<float>(0, k) * (double)Scw.at<float>(0, k);
+    const float scw = (float)std::sqrt(d);
+    const float inv = (float)(1.0 / (double)scw);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) P.R[r * 3 + c] = Scw.at<float>(r, c) * inv + 0.0f;
+        P.t[r] = Scw.at<float>(r, 3) * inv + 0.0f;
+    }
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)P.R[k * 3 + i] * (double)P.t[k];
+        P.Ow[i] = (float)(s * -1.0);
+    }
+}
+// :829-838
+static void pose_of(KeyFrame *pKF, Pose3 &P) {
+    cv::Mat Rcw = pKF->GetRotation(), tcw = pKF->GetTranslation(), Ow = pKF->GetCameraCenter();
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) P.R[r * 3 + c] = Rcw.at<float>(r, c);
+        P.t[r] = tcw.at<float>(r); P.Ow[r] = Ow.at<float>(r);
+    }
+}
+static inline float gemm_row(const float *a, const float *b, float c) {
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)a[k] * (double)b[k];
+    return (float)(s + (double)c);
+}
+static void empty_query(orbm_window_query_t &o) {
+    std::memset(&o, 0, sizeof(o));
+    o.min_level = o.max_level = -1; o.ur_tol = -1.0f; o.blocks = 1;
+}
+// :320-360 / :854-892 / :1010-1051: one map point -> one search window in pKF
+static void project_to_window(MapPoint *pMP, const Pose3 &P, KeyFrame *pKF, float th, orbm_window_query_t &o, uint8_t *qd) {
+    cv::Mat p3Dw = pMP->GetWorldPos();
+    const float pw[3] = {p3Dw.at<float>(0), p3Dw.at<float>(1), p3Dw.at<float>(2)};
+    float pc[3];
+    for (int r = 0; r < 3; r++) pc[r] = gemm_row(P.R + 3 * r, pw, P.t[r]);
+    if (pc[2] < 0.0) return;                                     // depth must be positive
+    const float invz = 1 / pc[2];
+    const float x = pc[0] * invz, y = pc[1] * invz;
+    const float u = pKF->fx * x + pKF->cx, v = pKF->fy * y + pKF->cy;
+    if (!pKF->IsInImage(u, v)) return;
+    const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+    const float PO[3] = {pw[0] - P.Ow[0], pw[1] - P.Ow[1], pw[2] - P.Ow[2]};
+    const float dist = (float)std::sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+    if (dist < minDistance || dist > maxDistance) return;
+    cv::Mat Pn = pMP->GetNormal();                               // viewing angle must be less than 60 deg
+    const double dot = (double)PO[0] * Pn.at<float>(0) + (double)PO[1] * Pn.at<float>(1) + (double)PO[2] * Pn.at<float>(2);
+    if (dot < 0.5 * dist) return;
+    const int nPredictedLevel = pMP->PredictScale(dist, pKF);
+    o.valid = 1; o.u = u; o.v = v;
+    o.radius = th * pKF->mvScaleFactors[nPredictedLevel];
+    o.min_level = nPredictedLevel - 1; o.max_level = nPredictedLevel;
+    o.ur_c = u - pKF->mbf * invz;                                // ur of Fuse (:872)
+    cv::Mat dMP = pMP->GetDescriptor();
+    std::memcpy(qd, dMP.ptr(0), 32);
+}
+// the KeyFrame queries with its own int bounds the cell lists its Frame built with float bounds
+static orbm_grid_geom_t grid_query_of(const KeyFrame *pKF) {
+    orbm_grid_geom_t g;
+    g.min_x = (float)pKF->mnMinX; g.min_y = (float)pKF->mnMinY; g.max_x = (float)pKF->mnMaxX; g.max_y = (float)pKF->mnMaxY;
+    g.inv_w = pKF->mfGridElementWidthInv; g.inv_h = pKF->mfGridElementHeightInv;
+    return g;
+}
+static orbm_grid_geom_t grid_assign_of(const KeyFrame *pKF) {
+    orbm_grid_geom_t g;
+    g.min_x = Frame::mnMinX; g.min_y = Frame::mnMinY; g.max_x = Frame::mnMaxX; g.max_y = Frame::mnMaxY;
+    g.inv_w = pKF->mfGridElementWidthInv; g.inv_h = pKF->mfGridElementHeightInv;
+    return g;
+}
+
+int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints,
+                                   std::vector<MapPoint *> &vpMatched, int th) {
+    const int n = (int)pKF->mvKeysUn.size(), m = (int)vpPoints.size();
+    if (n == 0 || m == 0) return 0;
+    Pose3 P;
+    decompose_sim3(Scw, P);
+    std::set<MapPoint *> spAlreadyFound(vpMatched.begin(), vpMatched.end());   // :306-307
+    spAlreadyFound.erase(static_cast<MapPoint *>(NULL));
+    std::vector<orbm_window_query_t> q(m);
+    std::vector<uint8_t> qd((size_t)32 * m);
+    for (int i = 0; i < m; i++) {
+        empty_query(q[i]);
+        MapPoint *pMP = vpPoints[i];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        project_to_window(pMP, P, pKF, (float)th, q[i], &qd[(size_t)32 * i]);
+        q[i].ur_tol = -1.0f;
+    }
+    std::vector<orbx_keypoint_t> kun; gather_keypoints(pKF->mvKeysUn, kun);
+    std::vector<uint8_t> desc; gather_descriptors(pKF->mDescriptors, n, desc);
+    std::vector<int32_t> holder(n, -1);
+    for (int i = 0; i < n; i++) if (vpMatched[i]) holder[i] = -2;              // if(vpMatched[idx]) continue; (:375)
+    const orbm_grid_geom_t g = grid_query_of(pKF), ga = grid_assign_of(pKF);
+    int nmatches = 0;
+    if (orbm_match_windows(kun.data(), desc.data(), NULL, n, &g, &ga, q.data(), qd.data(), m, holder.data(), NULL, TH_LOW, 0,
+                           device, &nmatches) != ORBX_OK)
+        return fail("SearchByProjection");
+    for (int i = 0; i < n; i++) if (holder[i] >= 0) vpMatched[i] = vpPoints[holder[i]];   // :396
+    return nmatches;
+}
+
+int ORBmatcher::Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th) {
+    const int n = (int)pKF->mvKeysUn.size(), nMPs = (int)vpMapPoints.size();
+    if (n == 0 || nMPs == 0) return 0;
+    Pose3 P;
+    pose_of(pKF, P);
+    // The window search of a point never reads what an earlier point changed (descriptors and positions
+    // only change for points that are already done or already in pKF), so all searches run first, in
+    // parallel on the GPU; the map-point bookkeeping then runs in the reference's order.
+    std::vector<orbm_window_query_t> q(nMPs);
+    std::vector<uint8_t> qd((size_t)32 * nMPs);
+    for (int i = 0; i < nMPs; i++) {
+        empty_query(q[i]);
+        MapPoint *pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+        project_to_window(pMP, P, pKF, th, q[i], &qd[(size_t)32 * i]);
+    }
+    std::vector<orbx_keypoint_t> kun; gather_keypoints(pKF->mvKeysUn, kun);
+    std::vector<uint8_t> desc; gather_descriptors(pKF->mDescriptors, n, desc);
+    std::vector<int32_t> bestIdx(nMPs), bestDist(nMPs);
+    const orbm_grid_geom_t g = grid_query_of(pKF), ga = grid_assign_of(pKF);
+    if (orbm_best_in_windows(kun.data(), desc.data(), pKF->mvuRight.data(), n, &g, &ga, q.data(), qd.data(), nMPs,
+                             pKF->mvInvLevelSigma2.data(), (int)pKF->mvInvLevelSigma2.size(), bestIdx.data(),
+                             bestDist.data(), device) != ORBX_OK)
+        return fail("Fuse");
+    int nFused = 0;
+    for (int i = 0; i < nMPs; i++) {
+        MapPoint *pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;    // :851, with the state of THIS moment
+        if (!q[i].valid) continue;
+        if (bestDist[i] <= TH_LOW) {                             // :954-973
+            MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx[i]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, bestIdx[i]);
+                pKF->AddMapPoint(pMP, bestIdx[i]);
+            }
+            nFused++;
+        }
+    }
+    return nFused;
+}
+
+int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, float th,
+                     std::vector<MapPoint *> &vpReplacePoint) {
+    const int n = (int)pKF->mvKeysUn.size(), nPoints = (int)vpPoints.size();
+    if (n == 0 || nPoints == 0) return 0;
+    Pose3 P;
+    decompose_sim3(Scw, P);
+    const std::set<MapPoint *> spAlreadyFound = pKF->GetMapPoints();           // :995
+    std::vector<orbm_window_query_t> q(nPoints);
+    std::vector<uint8_t> qd((size_t)32 * nPoints);
+    for (int i = 0; i < nPoints; i++) {
+        empty_query(q[i]);
+        MapPoint *pMP = vpPoints[i];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        project_to_window(pMP, P, pKF, th, q[i], &qd[(size_t)32 * i]);
+    }
+    std::vector<orbx_keypoint_t> kun; gather_keypoints(pKF->mvKeysUn, kun);
+    std::vector<uint8_t> desc; gather_descriptors(pKF->mDescriptors, n, desc);
+    std::vector<int32_t> bestIdx(nPoints), bestDist(nPoints);
+    const orbm_grid_geom_t g = grid_query_of(pKF), ga = grid_assign_of(pKF);
+    if (orbm_best_in_windows(kun.data(), desc.data(), NULL, n, &g, &ga, q.data(), qd.data(), nPoints, NULL, 0, bestIdx.data(),
+                             bestDist.data(), device) != ORBX_OK)
+        return fail("Fuse");
+    int nFused = 0;
+    for (int iMP = 0; iMP < nPoints; iMP++) {
+        if (!q[iMP].valid || bestDist[iMP] > TH_LOW) continue;
+        MapPoint *pMP = vpPoints[iMP];
+        MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx[iMP]);                    // :1086-1097
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
+        } else {
+            pMP->AddObservation(pKF, bestIdx[iMP]);
+            pKF->AddMapPoint(pMP, bestIdx[iMP]);
+        }
+        nFused++;
+    }
+    return nFused;
+}
+
+int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12,
+                             const cv::Mat &R12, const cv::Mat &t12, const float th) {
+    const float fx = pKF1->fx, fy = pKF1->fy, cx = pKF1->cx, cy = pKF1->cy;    // :1107-1110 (KF1's for both)
+    Pose3 P1, P2;
+    pose_of(pKF1, P1); pose_of(pKF2, P2);
+    float sR12[9], sR21[9], t12f[3], t21[3];
+    const float a12 = s12, a21 = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) {
+            sR12[r * 3 + c] = R12.at<float>(r, c) * a12 + 0.0f;                // :1121
+            sR21[r * 3 + c] = R12.at<float>(c, r) * a21 + 0.0f;                // :1122
+        }
+        t12f[r] = t12.at<float>(r);
+    }
+    for (int i = 0; i < 3; i++) {                                              // :1123
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)sR21[i * 3 + k] * (double)t12f[k];
+        t21[i] = (float)(s * -1.0);
+    }
+    const std::vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
+    if (N1 == 0 || N2 == 0) return 0;
+    std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+    for (int i = 0; i < N1; i++) {                                             // :1134-1144
+        MapPoint *pMP = vpMatches12[i];
+        if (pMP) {
+            vbAlreadyMatched1[i] = true;
+            int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+            if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+        }
+    }
+    std::vector<int32_t> vnMatch[2], bestDist[2];
+    for (int dir = 0; dir < 2; dir++) {   // 0: KF1's points into KF2 (:1150-1227), 1: KF2's into KF1 (:1230-1307)
+        const std::vector<MapPoint *> &src = dir ? vpMapPoints2 : vpMapPoints1;
+        const std::vector<bool> &already = dir ? vbAlreadyMatched2 : vbAlreadyMatched1;
+        KeyFrame *pKFdst = dir ? pKF1 : pKF2;
+        const Pose3 &Pw = dir ? P2 : P1;
+        const float *sR = dir ? sR12 : sR21, *tt = dir ? t12f : t21;
+        const int ns = (int)src.size(), nd = (int)pKFdst->mvKeysUn.size();
+        std::vector<orbm_window_query_t> q(ns);
+        std::vector<uint8_t> qd((size_t)32 * ns);
+        for (int i = 0; i < ns; i++) {
+            empty_query(q[i]);
+            MapPoint *pMP = src[i];
+            if (!pMP || already[i]) continue;
+            if (pMP->isBad()) continue;
+            cv::Mat p3Dw = pMP->GetWorldPos();
+            const float pw[3] = {p3Dw.at<float>(0), p3Dw.at<float>(1), p3Dw.at<float>(2)};
+            float pa[3], pb[3];
+            for (int r = 0; r < 3; r++) pa[r] = gemm_row(Pw.R + 3 * r, pw, Pw.t[r]);
+            for (int r = 0; r < 3; r++) pb[r] = gemm_row(sR + 3 * r, pa, tt[r]);
+            if (pb[2] < 0.0) continue;
+            const float invz = 1.0 / pb[2];
+            const float x = pb[0] * invz, y = pb[1] * invz;
+            const float u = fx * x + cx, v = fy * y + cy;
+            if (!pKFdst->IsInImage(u, v)) continue;
+            const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+            const float dist3D = (float)std::sqrt((double)pb[0] * pb[0] + (double)pb[1] * pb[1] + (double)pb[2] * pb[2]);
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            const int nPredictedLevel = pMP->PredictScale(dist3D, pKFdst);
+            q[i].valid = 1; q[i].u = u; q[i].v = v;
+            q[i].radius = th * pKFdst->mvScaleFactors[nPredictedLevel];
+            q[i].min_level = nPredictedLevel - 1; q[i].max_level = nPredictedLevel;
+            cv::Mat dMP = pMP->GetDescriptor();
+            std::memcpy(&qd[(size_t)32 * i], dMP.ptr(0), 32);
+        }
+        std::vector<orbx_keypoint_t> kun; gather_keypoints(pKFdst->mvKeysUn, kun);
+        std::vector<uint8_t> desc; gather_descriptors(pKFdst->mDescriptors, nd, desc);
+        vnMatch[dir].assign(ns, -1); bestDist[dir].assign(ns, 256);
+        const orbm_grid_geom_t g = grid_query_of(pKFdst), ga = grid_assign_of(pKFdst);
+        if (orbm_best_in_windows(kun.data(), desc.data(), NULL, nd, &g, &ga, q.data(), qd.data(), ns, NULL, 0,
+                                 vnMatch[dir].data(), bestDist[dir].data(), device) != ORBX_OK)
+            return fail("SearchBySim3");
+        for (int i = 0; i < ns; i++)
+            if (bestDist[dir][i] > TH_HIGH) vnMatch[dir][i] = -1;              // :1223 / :1303
+    }
+    int nFound = 0;                                                            // :1309-1325
+    for (int i1 = 0; i1 < N1; i1++) {
+        const int idx2 = vnMatch[0][i1];
+        if (idx2 >= 0) {
+            const int idx1 = vnMatch[1][idx2];
+            if (idx1 == i1) { vpMatches12[i1] = vpMapPoints2[idx2]; nFound++; }
+        }
+    }
+    return nFound;
 }
 
 int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched,

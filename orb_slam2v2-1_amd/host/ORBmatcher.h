@@ -1,7 +1,7 @@
 // ORBmatcher.h — the hot routines of the reference's include/ORBmatcher.h:37-102 with the
 // same names, signatures and constants, executed on an MI355X through include/orbx.h.
-// (SearchByBoW / Fuse / SearchBySim3 / SearchForTriangulation / the KeyFrame projections are
-// SURVEY §8(f) "next" and stay on the reference's CPU implementation for now.)
+// (SearchByBoW x2 and SearchForTriangulation are SURVEY §8(f) rank 3 and stay on the reference's
+// CPU implementation.)
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
@@ -32,6 +32,24 @@ public:
     // Used in relocalisation (Tracking)                              (src/ORBmatcher.cc:1474-1601)
     int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th,
                            const int ORBdist);
+
+    // Project MapPoints using a Similarity Transformation and search matches.
+    // Used in loop detection (Loop Closing)                          (src/ORBmatcher.cc:290-403)
+    int SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints,
+                           std::vector<MapPoint *> &vpMatched, int th);
+
+    // Search matches between MapPoints seen in KF1 and KF2 transforming by a Sim3 [s12*R12|t12]
+    // In the stereo and RGB-D case, s12=1                            (src/ORBmatcher.cc:1104-1328)
+    int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12,
+                     const cv::Mat &R12, const cv::Mat &t12, const float th);
+
+    // Project MapPoints into KeyFrame and search for duplicated MapPoints. (src/ORBmatcher.cc:827-977)
+    int Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th = 3.0);
+
+    // Project MapPoints into KeyFrame using a given Sim3 and search for duplicated MapPoints.
+    //                                                                (src/ORBmatcher.cc:979-1102)
+    int Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, float th,
+             std::vector<MapPoint *> &vpReplacePoint);
 
     // Matching for the Map Initialization (only used in the monocular case) (src/ORBmatcher.cc:405-520)
     int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched,

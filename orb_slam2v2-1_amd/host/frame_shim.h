@@ -9,6 +9,7 @@
 #include "MapPoint.h"
 #else
 #include <cmath>
+#include <map>
 #include <set>
 #include <vector>
 #include "cv_shim.h"
@@ -17,6 +18,7 @@
 namespace ORB_SLAM2 {
 
 class Frame;
+class KeyFrame;
 
 class MapPoint {
 public:
@@ -34,10 +36,19 @@ public:
     float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
     float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
     inline int PredictScale(const float &currentDist, Frame *pF);
+    inline int PredictScale(const float &currentDist, KeyFrame *pKF);   // src/MapPoint.cc:397-412
+    cv::Mat GetNormal() { return mNormalVector.clone(); }
+    // observation graph, reduced to what ORBmatcher::Fuse / SearchBySim3 touch
+    bool IsInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) != 0; }            // src/MapPoint.cc
+    int GetIndexInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) ? (int)mObservations[pKF] : -1; }
+    inline void AddObservation(KeyFrame *pKF, size_t idx);                                // src/MapPoint.cc:108-119
+    inline void Replace(MapPoint *pMP);                                                   // src/MapPoint.cc:187-225
     bool mbBad;
     int nObs;
     float mfMinDistance = 0.f, mfMaxDistance = 0.f;
     cv::Mat mDescriptor, mWorldPos;
+    cv::Mat mNormalVector = cv::Mat::zeros(3, 1, CV_32F);
+    std::map<KeyFrame *, size_t> mObservations;
 };
 
 class Frame {
@@ -69,12 +80,79 @@ inline int MapPoint::PredictScale(const float &currentDist, Frame *pF) {
     return nScale;
 }
 
-class KeyFrame {
+class KeyFrame {   // include/KeyFrame.h: the members the projection matchers read or write
 public:
     std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }  // src/KeyFrame.cc
+    std::set<MapPoint *> GetMapPoints() {
+        std::set<MapPoint *> s;
+        for (size_t i = 0; i < mvpMapPoints.size(); i++)
+            if (mvpMapPoints[i] && !mvpMapPoints[i]->isBad()) s.insert(mvpMapPoints[i]);
+        return s;
+    }
+    MapPoint *GetMapPoint(const size_t &idx) { return mvpMapPoints[idx]; }
+    void AddMapPoint(MapPoint *pMP, const size_t &idx) { mvpMapPoints[idx] = pMP; }
+    void ReplaceMapPointMatch(const size_t &idx, MapPoint *pMP) { mvpMapPoints[idx] = pMP; }
+    void EraseMapPointMatch(const size_t &idx) { mvpMapPoints[idx] = static_cast<MapPoint *>(NULL); }
+    cv::Mat GetPose() { return Tcw.clone(); }
+    cv::Mat GetRotation() {
+        cv::Mat R(3, 3, CV_32F);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R.at<float>(r, c) = Tcw.at<float>(r, c);
+        return R;
+    }
+    cv::Mat GetTranslation() {
+        cv::Mat t(3, 1, CV_32F);
+        for (int r = 0; r < 3; r++) t.at<float>(r) = Tcw.at<float>(r, 3);
+        return t;
+    }
+    cv::Mat GetCameraCenter() { return Ow.clone(); }
+    void SetPose(const cv::Mat &Tcw_) {   // src/KeyFrame.cc:70-84: Ow = -Rwc*tcw (gemm, alpha = -1)
+        Tcw = Tcw_.clone();
+        Ow = cv::Mat(3, 1, CV_32F);
+        for (int i = 0; i < 3; i++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += (double)Tcw.at<float>(k, i) * (double)Tcw.at<float>(k, 3);
+            Ow.at<float>(i) = (float)(s * -1.0);
+        }
+    }
+    bool IsInImage(const float &x, const float &y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }
+    float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
+    int N = 0;
     std::vector<cv::KeyPoint> mvKeysUn;
+    std::vector<float> mvuRight;
+    cv::Mat mDescriptors;
+    int mnScaleLevels = 0;
+    float mfLogScaleFactor = 0.f;
+    std::vector<float> mvScaleFactors, mvInvLevelSigma2;
+    int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;   // ints: include/KeyFrame.h:199-202
+    float mfGridElementWidthInv = 0.f, mfGridElementHeightInv = 0.f;
     std::vector<MapPoint *> mvpMapPoints;
+    cv::Mat Tcw = cv::Mat::eye(4, 4, CV_32F), Ow = cv::Mat::zeros(3, 1, CV_32F);
 };
+
+inline int MapPoint::PredictScale(const float &currentDist, KeyFrame *pKF) {
+    using namespace std;
+    float ratio = mfMaxDistance / currentDist;
+    int nScale = ceil(log(ratio) / pKF->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= pKF->mnScaleLevels) nScale = pKF->mnScaleLevels - 1;
+    return nScale;
+}
+inline void MapPoint::AddObservation(KeyFrame *pKF, size_t idx) {
+    if (mObservations.count(pKF)) return;
+    mObservations[pKF] = idx;
+    if (pKF->mvuRight[idx] >= 0) nObs += 2; else nObs++;
+}
+inline void MapPoint::Replace(MapPoint *pMP) {   // without the found/visible counters, descriptor refresh and Map erase
+    if (pMP == this) return;
+    std::map<KeyFrame *, size_t> obs = mObservations;
+    mObservations.clear();
+    mbBad = true;
+    for (std::map<KeyFrame *, size_t>::iterator mit = obs.begin(), mend = obs.end(); mit != mend; mit++) {
+        KeyFrame *pKF = mit->first;
+        if (!pMP->IsInKeyFrame(pKF)) { pKF->ReplaceMapPointMatch(mit->second, pMP); pMP->AddObservation(pKF, mit->second); }
+        else pKF->EraseMapPointMatch(mit->second);
+    }
+}
 
 }  // namespace ORB_SLAM2
 #endif

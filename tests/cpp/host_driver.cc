@@ -51,9 +51,162 @@ static void fill_frame(Frame &F, ORBextractor *ex, const cv::Mat &im, int w, int
     F.mTcw = cv::Mat::eye(4, 4, CV_32F);
 }
 
+// ---- KeyFrame-side matchers (SearchByProjection(KF,Scw) / Fuse x2 / SearchBySim3) ----
+struct Mp3d { int valid; float wx, wy, wz, nx, ny, nz, maxd, mind; };
+static void fill_keyframe(KeyFrame &KF, ORBextractor *ex, const cv::Mat &im, const float *bounds, const float *cam) {
+    std::vector<cv::KeyPoint> keys;
+    (*ex)(im, cv::Mat(), keys, KF.mDescriptors);
+    KF.mvKeysUn = keys; KF.N = (int)keys.size();
+    KF.mvuRight.assign(KF.N, -1.f);
+    KF.mvpMapPoints.assign(KF.N, (MapPoint *)NULL);
+    KF.mvScaleFactors = ex->GetScaleFactors(); KF.mvInvLevelSigma2 = ex->GetInverseScaleSigmaSquares();
+    KF.mnScaleLevels = ex->GetLevels(); KF.mfLogScaleFactor = log(ex->GetScaleFactor());   // src/Frame.cc:69-71
+    Frame::mnMinX = bounds[0]; Frame::mnMinY = bounds[1]; Frame::mnMaxX = bounds[2]; Frame::mnMaxY = bounds[3];
+    Frame::mfGridElementWidthInv = 64.f / (Frame::mnMaxX - Frame::mnMinX);
+    Frame::mfGridElementHeightInv = 48.f / (Frame::mnMaxY - Frame::mnMinY);
+    KF.mnMinX = Frame::mnMinX; KF.mnMinY = Frame::mnMinY; KF.mnMaxX = Frame::mnMaxX; KF.mnMaxY = Frame::mnMaxY;  // float -> int (src/KeyFrame.cc:41)
+    KF.mfGridElementWidthInv = Frame::mfGridElementWidthInv; KF.mfGridElementHeightInv = Frame::mfGridElementHeightInv;
+    KF.fx = cam[0]; KF.fy = cam[1]; KF.cx = cam[2]; KF.cy = cam[3]; KF.mbf = cam[4];
+}
+static void fill_points(std::vector<MapPoint> &pts, const Mp3d *mp, const unsigned char *desc, int m) {
+    pts.resize(m);
+    for (int i = 0; i < m; i++) {
+        pts[i].mWorldPos.at<float>(0) = mp[i].wx; pts[i].mWorldPos.at<float>(1) = mp[i].wy; pts[i].mWorldPos.at<float>(2) = mp[i].wz;
+        pts[i].mNormalVector.at<float>(0) = mp[i].nx; pts[i].mNormalVector.at<float>(1) = mp[i].ny; pts[i].mNormalVector.at<float>(2) = mp[i].nz;
+        pts[i].mfMaxDistance = mp[i].maxd; pts[i].mfMinDistance = mp[i].mind;
+        pts[i].mDescriptor = cv::Mat(1, 32, CV_8U);
+        memcpy(pts[i].mDescriptor.ptr(0), desc + (size_t)32 * i, 32);
+    }
+}
+static cv::Mat mat4(const float *v) {
+    cv::Mat T(4, 4, CV_32F);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T.at<float>(r, c) = v[r * 4 + c];
+    return T;
+}
+
+static int kf_modes(int argc, char **argv) {
+    // argv: kf <sub> img w h nf minx,miny,maxx,maxy fx,fy,cx,cy,mbf pts.bin pdesc.bin aux.bin th out
+    if (argc != 14) return 2;
+    const std::string sub = argv[2];
+    const int w = atoi(argv[4]), h = atoi(argv[5]), nf = atoi(argv[6]);
+    float bounds[4], cam[5];
+    sscanf(argv[7], "%f,%f,%f,%f", &bounds[0], &bounds[1], &bounds[2], &bounds[3]);
+    sscanf(argv[8], "%f,%f,%f,%f,%f", &cam[0], &cam[1], &cam[2], &cam[3], &cam[4]);
+    std::vector<unsigned char> img = slurp(argv[3]), praw = slurp(argv[9]), draw = slurp(argv[10]), aux = slurp(argv[11]);
+    const float th = (float)atof(argv[12]);
+    const std::string out = argv[13];
+    ORBextractor ex(nf, 1.2f, 8, 20, 7);
+    if (!ex.ok()) return 3;
+    KeyFrame KF;
+    fill_keyframe(KF, &ex, cv::Mat(h, w, CV_8UC1, img.data()), bounds, cam);
+    const int n = KF.N, m = (int)(praw.size() / sizeof(Mp3d));
+    const Mp3d *mp = (const Mp3d *)praw.data();
+    std::vector<MapPoint> pts;
+    fill_points(pts, mp, draw.data(), m);
+    std::vector<MapPoint> ext(n);                        // holders that are not in the list
+    std::vector<MapPoint *> vp(m);
+    for (int i = 0; i < m; i++) vp[i] = &pts[i];
+    const float *fa = (const float *)aux.data();
+    ORBmatcher matcher(0.8f, true);
+    std::vector<int> res;
+    int ret = 0;
+    if (sub == "projsim3") {
+        // aux: Scw[16] f32, matched[n] i32 (-1 / -2)
+        if (aux.size() != 64 + 4 * (size_t)n) { fprintf(stderr, "aux size: n=%d\n", n); return 6; }
+        const int *matched0 = (const int *)(fa + 16);
+        std::vector<MapPoint *> vpMatched(n, (MapPoint *)NULL);
+        for (int j = 0; j < n; j++) if (matched0[j] == -2) vpMatched[j] = &ext[j];
+        for (int i = 0; i < m; i++) if (!mp[i].valid) pts[i].mbBad = true;
+        ret = matcher.SearchByProjection(&KF, mat4(fa), vp, vpMatched, (int)th);
+        res.assign(n, -1);
+        for (int j = 0; j < n; j++)
+            if (vpMatched[j]) res[j] = (vpMatched[j] >= &pts[0] && vpMatched[j] < &pts[0] + m) ? (int)(vpMatched[j] - &pts[0]) : -2;
+    } else if (sub == "fuse" || sub == "fusesim3") {
+        // aux: T[16] f32, uright[n] f32, slot[n], ext_obs[n], ext_bad[n], bad[m], obs[m], null[m] i32
+        if (aux.size() != 64 + 4 * (size_t)(4 * n + 3 * m)) { fprintf(stderr, "aux size: n=%d\n", n); return 6; }
+        const float *ur = fa + 16;
+        const int *slot = (const int *)(ur + n), *eobs = slot + n, *ebad = eobs + n, *bad = ebad + n, *obs = bad + m, *isnull = obs + m;
+        for (int j = 0; j < n; j++) KF.mvuRight[j] = ur[j];
+        for (int i = 0; i < m; i++) { pts[i].mbBad = bad[i] != 0; pts[i].nObs = obs[i]; }
+        for (int j = 0; j < n; j++) {
+            if (slot[j] >= 0) { KF.mvpMapPoints[j] = &pts[slot[j]]; pts[slot[j]].mObservations[&KF] = j; }
+            else if (slot[j] == -2) { KF.mvpMapPoints[j] = &ext[j]; ext[j].nObs = eobs[j]; ext[j].mbBad = ebad[j] != 0; ext[j].mObservations[&KF] = j; }
+        }
+        std::vector<MapPoint *> vpReplace(m, (MapPoint *)NULL);
+        if (sub == "fuse") {
+            for (int i = 0; i < m; i++) if (isnull[i]) vp[i] = NULL;
+            KF.SetPose(mat4(fa));
+            ret = matcher.Fuse(&KF, vp, th);
+        } else {
+            ret = matcher.Fuse(&KF, mat4(fa), vp, th, vpReplace);
+        }
+        // out: slot[n], ext_bad[n], bad[m], in_kf[m], obs[m], replace[m]
+        for (int j = 0; j < n; j++) {
+            MapPoint *p = KF.mvpMapPoints[j];
+            res.push_back(!p ? -1 : (p >= &pts[0] && p < &pts[0] + m) ? (int)(p - &pts[0]) : -2);
+        }
+        for (int j = 0; j < n; j++) res.push_back(ext[j].mbBad ? 1 : 0);
+        for (int i = 0; i < m; i++) res.push_back(pts[i].mbBad ? 1 : 0);
+        for (int i = 0; i < m; i++) res.push_back(pts[i].IsInKeyFrame(&KF) ? 1 : 0);
+        for (int i = 0; i < m; i++) res.push_back(pts[i].nObs);
+        for (int i = 0; i < m; i++) {
+            MapPoint *p = vpReplace[i];
+            res.push_back(!p ? -1 : (p >= &pts[0] && p < &pts[0] + m) ? (int)(p - &pts[0]) : -2);
+        }
+    } else return 2;
+    dump(out + ".i32", res.data(), res.size() * 4);
+    printf("%d %d\n", n, ret);
+    return 0;
+}
+
+static int sim3_mode(int argc, char **argv) {
+    // argv: sim3 img1 img2 w h nf bounds cam pts1.bin pd1.bin pts2.bin pd2.bin aux.bin th out
+    // aux: T1w[16], T2w[16], s12, R12[9], t12[3] f32; pre12[n1] i32 (-1 or index of a KF2 slot)
+    if (argc != 16) return 2;
+    const int w = atoi(argv[4]), h = atoi(argv[5]), nf = atoi(argv[6]);
+    float bounds[4], cam[5];
+    sscanf(argv[7], "%f,%f,%f,%f", &bounds[0], &bounds[1], &bounds[2], &bounds[3]);
+    sscanf(argv[8], "%f,%f,%f,%f,%f", &cam[0], &cam[1], &cam[2], &cam[3], &cam[4]);
+    std::vector<unsigned char> i1 = slurp(argv[2]), i2 = slurp(argv[3]), p1 = slurp(argv[9]), d1 = slurp(argv[10]),
+                               p2 = slurp(argv[11]), d2 = slurp(argv[12]), aux = slurp(argv[13]);
+    const float th = (float)atof(argv[14]);
+    const std::string out = argv[15];
+    ORBextractor ex(nf, 1.2f, 8, 20, 7);
+    if (!ex.ok()) return 3;
+    KeyFrame KF1, KF2;
+    fill_keyframe(KF1, &ex, cv::Mat(h, w, CV_8UC1, i1.data()), bounds, cam);
+    fill_keyframe(KF2, &ex, cv::Mat(h, w, CV_8UC1, i2.data()), bounds, cam);
+    const int n1 = KF1.N, n2 = KF2.N;
+    if ((int)(p1.size() / sizeof(Mp3d)) != n1 || (int)(p2.size() / sizeof(Mp3d)) != n2) { fprintf(stderr, "n1=%d n2=%d\n", n1, n2); return 6; }
+    std::vector<MapPoint> pts1, pts2;
+    fill_points(pts1, (const Mp3d *)p1.data(), d1.data(), n1);
+    fill_points(pts2, (const Mp3d *)p2.data(), d2.data(), n2);
+    const Mp3d *m1 = (const Mp3d *)p1.data(), *m2 = (const Mp3d *)p2.data();
+    // valid: 1 = a good point, 0 = no point in the slot, 2 = a bad point
+    for (int i = 0; i < n1; i++) if (m1[i].valid) { KF1.mvpMapPoints[i] = &pts1[i]; pts1[i].mObservations[&KF1] = i; pts1[i].mbBad = m1[i].valid == 2; }
+    for (int i = 0; i < n2; i++) if (m2[i].valid) { KF2.mvpMapPoints[i] = &pts2[i]; pts2[i].mObservations[&KF2] = i; pts2[i].mbBad = m2[i].valid == 2; }
+    const float *fa = (const float *)aux.data();
+    KF1.SetPose(mat4(fa)); KF2.SetPose(mat4(fa + 16));
+    const float s12 = fa[32];
+    cv::Mat R12(3, 3, CV_32F), t12(3, 1, CV_32F);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R12.at<float>(r, c) = fa[33 + r * 3 + c]; t12.at<float>(r) = fa[42 + r]; }
+    const int *pre = (const int *)(fa + 45);
+    std::vector<MapPoint *> vpMatches12(n1, (MapPoint *)NULL);
+    for (int i = 0; i < n1; i++) if (pre[i] >= 0) vpMatches12[i] = &pts2[pre[i]];
+    ORBmatcher matcher(0.75f, true);  // src/LoopClosing.cc
+    const int ret = matcher.SearchBySim3(&KF1, &KF2, vpMatches12, s12, R12, t12, th);
+    std::vector<int> res(n1, -1);
+    for (int i = 0; i < n1; i++) if (vpMatches12[i]) res[i] = (int)(vpMatches12[i] - &pts2[0]);
+    dump(out + ".i32", res.data(), res.size() * 4);
+    printf("%d %d %d\n", n1, n2, ret);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) return 2;
     const std::string mode = argv[1];
+    if (mode == "kf") return kf_modes(argc, argv);
+    if (mode == "sim3") return sim3_mode(argc, argv);
     if (mode == "extract" && argc == 7) {
         const int w = atoi(argv[3]), h = atoi(argv[4]), nf = atoi(argv[5]);
         const std::string out = argv[6];
@@ -189,6 +342,6 @@ int main(int argc, char **argv) {
         printf("%d %d\n", F.N, n);
         return 0;
     }
-    fprintf(stderr, "usage: host_driver extract|stereo|init|projmp|projkf ...\n");
+    fprintf(stderr, "usage: host_driver extract|stereo|init|projmp|projkf|kf|sim3 ...\n");
     return 2;
 }

@@ -146,3 +146,154 @@ def test_search_by_projection_through_keyframe(driver, oracle, synth, tmp_path):
                                              np.full(len(k), -1, np.int32), th, orbdist)
     assert N == len(k) and nm == on > 100
     np.testing.assert_array_equal(np.fromfile(str(tmp_path / "k.held"), np.int32), ocm)
+
+
+# ---- KeyFrame-side matchers through the C++ classes
+def _kf_setup(oracle, synth, seed, distorted, tmp_path, m=1500):
+    import kf_scene as ks
+    w, h, nf = 1241, 376, 1000
+    rng = np.random.default_rng(seed)
+    img = synth.frame(w, h, 40 + seed)
+    img.tofile(tmp_path / "kf.raw")
+    orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    k, d = orc.extract(img)
+    sf = orc.scale_factors
+    cam = oracle.Cam(ks.FX, ks.FY, ks.CX, ks.CY, ks.MBF, np.float32(ks.MBF) / np.float32(ks.FX))
+    g, ga, b = ks.geoms(oracle, w, h, distorted)
+    args = dict(w=w, h=h, nf=nf, bounds="%r,%r,%r,%r" % tuple(float(v) for v in b),
+                cam="%r,%r,%r,%r,%r" % (ks.FX, ks.FY, ks.CX, ks.CY, ks.MBF))
+    return ks, rng, k, d, sf, cam, np.float32(np.log(np.float32(1.2))), g, ga, args, m
+
+
+def _kf_run(driver, sub, tmp_path, args, pts, pd, aux, th):
+    pts.tofile(tmp_path / "pts.bin"); pd.tofile(tmp_path / "pd.bin")
+    with open(tmp_path / "aux.bin", "wb") as f:
+        for a in aux:
+            f.write(np.ascontiguousarray(a).tobytes())
+    n, ret = _run(driver, "kf", sub, tmp_path / "kf.raw", args["w"], args["h"], args["nf"], args["bounds"], args["cam"],
+                  tmp_path / "pts.bin", tmp_path / "pd.bin", tmp_path / "aux.bin", th, tmp_path / "o")
+    return n, ret, np.fromfile(str(tmp_path / "o.i32"), np.int32)
+
+
+@pytest.mark.parametrize("distorted", [False, True])
+def test_search_by_projection_sim3_class(driver, oracle, synth, tmp_path, distorted):
+    """ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:290-403)."""
+    ks, rng, k, d, sf, cam, log_sf, g, ga, args, m = _kf_setup(oracle, synth, 1, distorted, tmp_path)
+    S = ks.pose(rng, scale=0.93)
+    pts, pd, _ = ks.points_for(oracle, rng, k, d, sf, S, m, scale=0.93)
+    pts["valid"] = rng.random(m) > 0.1          # invalid -> the driver marks the point bad
+    matched = np.full(len(k), -1, np.int32)
+    matched[rng.choice(len(k), 50, replace=False)] = -2
+    on, om = oracle.search_by_projection_sim3(k, d, g, sf, log_sf, cam, S, pts, pd, matched, 10, ga)
+    n, ret, res = _kf_run(driver, "projsim3", tmp_path, args, pts, pd, [S, matched], 10)
+    assert n == len(k) and on > 200
+    assert ret == on
+    np.testing.assert_array_equal(res, om)
+
+
+@pytest.mark.parametrize("distorted", [False, True])
+def test_fuse_class(driver, oracle, synth, tmp_path, distorted):
+    """ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:827-977): GPU window search with the
+    stereo / mono reprojection gate + the reference's replace / add bookkeeping on the host."""
+    ks, rng, k, d, sf, cam, log_sf, g, ga, args, m = _kf_setup(oracle, synth, 2, distorted, tmp_path)
+    n = len(k)
+    T = ks.pose(rng)
+    pts, pd, _ = ks.points_for(oracle, rng, k, d, sf, T, m)
+    isnull = (rng.random(m) < 0.05).astype(np.int32)
+    pts["valid"] = 1 - isnull
+    bad, in_kf, obs, slot, ext_obs, ext_bad = ks.fuse_state(rng, n, m)
+    uright = np.where(rng.random(n) < 0.5, k["x"] - rng.uniform(1, 30, n), -1).astype(np.float32)
+    inv_s2 = (np.float32(1.0) / (sf * sf)).astype(np.float32)
+    on, obi, oact, st = oracle.fuse(k, d, uright, g, sf, inv_s2, log_sf, cam, T, pts, pd, bad, in_kf, obs, slot, ext_obs,
+                                    ext_bad, 3.0, ga)
+    assert on > 200 and all((oact == a).sum() > 0 for a in (1, 2, 3, 4))
+    nk, ret, res = _kf_run(driver, "fuse", tmp_path, args, pts, pd, [T, uright, slot, ext_obs, ext_bad, bad, obs, isnull], 3.0)
+    assert nk == n and ret == on
+    o = np.split(res, np.cumsum([n, n, m, m, m]))
+    np.testing.assert_array_equal(o[0], st["slot"])
+    np.testing.assert_array_equal(o[1][slot == -2], st["ext_bad"][slot == -2])
+    np.testing.assert_array_equal(o[2], st["bad"])
+    np.testing.assert_array_equal(o[3], st["in_kf"])
+    np.testing.assert_array_equal(o[4], st["obs"])
+
+
+def test_fuse_sim3_class(driver, oracle, synth, tmp_path):
+    """ORBmatcher::Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:979-1102)."""
+    ks, rng, k, d, sf, cam, log_sf, g, ga, args, m = _kf_setup(oracle, synth, 3, True, tmp_path)
+    n = len(k)
+    S = ks.pose(rng, scale=1.11)
+    pts, pd, _ = ks.points_for(oracle, rng, k, d, sf, S, m, scale=1.11)
+    bad, in_kf, obs, slot, ext_obs, ext_bad = ks.fuse_state(rng, n, m)
+    pts["valid"] = (bad == 0) & ~((in_kf == 1) & (bad == 0))     # !isBad && !spAlreadyFound.count(pMP)
+    on, obi, orep, oslot = oracle.fuse_sim3(k, d, g, sf, log_sf, cam, S, pts, pd, bad, slot, ext_bad, 4.0, ga)
+    assert on > 200 and (orep >= 0).sum() > 0 and (orep == -2).sum() > 0 and (oslot != slot).sum() > 0
+    uright = np.full(n, -1, np.float32)
+    nk, ret, res = _kf_run(driver, "fusesim3", tmp_path, args, pts, pd,
+                           [S, uright, slot, ext_obs, ext_bad, bad, obs, np.zeros(m, np.int32)], 4.0)
+    assert nk == n and ret == on
+    o = np.split(res, np.cumsum([n, n, m, m, m]))
+    np.testing.assert_array_equal(o[0], oslot)
+    np.testing.assert_array_equal(o[5], orep)
+
+
+def test_search_by_sim3_class(driver, oracle, synth, tmp_path):
+    """ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1104-1328): two keyframes, mutual window search."""
+    import kf_scene as ks
+    w, h, nf = 1241, 376, 1000
+    rng = np.random.default_rng(5)
+    img = synth.frame(w, h, 46)
+    img.tofile(tmp_path / "a.raw")
+    orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    k, d = orc.extract(img)
+    n = len(k)
+    sf = orc.scale_factors
+    log_sf = np.float32(np.log(np.float32(1.2)))
+    cam = oracle.Cam(ks.FX, ks.FY, ks.CX, ks.CY, ks.MBF, np.float32(ks.MBF) / np.float32(ks.FX))
+    g, ga, b = ks.geoms(oracle, w, h, True)
+    # world = camera 1 up to a small pose; camera 2 = slightly moved; p1 = s12*R12*p2 + t12
+    T1 = ks.pose(rng).astype(np.float64)
+    D = np.eye(4); D[:3, :3] = ks.rot(*rng.normal(0, 0.002, 3)); D[:3, 3] = rng.normal(0, 0.02, 3)
+    T2 = D @ T1
+    s12 = np.float32(1.03)
+    R12 = D[:3, :3].T
+    t12 = -R12 @ D[:3, 3]
+    T1f, T2f, R12f, t12f = [np.ascontiguousarray(a, np.float32) for a in (T1, T2, R12, t12)]
+
+    def slot_points(T):
+        z = rng.uniform(4, 40, n)
+        pc = np.stack([(k["x"] + rng.normal(0, 1, n) - ks.CX) / ks.FX * z, (k["y"] + rng.normal(0, 1, n) - ks.CY) / ks.FY * z, z], 1)
+        pw = (pc - T[:3, 3]) @ T[:3, :3]
+        p = np.zeros(n, oracle.MP3D_DTYPE)
+        p["wx"], p["wy"], p["wz"] = pw[:, 0], pw[:, 1], pw[:, 2]
+        p["max_distance"] = z * sf[k["octave"]] * rng.uniform(0.9, 1.1, n)
+        p["min_distance"] = p["max_distance"] / sf[7] * rng.uniform(0.5, 1.0, n)
+        r = rng.random(n)
+        p["valid"] = np.where(r < 0.15, 0, np.where(r < 0.22, 2, 1))      # no point / bad point / good point
+        flips = rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8) & \
+            rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        return p, d ^ flips
+    p1, pd1 = slot_points(T1)
+    p2, pd2 = slot_points(T2)
+    pre = np.full(n, -1, np.int32)
+    cand = np.flatnonzero(p2["valid"] == 1)
+    pick = rng.choice(n, 40, replace=False)
+    pre[pick] = rng.choice(cand, 40, replace=False)
+    # the flat "valid" of the oracle: point present, not already matched, not bad (:1134-1158, :1234-1238)
+    already1 = pre >= 0
+    already2 = np.zeros(n, bool); already2[pre[pre >= 0]] = True
+    o1 = p1.copy(); o1["valid"] = (p1["valid"] == 1) & ~already1
+    o2 = p2.copy(); o2["valid"] = (p2["valid"] == 1) & ~already2
+    on, om12 = oracle.search_by_sim3(k, d, k, d, g, sf, log_sf, cam, T1f, T2f, s12, R12f, t12f, o1, pd1, o2, pd2, 7.5, ga)
+    assert on > 200
+    p1.tofile(tmp_path / "p1.bin"); pd1.tofile(tmp_path / "d1.bin"); p2.tofile(tmp_path / "p2.bin"); pd2.tofile(tmp_path / "d2.bin")
+    with open(tmp_path / "aux.bin", "wb") as f:
+        for a in (T1f, T2f, np.array([s12], np.float32), R12f, t12f, pre):
+            f.write(np.ascontiguousarray(a).tobytes())
+    bounds = "%r,%r,%r,%r" % tuple(float(v) for v in b)
+    camarg = "%r,%r,%r,%r,%r" % (ks.FX, ks.FY, ks.CX, ks.CY, ks.MBF)
+    n1, n2, ret = _run(driver, "sim3", tmp_path / "a.raw", tmp_path / "a.raw", w, h, nf, bounds, camarg, tmp_path / "p1.bin",
+                       tmp_path / "d1.bin", tmp_path / "p2.bin", tmp_path / "d2.bin", tmp_path / "aux.bin", 7.5, tmp_path / "o")
+    assert n1 == n2 == n and ret == on
+    res = np.fromfile(str(tmp_path / "o.i32"), np.int32)
+    expect = np.where(om12 >= 0, om12, pre)
+    np.testing.assert_array_equal(res, expect)

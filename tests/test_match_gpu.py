@@ -295,3 +295,59 @@ def test_match_windows_generic_paths_agree(pkg, oracle, synth, matcher_path):
     gn, gh = pkg.match_windows(k, d, uright, pkg.grid_geom(w, h), q, qd, holder, None, 100, True)
     assert gn == en > 100
     np.testing.assert_array_equal(gh, eh)
+
+
+# ---- SURVEY §8(f) rank 1, KeyFrame side: SearchByProjection(KeyFrame*, Scw), Fuse x2, SearchBySim3
+def _kfside(oracle, synth, seed, distorted, m=1800):
+    import kf_scene as ks
+    w, h = 1241, 376
+    rng = np.random.default_rng(seed)
+    _, k, d = _features(oracle, synth.frame(w, h, 30 + seed), 1000)
+    sf = oracle.Extractor(1000, 1.2, 8, 20, 7).scale_factors
+    cam = oracle.Cam(ks.FX, ks.FY, ks.CX, ks.CY, ks.MBF, np.float32(ks.MBF) / np.float32(ks.FX))
+    return ks, w, h, rng, k, d, sf, cam, np.float32(np.log(np.float32(1.2))), m
+
+
+@pytest.mark.parametrize("distorted", [False, True])
+@pytest.mark.parametrize("gate", [False, True])
+def test_best_in_windows(pkg, oracle, synth, distorted, gate):
+    """orbm_best_in_windows (the search of Fuse / SearchBySim3, src/ORBmatcher.cc:905-951,1064-1081,
+    1203-1221) against the oracle's grid walk, with and without Fuse's reprojection gate, and with
+    a KeyFrame whose int-truncated bounds differ from the bounds its cells were built with."""
+    ks, w, h, rng, k, d, sf, cam, log_sf, m = _kfside(oracle, synth, 3, distorted)
+    T = ks.pose(rng)
+    pts, pd, _ = ks.points_for(oracle, rng, k, d, sf, T, m)
+    og, oga, _ = ks.geoms(oracle, w, h, distorted)
+    pg, pga, _ = ks.geoms(pkg, w, h, distorted)
+    q = oracle.pose_window_queries(pts, og, sf, log_sf, cam, T, 3.0)
+    assert 0.5 * m < q["valid"].sum() < m
+    uright = np.where(rng.random(len(k)) < 0.5, k["x"] - rng.uniform(1, 40, len(k)), -1).astype(np.float32)
+    inv_s2 = (1.0 / (sf * sf)).astype(np.float32) if gate else None
+    obi, obd = oracle.best_in_windows(k, d, uright, og, q, pd, inv_s2, oga)
+    gbi, gbd = pkg.best_in_windows(k, d, uright, pg, q, pd, inv_s2, 0, pga)
+    assert (obi >= 0).sum() > 300
+    np.testing.assert_array_equal(gbi, obi)
+    np.testing.assert_array_equal(gbd, obd)
+    if gate:   # the gate must actually reject something the ungated search accepts
+        ubi, _ = oracle.best_in_windows(k, d, uright, og, q, pd, None, oga)
+        assert (ubi != obi).sum() > 10
+
+
+@pytest.mark.parametrize("distorted", [False, True])
+def test_search_by_projection_sim3(pkg, oracle, synth, matcher_path, distorted):
+    """SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:290-403):
+    Sim3 projection (oracle stage) + orbm_match_windows with TH_LOW, no orientation check."""
+    ks, w, h, rng, k, d, sf, cam, log_sf, m = _kfside(oracle, synth, 4, distorted)
+    S = ks.pose(rng, scale=1.07)
+    pts, pd, _ = ks.points_for(oracle, rng, k, d, sf, S, m, scale=1.07)
+    pts["valid"] = rng.random(m) > 0.1
+    og, oga, _ = ks.geoms(oracle, w, h, distorted)
+    pg, pga, _ = ks.geoms(pkg, w, h, distorted)
+    matched = np.full(len(k), -1, np.int32)
+    matched[rng.choice(len(k), 60, replace=False)] = -2
+    on, om = oracle.search_by_projection_sim3(k, d, og, sf, log_sf, cam, S, pts, pd, matched, 10, oga)
+    q = oracle.sim3_window_queries(pts, og, sf, log_sf, cam, S, 10.0)
+    gn, gm = pkg.match_windows(k, d, None, pg, q, pd, matched, None, 50, False, 0, pga)
+    assert on > 200
+    assert gn == on
+    np.testing.assert_array_equal(gm, om)

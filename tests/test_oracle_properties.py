@@ -110,3 +110,79 @@ def test_stereo_oracle_self_consistency(oracle, synth):
     assert (disp > 0).all() and (disp < 435.2).all()
     np.testing.assert_allclose(dp[m], np.float32(mbf) / disp, rtol=1e-6)
     assert ((dp >= 0) == m).all()
+
+
+def test_fuse_bookkeeping_hand_built(oracle):
+    """Hand-built Fuse (src/ORBmatcher.cc:827-977) on three keypoints: add to an empty slot, lose
+    against a better-observed holder, replace a weaker holder, skip a null entry, and replace a
+    point that an EARLIER iteration of the same call added (the sequential dependence)."""
+    fx = fy = 100.0
+    cx, cy, w, h = 320.0, 240.0, 640, 480
+    k = np.zeros(3, oracle.KP_DTYPE)
+    k["x"], k["y"], k["octave"] = [100, 300, 500], [100, 200, 300], [0, 0, 1]
+    d = np.zeros((3, 32), np.uint8)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    inv_s2 = (1 / (sf * sf)).astype(np.float32)
+    cam = oracle.Cam(fx, fy, cx, cy, 40.0, 0.4)
+    g = oracle.grid_geom(w, h)
+
+    def point(kp, z, grow):
+        p = np.array([(kp["x"] - cx) / fx * z, (kp["y"] - cy) / fy * z, z], np.float64)
+        dist = np.linalg.norm(p)
+        return (1, p[0], p[1], p[2], *(p / dist), dist * grow, dist * 0.1)
+    pts = np.zeros(5, oracle.MP3D_DTYPE)
+    pts[0] = point(k[0], 10.0, 1.0)      # A -> keypoint 0 (empty slot)
+    pts[1] = point(k[1], 8.0, 1.0)       # B -> keypoint 1, holder has more observations
+    pts[2] = point(k[2], 12.0, 1.15)     # C -> keypoint 2 (octave 1), holder has fewer observations
+    pts[3] = point(k[0], 10.0, 1.0); pts[3]["valid"] = 0   # null entry
+    pts[4] = point(k[0], 9.0, 1.0)       # E -> keypoint 0 again, now held by A
+    pd = np.zeros((5, 32), np.uint8)
+    bad = np.zeros(5, np.int32); in_kf = np.zeros(5, np.int32)
+    obs = np.array([1, 2, 3, 9, 7], np.int32)
+    slot = np.array([-1, -2, -2], np.int32)
+    ext_obs = np.array([0, 5, 1], np.int32); ext_bad = np.zeros(3, np.int32)
+    uright = np.array([-1, -1, 500 - 40.0 / 12.0 + 0.5], np.float32)   # ur of C is u - bf/z
+    T = np.eye(4, dtype=np.float32)
+    n, bi, act, st = oracle.fuse(k, d, uright, g, sf, inv_s2, np.float32(np.log(np.float32(1.2))), cam, T, pts, pd, bad,
+                                 in_kf, obs, slot, ext_obs, ext_bad, 3.0)
+    assert n == 4
+    assert list(act) == [1, 2, 3, 0, 3]
+    assert list(bi) == [0, 1, 2, -1, 0]
+    assert list(st["slot"]) == [4, -2, 2]
+    assert list(st["bad"]) == [1, 1, 0, 0, 0]          # A replaced by E, B replaced by its holder
+    assert list(st["in_kf"]) == [0, 0, 1, 0, 1]
+    assert list(st["obs"]) == [2, 2, 5, 9, 8]          # C gains 2 (stereo keypoint), A and E gain 1
+    assert list(st["ext_bad"]) == [0, 0, 1]
+    # the stereo gate: move C's right coordinate far from the keypoint's -> candidate rejected
+    uright[2] = 300.0
+    n2, bi2, act2, _ = oracle.fuse(k, d, uright, g, sf, inv_s2, np.float32(np.log(np.float32(1.2))), cam, T, pts, pd, bad,
+                                   in_kf, obs, slot, ext_obs, ext_bad, 3.0)
+    assert n2 == 3 and act2[2] == 0 and bi2[2] == -1
+
+
+def test_search_by_sim3_needs_mutual_agreement(oracle):
+    """SearchBySim3 (src/ORBmatcher.cc:1104-1328): identical keyframes, identity Sim3: every good
+    slot matches itself; dropping the point of slot j in KF2 removes exactly the pair (j, j)."""
+    fx = fy = 100.0
+    cx, cy, w, h = 320.0, 240.0, 640, 480
+    rng = np.random.default_rng(3)
+    n = 40
+    k = np.zeros(n, oracle.KP_DTYPE)
+    k["x"] = rng.uniform(40, 600, n).astype(np.float32); k["y"] = rng.uniform(40, 440, n).astype(np.float32)
+    d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    cam = oracle.Cam(fx, fy, cx, cy, 40.0, 0.4)
+    g = oracle.grid_geom(w, h)
+    z = 10.0
+    p = np.zeros(n, oracle.MP3D_DTYPE)
+    p["valid"] = 1
+    p["wx"], p["wy"], p["wz"] = (k["x"] - cx) / fx * z, (k["y"] - cy) / fy * z, z
+    dist = np.sqrt(p["wx"] ** 2 + p["wy"] ** 2 + p["wz"] ** 2)
+    p["max_distance"], p["min_distance"] = dist, dist * 0.1
+    I4 = np.eye(4, dtype=np.float32); I3 = np.eye(3, dtype=np.float32); z3 = np.zeros(3, np.float32)
+    lsf = np.float32(np.log(np.float32(1.2)))
+    nf, m12 = oracle.search_by_sim3(k, d, k, d, g, sf, lsf, cam, I4, I4, 1.0, I3, z3, p, d, p, d, 1.0)
+    assert nf == n and list(m12) == list(range(n))
+    p2 = p.copy(); p2["valid"][7] = 0
+    nf, m12 = oracle.search_by_sim3(k, d, k, d, g, sf, lsf, cam, I4, I4, 1.0, I3, z3, p, d, p2, d, 1.0)
+    assert nf == n - 1 and m12[7] == -1 and (np.delete(m12, 7) == np.delete(np.arange(n), 7)).all()
