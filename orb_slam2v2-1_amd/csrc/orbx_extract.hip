@@ -185,6 +185,175 @@ __global__ __launch_bounds__(256) void k_pyramid_fused(
 }
 
 // ------------------------------------------------------------------------------------
+// K1 (level-per-launch form, the default): ComputePyramid as  pad(level 0) -> resize 1..L-1 -> pad(1..L-1).
+//  * k_pyr_level: a wave owns 128 output columns x PYR_RW output rows; a lane owns TWO fixed
+//    columns (2j-1, 2j: the pair is 2-byte aligned in the padded row), so everything that depends
+//    on the column — source offset, v_perm selector that lifts the two source bytes into a u16
+//    pair, the packed (a0,a1) — is set up once.  Per source row and lane: ONE aligned 8-byte load,
+//    two v_perm + two v_dot2_u32_u16 (the horizontal pass of both columns); consecutive output
+//    rows share a source row (sy advances by 1 or 2), which is kept in registers, so a row costs
+//    ~1.2 loads.  Vertical pass and rounding exactly as cv::resize's VResizeLinear (8UC1, <= 3.3).
+//  * k_pyr_pad: copyMakeBorder(REFLECT_101) (:1122-1128) as a gather, one aligned dword per
+//    thread; for level 0 it also is the copy of the input into the padded buffer.
+// No LDS, no barriers, no dependent chain inside a workgroup (the fused kernel above waits ~45 %
+// of its time on its 8-level chain).
+#define PYR_RW 8   // output rows per wave
+#define PYR_SR 12  // source rows fetched up front: covers PYR_RW rows at scale factors up to ~1.4
+__device__ __forceinline__ int reflect101c(int p, int n) {   // reflect101 + clamp (dword tails past the frame)
+    p = p < 0 ? -p : p;
+    p = p >= n ? 2 * (n - 1) - p : p;
+    return min(max(p, 0), n - 1);
+}
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b), 0u, false);
+}
+
+__global__ __launch_bounds__(256) void k_pyr_level(uint8_t *__restrict__ pyr, size_t pyrImgBytes,
+                                                   const LevelGeom *__restrict__ geom, int l,
+                                                   const int32_t *__restrict__ tab, int nxc, int nbands) {
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (wave >= nxc * nbands) return;
+    const int band = wave / nxc, xc = wave - band * nxc;
+    const LevelGeom G = geom[l];
+    const int sw = geom[l - 1].w, sh = geom[l - 1].h, sps = geom[l - 1].pstride;
+    uint8_t *base = pyr + (size_t)blockIdx.y * pyrImgBytes;
+    const uint8_t *srow0 = base + geom[l - 1].poff + (size_t)ORBX_EDGE * sps;   // padded row of source row 0
+    uint8_t *drow0 = base + G.poff + (size_t)ORBX_EDGE * G.pstride + ORBX_EDGE;
+    const int x0 = xc * 128 + 2 * lane - 1, x1 = x0 + 1;
+    // The pair store is 2-byte aligned (ORBX_EDGE + x0 is even).  Columns -1 and w fall on frame bytes
+    // next to the inner row, which k_pyr_pad rewrites afterwards; lanes further right store nothing.
+    const bool vst = x0 < G.w;
+    const int xa = min(max(x0, 0), G.w - 1), xb = min(x1, G.w - 1);
+    const int ca = ORBX_EDGE + tab[G.xofsOff + xa], cb = ORBX_EDGE + tab[G.xofsOff + xb];   // byte column in the padded source row
+    const uint32_t aa = (uint32_t)tab[G.xalphaOff + xa], ab = (uint32_t)tab[G.xalphaOff + xb];
+    const int A = ca & ~3;                         // cb - ca <= 2: both byte pairs lie inside [A, A+8)
+    const uint32_t oa = (uint32_t)(ca - A), ob = (uint32_t)(cb - A);
+    const uint32_t selA = oa | ((oa + 1) << 16) | 0x0C000C00u, selB = ob | ((ob + 1) << 16) | 0x0C000C00u;
+    (void)sw;
+    const int y0 = band * PYR_RW, nrow = min(PYR_RW, G.h - y0);
+    // fast path: the band's source rows rf .. rf+PYR_SR-1 are fetched up front (one memory latency per
+    // wave), then consumed in order.  Lane i < 8 holds the row table of output row y0+i; bit k of
+    // `mask` says "the output row whose second source row is rf+k is due after source row k".
+    const int yl = min(y0 + (lane & 7), G.h - 1);
+    const int vsy = tab[G.yofsOff + yl];
+    const uint32_t vbt = (uint32_t)tab[G.ybetaOff + yl];
+    const int rf = __builtin_amdgcn_readfirstlane(vsy);
+    const int kk = vsy + 1 - rf;
+    const int prevsy = __shfl_up(vsy, 1);
+    const bool okl = (lane & 7) >= nrow || (rf >= 0 && vsy + 1 <= sh - 1 && kk < PYR_SR && ((lane & 7) == 0 || vsy > prevsy));
+    const bool regular = (__ballot(okl) & 0xFFull) == 0xFFull;
+    if (regular) {
+        uint32_t m = (lane & 7) < nrow ? 1u << (kk & 31) : 0u;
+        m |= __shfl_xor(m, 1); m |= __shfl_xor(m, 2); m |= __shfl_xor(m, 4);
+        const uint32_t mask = __builtin_amdgcn_readfirstlane(m);
+        uint2 q[PYR_SR];
+#pragma unroll
+        for (int k = 0; k < PYR_SR; k++) q[k] = *(const uint2 *)(srow0 + (size_t)min(rf + k, sh - 1) * sps + A);
+        uint32_t tpa = 0, tpb = 0;
+        int cnt = 0;
+        uint8_t *d = drow0 + (size_t)y0 * G.pstride + x0;
+#pragma unroll
+        for (int k = 0; k < PYR_SR; k++) {
+            const uint32_t tca = udot2_u16(__builtin_amdgcn_perm(q[k].y, q[k].x, selA), aa) >> 4;
+            const uint32_t tcb = udot2_u16(__builtin_amdgcn_perm(q[k].y, q[k].x, selB), ab) >> 4;
+            if (k > 0 && ((mask >> k) & 1u)) {   // wave-uniform
+                const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)vbt, cnt);
+                const uint32_t b0 = bb & 0xFFFFu, b1 = bb >> 16;
+                const uint32_t pa = (((b0 * tpa) >> 16) + ((b1 * tca) >> 16) + 2) >> 2;
+                const uint32_t pb = (((b0 * tpb) >> 16) + ((b1 * tcb) >> 16) + 2) >> 2;
+                if (vst) *(uint16_t *)d = (uint16_t)(pa | (pb << 8));
+                d += G.pstride;
+                cnt++;
+            }
+            tpa = tca; tpb = tcb;
+        }
+        return;
+    }
+    // general path (clamped source rows): one output row at a time
+    int cr0 = -1, cr1 = -1;
+    uint32_t t0a = 0, t0b = 0, t1a = 0, t1b = 0;
+    for (int y = y0; y < y0 + nrow; y++) {
+        const int syy = tab[G.yofsOff + y];
+        const uint32_t bb = (uint32_t)tab[G.ybetaOff + y];
+        const int r0 = min(max(syy, 0), sh - 1), r1 = min(max(syy + 1, 0), sh - 1);
+        if (r0 == cr1) { t0a = t1a; t0b = t1b; cr0 = cr1; }
+        else if (r0 != cr0) {
+            const uint2 q = *(const uint2 *)(srow0 + (size_t)r0 * sps + A);
+            t0a = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selA), aa) >> 4;
+            t0b = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selB), ab) >> 4;
+            cr0 = r0;
+        }
+        if (r1 != cr1) {
+            if (r1 == cr0) { t1a = t0a; t1b = t0b; }
+            else {
+                const uint2 q = *(const uint2 *)(srow0 + (size_t)r1 * sps + A);
+                t1a = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selA), aa) >> 4;
+                t1b = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selB), ab) >> 4;
+            }
+            cr1 = r1;
+        }
+        const uint32_t b0 = bb & 0xFFFFu, b1 = bb >> 16;
+        const uint32_t pa = (((b0 * t0a) >> 16) + ((b1 * t1a) >> 16) + 2) >> 2;
+        const uint32_t pb = (((b0 * t0b) >> 16) + ((b1 * t1b) >> 16) + 2) >> 2;
+        if (vst) *(uint16_t *)(drow0 + (size_t)y * G.pstride + x0) = (uint16_t)(pa | (pb << 8));
+    }
+}
+
+// FULL: every dword of the padded level from the input image (level 0).  !FULL: only the dwords
+// that contain frame bytes, gathered from the level's own inner pixels (levels >= 1, blockIdx.y).
+template <bool FULL>
+__global__ __launch_bounds__(256) void k_pyr_pad(const uint8_t *__restrict__ img, int sstride, size_t simg,
+                                                 uint8_t *__restrict__ pyr, size_t pyrImgBytes,
+                                                 const LevelGeom *__restrict__ geom, int l0) {
+    const int l = l0 + blockIdx.y;
+    const LevelGeom G = geom[l];
+    uint8_t *lvl = pyr + (size_t)blockIdx.z * pyrImgBytes + G.poff;
+    const uint8_t *src = FULL ? img + (size_t)blockIdx.z * simg : lvl + (size_t)ORBX_EDGE * G.pstride + ORBX_EDGE;
+    const int ss = FULL ? sstride : G.pstride;
+    const int pw4 = (G.w + 2 * ORBX_EDGE + 3) >> 2, rows = G.h + 2 * ORBX_EDGE;
+    const int LW = (ORBX_EDGE >> 2) + 1, R0 = (ORBX_EDGE + G.w) >> 2, side = LW + (pw4 - R0);
+    if (FULL) {   // 16-byte chunks of the padded rows; interior chunks are one (unaligned) 16-byte load
+        const int pc = G.pstride >> 4, totalc = pc * rows;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < totalc; i += gridDim.x * 256) {
+            const int py = i / pc, c = i - py * pc;
+            const uint8_t *srow = src + (size_t)reflect101c(py - ORBX_EDGE, G.h) * ss;
+            const int px = c * 16 - ORBX_EDGE;
+            uint4 v;
+            if (px >= 0 && px + 15 < G.w) __builtin_memcpy(&v, srow + px, 16);
+            else {
+                uint32_t t[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    t[u] = (uint32_t)srow[reflect101c(px + 4 * u, G.w)] | ((uint32_t)srow[reflect101c(px + 4 * u + 1, G.w)] << 8) |
+                           ((uint32_t)srow[reflect101c(px + 4 * u + 2, G.w)] << 16) | ((uint32_t)srow[reflect101c(px + 4 * u + 3, G.w)] << 24);
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            *(uint4 *)(lvl + (size_t)py * G.pstride + c * 16) = v;
+        }
+        return;
+    }
+    const int total = 2 * ORBX_EDGE * pw4 + G.h * side;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int py, p4;
+        if (i < 2 * ORBX_EDGE * pw4) {
+            const int r = i / pw4;
+            p4 = i - r * pw4;
+            py = r < ORBX_EDGE ? r : G.h + r;           // top frame rows, then bottom frame rows
+        } else {
+            const int j = i - 2 * ORBX_EDGE * pw4, r = j / side, k = j - r * side;
+            py = ORBX_EDGE + r;
+            p4 = k < LW ? k : R0 + (k - LW);
+        }
+        const uint8_t *srow = src + (size_t)reflect101c(py - ORBX_EDGE, G.h) * ss;
+        const int px = p4 * 4 - ORBX_EDGE;
+        const uint32_t v = (uint32_t)srow[reflect101c(px, G.w)] | ((uint32_t)srow[reflect101c(px + 1, G.w)] << 8) |
+                           ((uint32_t)srow[reflect101c(px + 2, G.w)] << 16) | ((uint32_t)srow[reflect101c(px + 3, G.w)] << 24);
+        *(uint32_t *)(lvl + (size_t)py * G.pstride + p4 * 4) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // K2: one wave per 30-px cell (:789-829).  The cell window (cell + 6 px) is staged in LDS
 // as one dword per pixel holding the pixel PAIR (p, p+1) in two 16-bit halves, so that the
 // FAST-9/16 score of two horizontally adjacent pixels is computed at once with packed 16-bit
@@ -1802,7 +1971,22 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
         ev = h->ev[slot];
         ORBX_HIP(hipEventRecord(ev[0], st));
     }
-    {   // K1
+    if (g_debug[5] == 0 && h->scale_factor <= 3.0) {   // K1, one launch per level (a lane's two source byte pairs fit 8 bytes)
+        const LevelGeom &g0 = h->geom[0];
+        hipLaunchKernelGGL(k_pyr_pad<true>, dim3(((g0.pstride >> 4) * g0.prows + 255) / 256, 1, B), dim3(256), 0, st, d_imgs, stride,
+                           img_stride, h->d_pyr, h->pyrImgBytes, h->d_geom, 0);
+        for (int l = 1; l < nl; l++) {
+            const int nxc = (h->geom[l].w + 1 + 127) / 128, nbands = (h->geom[l].h + PYR_RW - 1) / PYR_RW;
+            hipLaunchKernelGGL(k_pyr_level, dim3((nxc * nbands + 3) / 4, B), dim3(256), 0, st, h->d_pyr, h->pyrImgBytes,
+                               h->d_geom, l, h->d_tab, nxc, nbands);
+        }
+        if (nl > 1) {
+            const LevelGeom &g1 = h->geom[1];
+            const int p1 = (g1.w + 2 * ORBX_EDGE + 3) >> 2, tot1 = 2 * ORBX_EDGE * p1 + g1.h * 12;
+            hipLaunchKernelGGL(k_pyr_pad<false>, dim3((tot1 + 255) / 256, nl - 1, B), dim3(256), 0, st, d_imgs, stride,
+                               img_stride, h->d_pyr, h->pyrImgBytes, h->d_geom, 1);
+        }
+    } else {   // K1, fused form (orbx_debug_set(5, 1))
         hipLaunchKernelGGL(k_pyramid_fused, dim3(h->pyrTilesX * h->pyrTilesY, B), dim3(256), h->pyrLdsBytes, st, d_imgs,
                            stride, img_stride, h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->d_tab, h->pyrXSpanOff,
                            h->pyrYSpanOff, h->pyrTilesX, h->pyrTilesY, h->pyrBufBytes, h->pyrMaxPar);

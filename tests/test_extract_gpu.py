@@ -200,6 +200,29 @@ def _pyr(oracle, img, nf, level):
     return o.pyramid_level(level)
 
 
+def test_fused_pyramid_kernel(pkg, oracle, synth):
+    """k_pyramid_fused (all levels in one launch) is kept as the alternative to the level-per-launch
+    pyramid (and is used for scale factors > 3): same bytes, frame included."""
+    pkg.lib().orbx_debug_set(5, 1)
+    try:
+        _compare(pkg, oracle, synth.frame(752, 480, 82), 1000)
+        img = synth.frame(641, 479, 83)
+        ex = pkg.ORBextractor(500, 1.2, 8, 20, 7)
+        ex(img)
+        o = oracle.Extractor(500, 1.2, 8, 20, 7)
+        o.extract(img)
+        for lvl in range(8):
+            np.testing.assert_array_equal(ex.pyramid_level(lvl, padded=True), o.pyramid_level(lvl, padded=True), err_msg=str(lvl))
+    finally:
+        pkg.lib().orbx_debug_set(5, 0)
+
+
+def test_large_scale_factor(pkg, oracle, synth):
+    """scaleFactor 2.6 and 3.4: source columns of a lane's pixel pair up to 4 apart (3.4 takes the fused kernel)."""
+    _compare(pkg, oracle, synth.frame(1920, 1080, 84), 500, sf=2.6, nl=3)
+    _compare(pkg, oracle, synth.frame(1920, 1080, 85), 500, sf=3.4, nl=3)
+
+
 def test_quadtree_sweep_kernel_alone(pkg, oracle, synth):
     """k_octree (one key sweep per pass) is the exact fallback of k_octree_pyr: run it alone."""
     pkg.lib().orbx_debug_set(4, 1)
