@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ ge
 //    fixes "later-created first" == smaller list index first.
 //  * a key's child is a pure function of (x, y, parent box): keys never move in memory,
 //    only their 16-bit node index is rewritten.
-#define OCT_T 1024
+#define OCT_T 512   // 1024-thread workgroups are resident one per CU only; 512 packs 2x better at batch 128 and costs 6 us on a single frame
 
 struct OctLds {
     short4 *box[2];
@@ -790,8 +790,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
 
     const uint32_t *keys = cand + (size_t)b * keysPerImg + g.keyOff;
     const int n = candCnt[b * nlevels + l];
-    const uint8_t *rootOf = (const uint8_t *)tab + g.rootTabOff;
-    const int32_t *rootX = tab + g.rootBoxOff;
+    const int32_t *xPath = tab + g.xPathOff, *yPath = tab + g.yPathOff;
     const uint32_t offDeep = (uint32_t)nIni * (((1u << (2 * Dm)) - 1u) / 3u);
 
     // ---- 1. histogram of the keys at depth Dm (two 16-bit counters per word)
@@ -799,23 +798,14 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
     if (tid == 0) sh_abort = 0;
     __syncthreads();
     for (int i0 = 4 * tid; i0 < n; i0 += 4 * OCT_T) {
-        uint32_t key[4];
+        uint32_t key[4], c[4];
         load_keys4(keys, i0, n, key);
 #pragma unroll
+        for (int u = 0; u < 4; u++)   // unconditional (a missing key is 0): all 8 lookups in flight at once
+            c[u] = (uint32_t)xPath[key[u] & 0xFFF] | (uint32_t)yPath[(key[u] >> 12) & 0xFFF];
+#pragma unroll
         for (int u = 0; u < 4; u++)
-            if (i0 + u < n) {
-                const int x = key[u] & 0xFFF, y = (key[u] >> 12) & 0xFFF;
-                const int r = rootOf[x];
-                short4 bx;
-                bx.x = (short)rootX[r]; bx.y = (short)rootX[r + 1]; bx.z = 0; bx.w = (short)g.regH;
-                uint32_t c = (uint32_t)r;
-                for (int d = 0; d < Dm; d++) {
-                    const int q = child_of(x, y, bx);
-                    bx = child_box(bx, q);
-                    c = 4 * c + q;
-                }
-                atomicAdd(&pyr[offDeep + (c >> 1)], 1u << (16 * (c & 1)));
-            }
+            if (i0 + u < n) atomicAdd(&pyr[offDeep + (c[u] >> 1)], 1u << (16 * (c[u] & 1)));
     }
     __syncthreads();
     // ---- 2. counts of the shallower depths
@@ -1039,26 +1029,33 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
     }
     // ---- 6. every key walks down to its leaf; best key of the node, first maximum wins (:744-760)
     for (int i0 = 4 * tid; i0 < n; i0 += 4 * OCT_T) {
-        uint32_t key[4];
+        uint32_t key[4], cd[4], node[4];
         load_keys4(keys, i0, n, key);
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (i0 + u < n) {
-                const int x = key[u] & 0xFFF, y = (key[u] >> 12) & 0xFFF;
-                const int r = rootOf[x];
-                short4 bx;
-                bx.x = (short)rootX[r]; bx.y = (short)rootX[r + 1]; bx.z = 0; bx.w = (short)g.regH;
-                uint32_t c = (uint32_t)r, node = 0xFFFFFFFFu;
-                for (int d = 0; d <= Dm; d++) {
-                    const uint32_t off = (uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u);
-                    const uint32_t v = d == Dm ? (uint32_t)((const uint16_t *)(pyr + off))[c] : pyr[off + c];
-                    if (d == Dm ? (v != 0xFFFFu) : (v != 0xFFFFFFFFu)) { node = v; break; }
-                    const int q = child_of(x, y, bx);
-                    bx = child_box(bx, q);
-                    c = 4 * c + q;
-                }
-                if (node != 0xFFFFFFFFu) atomicMax(&hist[node], ((key[u] >> 24) << 20) | (0xFFFFFu - (uint32_t)(i0 + u)));
+        for (int u = 0; u < 4; u++) {
+            cd[u] = (uint32_t)xPath[key[u] & 0xFFF] | (uint32_t)yPath[(key[u] >> 12) & 0xFFF];
+            node[u] = 0xFFFFFFFFu;
+        }
+        // the leaves partition the region: exactly one cell on a key's path is in the map, so the depths
+        // are probed independently (4 keys x 1 depth in flight) instead of as a dependent descent
+        for (int d = 0; d < Dm; d++) {
+            const uint32_t off = (uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u);
+            const int sh = 2 * (Dm - d);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t v = pyr[off + (cd[u] >> sh)];
+                node[u] = v != 0xFFFFFFFFu ? v : node[u];
             }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t v = ((const uint16_t *)(pyr + offDeep))[cd[u]];
+            node[u] = v != 0xFFFFu ? v : node[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + u < n && node[u] != 0xFFFFFFFFu)
+                atomicMax(&hist[node[u]], ((key[u] >> 24) << 20) | (0xFFFFFu - (uint32_t)(i0 + u)));
     }
     __syncthreads();
     // ---- 7. output in list order
@@ -1847,6 +1844,36 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
                 size_t r = (size_t)((float)x / hX);
                 if (r >= (size_t)g.nIni) r = g.nIni - 1;
                 rt[x] = (uint8_t)r;
+            }
+            // DivideNode splits x and y independently (:483-484, :513-525), so the path of a key down to depth
+            // pyrDepth is (bits decided by x alone) interleaved with (bits decided by y alone): two lookups
+            // replace pyrDepth rounds of box arithmetic per key in k_octree_pyr.  Cell code at depth d =
+            // (xPath[x] | yPath[y]) >> 2*(pyrDepth - d), child index = xbit | ybit << 1 like child_of().
+            const int D = g.pyrDepth;
+            g.xPathOff = (int)tab.size();
+            for (int x = 0; x < g.regW; x++) {
+                const int r = ((const uint8_t *)&tab[base])[x];
+                int lo = tab[g.rootBoxOff + r], hi = tab[g.rootBoxOff + r + 1];
+                uint32_t p = 0;
+                for (int d = 0; d < D; d++) {
+                    const int mx = lo + ((hi - lo + 1) >> 1);
+                    const uint32_t bit = x < mx ? 0u : 1u;
+                    if (bit) lo = mx; else hi = mx;
+                    p = (p << 2) | bit;
+                }
+                tab.push_back((int32_t)(((uint32_t)r << (2 * D)) | p));
+            }
+            g.yPathOff = (int)tab.size();
+            for (int y = 0; y < g.regH; y++) {
+                int lo = 0, hi = g.regH;
+                uint32_t p = 0;
+                for (int d = 0; d < D; d++) {
+                    const int my = lo + ((hi - lo + 1) >> 1);
+                    const uint32_t bit = y < my ? 0u : 1u;
+                    if (bit) lo = my; else hi = my;
+                    p = (p << 2) | (bit << 1);
+                }
+                tab.push_back((int32_t)p);
             }
         }
     }

@@ -50,6 +50,7 @@ struct LevelGeom {
     int lvlKpOff;                    // offset of this level's kept keypoints in the per-image list
     int xofsOff, xalphaOff, yofsOff, ybetaOff;  // resize tables (int32 units into d_tab), levels >= 1
     int rootTabOff, rootBoxOff;      // byte offset (uint8 rootOf[x]) / int32 offset (root x bounds)
+    int xPathOff, yPathOff;          // int32 offsets: quad-tree path of a key at depth pyrDepth, per x (root<<2D | even bits) / per y (odd bits)
     float scale;                     // mvScaleFactor[level]
     float size;                      // (float)(int)(31*scale)                            (:837,846)
 };
