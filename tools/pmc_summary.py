@@ -7,6 +7,7 @@ for d in sys.argv[1:]:
         n = collections.defaultdict(lambda: collections.defaultdict(int))
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
+            k = k[5:] if k.startswith("void ") else k
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             n[k][r["Counter_Name"]] += 1
         for k in sorted(acc):

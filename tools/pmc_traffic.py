@@ -16,7 +16,9 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            rows[r["Kernel_Name"].split("(")[0]].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+            name = r["Kernel_Name"].split("(")[0]
+            name = name[5:] if name.startswith("void ") else name          # template instances: "void k_pyr_pad<true>"
+            rows[name].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     out = {}
     for k, v in rows.items():
         if not k.startswith("k_"):
