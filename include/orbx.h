@@ -245,6 +245,15 @@ int orbm_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const 
                          int m, const float *inv_level_sigma2, int nlevels, int32_t *best_idx, int32_t *best_dist,
                          int device);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:252-317), batched over map points
+ * (SURVEY §8(f) rank 4).  Map point p owns the descriptors desc[offsets[p] .. offsets[p+1]) (the rows
+ * of its non-bad observing keyframes, in std::map iteration order).  For each row i: all Hamming
+ * distances to the point's rows (itself included, 0), median = sorted[(size_t)(0.5*(N-1))]; the FIRST
+ * row with the least median wins.  Out: best_row[p] (index inside the point's block, -1 if it has no
+ * rows), best_median[p] (may be NULL).  The caller copies row best_row[p] into mDescriptor. */
+int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, int npoints, int32_t *best_row,
+                                 int32_t *best_median, int device);
+
 /* Developer knobs for kernel ablation timing (key 0: stop k_fast_cells after phase n; 0 = off;
  * key 1: stop k_octree early; key 2: force the exact one-workgroup matcher kernels;
  * key 3: pyramid tile size; key 4: quad-tree by k_octree alone, without the count pyramid).

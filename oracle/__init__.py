@@ -139,6 +139,8 @@ def lib():
         L.oracle_search_by_sim3.restype = i32
         L.oracle_search_by_sim3.argtypes = [vp, vp, i32, vp, vp, i32, G, G, vp, i32, f32, K, vp, vp, f32, vp, vp, vp, vp, vp, vp,
                                             f32, vp]
+        L.oracle_distinctive_descriptor.restype = i32
+        L.oracle_distinctive_descriptor.argtypes = [vp, i32, C.POINTER(i32)]
         _lib = L
     return _lib
 
@@ -442,3 +444,11 @@ def search_by_sim3(k1, d1, k2, d2, geom, sf, log_sf, cam, T1w, T2w, s12, R12, t1
                                     float(log_sf), C.byref(cam), _p(T1), _p(T2), float(s12), _p(R), _p(t), _p(pts1),
                                     _p(pd1), _p(pts2), _p(pd2), float(th), _p(m12))
     return n, m12
+
+
+def distinctive_descriptor(desc):
+    """-> (BestIdx, BestMedian) of MapPoint::ComputeDistinctiveDescriptors for one map point"""
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    med = C.c_int(0)
+    i = lib().oracle_distinctive_descriptor(_p(desc), len(desc), C.byref(med))
+    return i, med.value

@@ -207,6 +207,9 @@ int oracle_search_by_sim3(const oracle_kp_t *k1, const uint8_t *d1, int n1, cons
                           const float *t12, const oracle_mappoint3d_t *pts1, const uint8_t *pd1,
                           const oracle_mappoint3d_t *pts2, const uint8_t *pd2, float th, int32_t *match12);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:252-317), one map point; returns BestIdx (-1: no rows) */
+int oracle_distinctive_descriptor(const uint8_t *desc, int n, int *median_out);
+
 #ifdef __cplusplus
 }
 #endif

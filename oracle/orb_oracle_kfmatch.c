@@ -314,3 +314,28 @@ int oracle_search_by_sim3(const oracle_kp_t *k1, const uint8_t *d1, int n1, cons
     free(q1); free(q2); free(m1); free(m2); free(b1); free(b2);
     return nFound;
 }
+
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:252-317) for one map point with n observed
+ * descriptors: returns BestIdx, *median_out = BestMedian.  Literal: full distance matrix, sort per row. */
+static int int_cmp(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+int oracle_distinctive_descriptor(const uint8_t *desc, int n, int *median_out) {
+    if (n <= 0) { if (median_out) *median_out = 0; return -1; }
+    int *dist = (int *)malloc(sizeof(int) * (size_t)n * n), *row = (int *)malloc(sizeof(int) * n);
+    for (int i = 0; i < n; i++) {
+        dist[(size_t)i * n + i] = 0;
+        for (int j = i + 1; j < n; j++) {
+            const int d = oracle_hamming(desc + 32 * (size_t)i, desc + 32 * (size_t)j);
+            dist[(size_t)i * n + j] = d; dist[(size_t)j * n + i] = d;
+        }
+    }
+    int BestMedian = 0x7FFFFFFF, BestIdx = 0;
+    for (int i = 0; i < n; i++) {
+        memcpy(row, dist + (size_t)i * n, sizeof(int) * n);
+        qsort(row, n, sizeof(int), int_cmp);
+        const int median = row[(size_t)(0.5 * (n - 1))];
+        if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+    }
+    free(dist); free(row);
+    if (median_out) *median_out = BestMedian;
+    return BestIdx;
+}

@@ -38,7 +38,7 @@ EXPORTS = [
     "orbx_pyramid_host", "orbx_pyramid_device", "orbx_debug_level_points", "orbx_set_profiling",
     "orbx_get_stage_ms", "orbx_debug_set", "orbm_hamming", "orbm_hamming_matrix_device", "orbm_stereo_batch_device",
     "orbm_stereo", "orbm_search_for_initialization", "orbm_search_by_projection_mp",
-    "orbm_search_by_projection_frame", "orbm_match_windows", "orbm_best_in_windows", "orbx_last_error", "orbx_version", "orbx_device_count",
+    "orbm_search_by_projection_frame", "orbm_match_windows", "orbm_best_in_windows", "orbm_distinctive_descriptors", "orbx_last_error", "orbx_version", "orbx_device_count",
 ]
 
 
@@ -137,6 +137,7 @@ def lib():
     L.orbm_search_by_projection_frame.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp, i32, C.POINTER(Camera),
                                                   vp, vp, vp, vp, i32, vp, vp, f32, i32, i32, i32, C.POINTER(i32)]
     L.orbm_match_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, vp, i32, i32, i32, C.POINTER(i32)]
+    L.orbm_distinctive_descriptors.argtypes = [vp, vp, i32, vp, vp, i32]
     L.orbm_best_in_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, i32, vp, vp, i32]
     L.orbx_last_error.restype = C.c_char_p
     L.orbx_version.restype = C.c_char_p
@@ -396,3 +397,13 @@ def best_in_windows(kun, desc, uright, geom, queries, query_desc, inv_level_sigm
                                       None if geom_assign is None else C.byref(geom_assign), _p(q), _p(qd), len(q), _p(s2),
                                       0 if s2 is None else len(s2), _p(bi), _p(bd), int(device)))
     return bi, bd
+
+
+def distinctive_descriptors(desc, offsets, device=0):
+    """orbm_distinctive_descriptors: MapPoint::ComputeDistinctiveDescriptors batched -> (best_row, best_median)"""
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    off = np.ascontiguousarray(offsets, np.int32)
+    m = len(off) - 1
+    br = np.zeros(m, np.int32); bm = np.zeros(m, np.int32)
+    _check(lib().orbm_distinctive_descriptors(_p(desc), _p(off), m, _p(br), _p(bm), int(device)))
+    return br, bm

@@ -122,4 +122,6 @@ int fast_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const 
                          const orbm_grid_geom_t *g, const orbm_grid_geom_t *ga, const orbm_window_query_t *q,
                          const uint8_t *qdesc, int m, const float *inv_sigma2, int nlevels, int32_t *best_idx,
                          int32_t *best_dist, int device);
+int fast_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, int npoints, int32_t *best_row,
+                                 int32_t *best_median, int device);
 extern int g_debug[8];  // developer knobs (orbx_debug_set); [2] != 0 forces the exact one-workgroup matcher kernels

@@ -863,6 +863,17 @@ __global__ __launch_bounds__(SQ_T) void k_match_windows_exact(
     if (tid == 0) *nmatches_out = nm;
 }
 
+extern "C" int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, int npoints, int32_t *best_row,
+                                            int32_t *best_median, int device) {
+    if (npoints < 0 || (npoints > 0 && (!offsets || !best_row))) { orbx_set_error("orbm_distinctive_descriptors: bad arguments"); return ORBX_ERR_ARG; }
+    if (npoints == 0) return ORBX_OK;
+    if (offsets[0] < 0) { orbx_set_error("offsets[0] < 0"); return ORBX_ERR_ARG; }
+    for (int p = 0; p < npoints; p++)
+        if (offsets[p + 1] < offsets[p]) { orbx_set_error("offsets not monotonic at %d", p); return ORBX_ERR_ARG; }
+    if (offsets[npoints] > 0 && !desc) { orbx_set_error("orbm_distinctive_descriptors: desc is NULL"); return ORBX_ERR_ARG; }
+    return fast_distinctive_descriptors(desc, offsets, npoints, best_row, best_median, device);
+}
+
 extern "C" int orbm_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
                                     const orbm_grid_geom_t *g, const orbm_grid_geom_t *g_assign,
                                     const orbm_window_query_t *queries,

@@ -839,3 +839,74 @@ int fast_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const 
     ORBX_HIP(hipStreamSynchronize(st));
     return ORBX_OK;
 }
+
+// ---- D. MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:252-317), one wave per map point.
+// Lane j keeps the distances of the current row to rows j, j+64, ... in registers (DD_CH chunks);
+// the median of a row is found by bisection on the VALUE (0..256): count(d <= mid) by ballot +
+// popcount, 9 steps, no sort and no N x N matrix.  Points with more than 64*DD_CH rows recompute
+// the distances in every bisection step instead of caching them.
+#define DD_CH 4
+__global__ __launch_bounds__(256) void k_distinctive(const uint8_t *__restrict__ desc, const int32_t *__restrict__ offsets,
+                                                     int npoints, int32_t *__restrict__ best_row,
+                                                     int32_t *__restrict__ best_median) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= npoints) return;
+    const int o0 = offsets[p], N = offsets[p + 1] - o0;
+    if (N <= 0) { if (lane == 0) { best_row[p] = -1; if (best_median) best_median[p] = 0; } return; }
+    const uint8_t *D = desc + (size_t)o0 * 32;
+    const int k = (N - 1) >> 1;                       // (size_t)(0.5*(N-1))
+    int bestMedian = INT_MAX, bestIdx = 0;
+    const bool cached = N <= 64 * DD_CH;
+    Desc256 dj[DD_CH];
+    if (cached) {
+#pragma unroll
+        for (int c = 0; c < DD_CH; c++) dj[c] = load_desc(D + (size_t)min(c * 64 + lane, N - 1) * 32);
+    }
+    for (int i = 0; i < N; i++) {
+        const Desc256 di = load_desc(D + (size_t)i * 32);
+        int dist[DD_CH];
+        if (cached) {
+#pragma unroll
+            for (int c = 0; c < DD_CH; c++) dist[c] = c * 64 + lane < N ? ham(di, dj[c]) : 1000;
+        }
+        int lo = 0, hi = 256;                         // smallest v with count(d <= v) >= k+1
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            if (cached) {
+#pragma unroll
+                for (int c = 0; c < DD_CH; c++) cnt += __popcll(__ballot(dist[c] <= mid));
+            } else {
+                for (int j0 = 0; j0 < N; j0 += 64) {
+                    const int j = j0 + lane;
+                    const bool le = j < N && ham(di, load_desc(D + (size_t)j * 32)) <= mid;
+                    cnt += __popcll(__ballot(le));
+                }
+            }
+            if (cnt >= k + 1) hi = mid; else lo = mid + 1;
+        }
+        if (lo < bestMedian) { bestMedian = lo; bestIdx = i; }   // :304-308, first minimum
+    }
+    if (lane == 0) { best_row[p] = bestIdx; if (best_median) best_median[p] = bestMedian; }
+}
+
+int fast_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, int npoints, int32_t *best_row,
+                                 int32_t *best_median, int device) {
+    const int total = offsets[npoints];
+    const size_t need = (size_t)total * 32 + (size_t)npoints * 16 + 65536;
+    int rc = arena_begin(device, need);
+    if (rc) return rc;
+    hipStream_t st = g_ar.st;
+    uint8_t *dd = arena_get<uint8_t>((size_t)32 * (total > 0 ? total : 1));
+    int32_t *doff = arena_get<int32_t>(npoints + 1), *dbr = arena_get<int32_t>(npoints), *dbm = arena_get<int32_t>(npoints);
+    if (total > 0) UP(dd, desc, (size_t)32 * total);
+    UP(doff, offsets, npoints + 1);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_distinctive, dim3((npoints + 3) / 4), dim3(256), 0, st, dd, doff, npoints, dbr, dbm);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(best_row, dbr, sizeof(int32_t) * (size_t)npoints, hipMemcpyDeviceToHost, st));
+    if (best_median) ORBX_HIP(hipMemcpyAsync(best_median, dbm, sizeof(int32_t) * (size_t)npoints, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    return ORBX_OK;
+}

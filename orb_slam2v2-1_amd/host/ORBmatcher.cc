@@ -507,6 +507,40 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Po
     return nmatches;
 }
 
+int ComputeDistinctiveDescriptorsHIP(const std::vector<MapPoint *> &vpMapPoints, std::vector<cv::Mat> &vBest) {
+    const int m = (int)vpMapPoints.size();
+    vBest.assign(m, cv::Mat());
+    std::vector<int32_t> offsets(m + 1, 0);
+    std::vector<uint8_t> rows;
+    std::vector<cv::Mat> src;   // the candidate rows, in the order the reference visits them
+    for (int p = 0; p < m; p++) {
+        MapPoint *pMP = vpMapPoints[p];
+        if (pMP && !pMP->isBad()) {                                            // :260-262
+            std::map<KeyFrame *, size_t> observations = pMP->GetObservations();
+            for (std::map<KeyFrame *, size_t>::iterator mit = observations.begin(), mend = observations.end(); mit != mend; mit++) {
+                KeyFrame *pKF = mit->first;
+                if (!pKF->isBad()) {                                           // :275-276
+                    cv::Mat row = pKF->mDescriptors.row((int)mit->second);
+                    rows.insert(rows.end(), row.ptr(0), row.ptr(0) + 32);
+                    src.push_back(row);
+                }
+            }
+        }
+        offsets[p + 1] = (int32_t)src.size();
+    }
+    if (m == 0) return 0;
+    std::vector<int32_t> best(m, -1);
+    if (orbm_distinctive_descriptors(rows.empty() ? NULL : rows.data(), offsets.data(), m, best.data(), NULL,
+                                     ORBmatcher::device) != ORBX_OK) {
+        std::fprintf(stderr, "ComputeDistinctiveDescriptors: %s\n", orbx_last_error());
+        return -1;
+    }
+    int n = 0;
+    for (int p = 0; p < m; p++)
+        if (best[p] >= 0) { vBest[p] = src[offsets[p] + best[p]].clone(); n++; }   // :313-316
+    return n;
+}
+
 int ComputeStereoMatchesHIP(Frame &F) {
     const int N = F.N, Nr = (int)F.mvKeysRight.size();
     F.mvuRight = std::vector<float>(N, -1.0f);  // :483-484

@@ -72,5 +72,13 @@ protected:
 // Call it from Frame::ComputeStereoMatches() in place of the CPU body. Returns #matches (<0: error).
 int ComputeStereoMatchesHIP(Frame &F);
 
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:252-317) for MANY map points in one GPU call
+// (the reference calls it point by point inside loops: src/LocalMapping.cc:170-180,520-535,
+// src/Tracking.cc CreateInitialMap*, src/LoopClosing.cc SearchAndFuse).  Gathers the descriptors of every
+// point's non-bad observing keyframes, picks the row with the least median Hamming distance on the GPU and
+// returns it per point (empty Mat: the reference returns early and leaves mDescriptor untouched).
+// In the reference tree MapPoint::ComputeDistinctiveDescriptors() itself keeps the final locked store.
+int ComputeDistinctiveDescriptorsHIP(const std::vector<MapPoint *> &vpMapPoints, std::vector<cv::Mat> &vBest);
+
 }  // namespace ORB_SLAM2
 #endif

@@ -43,6 +43,8 @@ public:
     int GetIndexInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) ? (int)mObservations[pKF] : -1; }
     inline void AddObservation(KeyFrame *pKF, size_t idx);                                // src/MapPoint.cc:108-119
     inline void Replace(MapPoint *pMP);                                                   // src/MapPoint.cc:187-225
+    std::map<KeyFrame *, size_t> GetObservations() { return mObservations; }
+    void SetDescriptor(const cv::Mat &d) { mDescriptor = d.clone(); }   // the store at src/MapPoint.cc:313-316 (test shim only)
     bool mbBad;
     int nObs;
     float mfMinDistance = 0.f, mfMaxDistance = 0.f;
@@ -89,6 +91,8 @@ public:
             if (mvpMapPoints[i] && !mvpMapPoints[i]->isBad()) s.insert(mvpMapPoints[i]);
         return s;
     }
+    bool isBad() { return mbBad; }
+    bool mbBad = false;
     MapPoint *GetMapPoint(const size_t &idx) { return mvpMapPoints[idx]; }
     void AddMapPoint(MapPoint *pMP, const size_t &idx) { mvpMapPoints[idx] = pMP; }
     void ReplaceMapPointMatch(const size_t &idx, MapPoint *pMP) { mvpMapPoints[idx] = pMP; }

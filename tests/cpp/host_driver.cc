@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <algorithm>
 #include <set>
 #include <string>
 #include <vector>
@@ -202,11 +203,45 @@ static int sim3_mode(int argc, char **argv) {
     return 0;
 }
 
+static int distinct_mode(int argc, char **argv) {
+    // argv: distinct offsets.bin(int32[m+1]) desc.bin(u8[total][32]) badkf out
+    // point p is observed by keyframes 0..N_p-1 at index p; keyframe `badkf` is bad (its rows are skipped, :275)
+    if (argc != 6) return 2;
+    std::vector<unsigned char> oraw = slurp(argv[2]), draw = slurp(argv[3]);
+    const int badkf = atoi(argv[4]);
+    const std::string out = argv[5];
+    const int m = (int)(oraw.size() / 4) - 1;
+    const int *off = (const int *)oraw.data();
+    int K = 0;
+    for (int p = 0; p < m; p++) K = std::max(K, off[p + 1] - off[p]);
+    std::vector<KeyFrame> kfs(K);            // contiguous: std::map<KeyFrame*,...> iterates them in index order
+    for (int k = 0; k < K; k++) { kfs[k].mDescriptors = cv::Mat::zeros(m, 32, CV_8U); kfs[k].mvuRight.assign(m, -1.f); kfs[k].mbBad = k == badkf; }
+    std::vector<MapPoint> pts(m);
+    std::vector<MapPoint *> vp(m);
+    for (int p = 0; p < m; p++) {
+        for (int k = 0; k < off[p + 1] - off[p]; k++) {
+            memcpy(kfs[k].mDescriptors.ptr(p), &draw[(size_t)32 * (off[p] + k)], 32);
+            pts[p].AddObservation(&kfs[k], p);
+        }
+        vp[p] = &pts[p];
+        if (p % 11 == 10) pts[p].mbBad = true;   // bad points return early (:260-262)
+    }
+    std::vector<cv::Mat> best;
+    const int n = ComputeDistinctiveDescriptorsHIP(vp, best);
+    std::vector<unsigned char> res((size_t)33 * m, 0);
+    for (int p = 0; p < m; p++)
+        if (!best[p].empty()) { res[(size_t)33 * p] = 1; memcpy(&res[(size_t)33 * p + 1], best[p].ptr(0), 32); }
+    dump(out + ".best", res.data(), res.size());
+    printf("%d %d\n", m, n);
+    return n < 0 ? 5 : 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) return 2;
     const std::string mode = argv[1];
     if (mode == "kf") return kf_modes(argc, argv);
     if (mode == "sim3") return sim3_mode(argc, argv);
+    if (mode == "distinct") return distinct_mode(argc, argv);
     if (mode == "extract" && argc == 7) {
         const int w = atoi(argv[3]), h = atoi(argv[4]), nf = atoi(argv[5]);
         const std::string out = argv[6];

@@ -297,3 +297,32 @@ def test_search_by_sim3_class(driver, oracle, synth, tmp_path):
     res = np.fromfile(str(tmp_path / "o.i32"), np.int32)
     expect = np.where(om12 >= 0, om12, pre)
     np.testing.assert_array_equal(res, expect)
+
+
+def test_compute_distinctive_descriptors_batched(driver, oracle, tmp_path):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:252-317) for a batch of map points through
+    the C++ gather (observations in std::map order, bad keyframes and bad points skipped)."""
+    rng = np.random.default_rng(9)
+    sizes = [0, 1, 2, 5, 64, 65, 130] + list(rng.integers(1, 30, 60))
+    blocks, offsets = [], [0]
+    for n in sizes:
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        d = base[None, :] ^ (rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8) & np.uint8(0x33))
+        blocks.append(d)
+        offsets.append(offsets[-1] + n)
+    np.array(offsets, np.int32).tofile(tmp_path / "off.bin")
+    np.concatenate(blocks).tofile(tmp_path / "desc.bin")
+    badkf = 3
+    m, n = _run(driver, "distinct", tmp_path / "off.bin", tmp_path / "desc.bin", badkf, tmp_path / "o")
+    res = np.fromfile(str(tmp_path / "o.best"), np.uint8).reshape(m, 33)
+    expect_n = 0
+    for p, d in enumerate(blocks):
+        rows = np.delete(d, badkf, axis=0) if len(d) > badkf else d        # keyframe 3 is bad: its row is skipped
+        if p % 11 == 10 or len(rows) == 0:
+            assert res[p, 0] == 0
+            continue
+        oi, _ = oracle.distinctive_descriptor(rows)
+        assert res[p, 0] == 1
+        np.testing.assert_array_equal(res[p, 1:], rows[oi], err_msg=str(p))
+        expect_n += 1
+    assert m == len(sizes) and n == expect_n > 40

@@ -351,3 +351,34 @@ def test_search_by_projection_sim3(pkg, oracle, synth, matcher_path, distorted):
     assert on > 200
     assert gn == on
     np.testing.assert_array_equal(gm, om)
+
+
+def test_distinctive_descriptors(pkg, oracle):
+    """orbm_distinctive_descriptors (MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:252-317) for a
+    batch of map points with 0..300 observations: least-median row, first minimum wins; sizes around the
+    64-lane chunks and past the register-cached limit (256) included."""
+    rng = np.random.default_rng(31)
+    sizes = [0, 1, 2, 3, 4, 5, 17, 63, 64, 65, 128, 129, 255, 256, 257, 300] + list(rng.integers(1, 40, 200))
+    blocks, offsets = [], [0]
+    for n in sizes:
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        # a cluster around one descriptor with a few outliers; coarse noise makes equal medians frequent
+        noise = rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8) & \
+            rng.integers(0, 256, (n, 32), dtype=np.uint8) & np.uint8(0x0F)
+        d = base[None, :] ^ noise
+        out = rng.random(n) < 0.15
+        d[out] = rng.integers(0, 256, (int(out.sum()), 32), dtype=np.uint8)
+        if n > 3:
+            d[n // 2] = d[0]            # exact duplicates: equal medians, the first must win
+        blocks.append(d)
+        offsets.append(offsets[-1] + n)
+    desc = np.concatenate(blocks)
+    br, bm = pkg.distinctive_descriptors(desc, offsets)
+    ties = 0
+    for p, d in enumerate(blocks):
+        oi, om = oracle.distinctive_descriptor(d)
+        assert br[p] == oi, (p, len(d))
+        if len(d):
+            assert bm[p] == om
+            ties += 1 if len(d) > 3 else 0
+    assert ties > 100

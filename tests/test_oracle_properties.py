@@ -186,3 +186,20 @@ def test_search_by_sim3_needs_mutual_agreement(oracle):
     p2 = p.copy(); p2["valid"][7] = 0
     nf, m12 = oracle.search_by_sim3(k, d, k, d, g, sf, lsf, cam, I4, I4, 1.0, I3, z3, p, d, p2, d, 1.0)
     assert nf == n - 1 and m12[7] == -1 and (np.delete(m12, 7) == np.delete(np.arange(n), 7)).all()
+
+
+def test_distinctive_descriptor_hand_built(oracle):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:252-317): median index (size_t)(0.5*(N-1)),
+    self distance included, first minimum wins."""
+    def rows(*bits):   # descriptor with the given number of leading one-bits
+        out = np.zeros((len(bits), 32), np.uint8)
+        for i, b in enumerate(bits):
+            out[i] = np.packbits(np.arange(256) < b)
+        return out
+    # distances |a-b|: rows at 0, 10, 20, 100 -> medians (index 1 of the sorted row): 10, 10, 10, 80
+    assert oracle.distinctive_descriptor(rows(0, 10, 20, 100)) == (0, 10)
+    # N = 5, index 2: rows 0,4,10,30,100 -> medians 10, 6, 10, 26, 90 -> row 1
+    assert oracle.distinctive_descriptor(rows(0, 4, 10, 30, 100)) == (1, 6)
+    assert oracle.distinctive_descriptor(rows(7)) == (0, 0)
+    assert oracle.distinctive_descriptor(rows(7, 200)) == (0, 0)      # N = 2: index 0 -> the self distance
+    assert oracle.distinctive_descriptor(rows()) == (-1, 0)
