@@ -66,7 +66,8 @@ struct StereoLevels {
     int nlevels, nRows;
 };
 
-#define ST_WAVES 4
+#define ST_WAVES 8
+#define ST_CAND 256   // candidates of one left keypoint kept in LDS before the Hamming step
 // right keypoints in the compact form the candidate loop needs (8 B, coalesced):
 // x = minr | maxr << 12 | octave << 24 (row band floor(y-r)..ceil(y+r), r = 2*scale, :498-508), y = bits of pt.x
 __global__ __launch_bounds__(256) void k_stereo_prep(StereoLevels lv, const orbx_keypoint_t *__restrict__ kr,
@@ -92,9 +93,19 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
     const int32_t *__restrict__ nl, const orbx_keypoint_t *__restrict__ kr, const uint8_t *__restrict__ dr,
     const int32_t *__restrict__ nr, int cap, float mbf, float mb, float *__restrict__ uright,
     float *__restrict__ depth, int32_t *__restrict__ sad, const uint2 *__restrict__ rc) {
+    // The right keypoints' compact records are staged in LDS once per workgroup (ST_WAVES left keypoints of
+    // one frame share them): the candidate filter then never waits on global memory, and the few survivors
+    // are compacted (ballot prefix, increasing iR) so that their descriptors are fetched by all lanes at once.
+    extern __shared__ uint2 s_rc[];
+    __shared__ uint16_t s_cand[ST_WAVES][ST_CAND];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int iL = blockIdx.x * ST_WAVES + wave, b = blockIdx.y;
     const int N = min(nl[b], cap), Nr = min(nr[b], cap);
+    {
+        const uint2 *rcb = rc + (size_t)b * cap;
+        for (int i = threadIdx.x; i < Nr; i += 64 * ST_WAVES) s_rc[i] = rcb[i];
+    }
+    __syncthreads();
     if (iL >= cap) return;
     const size_t o = (size_t)b * cap + iL;
     if (iL >= N) {
@@ -115,20 +126,38 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
         u64 best = ~0ull;
         const orbx_keypoint_t *krb = kr + (size_t)b * cap;
         const uint8_t *drb = dr + (size_t)b * cap * 32;
-        const uint2 *rcb = rc + (size_t)b * cap;
-        for (int iR = lane; iR < Nr; iR += 64) {
-            const uint2 q = rcb[iR];
-            const int minr = (int)(q.x & 0xFFF), maxr = (int)((q.x >> 12) & 0xFFF), octR = (int)(q.x >> 24);
-            if (row < minr || row > maxr) continue;
-            if (octR < levelL - 1 || octR > levelL + 1) continue;
-            const float uR = __uint_as_float(q.y);
-            if (uR >= minU && uR <= maxU) {
-                const int dist = ham(dL, load_desc(drb + (size_t)iR * 32));
-                if (dist < TH_HIGH) {
-                    const u64 key = ((u64)dist << 32) | (unsigned)iR;
-                    best = key < best ? key : best;
-                }
+        uint16_t *cl = s_cand[wave];
+        int cnt = 0;
+        for (int i0 = 0; i0 < Nr; i0 += 64) {
+            const int iR = i0 + lane;
+            bool pass = false;
+            if (iR < Nr) {
+                const uint2 q = s_rc[iR];
+                const int minr = (int)(q.x & 0xFFF), maxr = (int)((q.x >> 12) & 0xFFF), octR = (int)(q.x >> 24);
+                const float uR = __uint_as_float(q.y);
+                pass = row >= minr && row <= maxr && octR >= levelL - 1 && octR <= levelL + 1 && uR >= minU && uR <= maxU;
             }
+            const u64 m = __ballot(pass);
+            if (m) {
+                if (cnt + __popcll(m) > ST_CAND) {   // list full (wave-uniform): score what is staged, start over
+                    wave_sync();
+                    for (int c = lane; c < cnt; c += 64) {
+                        const int jR = cl[c];
+                        const int dist = ham(dL, load_desc(drb + (size_t)jR * 32));
+                        if (dist < TH_HIGH) { const u64 key = ((u64)dist << 32) | (unsigned)jR; best = key < best ? key : best; }
+                    }
+                    wave_sync();
+                    cnt = 0;
+                }
+                if (pass) cl[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)iR;
+                cnt += __popcll(m);
+            }
+        }
+        wave_sync();
+        for (int c = lane; c < cnt; c += 64) {
+            const int jR = cl[c];
+            const int dist = ham(dL, load_desc(drb + (size_t)jR * 32));
+            if (dist < TH_HIGH) { const u64 key = ((u64)dist << 32) | (unsigned)jR; best = key < best ? key : best; }
         }
         best = wave_min_u64(best);
         const int bestDist = best == ~0ull ? TH_HIGH : (int)(best >> 32);
@@ -310,8 +339,11 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream
     dim3 grid((cap + ST_WAVES - 1) / ST_WAVES, B);
     (void)hipGetLastError();
+    if (cap > 16000) { orbx_set_error("orbm_stereo: %d keypoints per image exceed the LDS plan (16000)", cap); return ORBX_ERR_UNSUPPORTED; }
+    if (sizeof(uint2) * (size_t)cap > 48 * 1024)
+        ORBX_HIP(hipFuncSetAttribute((const void *)k_stereo_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint2) * (size_t)cap)));
     hipLaunchKernelGGL(k_stereo_prep, dim3((cap + 255) / 256, B), dim3(256), 0, st, lv, d_kr, d_nr, cap, g_ss.d_rc);
-    hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), 0, st, lv, hl->d_pyr + (size_t)left_slot0 * hl->pyrImgBytes, hl->pyrImgBytes,
+    hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), sizeof(uint2) * (size_t)cap, st, lv, hl->d_pyr + (size_t)left_slot0 * hl->pyrImgBytes, hl->pyrImgBytes,
                        hr->d_pyr + (size_t)right_slot0 * hr->pyrImgBytes, hr->pyrImgBytes, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
                        g_ss.d_sad, g_ss.d_rc);
     hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(SM_T), sizeof(int32_t) * cap, st, d_nl, cap, d_uright,

@@ -13,6 +13,12 @@
 
 typedef unsigned long long u64;
 
+// LDS hand-off inside ONE wave (lanes of a wave run in lock step; the fence orders the LDS accesses)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 struct Desc256 { u64 w[4]; };
 __device__ __forceinline__ Desc256 load_desc(const uint8_t *p) {
     Desc256 d;
