@@ -196,6 +196,37 @@ int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
                                     const int32_t *ext_obs, float th, int mono, int check_orientation,
                                     int device, int *nmatches);
 
+/* ---- the step before SearchByProjection(F, MPs) — Frame::isInFrustum
+ * (src/Frame.cc:284-340) for all local map points at once (Tracking::SearchLocalPoints,
+ * src/Tracking.cc:1290-1340).  A point's tracking variables come back as orbm_mappoint_t. */
+typedef struct {
+    int32_t valid;                      /* candidate: not already matched in this frame, !isBad() (:1306-1317) */
+    float wx, wy, wz;                   /* GetWorldPos() */
+    float nx, ny, nz;                   /* GetNormal() */
+    float max_distance, min_distance;   /* mfMaxDistance, mfMinDistance (invariance range = 1.2x / 0.8x) */
+    int32_t observations;               /* Observations(), copied to the output record */
+} orbm_worldpoint_t;
+/* MapPoint::PredictScale (src/MapPoint.cc:414-429) is ceil(log(ratio)/mfLogScaleFactor) with the C
+ * library's float log, which a GPU cannot reproduce bit for bit at level boundaries.  The device
+ * therefore compares ratio = mfMaxDistance/dist with nlevels-1 float thresholds that this HOST function
+ * finds by bisection with the host's own logf: thresholds[k] = the smallest float r with
+ * ceil(logf(r)/log_scale_factor) >= k+1.  Level = number of thresholds <= ratio (exact wherever logf is
+ * monotonic).  No GPU needed. */
+int orbm_predict_scale_thresholds(float log_scale_factor, int nlevels, float *thresholds);
+/* Tcw16: row-major 4x4 camera pose; g: image bounds mnMinX..mnMaxY; out[m] as Frame::isInFrustum leaves
+ * mbTrackInView / mTrackProjX / mTrackProjXR / mTrackProjY / mnTrackScaleLevel / mTrackViewCos. */
+int orbm_is_in_frustum(const orbm_worldpoint_t *pts, int m, const float *Tcw16, const orbm_camera_t *cam,
+                       const orbm_grid_geom_t *g, float viewing_cos_limit, const float *thresholds, int nlevels,
+                       orbm_mappoint_t *out, int device);
+/* isInFrustum + SearchByProjection(F, MPs) without the host round trip of the projections
+ * (Tracking::SearchLocalPoints).  proj_out[m] (may be NULL) receives the isInFrustum records. */
+int orbm_search_local_points(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                             const orbm_grid_geom_t *g, const float *scale_factors, int nlevels,
+                             const orbm_worldpoint_t *pts, const uint8_t *mp_desc, int m, const float *Tcw16,
+                             const orbm_camera_t *cam, float viewing_cos_limit, const float *thresholds,
+                             int32_t *frame_mp, const int32_t *ext_obs, float th, float nnratio, int device,
+                             int *nmatches, orbm_mappoint_t *proj_out);
+
 /* Generic projected-window matcher: the common core of the reference's SearchByProjection
  * family once the caller has projected its map points.  For every valid
  * query, in order: candidates = Frame::GetFeaturesInArea(u, v, radius, min_level, max_level)

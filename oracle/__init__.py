@@ -139,6 +139,9 @@ def lib():
         L.oracle_search_by_sim3.restype = i32
         L.oracle_search_by_sim3.argtypes = [vp, vp, i32, vp, vp, i32, G, G, vp, i32, f32, K, vp, vp, f32, vp, vp, vp, vp, vp, vp,
                                             f32, vp]
+        L.oracle_predict_scale_ratio.restype = i32
+        L.oracle_predict_scale_ratio.argtypes = [f32, f32, i32]
+        L.oracle_is_in_frustum.argtypes = [vp, vp, i32, vp, K, G, f32, f32, i32, vp]
         L.oracle_distinctive_descriptor.restype = i32
         L.oracle_distinctive_descriptor.argtypes = [vp, i32, C.POINTER(i32)]
         _lib = L
@@ -452,3 +455,13 @@ def distinctive_descriptor(desc):
     med = C.c_int(0)
     i = lib().oracle_distinctive_descriptor(_p(desc), len(desc), C.byref(med))
     return i, med.value
+
+
+def is_in_frustum(pts, obs, Tcw, cam, geom, viewing_cos_limit, log_sf, nlevels):
+    """Frame::isInFrustum for a list of map points -> MP_DTYPE records"""
+    pts = np.ascontiguousarray(pts, MP3D_DTYPE); T = _f32(Tcw)
+    ob = None if obs is None else np.ascontiguousarray(obs, np.int32)
+    out = np.zeros(len(pts), MP_DTYPE)
+    lib().oracle_is_in_frustum(_p(pts), _p(ob), len(pts), _p(T), C.byref(cam), C.byref(geom), float(viewing_cos_limit),
+                               float(log_sf), int(nlevels), _p(out))
+    return out

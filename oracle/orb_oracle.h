@@ -207,6 +207,12 @@ int oracle_search_by_sim3(const oracle_kp_t *k1, const uint8_t *d1, int n1, cons
                           const float *t12, const oracle_mappoint3d_t *pts1, const uint8_t *pd1,
                           const oracle_mappoint3d_t *pts2, const uint8_t *pd2, float th, int32_t *match12);
 
+/* MapPoint::PredictScale (src/MapPoint.cc:414-429) given ratio = mfMaxDistance/currentDist */
+int oracle_predict_scale_ratio(float ratio, float log_sf, int nlevels);
+/* Frame::isInFrustum (src/Frame.cc:284-340) for m map points */
+void oracle_is_in_frustum(const oracle_mappoint3d_t *pts, const int32_t *obs, int m, const float *Tcw,
+                          const oracle_cam_t *cam, const oracle_grid_geom_t *g, float viewingCosLimit, float log_sf,
+                          int nlevels, oracle_mp_t *out);
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:252-317), one map point; returns BestIdx (-1: no rows) */
 int oracle_distinctive_descriptor(const uint8_t *desc, int n, int *median_out);
 

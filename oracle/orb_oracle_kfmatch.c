@@ -50,6 +50,11 @@ void oracle_decompose_sim3(const float *S, float *Rcw, float *tcw, float *Ow) {
     }
 }
 
+int oracle_predict_scale_ratio(float ratio, float log_sf, int nlevels) {   /* MapPoint::PredictScale from ratio on */
+    int nScale = (int)ceilf(logf(ratio) / log_sf);
+    if (nScale < 0) nScale = 0; else if (nScale >= nlevels) nScale = nlevels - 1;
+    return nScale;
+}
 static int predict_scale(float max_distance, float dist, float log_sf, int nlevels) {
     const float ratio = max_distance / dist;
     int nScale = (int)ceilf(logf(ratio) / log_sf);
@@ -338,4 +343,38 @@ int oracle_distinctive_descriptor(const uint8_t *desc, int n, int *median_out) {
     free(dist); free(row);
     if (median_out) *median_out = BestMedian;
     return BestIdx;
+}
+
+/* Frame::isInFrustum (src/Frame.cc:284-340) for m map points; PredictScale with the C
+ * library's logf exactly as src/MapPoint.cc:414-429.  pts[i].valid = the caller's skip conditions
+ * (src/Tracking.cc:1312-1316); obs[i] is copied to the output. */
+void oracle_is_in_frustum(const oracle_mappoint3d_t *pts, const int32_t *obs, int m, const float *Tcw,
+                          const oracle_cam_t *cam, const oracle_grid_geom_t *g, float viewingCosLimit, float log_sf,
+                          int nlevels, oracle_mp_t *out) {
+    float R[9], t[3], Ow[3];
+    pose_parts(Tcw, R, t, Ow);                              /* mRcw, mtcw, mOw (src/Frame.cc:272-279) */
+    for (int i = 0; i < m; i++) {
+        oracle_mp_t *o = &out[i];
+        memset(o, 0, sizeof(*o));
+        o->observations = obs ? obs[i] : 0;
+        if (!pts[i].valid) continue;
+        const float P[3] = {pts[i].wx, pts[i].wy, pts[i].wz};
+        float Pc[3];
+        for (int r = 0; r < 3; r++) Pc[r] = row_madd(R + 3 * r, 1, P, t[r]);
+        if (Pc[2] < 0.0f) continue;
+        const float invz = 1.0f / Pc[2];
+        const float u = cam->fx * Pc[0] * invz + cam->cx;
+        const float v = cam->fy * Pc[1] * invz + cam->cy;
+        if (u < g->min_x || u > g->max_x) continue;
+        if (v < g->min_y || v > g->max_y) continue;
+        const float maxDistance = 1.2f * pts[i].max_distance, minDistance = 0.8f * pts[i].min_distance;
+        const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+        const float dist = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float viewCos = (float)(((double)PO[0] * pts[i].nx + (double)PO[1] * pts[i].ny + (double)PO[2] * pts[i].nz) / dist);
+        if (viewCos < viewingCosLimit) continue;
+        o->in_view = 1; o->proj_x = u; o->proj_xr = u - cam->mbf * invz; o->proj_y = v;
+        o->level = predict_scale(pts[i].max_distance, dist, log_sf, nlevels);
+        o->view_cos = viewCos;
+    }
 }

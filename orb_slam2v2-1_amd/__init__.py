@@ -38,7 +38,8 @@ EXPORTS = [
     "orbx_pyramid_host", "orbx_pyramid_device", "orbx_debug_level_points", "orbx_set_profiling",
     "orbx_get_stage_ms", "orbx_debug_set", "orbm_hamming", "orbm_hamming_matrix_device", "orbm_stereo_batch_device",
     "orbm_stereo", "orbm_search_for_initialization", "orbm_search_by_projection_mp",
-    "orbm_search_by_projection_frame", "orbm_match_windows", "orbm_best_in_windows", "orbm_distinctive_descriptors", "orbx_last_error", "orbx_version", "orbx_device_count",
+    "orbm_search_by_projection_frame", "orbm_match_windows", "orbm_best_in_windows", "orbm_distinctive_descriptors", "orbm_predict_scale_thresholds", "orbm_is_in_frustum",
+    "orbm_search_local_points", "orbx_last_error", "orbx_version", "orbx_device_count",
 ]
 
 
@@ -138,6 +139,10 @@ def lib():
                                                   vp, vp, vp, vp, i32, vp, vp, f32, i32, i32, i32, C.POINTER(i32)]
     L.orbm_match_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, vp, i32, i32, i32, C.POINTER(i32)]
     L.orbm_distinctive_descriptors.argtypes = [vp, vp, i32, vp, vp, i32]
+    L.orbm_predict_scale_thresholds.argtypes = [f32, i32, vp]
+    L.orbm_is_in_frustum.argtypes = [vp, i32, vp, C.POINTER(Camera), C.POINTER(GridGeom), f32, vp, i32, vp, i32]
+    L.orbm_search_local_points.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp, i32, vp, vp, i32, vp, C.POINTER(Camera), f32,
+                                           vp, vp, vp, f32, f32, i32, C.POINTER(i32), vp]
     L.orbm_best_in_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, i32, vp, vp, i32]
     L.orbx_last_error.restype = C.c_char_p
     L.orbx_version.restype = C.c_char_p
@@ -407,3 +412,41 @@ def distinctive_descriptors(desc, offsets, device=0):
     br = np.zeros(m, np.int32); bm = np.zeros(m, np.int32)
     _check(lib().orbm_distinctive_descriptors(_p(desc), _p(off), m, _p(br), _p(bm), int(device)))
     return br, bm
+
+
+WORLDPOINT_DTYPE = np.dtype([("valid", "<i4"), ("wx", "<f4"), ("wy", "<f4"), ("wz", "<f4"), ("nx", "<f4"), ("ny", "<f4"),
+                             ("nz", "<f4"), ("max_distance", "<f4"), ("min_distance", "<f4"), ("observations", "<i4")])
+
+
+def predict_scale_thresholds(log_scale_factor, nlevels):
+    """orbm_predict_scale_thresholds (host code, no GPU): MapPoint::PredictScale as nlevels-1 float thresholds"""
+    t = np.zeros(max(nlevels - 1, 1), np.float32)
+    _check(lib().orbm_predict_scale_thresholds(float(log_scale_factor), int(nlevels), _p(t)))
+    return t[:nlevels - 1]
+
+
+def is_in_frustum(pts, Tcw, cam, geom, viewing_cos_limit, thresholds, nlevels, device=0):
+    """orbm_is_in_frustum: Frame::isInFrustum for a list of map points -> MP_DTYPE records"""
+    pts = np.ascontiguousarray(pts, WORLDPOINT_DTYPE); T = np.ascontiguousarray(Tcw, np.float32)
+    thr = np.ascontiguousarray(thresholds, np.float32)
+    out = np.zeros(len(pts), MP_DTYPE)
+    _check(lib().orbm_is_in_frustum(_p(pts), len(pts), _p(T), C.byref(cam), C.byref(geom), float(viewing_cos_limit), _p(thr),
+                                    int(nlevels), _p(out), int(device)))
+    return out
+
+
+def search_local_points(kun, desc, uright, geom, sf, pts, mp_desc, Tcw, cam, viewing_cos_limit, thresholds, frame_mp,
+                        ext_obs, th, nnratio, device=0):
+    """orbm_search_local_points: isInFrustum + SearchByProjection(F, MPs) -> (nmatches, frame_mp', projections)"""
+    kun = np.ascontiguousarray(kun, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    ur = np.ascontiguousarray(uright, np.float32); sf = np.ascontiguousarray(sf, np.float32)
+    pts = np.ascontiguousarray(pts, WORLDPOINT_DTYPE); md = np.ascontiguousarray(mp_desc, np.uint8)
+    T = np.ascontiguousarray(Tcw, np.float32); thr = np.ascontiguousarray(thresholds, np.float32)
+    fm = np.ascontiguousarray(frame_mp, np.int32).copy()
+    eo = None if ext_obs is None else np.ascontiguousarray(ext_obs, np.int32)
+    proj = np.zeros(len(pts), MP_DTYPE)
+    n = C.c_int(0)
+    _check(lib().orbm_search_local_points(_p(kun), _p(desc), _p(ur), len(kun), C.byref(geom), _p(sf), len(sf), _p(pts), _p(md),
+                                          len(pts), _p(T), C.byref(cam), float(viewing_cos_limit), _p(thr), _p(fm), _p(eo),
+                                          float(th), float(nnratio), int(device), C.byref(n), _p(proj)))
+    return n.value, fm, proj

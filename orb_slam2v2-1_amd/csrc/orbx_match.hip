@@ -11,6 +11,7 @@
 // 64-bit keys (distance | scan-order | index) with wavefront shuffles, so the result is the
 // same element the reference's sequential "first strictly smaller wins" scan selects.
 #include "orbx_match_dev.h"
+#define ORBX_FAST_FALLBACK_RC 1   // what the fast_* entry points return when the exact kernels must run
 #include <math.h>
 #include <algorithm>
 
@@ -611,6 +612,77 @@ __global__ __launch_bounds__(SQ_T) void k_search_proj_mp(
     if (tid == 0) *nmatches_out = nm;
 }
 
+static int exact_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                                         const orbm_grid_geom_t *g, const float *scale_factors, int nlevels,
+                                         const orbm_mappoint_t *mps, const uint8_t *mp_desc, int m, int32_t *frame_mp,
+                                         const int32_t *ext_obs, float th, float nnratio, int device, int *nmatches);
+
+// MapPoint::PredictScale as a threshold table (see include/orbx.h): host code, uses the host's logf on purpose
+static int predict_scale_host(float ratio, float log_sf, int nlevels) {
+    int nScale = (int)ceilf(logf(ratio) / log_sf);
+    if (nScale < 0) nScale = 0; else if (nScale >= nlevels) nScale = nlevels - 1;
+    return nScale;
+}
+extern "C" int orbm_predict_scale_thresholds(float log_scale_factor, int nlevels, float *thresholds) {
+    if (!(log_scale_factor > 0.0f) || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || (nlevels > 1 && !thresholds)) {
+        orbx_set_error("orbm_predict_scale_thresholds: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    for (int k = 0; k + 1 < nlevels; k++) {
+        // smallest positive float r with predict_scale(r) >= k+1: bisection on the bit pattern (floats > 0 are ordered like ints)
+        uint32_t lo = 0x3F800000u /* 1.0f -> level 0 */, hi = 0x7F7FFFFFu /* FLT_MAX -> top level */;
+        while (lo + 1 < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            float r;
+            memcpy(&r, &mid, 4);
+            if (predict_scale_host(r, log_scale_factor, nlevels) >= k + 1) hi = mid; else lo = mid;
+        }
+        memcpy(&thresholds[k], &hi, 4);
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbm_is_in_frustum(const orbm_worldpoint_t *pts, int m, const float *Tcw16, const orbm_camera_t *cam,
+                                  const orbm_grid_geom_t *g, float viewing_cos_limit, const float *thresholds, int nlevels,
+                                  orbm_mappoint_t *out, int device) {
+    if (m < 0 || !Tcw16 || !cam || !g || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || (nlevels > 1 && !thresholds) || (m > 0 && (!pts || !out))) {
+        orbx_set_error("orbm_is_in_frustum: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    if (m == 0) return ORBX_OK;
+    return fast_is_in_frustum(pts, m, Tcw16, cam, g, viewing_cos_limit, thresholds, nlevels, out, device);
+}
+
+extern "C" int orbm_search_local_points(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                                        const orbm_grid_geom_t *g, const float *scale_factors, int nlevels,
+                                        const orbm_worldpoint_t *pts, const uint8_t *mp_desc, int m, const float *Tcw16,
+                                        const orbm_camera_t *cam, float viewing_cos_limit, const float *thresholds,
+                                        int32_t *frame_mp, const int32_t *ext_obs, float th, float nnratio, int device,
+                                        int *nmatches, orbm_mappoint_t *proj_out) {
+    if (n < 0 || m < 0 || !g || !scale_factors || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || !nmatches || !Tcw16 || !cam ||
+        (nlevels > 1 && !thresholds) || (n > 0 && (!kun || !desc || !uright || !frame_mp)) || (m > 0 && (!pts || !mp_desc)) || n > 65535) {
+        orbx_set_error("orbm_search_local_points: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    *nmatches = 0;
+    if (m == 0) return ORBX_OK;
+    std::vector<orbm_mappoint_t> tmp;
+    if (!proj_out) { tmp.resize(m); proj_out = tmp.data(); }
+    if (n == 0) return fast_is_in_frustum(pts, m, Tcw16, cam, g, viewing_cos_limit, thresholds, nlevels, proj_out, device);
+    FrustumArgs w = {pts, Tcw16, cam, viewing_cos_limit, thresholds};
+    int frc = ORBX_FAST_FALLBACK_RC;
+    if (!g_debug[2])
+        frc = fast_search_by_projection_mp(kun, desc, uright, n, g, scale_factors, nlevels, nullptr, mp_desc, m, frame_mp, ext_obs,
+                                           th, nnratio, device, nmatches, &w, proj_out);
+    else {
+        const int rc = fast_is_in_frustum(pts, m, Tcw16, cam, g, viewing_cos_limit, thresholds, nlevels, proj_out, device);
+        if (rc) return rc;
+    }
+    if (frc <= 0) return frc;
+    return exact_search_by_projection_mp(kun, desc, uright, n, g, scale_factors, nlevels, proj_out, mp_desc, m, frame_mp, ext_obs,
+                                         th, nnratio, device, nmatches);
+}
+
 extern "C" int orbm_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright,
                                             int n, const orbm_grid_geom_t *g, const float *scale_factors,
                                             int nlevels, const orbm_mappoint_t *mps, const uint8_t *mp_desc, int m,
@@ -633,6 +705,14 @@ extern "C" int orbm_search_by_projection_mp(const orbx_keypoint_t *kun, const ui
                                                      frame_mp, ext_obs, th, nnratio, device, nmatches);
         if (frc <= 0) return frc;
     }
+    return exact_search_by_projection_mp(kun, desc, uright, n, g, scale_factors, nlevels, mps, mp_desc, m, frame_mp, ext_obs,
+                                         th, nnratio, device, nmatches);
+}
+
+static int exact_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                                         const orbm_grid_geom_t *g, const float *scale_factors, int nlevels,
+                                         const orbm_mappoint_t *mps, const uint8_t *mp_desc, int m, int32_t *frame_mp,
+                                         const int32_t *ext_obs, float th, float nnratio, int device, int *nmatches) {
     ORBX_HIP(hipSetDevice(device));
     DevBuf bk, bd, bu, bsf, bmp, bmd, bfm, beo, bcode, bnm;
     DEV_ALLOC(bk, sizeof(orbx_keypoint_t) * n); DEV_ALLOC(bd, (size_t)32 * n); DEV_ALLOC(bu, 4 * (size_t)n);

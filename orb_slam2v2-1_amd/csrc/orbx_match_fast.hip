@@ -569,6 +569,61 @@ __global__ __launch_bounds__(256) void k_queries_frame(const orbm_lastpoint_t *_
     q[i] = Q;
 }
 
+// ---- Frame::isInFrustum (src/Frame.cc:284-340) for a list of map points.  cv::Mat arithmetic as OpenCV
+// evaluates it: Rcw*P+tcw is a gemm (double accumulation, one rounding), cv::norm and Mat::dot accumulate in
+// double; PredictScale through the host-built threshold table (see orbm_predict_scale_thresholds).
+struct FrustumPose { float R[9], t[3], Ow[3]; };
+__global__ __launch_bounds__(256) void k_frustum(const orbm_worldpoint_t *__restrict__ pts, int m, FrustumPose P,
+                                                 orbm_camera_t cam, orbm_grid_geom_t g, float viewCosLimit,
+                                                 const float *__restrict__ thr, int nlevels,
+                                                 orbm_mappoint_t *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const orbm_worldpoint_t p = pts[i];
+    orbm_mappoint_t o;
+    o.in_view = 0; o.proj_x = 0; o.proj_y = 0; o.proj_xr = 0; o.level = 0; o.view_cos = 0; o.observations = p.observations;
+    if (p.valid) {
+        const float pw[3] = {p.wx, p.wy, p.wz};
+        float pc[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s += (double)P.R[r * 3 + k] * (double)pw[k];
+            pc[r] = (float)(s + (double)P.t[r]);
+        }
+        if (!(pc[2] < 0.0f)) {
+            const float invz = 1.0f / pc[2];
+            const float u = cam.fx * pc[0] * invz + cam.cx, v = cam.fy * pc[1] * invz + cam.cy;
+            if (!(u < g.min_x || u > g.max_x) && !(v < g.min_y || v > g.max_y)) {
+                const float maxDistance = 1.2f * p.max_distance, minDistance = 0.8f * p.min_distance;
+                const float PO[3] = {pw[0] - P.Ow[0], pw[1] - P.Ow[1], pw[2] - P.Ow[2]};
+                const float dist = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+                if (!(dist < minDistance || dist > maxDistance)) {
+                    const double dot = (double)PO[0] * p.nx + (double)PO[1] * p.ny + (double)PO[2] * p.nz;
+                    const float viewCos = (float)(dot / (double)dist);
+                    if (!(viewCos < viewCosLimit)) {
+                        const float ratio = p.max_distance / dist;
+                        int lvl = 0;
+                        for (int k = 0; k < nlevels - 1; k++) lvl += ratio >= thr[k] ? 1 : 0;
+                        o.in_view = 1; o.proj_x = u; o.proj_xr = u - cam.mbf * invz; o.proj_y = v;
+                        o.level = lvl; o.view_cos = viewCos;
+                    }
+                }
+            }
+        }
+    }
+    out[i] = o;
+}
+static void frustum_pose(const float *T, FrustumPose &P) {   // mRcw, mtcw, mOw = -mRcw.t()*mtcw (src/Frame.cc:272-279)
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) P.R[r * 3 + c] = T[r * 4 + c]; P.t[r] = T[r * 4 + 3]; }
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)P.R[k * 3 + i] * (double)P.t[k];
+        P.Ow[i] = (float)(s * -1.0);
+    }
+}
+
 // ---- host side: one grow-only device arena per host thread (no hipMalloc per call)
 struct Arena {
     uint8_t *base = nullptr; size_t cap = 0, off = 0; int device = -1; hipStream_t st = nullptr;
@@ -635,12 +690,35 @@ int fast_search_for_initialization(const orbx_keypoint_t *k1, const uint8_t *d1,
     return ORBX_OK;
 }
 
+int fast_is_in_frustum(const orbm_worldpoint_t *pts, int m, const float *Tcw16, const orbm_camera_t *cam,
+                       const orbm_grid_geom_t *g, float viewCosLimit, const float *thr, int nlevels, orbm_mappoint_t *out,
+                       int device) {
+    int rc = arena_begin(device, (size_t)m * (sizeof(orbm_worldpoint_t) + sizeof(orbm_mappoint_t)) + 65536);
+    if (rc) return rc;
+    hipStream_t st = g_ar.st;
+    orbm_worldpoint_t *dw = arena_get<orbm_worldpoint_t>(m);
+    orbm_mappoint_t *dmp = arena_get<orbm_mappoint_t>(m);
+    float *dthr = arena_get<float>(nlevels);
+    UP(dw, pts, m);
+    if (nlevels > 1) UP(dthr, thr, nlevels - 1);
+    FrustumPose P;
+    frustum_pose(Tcw16, P);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_frustum, dim3((m + 255) / 256), dim3(256), 0, st, dw, m, P, *cam, *g, viewCosLimit, dthr, nlevels, dmp);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(out, dmp, sizeof(orbm_mappoint_t) * (size_t)m, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    return ORBX_OK;
+}
+
+// world != NULL: the map-point records are produced on the device by k_frustum (no upload of projections);
+// proj_out (host, may be NULL) then receives them — always before a fallback is reported.
 int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
                                  const orbm_grid_geom_t *g, const float *sf, int nlevels, const orbm_mappoint_t *mps,
                                  const uint8_t *mp_desc, int m, int32_t *frame_mp, const int32_t *ext_obs, float th,
-                                 float nnratio, int device, int *nmatches) {
-    if (n > 60000) return ORBX_FAST_FALLBACK;
-    const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)m * (28 + 32 + QK * 8 + 64) + 65536;
+                                 float nnratio, int device, int *nmatches, const FrustumArgs *world, orbm_mappoint_t *proj_out) {
+    if (n > 60000 && !world) return ORBX_FAST_FALLBACK;
+    const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)m * (28 + 32 + QK * 8 + 64 + sizeof(orbm_worldpoint_t)) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
     hipStream_t st = g_ar.st;
@@ -652,10 +730,22 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
     uint16_t *dcode = arena_get<uint16_t>(n);
     GQuery *dq = arena_get<GQuery>(m);
     u64 *dkeys = arena_get<u64>((size_t)m * QK);
-    UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(du, uright, n); UP(dsf, sf, nlevels); UP(dmp, mps, m);
+    UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(du, uright, n); UP(dsf, sf, nlevels);
     UP(dmd, mp_desc, (size_t)32 * m); UP(dfm, frame_mp, n);
     if (ext_obs) UP(deo, ext_obs, n);
     (void)hipGetLastError();
+    if (world) {
+        orbm_worldpoint_t *dw = arena_get<orbm_worldpoint_t>(m);
+        float *dthr = arena_get<float>(nlevels);
+        UP(dw, world->pts, m);
+        if (nlevels > 1) UP(dthr, world->thr, nlevels - 1);
+        FrustumPose P;
+        frustum_pose(world->Tcw16, P);
+        hipLaunchKernelGGL(k_frustum, dim3((m + 255) / 256), dim3(256), 0, st, dw, m, P, *world->cam, *g, world->viewCosLimit, dthr,
+                           nlevels, dmp);
+        if (proj_out) ORBX_HIP(hipMemcpyAsync(proj_out, dmp, sizeof(orbm_mappoint_t) * (size_t)m, hipMemcpyDeviceToHost, st));
+        if (n > 60000) { ORBX_HIP(hipStreamSynchronize(st)); return ORBX_FAST_FALLBACK; }
+    } else UP(dmp, mps, m);
     const int mx = std::max(n, m);
     hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *g, dcode);
     hipLaunchKernelGGL(k_queries_mp, dim3((mx + 255) / 256), dim3(256), 0, st, dmp, m, dsf, th, dq, dfm,

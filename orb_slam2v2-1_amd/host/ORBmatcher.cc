@@ -42,6 +42,7 @@ static orbm_grid_geom_t grid_of(const Frame &) {
     g.inv_w = Frame::mfGridElementWidthInv; g.inv_h = Frame::mfGridElementHeightInv;
     return g;
 }
+#define ORBX_HOST_MAX_LEVELS 16
 static int fail(const char *what) { std::fprintf(stderr, "ORBmatcher::%s: %s\n", what, orbx_last_error()); return 0; }
 
 int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th) {
@@ -504,6 +505,70 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Po
         vnMatches12[i] = m12[i];
         vbPrevMatched[i].x = prev[2 * i]; vbPrevMatched[i].y = prev[2 * i + 1];  // :514-517
     }
+    return nmatches;
+}
+
+int SearchLocalPointsHIP(Frame &F, const std::vector<MapPoint *> &vpLocalMapPoints, float th, float nnratio, int &nToMatch) {
+    nToMatch = 0;
+    const int n = F.N, m = (int)vpLocalMapPoints.size();
+    if (m == 0) return 0;
+    std::vector<orbm_worldpoint_t> pts(m);
+    std::vector<uint8_t> mpd((size_t)32 * m);
+    std::map<MapPoint *, int> index;
+    for (int i = 0; i < m; i++) {
+        MapPoint *pMP = vpLocalMapPoints[i];
+        index[pMP] = i;
+        std::memset(&pts[i], 0, sizeof(pts[i]));
+        pts[i].observations = pMP->Observations();
+        if (pMP->mnLastFrameSeen == F.mnId) continue;          // src/Tracking.cc:1312-1313
+        if (pMP->isBad()) continue;                            // :1314-1315
+        pts[i].valid = 1;
+        cv::Mat P = pMP->GetWorldPos(), Pn = pMP->GetNormal();
+        pts[i].wx = P.at<float>(0); pts[i].wy = P.at<float>(1); pts[i].wz = P.at<float>(2);
+        pts[i].nx = Pn.at<float>(0); pts[i].ny = Pn.at<float>(1); pts[i].nz = Pn.at<float>(2);
+        // mfMaxDistance / mfMinDistance are protected in include/MapPoint.h:156-157 (the getters return them
+        // scaled): in the reference tree declare this function a friend of MapPoint
+        pts[i].max_distance = pMP->mfMaxDistance;
+        pts[i].min_distance = pMP->mfMinDistance;
+        cv::Mat d = pMP->GetDescriptor();
+        std::memcpy(&mpd[(size_t)32 * i], d.ptr(0), 32);
+    }
+    std::vector<orbx_keypoint_t> kun; gather_keypoints(F.mvKeysUn, kun);
+    std::vector<uint8_t> desc; gather_descriptors(F.mDescriptors, n, desc);
+    std::vector<int32_t> holder(n, -1), ext(n, 0);
+    for (int i = 0; i < n; i++)
+        if (F.mvpMapPoints[i]) {
+            std::map<MapPoint *, int>::iterator it = index.find(F.mvpMapPoints[i]);
+            if (it != index.end()) holder[i] = it->second;
+            else { holder[i] = -2; ext[i] = F.mvpMapPoints[i]->Observations(); }
+        }
+    const std::vector<int32_t> before = holder;
+    const orbm_grid_geom_t g = grid_of(F);
+    orbm_camera_t cam;
+    cam.fx = Frame::fx; cam.fy = Frame::fy; cam.cx = Frame::cx; cam.cy = Frame::cy; cam.mbf = F.mbf; cam.mb = F.mb;
+    float T[16], thr[ORBX_HOST_MAX_LEVELS];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T[r * 4 + c] = F.mTcw.at<float>(r, c);
+    const int nlevels = (int)F.mvScaleFactors.size();
+    if (nlevels > ORBX_HOST_MAX_LEVELS || orbm_predict_scale_thresholds(F.mfLogScaleFactor, nlevels, thr) != ORBX_OK) return fail("SearchLocalPoints");
+    std::vector<orbm_mappoint_t> proj(m);
+    int nmatches = 0;
+    if (orbm_search_local_points(kun.data(), desc.data(), F.mvuRight.data(), n, &g, F.mvScaleFactors.data(), nlevels, pts.data(),
+                                 mpd.data(), m, T, &cam, 0.5f, thr, holder.data(), ext.data(), th, nnratio, ORBmatcher::device,
+                                 &nmatches, proj.data()) != ORBX_OK)
+        return fail("SearchLocalPoints");
+    for (int i = 0; i < m; i++) {
+        MapPoint *pMP = vpLocalMapPoints[i];
+        if (!pts[i].valid) continue;
+        pMP->mbTrackInView = proj[i].in_view != 0;             // src/Frame.cc:286,329
+        if (proj[i].in_view) {
+            pMP->mTrackProjX = proj[i].proj_x; pMP->mTrackProjXR = proj[i].proj_xr; pMP->mTrackProjY = proj[i].proj_y;
+            pMP->mnTrackScaleLevel = proj[i].level; pMP->mTrackViewCos = proj[i].view_cos;
+            pMP->IncreaseVisible();                            // src/Tracking.cc:1320-1322
+            nToMatch++;
+        }
+    }
+    for (int i = 0; i < n; i++)
+        if (holder[i] != before[i] && holder[i] >= 0) F.mvpMapPoints[i] = vpLocalMapPoints[holder[i]];
     return nmatches;
 }
 

@@ -72,6 +72,13 @@ protected:
 // Call it from Frame::ComputeStereoMatches() in place of the CPU body. Returns #matches (<0: error).
 int ComputeStereoMatchesHIP(Frame &F);
 
+// Tracking::SearchLocalPoints (src/Tracking.cc:1305-1339) from "Project points in frame" on: Frame::isInFrustum
+// (src/Frame.cc:284-340) of every local map point that was not seen in this frame and is not bad, then
+// ORBmatcher(nnratio).SearchByProjection(F, vpLocalMapPoints, th) — both in ONE GPU call.  Leaves on each point
+// what isInFrustum leaves (mbTrackInView, mTrackProjX/XR/Y, mnTrackScaleLevel, mTrackViewCos), calls
+// IncreaseVisible() for the points in view, fills F.mvpMapPoints; returns the matches, nToMatch as :1320-1323.
+int SearchLocalPointsHIP(Frame &F, const std::vector<MapPoint *> &vpLocalMapPoints, float th, float nnratio, int &nToMatch);
+
 // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:252-317) for MANY map points in one GPU call
 // (the reference calls it point by point inside loops: src/LocalMapping.cc:170-180,520-535,
 // src/Tracking.cc CreateInitialMap*, src/LoopClosing.cc SearchAndFuse).  Gathers the descriptors of every

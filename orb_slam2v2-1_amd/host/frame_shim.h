@@ -47,6 +47,9 @@ public:
     void SetDescriptor(const cv::Mat &d) { mDescriptor = d.clone(); }   // the store at src/MapPoint.cc:313-316 (test shim only)
     bool mbBad;
     int nObs;
+    long unsigned int mnLastFrameSeen = 0;   // include/MapPoint.h
+    int mnVisible = 1;
+    void IncreaseVisible(int n = 1) { mnVisible += n; }
     float mfMinDistance = 0.f, mfMaxDistance = 0.f;
     cv::Mat mDescriptor, mWorldPos;
     cv::Mat mNormalVector = cv::Mat::zeros(3, 1, CV_32F);
@@ -56,6 +59,7 @@ public:
 class Frame {
 public:
     Frame() : mpORBextractorLeft(nullptr), mpORBextractorRight(nullptr), mbf(0), mb(0), N(0) {}
+    long unsigned int mnId = 0;
     ORBextractor *mpORBextractorLeft, *mpORBextractorRight;
     static float fx, fy, cx, cy;
     float mbf, mb;

@@ -236,12 +236,66 @@ static int distinct_mode(int argc, char **argv) {
     return n < 0 ? 5 : 0;
 }
 
+static int local_mode(int argc, char **argv) {
+    // argv: local img w h nf fx,fy,cx,cy,mbf pts.bin(Mp3d[m]) pdesc.bin aux.bin th out
+    // aux: Tcw[16] f32; uright[n] f32; holder[n] i32 (-1 / -2 / list index); ext_obs[n] i32; obs[m] i32; seen[m] i32
+    if (argc != 12) return 2;
+    const int w = atoi(argv[3]), h = atoi(argv[4]), nf = atoi(argv[5]);
+    float cam[5];
+    sscanf(argv[6], "%f,%f,%f,%f,%f", &cam[0], &cam[1], &cam[2], &cam[3], &cam[4]);
+    std::vector<unsigned char> img = slurp(argv[2]), praw = slurp(argv[7]), draw = slurp(argv[8]), aux = slurp(argv[9]);
+    const float th = (float)atof(argv[10]);
+    const std::string out = argv[11];
+    ORBextractor ex(nf, 1.2f, 8, 20, 7);
+    if (!ex.ok()) return 3;
+    Frame F;
+    fill_frame(F, &ex, cv::Mat(h, w, CV_8UC1, img.data()), w, h);
+    Frame::fx = cam[0]; Frame::fy = cam[1]; Frame::cx = cam[2]; Frame::cy = cam[3];
+    F.mbf = cam[4]; F.mb = F.mbf / Frame::fx;
+    F.mnScaleLevels = ex.GetLevels(); F.mfScaleFactor = ex.GetScaleFactor(); F.mfLogScaleFactor = log(F.mfScaleFactor);
+    F.mnId = 7;
+    const int n = F.N, m = (int)(praw.size() / sizeof(Mp3d));
+    if (aux.size() != 64 + 4 * (size_t)(3 * n + 2 * m)) { fprintf(stderr, "aux size: n=%d m=%d\n", n, m); return 6; }
+    const float *fa = (const float *)aux.data();
+    F.mTcw = mat4(fa);
+    const float *ur = fa + 16;
+    const int *holder = (const int *)(ur + n), *eobs = holder + n, *obs = eobs + n, *seen = obs + m;
+    for (int j = 0; j < n; j++) F.mvuRight[j] = ur[j];
+    const Mp3d *mp = (const Mp3d *)praw.data();
+    std::vector<MapPoint> pts, ext(n);
+    fill_points(pts, mp, draw.data(), m);
+    std::vector<MapPoint *> vp(m);
+    for (int i = 0; i < m; i++) {
+        vp[i] = &pts[i];
+        pts[i].nObs = obs[i];
+        pts[i].mbBad = mp[i].valid == 0 && !seen[i];      // invalid = bad, or already seen in this frame
+        pts[i].mnLastFrameSeen = seen[i] ? F.mnId : 3;
+        pts[i].mbTrackInView = (i % 5) == 0;              // stale flags from an earlier frame must not matter
+    }
+    for (int j = 0; j < n; j++) {
+        if (holder[j] >= 0) F.mvpMapPoints[j] = &pts[holder[j]];
+        else if (holder[j] == -2) { F.mvpMapPoints[j] = &ext[j]; ext[j].nObs = eobs[j]; }
+    }
+    int nToMatch = 0;
+    const int ret = SearchLocalPointsHIP(F, vp, th, 0.8f, nToMatch);
+    std::vector<int> res;
+    for (int j = 0; j < n; j++) {
+        MapPoint *p = F.mvpMapPoints[j];
+        res.push_back(!p ? -1 : (p >= &pts[0] && p < &pts[0] + m) ? (int)(p - &pts[0]) : -2);
+    }
+    for (int i = 0; i < m; i++) res.push_back(pts[i].mnVisible);
+    dump(out + ".i32", res.data(), res.size() * 4);
+    printf("%d %d %d\n", n, ret, nToMatch);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) return 2;
     const std::string mode = argv[1];
     if (mode == "kf") return kf_modes(argc, argv);
     if (mode == "sim3") return sim3_mode(argc, argv);
     if (mode == "distinct") return distinct_mode(argc, argv);
+    if (mode == "local") return local_mode(argc, argv);
     if (mode == "extract" && argc == 7) {
         const int w = atoi(argv[3]), h = atoi(argv[4]), nf = atoi(argv[5]);
         const std::string out = argv[6];

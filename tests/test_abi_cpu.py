@@ -72,3 +72,26 @@ def test_product_never_imports_oracle():
                 code = "\n".join(l for l in txt.splitlines() if not l.strip().startswith(("#", "//", "*", "/*", '"""')))
                 assert "import oracle" not in code and "from oracle" not in code and "orb_oracle" not in code, \
                     "%s references the oracle" % f
+
+
+def test_predict_scale_threshold_table(oracle):
+    """orbm_predict_scale_thresholds (host code of the library): level = #thresholds <= ratio reproduces
+    MapPoint::PredictScale (src/MapPoint.cc:414-429, ceil(logf(ratio)/logf(sf))) for random ratios and for
+    every float within a few ulps of each level boundary."""
+    import importlib
+    pkg = importlib.import_module("orb_slam2v2-1_amd")
+    L = oracle.lib()
+    for sf, nl in ((1.2, 8), (1.1, 12), (1.5, 4), (2.0, 3)):
+        log_sf = np.float32(np.log(np.float32(sf)))
+        thr = pkg.predict_scale_thresholds(log_sf, nl)
+        assert len(thr) == nl - 1 and (np.diff(thr) > 0).all()
+        rng = np.random.default_rng(7)
+        ratios = list(np.exp(rng.uniform(-2, 5, 20000)).astype(np.float32))
+        for t in thr:
+            b = int(np.float32(t).view(np.uint32))
+            ratios += [np.array([b + d], np.uint32).view(np.float32)[0] for d in range(-6, 7)]
+        ratios += [np.float32(0.0), np.float32(1.0), np.float32(1e-30), np.float32(3e38)]
+        for r in ratios:
+            expect = L.oracle_predict_scale_ratio(float(r), float(log_sf), nl)
+            got = int((np.float32(r) >= thr).sum())
+            assert got == expect, (sf, float(r))

@@ -326,3 +326,45 @@ def test_compute_distinctive_descriptors_batched(driver, oracle, tmp_path):
         np.testing.assert_array_equal(res[p, 1:], rows[oi], err_msg=str(p))
         expect_n += 1
     assert m == len(sizes) and n == expect_n > 40
+
+
+def test_search_local_points_class(driver, oracle, synth, tmp_path):
+    """Tracking::SearchLocalPoints' projection loop + SearchByProjection (src/Tracking.cc:1305-1339,
+    src/Frame.cc:284-340) through SearchLocalPointsHIP: one fused GPU call."""
+    import kf_scene as ks
+    w, h, nf = 1241, 376, 1000
+    rng = np.random.default_rng(12)
+    img = synth.frame(w, h, 52)
+    img.tofile(tmp_path / "a.raw")
+    orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    k, d = orc.extract(img)
+    n, m = len(k), 2000
+    sf = orc.scale_factors
+    log_sf = np.float32(np.log(np.float32(1.2)))
+    cam = oracle.Cam(ks.FX, ks.FY, ks.CX, ks.CY, ks.MBF, np.float32(ks.MBF) / np.float32(ks.FX))
+    T = ks.pose(rng)
+    pts, pd, _ = ks.points_for(oracle, rng, k, d, sf, T, m)
+    seen = (rng.random(m) < 0.1).astype(np.int32)
+    badp = (rng.random(m) < 0.08) & (seen == 0)
+    pts["valid"] = (~badp) & (seen == 0)
+    obs = rng.integers(0, 6, m).astype(np.int32)
+    uright = np.where(rng.random(n) < 0.5, k["x"] - rng.uniform(1, 40, n), -1).astype(np.float32)
+    holder = np.full(n, -1, np.int32)
+    held = rng.choice(n, 120, replace=False)
+    holder[held[:60]] = rng.choice(np.flatnonzero(seen == 1), 60, replace=False)   # points already matched in this frame
+    holder[held[60:]] = -2
+    ext_obs = rng.integers(0, 3, n).astype(np.int32)
+    proj = oracle.is_in_frustum(pts, obs, T, cam, oracle.grid_geom(w, h), 0.5, log_sf, 8)
+    on, ofm = oracle.search_by_projection_mp(k, d, uright, oracle.grid_geom(w, h), sf, proj, pd, holder, ext_obs, 3.0, 0.8)
+    pts.tofile(tmp_path / "pts.bin"); pd.tofile(tmp_path / "pd.bin")
+    with open(tmp_path / "aux.bin", "wb") as f:
+        for a in (T, uright, holder, ext_obs, obs, seen):
+            f.write(np.ascontiguousarray(a).tobytes())
+    camarg = "%r,%r,%r,%r,%r" % (ks.FX, ks.FY, ks.CX, ks.CY, ks.MBF)
+    nk, ret, ntm = _run(driver, "local", tmp_path / "a.raw", w, h, nf, camarg, tmp_path / "pts.bin", tmp_path / "pd.bin",
+                        tmp_path / "aux.bin", 3.0, tmp_path / "o")
+    res = np.fromfile(str(tmp_path / "o.i32"), np.int32)
+    assert nk == n and on > 150
+    assert ret == on and ntm == int(proj["in_view"].sum())
+    np.testing.assert_array_equal(res[:n], ofm)
+    np.testing.assert_array_equal(res[n:], 1 + proj["in_view"])          # IncreaseVisible() exactly for the points in view

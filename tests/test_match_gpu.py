@@ -382,3 +382,68 @@ def test_distinctive_descriptors(pkg, oracle):
             assert bm[p] == om
             ties += 1 if len(d) > 3 else 0
     assert ties > 100
+
+
+# ---- Frame::isInFrustum on the device, alone and fused with SearchByProjection(F, MPs)
+def _local_map(pkg, oracle, synth, seed, m=3000):
+    ks, w, h, rng, k, d, sf, cam, log_sf, _ = _kfside(oracle, synth, seed, False, m)
+    T = ks.pose(rng)
+    pts3, pd, idx = ks.points_for(oracle, rng, k, d, sf, T, m, bits=3)
+    pts3["valid"] = rng.random(m) > 0.1
+    # level boundaries: make max_distance/dist land within a few ulps of sf^k for part of the points
+    R, t = T[:3, :3].astype(np.float64), T[:3, 3].astype(np.float64)
+    Ow = (-R.T @ t).astype(np.float32)
+    dist = np.sqrt(((np.stack([pts3["wx"], pts3["wy"], pts3["wz"]], 1) - Ow).astype(np.float64) ** 2).sum(1)).astype(np.float32)
+    edge = rng.random(m) < 0.3
+    kk = rng.integers(0, 8, m)
+    ulp = rng.integers(-3, 4, m)
+    target = (np.float32(1.2) ** kk).astype(np.float32)
+    md = (dist * target).astype(np.float32)
+    md = (md.view(np.int32) + ulp.astype(np.int32)).view(np.float32)
+    pts3["max_distance"] = np.where(edge, md, pts3["max_distance"])
+    pts3["min_distance"] = np.where(edge, md * np.float32(0.1), pts3["min_distance"])
+    obs = rng.integers(0, 6, m).astype(np.int32)
+    wp = np.zeros(m, pkg.WORLDPOINT_DTYPE)
+    for f in ("valid", "wx", "wy", "wz", "nx", "ny", "nz", "max_distance", "min_distance"):
+        wp[f] = pts3[f]
+    wp["observations"] = obs
+    return ks, w, h, rng, k, d, sf, cam, log_sf, T, pts3, wp, pd, obs
+
+
+def test_is_in_frustum(pkg, oracle, synth):
+    """orbm_is_in_frustum vs Frame::isInFrustum (src/Frame.cc:284-340) restated with the C library's logf: every
+    field identical, including the predicted level of points sitting within 3 ulps of a level boundary."""
+    ks, w, h, rng, k, d, sf, cam, log_sf, T, pts3, wp, pd, obs = _local_map(pkg, oracle, synth, 6)
+    want = oracle.is_in_frustum(pts3, obs, T, cam, oracle.grid_geom(w, h), 0.5, log_sf, 8)
+    thr = pkg.predict_scale_thresholds(log_sf, 8)
+    pcam = pkg.Camera(ks.FX, ks.FY, ks.CX, ks.CY, ks.MBF, np.float32(ks.MBF) / np.float32(ks.FX))
+    got = pkg.is_in_frustum(wp, T, pcam, pkg.grid_geom(w, h), 0.5, thr, 8)
+    assert 0.4 * len(wp) < want["in_view"].sum() < 0.95 * len(wp)
+    assert len(set(want["level"][want["in_view"] == 1])) == 8
+    for f in want.dtype.names:
+        np.testing.assert_array_equal(got[f], want[f], err_msg=f)
+
+
+def test_search_local_points_fused(pkg, oracle, synth, matcher_path):
+    """orbm_search_local_points = isInFrustum + SearchByProjection(F, MPs) on the device (Tracking::SearchLocalPoints,
+    src/Tracking.cc:1305-1339) against the two oracle stages chained on the host."""
+    ks, w, h, rng, k, d, sf, cam, log_sf, T, pts3, wp, pd, obs = _local_map(pkg, oracle, synth, 7, m=2500)
+    n = len(k)
+    uright = np.where(rng.random(n) < 0.5, k["x"] - rng.uniform(1, 40, n), -1).astype(np.float32)
+    frame_mp = np.full(n, -1, np.int32)
+    held = rng.choice(n, 150, replace=False)
+    frame_mp[held[:75]] = rng.choice(len(wp), 75, replace=False)
+    frame_mp[held[75:]] = -2
+    ext_obs = rng.integers(0, 3, n).astype(np.int32)
+    proj = oracle.is_in_frustum(pts3, obs, T, cam, oracle.grid_geom(w, h), 0.5, log_sf, 8)
+    for th in (1.0, 3.0):
+        on, ofm = oracle.search_by_projection_mp(k, d, uright, oracle.grid_geom(w, h), sf, proj, pd, frame_mp, ext_obs, th, 0.8)
+        thr = pkg.predict_scale_thresholds(log_sf, 8)
+        pcam = pkg.Camera(ks.FX, ks.FY, ks.CX, ks.CY, ks.MBF, np.float32(ks.MBF) / np.float32(ks.FX))
+        gn, gfm, gproj = pkg.search_local_points(k, d, uright, pkg.grid_geom(w, h), sf, wp, pd, T, pcam, 0.5, thr, frame_mp,
+                                                 ext_obs, th, 0.8)
+        assert on > 200
+        assert gn == on
+        np.testing.assert_array_equal(gfm, ofm)
+        for f in proj.dtype.names:
+            np.testing.assert_array_equal(gproj[f], proj[f], err_msg=f)
