@@ -292,6 +292,43 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
 int orbx_debug_set(int key, int value);
 
 /* ---- misc ---------------------------------------------------------------------------- */
+/* ---- DBoW2 vocabulary descent and the BoW-guided matchers.
+ * Vocabulary = the tree of Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:310-340 (nodes: parent, children in id
+ * order, 32-byte FORB descriptor, weight; leaves are words, numbered in node-id order) held on the GPU. */
+typedef struct orbv_vocabulary orbv_vocabulary_t;
+/* nnodes includes the root (node 0, no descriptor).  parent[i] < i for i >= 1.  is_leaf[i]: the loader's nIsLeaf
+ * flag (word ids follow it); a node is treated as a leaf by the descent iff it has no children (Node::isLeaf). */
+int orbv_create(int k, int L, int scoring, int weighting, int nnodes, const int32_t *parent, const uint8_t *is_leaf,
+                const uint8_t *desc, const double *weight, int device, orbv_vocabulary_t **out);
+/* TemplatedVocabulary::loadFromTextFile (:1351-1436, the ORBvoc.txt format).  Difference: the reference's
+ * `while(!f.eof())` loop turns the file's trailing empty line into one more child of the root with an
+ * UNINITIALISED descriptor (undefined behaviour); empty lines are skipped here. */
+int orbv_load_text(const char *path, int device, orbv_vocabulary_t **out);
+void orbv_destroy(orbv_vocabulary_t *v);
+int orbv_info(const orbv_vocabulary_t *v, int *k, int *L, int *scoring, int *weighting, int *nnodes, int *nwords);
+/* transform(feature, word_id, weight, nid, levelsup) of TemplatedVocabulary.h:1230-1271 for n descriptors:
+ * at every level the child with the smallest FORB::distance (first minimum in child order) until a leaf.
+ * word_id[n], node_id[n] (the node on the path at level L - levelsup; 0 when that level is <= 0), weight[n].
+ * The BowVector / FeatureVector maps are filled from these on the host, in feature order
+ * (orb_slam2v2-1_amd/host/ORBVocabulary.h), because their double sums depend on that order. */
+int orbv_transform(const orbv_vocabulary_t *v, const uint8_t *desc, int n, int levelsup, int32_t *word_id,
+                   int32_t *node_id, double *weight);
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:159-288) and SearchByBoW(KeyFrame*, KeyFrame*,
+ * ...) (:522-655) after the caller has intersected the two FeatureVectors: node j pairs the query features
+ * q_items[node_qstart[j] .. node_qstart[j+1]) with the candidate features c_items[node_cstart[j] .. ).  Queries are
+ * visited in that order; candidates in list order; a query needs q_valid (map point present and not bad), a
+ * candidate needs c_valid (NULL = all valid) and must not have been taken by an earlier query; accept iff
+ * best <= max_dist && (float)best < nnratio * (float)second (second = smallest distance among the other
+ * candidates, 256 if none); with check_orientation the matches outside the three largest 30-degree bins of
+ * (q_angle - c_angle) are dropped at the end.  A feature belongs to one node only, so nodes are independent:
+ * one wavefront per node.  match_q[nq]: candidate feature index or -1. */
+int orbm_search_by_bow(const uint8_t *q_desc, const float *q_angle, const uint8_t *q_valid, int nq,
+                       const uint8_t *c_desc, const float *c_angle, const uint8_t *c_valid, int nc,
+                       const int32_t *node_qstart, const int32_t *q_items, const int32_t *node_cstart,
+                       const int32_t *c_items, int nnodes, int max_dist, float nnratio, int check_orientation,
+                       int32_t *match_q, int *nmatches, int device);
+
 const char *orbx_last_error(void);      /* thread-local description of the last failure */
 const char *orbx_version(void);
 int orbx_device_count(void);            /* number of HIP devices visible (0 if none) */

@@ -142,6 +142,16 @@ def lib():
         L.oracle_predict_scale_ratio.restype = i32
         L.oracle_predict_scale_ratio.argtypes = [f32, f32, i32]
         L.oracle_is_in_frustum.argtypes = [vp, vp, i32, vp, K, G, f32, f32, i32, vp]
+        L.oracle_voc_create.restype = vp
+        L.oracle_voc_create.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, vp]
+        L.oracle_voc_free.argtypes = [vp]
+        L.oracle_voc_words.restype = i32
+        L.oracle_voc_words.argtypes = [vp]
+        L.oracle_voc_transform_one.argtypes = [vp, vp, i32, C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(i32)]
+        L.oracle_voc_transform.restype = i32
+        L.oracle_voc_transform.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, C.POINTER(i32)]
+        L.oracle_search_by_bow.restype = i32
+        L.oracle_search_by_bow.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp]
         L.oracle_distinctive_descriptor.restype = i32
         L.oracle_distinctive_descriptor.argtypes = [vp, i32, C.POINTER(i32)]
         _lib = L
@@ -465,3 +475,48 @@ def is_in_frustum(pts, obs, Tcw, cam, geom, viewing_cos_limit, log_sf, nlevels):
     lib().oracle_is_in_frustum(_p(pts), _p(ob), len(pts), _p(T), C.byref(cam), C.byref(geom), float(viewing_cos_limit),
                                float(log_sf), int(nlevels), _p(out))
     return out
+
+
+class Vocabulary:
+    """DBoW2 vocabulary tree (TemplatedVocabulary) from per-node arrays in file order."""
+
+    def __init__(self, k, L, scoring, weighting, parent, is_leaf, desc, weight):
+        self.parent = np.ascontiguousarray(parent, np.int32); self.is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        self.desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); self.weight = np.ascontiguousarray(weight, np.float64)
+        self.k, self.L = k, L
+        self.h = lib().oracle_voc_create(k, L, scoring, weighting, len(self.parent), _p(self.parent), _p(self.is_leaf),
+                                         _p(self.desc), _p(self.weight))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_voc_free(self.h)
+            self.h = None
+
+    def transform_one(self, feature, levelsup):
+        f = np.ascontiguousarray(feature, np.uint8)
+        w, nid, wt = C.c_int(0), C.c_int(0), C.c_double(0)
+        lib().oracle_voc_transform_one(self.h, _p(f), int(levelsup), C.byref(w), C.byref(wt), C.byref(nid))
+        return w.value, wt.value, nid.value
+
+    def transform(self, features, levelsup):
+        """-> (bow_word, bow_value, {node: [feature indices]})"""
+        f = np.ascontiguousarray(features, np.uint8).reshape(-1, 32)
+        n = len(f)
+        bw = np.zeros(n + 1, np.int32); bv = np.zeros(n + 1, np.float64)
+        fn = np.zeros(n + 1, np.int32); fs = np.zeros(n + 2, np.int32); fi = np.zeros(n + 1, np.int32)
+        nfv = C.c_int(0)
+        nb = lib().oracle_voc_transform(self.h, _p(f), n, int(levelsup), _p(bw), _p(bv), _p(fn), _p(fs), _p(fi), C.byref(nfv))
+        fv = {int(fn[p]): [int(x) for x in fi[fs[p]:fs[p + 1]]] for p in range(nfv.value)}
+        return bw[:nb].copy(), bv[:nb].copy(), fv
+
+
+def search_by_bow(qd, qa, qv, cd, ca, cv, nqs, qit, ncs, cit, th_low, strict_lt, nnratio, check_ori=True):
+    qd = np.ascontiguousarray(qd, np.uint8); qa = _f32(qa); qv = np.ascontiguousarray(qv, np.uint8)
+    cd = np.ascontiguousarray(cd, np.uint8); ca = _f32(ca)
+    cvv = None if cv is None else np.ascontiguousarray(cv, np.uint8)
+    nqs = np.ascontiguousarray(nqs, np.int32); qit = np.ascontiguousarray(qit, np.int32)
+    ncs = np.ascontiguousarray(ncs, np.int32); cit = np.ascontiguousarray(cit, np.int32)
+    mq = np.zeros(len(qa), np.int32)
+    n = lib().oracle_search_by_bow(_p(qd), _p(qa), _p(qv), len(qa), _p(cd), _p(ca), _p(cvv), len(ca), _p(nqs), _p(qit), _p(ncs),
+                                   _p(cit), len(nqs) - 1, int(th_low), int(strict_lt), float(nnratio), int(check_ori), _p(mq))
+    return n, mq

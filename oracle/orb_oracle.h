@@ -216,6 +216,21 @@ void oracle_is_in_frustum(const oracle_mappoint3d_t *pts, const int32_t *obs, in
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:252-317), one map point; returns BestIdx (-1: no rows) */
 int oracle_distinctive_descriptor(const uint8_t *desc, int n, int *median_out);
 
+/* ---- SURVEY §8(f) rank 3 (orb_oracle_bow.c): DBoW2 vocabulary transform and ORBmatcher::SearchByBoW x2 */
+typedef struct oracle_voc oracle_voc_t;
+oracle_voc_t *oracle_voc_create(int k, int L, int scoring, int weighting, int nnodes, const int32_t *parent,
+                                const uint8_t *is_leaf, const uint8_t *desc, const double *weight);
+void oracle_voc_free(oracle_voc_t *v);
+int oracle_voc_words(const oracle_voc_t *v);
+void oracle_voc_transform_one(const oracle_voc_t *v, const uint8_t *feature, int levelsup, int32_t *word_id, double *weight,
+                              int32_t *nid);
+int oracle_voc_transform(const oracle_voc_t *v, const uint8_t *features, int n, int levelsup, int32_t *bow_word,
+                         double *bow_value, int32_t *fv_node, int32_t *fv_start, int32_t *fv_items, int *nfv_out);
+int oracle_search_by_bow(const uint8_t *qd, const float *qa, const uint8_t *qv, int nq, const uint8_t *cd, const float *ca,
+                         const uint8_t *cv, int nc, const int32_t *nqs, const int32_t *qit, const int32_t *ncs,
+                         const int32_t *cit, int nnodes, int th_low, int strict_lt, float nnratio, int check_ori,
+                         int32_t *match_q);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,7 +39,8 @@ EXPORTS = [
     "orbx_get_stage_ms", "orbx_debug_set", "orbm_hamming", "orbm_hamming_matrix_device", "orbm_stereo_batch_device",
     "orbm_stereo", "orbm_search_for_initialization", "orbm_search_by_projection_mp",
     "orbm_search_by_projection_frame", "orbm_match_windows", "orbm_best_in_windows", "orbm_distinctive_descriptors", "orbm_predict_scale_thresholds", "orbm_is_in_frustum",
-    "orbm_search_local_points", "orbx_last_error", "orbx_version", "orbx_device_count",
+    "orbm_search_local_points", "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_transform",
+    "orbm_search_by_bow", "orbx_last_error", "orbx_version", "orbx_device_count",
 ]
 
 
@@ -140,6 +141,13 @@ def lib():
     L.orbm_match_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, vp, i32, i32, i32, C.POINTER(i32)]
     L.orbm_distinctive_descriptors.argtypes = [vp, vp, i32, vp, vp, i32]
     L.orbm_predict_scale_thresholds.argtypes = [f32, i32, vp]
+    L.orbv_create.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, C.POINTER(vp)]
+    L.orbv_load_text.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    L.orbv_destroy.argtypes = [vp]
+    L.orbv_destroy.restype = None
+    L.orbv_info.argtypes = [vp] + [C.POINTER(i32)] * 6
+    L.orbv_transform.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    L.orbm_search_by_bow.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, i32, vp, C.POINTER(i32), i32]
     L.orbm_is_in_frustum.argtypes = [vp, i32, vp, C.POINTER(Camera), C.POINTER(GridGeom), f32, vp, i32, vp, i32]
     L.orbm_search_local_points.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp, i32, vp, vp, i32, vp, C.POINTER(Camera), f32,
                                            vp, vp, vp, f32, f32, i32, C.POINTER(i32), vp]
@@ -450,3 +458,55 @@ def search_local_points(kun, desc, uright, geom, sf, pts, mp_desc, Tcw, cam, vie
                                           len(pts), _p(T), C.byref(cam), float(viewing_cos_limit), _p(thr), _p(fm), _p(eo),
                                           float(th), float(nnratio), int(device), C.byref(n), _p(proj)))
     return n.value, fm, proj
+
+
+class Vocabulary:
+    """DBoW2 vocabulary on the GPU (orbv_*): from per-node arrays in file order, or from an ORBvoc.txt file."""
+
+    def __init__(self, k=None, L=None, scoring=0, weighting=0, parent=None, is_leaf=None, desc=None, weight=None, path=None,
+                 device=0):
+        self._L = lib()
+        h = C.c_void_p()
+        if path is not None:
+            _check(self._L.orbv_load_text(str(path).encode(), int(device), C.byref(h)))
+        else:
+            parent = np.ascontiguousarray(parent, np.int32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+            desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); weight = np.ascontiguousarray(weight, np.float64)
+            _check(self._L.orbv_create(int(k), int(L), int(scoring), int(weighting), len(parent), _p(parent), _p(is_leaf), _p(desc),
+                                       _p(weight), int(device), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orbv_destroy(self._h)
+            self._h = None
+
+    def info(self):
+        v = [C.c_int(0) for _ in range(6)]
+        _check(self._L.orbv_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("k", "L", "scoring", "weighting", "nnodes", "nwords"), [x.value for x in v]))
+
+    def transform(self, desc, levelsup=4):
+        """orbv_transform -> (word_id, node_id, weight) per descriptor"""
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(d)
+        w = np.zeros(n, np.int32); nid = np.zeros(n, np.int32); wt = np.zeros(n, np.float64)
+        _check(self._L.orbv_transform(self._h, _p(d), n, int(levelsup), _p(w), _p(nid), _p(wt)))
+        return w, nid, wt
+
+
+def search_by_bow(q_desc, q_angle, q_valid, c_desc, c_angle, c_valid, node_qstart, q_items, node_cstart, c_items, max_dist,
+                  nnratio, check_orientation=True, device=0):
+    """orbm_search_by_bow -> (nmatches, match_q)"""
+    qd = np.ascontiguousarray(q_desc, np.uint8); qa = np.ascontiguousarray(q_angle, np.float32)
+    qv = np.ascontiguousarray(q_valid, np.uint8)
+    cd = np.ascontiguousarray(c_desc, np.uint8); ca = np.ascontiguousarray(c_angle, np.float32)
+    cv = None if c_valid is None else np.ascontiguousarray(c_valid, np.uint8)
+    nqs = np.ascontiguousarray(node_qstart, np.int32); qi = np.ascontiguousarray(q_items, np.int32)
+    ncs = np.ascontiguousarray(node_cstart, np.int32); ci = np.ascontiguousarray(c_items, np.int32)
+    mq = np.zeros(len(qa), np.int32)
+    n = C.c_int(0)
+    _check(lib().orbm_search_by_bow(_p(qd), _p(qa), _p(qv), len(qa), _p(cd), _p(ca), _p(cv), len(ca), _p(nqs), _p(qi), _p(ncs),
+                                    _p(ci), len(nqs) - 1, int(max_dist), float(nnratio), int(check_orientation), _p(mq),
+                                    C.byref(n), int(device)))
+    return n.value, mq

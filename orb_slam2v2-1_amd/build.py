@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "liborbx_hip.so")
-SOURCES = ["orbx_extract.hip", "orbx_match.hip", "orbx_match_fast.hip"]
+SOURCES = ["orbx_extract.hip", "orbx_match.hip", "orbx_match_fast.hip", "orbx_bow.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -31,7 +31,7 @@ HOST_LIB = os.path.join(HERE, "lib", "liborb_host.so")
 
 def build_host(force=False, verbose=False):
     """C++ host classes (ORB_SLAM2::ORBextractor / ORBmatcher mirrors) over the C ABI: g++ only."""
-    srcs = [os.path.join(HOST, f) for f in ("ORBextractor.cc", "ORBmatcher.cc")]
+    srcs = [os.path.join(HOST, f) for f in ("ORBextractor.cc", "ORBmatcher.cc", "ORBVocabulary.cc")]
     deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST)] + [LIB]
     if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps):
         return HOST_LIB

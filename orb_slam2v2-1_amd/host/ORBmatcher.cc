@@ -486,6 +486,70 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoin
     return nFound;
 }
 
+// ---------------------------------------------------------------------------------------------
+// BoW-guided matchers.  The merge of the two FeatureVectors (src/ORBmatcher.cc:176-248,
+// :542-625) runs here; the brute-force search inside each shared vocabulary node runs on the GPU, one
+// wavefront per node (a feature belongs to one node, so nodes never interact).
+static void intersect_feature_vectors(const DBoW2::FeatureVector &v1, const DBoW2::FeatureVector &v2,
+                                      std::vector<int32_t> &s1, std::vector<int32_t> &i1, std::vector<int32_t> &s2,
+                                      std::vector<int32_t> &i2) {
+    s1.assign(1, 0); s2.assign(1, 0); i1.clear(); i2.clear();
+    DBoW2::FeatureVector::const_iterator f1it = v1.begin(), f2it = v2.begin(), f1end = v1.end(), f2end = v2.end();
+    while (f1it != f1end && f2it != f2end) {
+        if (f1it->first == f2it->first) {
+            i1.insert(i1.end(), f1it->second.begin(), f1it->second.end());
+            i2.insert(i2.end(), f2it->second.begin(), f2it->second.end());
+            s1.push_back((int32_t)i1.size()); s2.push_back((int32_t)i2.size());
+            f1it++; f2it++;
+        } else if (f1it->first < f2it->first) f1it = v1.lower_bound(f2it->first);
+        else f2it = v2.lower_bound(f1it->first);
+    }
+}
+
+int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches) {
+    const std::vector<MapPoint *> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = std::vector<MapPoint *>(F.N, static_cast<MapPoint *>(NULL));   // :163
+    const int nq = (int)vpMapPointsKF.size(), nc = F.N;
+    if (nq == 0 || nc == 0) return 0;
+    std::vector<int32_t> sq, iq, sc, ic;
+    intersect_feature_vectors(pKF->mFeatVec, F.mFeatVec, sq, iq, sc, ic);
+    std::vector<uint8_t> qd, cd, qv(nq);
+    gather_descriptors(pKF->mDescriptors, nq, qd); gather_descriptors(F.mDescriptors, nc, cd);
+    std::vector<float> qa(nq), ca(nc);
+    for (int i = 0; i < nq; i++) { qa[i] = pKF->mvKeysUn[i].angle; MapPoint *p = vpMapPointsKF[i]; qv[i] = p && !p->isBad(); }   // :195-199, :237
+    for (int i = 0; i < nc; i++) ca[i] = F.mvKeys[i].angle;                                                                        // :241
+    std::vector<int32_t> match(nq, -1);
+    int nmatches = 0;
+    if (orbm_search_by_bow(qd.data(), qa.data(), qv.data(), nq, cd.data(), ca.data(), NULL, nc, sq.data(), iq.data(), sc.data(),
+                           ic.data(), (int)sq.size() - 1, TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0, match.data(), &nmatches,
+                           device) != ORBX_OK)
+        return fail("SearchByBoW");
+    for (int i = 0; i < nq; i++) if (match[i] >= 0) vpMapPointMatches[match[i]] = vpMapPointsKF[i];   // :235
+    return nmatches;
+}
+
+int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12) {
+    const std::vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+    vpMatches12 = std::vector<MapPoint *>(vpMapPoints1.size(), static_cast<MapPoint *>(NULL));      // :534
+    const int nq = (int)vpMapPoints1.size(), nc = (int)vpMapPoints2.size();
+    if (nq == 0 || nc == 0) return 0;
+    std::vector<int32_t> sq, iq, sc, ic;
+    intersect_feature_vectors(pKF1->mFeatVec, pKF2->mFeatVec, sq, iq, sc, ic);
+    std::vector<uint8_t> qd, cd, qv(nq), cv(nc);
+    gather_descriptors(pKF1->mDescriptors, nq, qd); gather_descriptors(pKF2->mDescriptors, nc, cd);
+    std::vector<float> qa(nq), ca(nc);
+    for (int i = 0; i < nq; i++) { qa[i] = pKF1->mvKeysUn[i].angle; MapPoint *p = vpMapPoints1[i]; qv[i] = p && !p->isBad(); }   // :560-564
+    for (int i = 0; i < nc; i++) { ca[i] = pKF2->mvKeysUn[i].angle; MapPoint *p = vpMapPoints2[i]; cv[i] = p && !p->isBad(); }   // :576-580
+    std::vector<int32_t> match(nq, -1);
+    int nmatches = 0;
+    if (orbm_search_by_bow(qd.data(), qa.data(), qv.data(), nq, cd.data(), ca.data(), cv.data(), nc, sq.data(), iq.data(), sc.data(),
+                           ic.data(), (int)sq.size() - 1, TH_LOW - 1 /* bestDist1 < TH_LOW, :599 */, mfNNratio,
+                           mbCheckOrientation ? 1 : 0, match.data(), &nmatches, device) != ORBX_OK)
+        return fail("SearchByBoW");
+    for (int i = 0; i < nq; i++) if (match[i] >= 0) vpMatches12[i] = vpMapPoints2[match[i]];       // :603
+    return nmatches;
+}
+
 int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched,
                                         std::vector<int> &vnMatches12, int windowSize) {
     const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();

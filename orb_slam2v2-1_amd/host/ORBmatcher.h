@@ -1,7 +1,6 @@
 // ORBmatcher.h — the hot routines of the reference's include/ORBmatcher.h:37-102 with the
 // same names, signatures and constants, executed on an MI355X through include/orbx.h.
-// (SearchByBoW x2 and SearchForTriangulation are SURVEY §8(f) rank 3 and stay on the reference's
-// CPU implementation.)
+// (SearchForTriangulation stays on the reference's CPU implementation.)
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
@@ -50,6 +49,12 @@ public:
     //                                                                (src/ORBmatcher.cc:979-1102)
     int Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, float th,
              std::vector<MapPoint *> &vpReplacePoint);
+
+    // Search matches between MapPoints in a KeyFrame and ORB in a Frame.
+    // Brute force constrained to ORB that belong to the same vocabulary node (at a certain level)
+    // Used in Relocalisation and Loop Detection                      (src/ORBmatcher.cc:159-288, 522-655)
+    int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);
+    int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12);
 
     // Matching for the Map Initialization (only used in the monocular case) (src/ORBmatcher.cc:405-520)
     int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched,

@@ -14,6 +14,7 @@
 #include <vector>
 #include "cv_shim.h"
 #include "ORBextractor.h"
+#include "ORBVocabulary.h"
 
 namespace ORB_SLAM2 {
 
@@ -60,6 +61,17 @@ class Frame {
 public:
     Frame() : mpORBextractorLeft(nullptr), mpORBextractorRight(nullptr), mbf(0), mb(0), N(0) {}
     long unsigned int mnId = 0;
+    // BoW (include/Frame.h:133-138, src/Frame.cc:410-417)
+    ORBVocabulary *mpORBvocabulary = nullptr;
+    DBoW2::BowVector mBowVec;
+    DBoW2::FeatureVector mFeatVec;
+    void ComputeBoW() {
+        if (mBowVec.empty()) {
+            std::vector<cv::Mat> vCurrentDesc;   // Converter::toDescriptorVector
+            for (int j = 0; j < mDescriptors.rows; j++) vCurrentDesc.push_back(mDescriptors.row(j));
+            mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4);
+        }
+    }
     ORBextractor *mpORBextractorLeft, *mpORBextractorRight;
     static float fx, fy, cx, cy;
     float mbf, mb;
@@ -97,6 +109,16 @@ public:
     }
     bool isBad() { return mbBad; }
     bool mbBad = false;
+    ORBVocabulary *mpORBvocabulary = nullptr;   // src/KeyFrame.cc:59-68
+    DBoW2::BowVector mBowVec;
+    DBoW2::FeatureVector mFeatVec;
+    void ComputeBoW() {
+        if (mBowVec.empty() || mFeatVec.empty()) {
+            std::vector<cv::Mat> vCurrentDesc;
+            for (int j = 0; j < mDescriptors.rows; j++) vCurrentDesc.push_back(mDescriptors.row(j));
+            mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4);
+        }
+    }
     MapPoint *GetMapPoint(const size_t &idx) { return mvpMapPoints[idx]; }
     void AddMapPoint(MapPoint *pMP, const size_t &idx) { mvpMapPoints[idx] = pMP; }
     void ReplaceMapPointMatch(const size_t &idx, MapPoint *pMP) { mvpMapPoints[idx] = pMP; }

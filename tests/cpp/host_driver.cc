@@ -289,6 +289,51 @@ static int local_mode(int argc, char **argv) {
     return 0;
 }
 
+static int bow_mode(int argc, char **argv) {
+    // argv: bow voc.txt d1.bin(u8[n1][32]) a1.bin(f32[n1]) v1.bin(u8[n1]: 0 no point, 1 good, 2 bad) d2.bin a2.bin v2.bin ratio out
+    // KeyFrame 1 = (d1, a1, v1); Frame / KeyFrame 2 = (d2, a2, v2).  Writes BowVec / FeatVec of both and the two SearchByBoW results.
+    if (argc != 11) return 2;
+    ORBVocabulary voc;
+    if (!voc.loadFromTextFile(argv[2])) return 3;
+    std::vector<unsigned char> d1 = slurp(argv[3]), a1 = slurp(argv[4]), v1 = slurp(argv[5]), d2 = slurp(argv[6]), a2 = slurp(argv[7]), v2 = slurp(argv[8]);
+    const float ratio = (float)atof(argv[9]);
+    const std::string out = argv[10];
+    const int n1 = (int)v1.size(), n2 = (int)v2.size();
+    KeyFrame K1, K2;
+    Frame F;
+    std::vector<MapPoint> p1(n1), p2(n2);
+    K1.mpORBvocabulary = K2.mpORBvocabulary = F.mpORBvocabulary = &voc;
+    K1.mDescriptors = cv::Mat(n1, 32, CV_8U, d1.data()).clone(); K2.mDescriptors = cv::Mat(n2, 32, CV_8U, d2.data()).clone();
+    F.mDescriptors = K2.mDescriptors.clone(); F.N = n2;
+    K1.mvKeysUn.resize(n1); K1.mvpMapPoints.assign(n1, (MapPoint *)NULL);
+    K2.mvKeysUn.resize(n2); K2.mvpMapPoints.assign(n2, (MapPoint *)NULL);
+    F.mvKeys.resize(n2);
+    for (int i = 0; i < n1; i++) { K1.mvKeysUn[i].angle = ((const float *)a1.data())[i]; if (v1[i]) { K1.mvpMapPoints[i] = &p1[i]; p1[i].mbBad = v1[i] == 2; } }
+    for (int i = 0; i < n2; i++) { K2.mvKeysUn[i].angle = F.mvKeys[i].angle = ((const float *)a2.data())[i]; if (v2[i]) { K2.mvpMapPoints[i] = &p2[i]; p2[i].mbBad = v2[i] == 2; } }
+    K1.ComputeBoW(); K2.ComputeBoW(); F.ComputeBoW();
+    {   // BowVec (word, value) pairs and FeatVec (node, count, items...) of keyframe 1
+        std::vector<double> bow;
+        for (DBoW2::BowVector::const_iterator it = K1.mBowVec.begin(); it != K1.mBowVec.end(); ++it) { bow.push_back((double)it->first); bow.push_back(it->second); }
+        dump(out + ".bow", bow.data(), bow.size() * 8);
+        std::vector<int> fv;
+        for (DBoW2::FeatureVector::const_iterator it = K1.mFeatVec.begin(); it != K1.mFeatVec.end(); ++it) {
+            fv.push_back((int)it->first); fv.push_back((int)it->second.size());
+            for (size_t j = 0; j < it->second.size(); j++) fv.push_back((int)it->second[j]);
+        }
+        dump(out + ".fv", fv.data(), fv.size() * 4);
+    }
+    ORBmatcher matcher(ratio, true);
+    std::vector<MapPoint *> mF, m12;
+    const int nA = matcher.SearchByBoW(&K1, F, mF);
+    const int nB = matcher.SearchByBoW(&K1, &K2, m12);
+    std::vector<int> res;
+    for (int i = 0; i < n2; i++) res.push_back(mF[i] ? (int)(mF[i] - &p1[0]) : -1);       // F feature -> KF1 point
+    for (int i = 0; i < n1; i++) res.push_back(m12[i] ? (int)(m12[i] - &p2[0]) : -1);     // KF1 feature -> KF2 point
+    dump(out + ".i32", res.data(), res.size() * 4);
+    printf("%d %d %d %d\n", n1, n2, nA, nB);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) return 2;
     const std::string mode = argv[1];
@@ -296,6 +341,7 @@ int main(int argc, char **argv) {
     if (mode == "sim3") return sim3_mode(argc, argv);
     if (mode == "distinct") return distinct_mode(argc, argv);
     if (mode == "local") return local_mode(argc, argv);
+    if (mode == "bow") return bow_mode(argc, argv);
     if (mode == "extract" && argc == 7) {
         const int w = atoi(argv[3]), h = atoi(argv[4]), nf = atoi(argv[5]);
         const std::string out = argv[6];

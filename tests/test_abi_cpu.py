@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     txt = open(os.path.join(ROOT, "include", "orbx.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(orb[xm]_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(orb[xmv]_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol(pkg):

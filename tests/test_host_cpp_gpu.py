@@ -368,3 +368,56 @@ def test_search_local_points_class(driver, oracle, synth, tmp_path):
     assert ret == on and ntm == int(proj["in_view"].sum())
     np.testing.assert_array_equal(res[:n], ofm)
     np.testing.assert_array_equal(res[n:], 1 + proj["in_view"])          # IncreaseVisible() exactly for the points in view
+
+
+def test_bow_classes(driver, oracle, tmp_path):
+    """ORBVocabulary::loadFromTextFile / transform (Frame::ComputeBoW, KeyFrame::ComputeBoW) and both
+    ORBmatcher::SearchByBoW overloads through the C++ classes, against the DBoW2 / ORBmatcher restatement."""
+    import bow_scene as bs
+    rng = np.random.default_rng(17)
+    voc = bs.make_vocabulary(rng, k=9, L=5, early_leaf=0.03)      # L = 5: ComputeBoW's levelsup = 4 -> nodes of level 1
+    ov = oracle.Vocabulary(9, 5, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    bs.write_text(voc, tmp_path / "voc.txt")
+    base = bs.features_near_words(rng, voc, 900, noise_bits=4)
+
+    def frame(n):
+        nd = n // 7
+        src = np.concatenate([rng.permutation(len(base))[:n - nd], rng.integers(0, len(base), nd)])
+        rng.shuffle(src)
+        noise = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        for _ in range(4):
+            noise &= rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        r = rng.random(n)
+        valid = np.where(r < 0.15, 0, np.where(r < 0.22, 2, 1)).astype(np.uint8)
+        return base[src] ^ noise, ((src * 0.4 + rng.normal(0, 4, n)) % 360).astype(np.float32), valid
+    d1, a1, v1 = frame(800)
+    d2, a2, v2 = frame(850)
+    for name, arr in (("d1", d1), ("a1", a1), ("v1", v1), ("d2", d2), ("a2", a2), ("v2", v2)):
+        np.ascontiguousarray(arr).tofile(tmp_path / (name + ".bin"))
+    ratio = 0.75
+    n1, n2, nA, nB = _run(driver, "bow", tmp_path / "voc.txt", *[tmp_path / (x + ".bin") for x in ("d1", "a1", "v1", "d2", "a2", "v2")],
+                          ratio, tmp_path / "o")
+    # BowVector / FeatureVector of keyframe 1
+    bw, bv, fv1 = ov.transform(d1, 4)
+    bow = np.fromfile(str(tmp_path / "o.bow"), np.float64).reshape(-1, 2)
+    np.testing.assert_array_equal(bow[:, 0].astype(np.int64), bw)
+    np.testing.assert_array_equal(bow[:, 1], bv)                              # bit-identical doubles
+    raw = np.fromfile(str(tmp_path / "o.fv"), np.int32)
+    got, p = {}, 0
+    while p < len(raw):
+        got[int(raw[p])] = [int(x) for x in raw[p + 2:p + 2 + raw[p + 1]]]
+        p += 2 + raw[p + 1]
+    assert got == fv1 and len(fv1) >= 8
+    _, _, fv2 = ov.transform(d2, 4)
+    nqs, qit, ncs, cit = bs.intersect(fv1, fv2)
+    res = np.fromfile(str(tmp_path / "o.i32"), np.int32)
+    # SearchByBoW(KF, F): all candidates, best <= TH_LOW; result indexed by the frame's features
+    onA, mA = oracle.search_by_bow(d1, a1, v1 == 1, d2, a2, None, nqs, qit, ncs, cit, 50, 0, ratio, True)
+    expectF = np.full(n2, -1, np.int32)
+    expectF[mA[mA >= 0]] = np.flatnonzero(mA >= 0)
+    assert nA == onA > 100
+    np.testing.assert_array_equal(res[:n2], expectF)
+    # SearchByBoW(KF1, KF2): candidates need a good map point, best < TH_LOW
+    onB, mB = oracle.search_by_bow(d1, a1, v1 == 1, d2, a2, v2 == 1, nqs, qit, ncs, cit, 50, 1, ratio, True)
+    assert nB == onB > 80
+    np.testing.assert_array_equal(res[n2:], mB)

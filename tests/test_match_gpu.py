@@ -447,3 +447,74 @@ def test_search_local_points_fused(pkg, oracle, synth, matcher_path):
         np.testing.assert_array_equal(gfm, ofm)
         for f in proj.dtype.names:
             np.testing.assert_array_equal(gproj[f], proj[f], err_msg=f)
+
+
+# ---- DBoW2 vocabulary descent + ORBmatcher::SearchByBoW
+@pytest.fixture(scope="module")
+def bow(pkg, oracle):
+    import bow_scene as bs
+    rng = np.random.default_rng(41)
+    voc = bs.make_vocabulary(rng, k=10, L=3)
+    ov = oracle.Vocabulary(10, 3, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    gv = pkg.Vocabulary(10, 3, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    return bs, rng, voc, ov, gv
+
+
+def test_vocabulary_transform(pkg, oracle, bow, tmp_path):
+    """orbv_transform vs TemplatedVocabulary::transform(feature, id, weight, nid, levelsup)
+    (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1230-1271): word, weight and the node `levelsup` levels above
+    the leaf for every feature, with early leaves, stopped words and levelsup beyond the tree depth; the same
+    through the ORBvoc.txt text format."""
+    bs, rng, voc, ov, gv = bow
+    feats = bs.features_near_words(rng, voc, 3000)
+    info = gv.info()
+    assert info["nnodes"] == len(voc["parent"]) and info["nwords"] == int(voc["is_leaf"].sum())
+    bs.write_text(voc, tmp_path / "voc.txt")
+    tv = pkg.Vocabulary(path=tmp_path / "voc.txt")
+    assert tv.info() == info
+    for levelsup in (0, 1, 2, 3, 4):
+        w, nid, wt = gv.transform(feats, levelsup)
+        w2, nid2, wt2 = tv.transform(feats, levelsup)
+        for i in range(0, len(feats), 7):
+            ow, owt, onid = ov.transform_one(feats[i], levelsup)
+            assert (w[i], nid[i], wt[i]) == (ow, onid, owt), (levelsup, i)
+        np.testing.assert_array_equal(w2, w); np.testing.assert_array_equal(nid2, nid); np.testing.assert_array_equal(wt2, wt)
+    w, nid, wt = gv.transform(feats, 1)
+    assert (wt == 0).sum() > 20 and len(set(nid)) > 50      # stopped words present, many level-2 nodes hit
+
+
+@pytest.mark.parametrize("variant", ["kf_frame", "kf_kf"])
+def test_search_by_bow(pkg, oracle, bow, variant):
+    """orbm_search_by_bow vs ORBmatcher::SearchByBoW (src/ORBmatcher.cc:159-288 KeyFrame-Frame: best <= TH_LOW, all
+    candidates; :522-655 KeyFrame-KeyFrame: best < TH_LOW, candidates need a good map point)."""
+    bs, rng, voc, ov, gv = bow
+    nq, nc = 1000, 1100
+    base = bs.features_near_words(rng, voc, 1200, noise_bits=4)
+    def frame(n):   # mostly distinct scene points (the ratio test can pass), some seen twice (contention for a candidate)
+        nd = n // 7
+        src = np.concatenate([rng.permutation(len(base))[:n - nd], rng.integers(0, len(base), nd)])
+        rng.shuffle(src)
+        d = base[src].copy()
+        noise = rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8) & \
+            rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8) & \
+            rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        ang = (src * 0.3 + rng.normal(0, 4, n)) % 360
+        return d ^ noise, ang.astype(np.float32)
+    qd, qa = frame(nq)
+    cd, ca = frame(nc)
+    ca = ((ca + 25) % 360).astype(np.float32)
+    _, _, fq = ov.transform(qd, 1)
+    _, _, fc = ov.transform(cd, 1)
+    nqs, qit, ncs, cit = bs.intersect(fq, fc)
+    assert len(nqs) > 50
+    qv = (rng.random(nq) > 0.2).astype(np.uint8)
+    if variant == "kf_frame":
+        cv, strict, maxd = None, 0, 50
+    else:
+        cv, strict, maxd = (rng.random(nc) > 0.15).astype(np.uint8), 1, 49
+    for ratio, ori in ((0.7, True), (0.9, False)):
+        on, om = oracle.search_by_bow(qd, qa, qv, cd, ca, cv, nqs, qit, ncs, cit, 50, strict, ratio, ori)
+        gn, gm = pkg.search_by_bow(qd, qa, qv, cd, ca, cv, nqs, qit, ncs, cit, maxd, ratio, ori)
+        assert on > 150
+        assert gn == on
+        np.testing.assert_array_equal(gm, om)

@@ -203,3 +203,26 @@ def test_distinctive_descriptor_hand_built(oracle):
     assert oracle.distinctive_descriptor(rows(7)) == (0, 0)
     assert oracle.distinctive_descriptor(rows(7, 200)) == (0, 0)      # N = 2: index 0 -> the self distance
     assert oracle.distinctive_descriptor(rows()) == (-1, 0)
+
+
+def test_vocabulary_transform_hand_built(oracle):
+    """TemplatedVocabulary::transform on a 2-ary, 2-level tree with known answers: first minimum in child order,
+    word ids in node-id order, TF-IDF sums in feature order, L1 normalisation, FeatureVector at level L-levelsup."""
+    def bits(n):
+        return np.packbits(np.arange(256) < n)
+    # nodes: 0 root | 1: 0 bits, 2: 200 bits | children of 1: 3 (0 bits, w 2.0), 4 (20 bits, w 0 = stopped) | of 2: 5 (180, w 1.5), 6 (220, w 4.0)
+    parent = [0, 0, 0, 1, 1, 2, 2]
+    is_leaf = [0, 0, 0, 1, 1, 1, 1]
+    desc = np.stack([bits(0), bits(0), bits(200), bits(0), bits(20), bits(180), bits(220)])
+    weight = [0, 0, 0, 2.0, 0.0, 1.5, 4.0]
+    v = oracle.Vocabulary(2, 2, 0, 0, parent, is_leaf, desc, weight)
+    assert v.transform_one(bits(3), 1) == (0, 2.0, 1)          # word 0 = node 3, node one level up = 1
+    assert v.transform_one(bits(10), 1) == (0, 2.0, 1)         # tie 10 vs 10 between nodes 3 and 4: the first child wins
+    assert v.transform_one(bits(11), 1) == (1, 0.0, 1)         # node 4: a stopped word
+    assert v.transform_one(bits(100), 0) == (1, 0.0, 4)        # tie at the root (100 vs 100): first child; then node 4 (80 < 100); levelsup 0 -> the leaf itself
+    assert v.transform_one(bits(201), 2) == (3, 4.0, 0)        # |201-180| = 21 > |201-220| = 19 -> node 6 = word 3; level 0 -> root
+    feats = np.stack([bits(3), bits(201), bits(11), bits(1), bits(230)])
+    bw, bv, fv = v.transform(feats, 1)
+    assert list(bw) == [0, 3]
+    np.testing.assert_array_equal(bv, np.array([4.0, 8.0]) / 12.0)   # 2+2 and 4+4, L1-normalised
+    assert fv == {1: [0, 3], 2: [1, 4]}                       # the stopped feature 2 is in neither vector
