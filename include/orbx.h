@@ -329,6 +329,22 @@ int orbm_search_by_bow(const uint8_t *q_desc, const float *q_angle, const uint8_
                        const int32_t *c_items, int nnodes, int max_dist, float nnratio, int check_orientation,
                        int32_t *match_q, int *nmatches, int device);
 
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-825) on the intersected node lists (same layout as
+ * orbm_search_by_bow).  flags: bit 0 = usable (query: no map point yet :703-704 and, with bOnlyStereo, stereo
+ * :708-710; candidate: no map point :724-725 and the stereo rule :729-731), bit 1 = mvuRight >= 0.  For each
+ * usable query, over the usable candidates of its node not taken by an earlier query, in list order:
+ * dist <= TH_LOW and dist <= best so far (:737), then - both monocular - the candidate must be at least
+ * sqrt(100*scale_factors[octave2]) away from the epipole (ex, ey) (:742-748), then CheckDistEpipolarLine
+ * (:140-157: squared distance to the line x1'F12 < 3.84*level_sigma2[octave2]); a passing candidate becomes the
+ * best — so among equal distances the LAST passing one wins.  F12_9: row-major 3x3.  Rotation consistency as in
+ * orbm_search_by_bow.  match_q[nq]: candidate feature index or -1. */
+int orbm_search_for_triangulation(const orbx_keypoint_t *kp1, const uint8_t *q_desc, const uint8_t *q_flags, int nq,
+                                  const orbx_keypoint_t *kp2, const uint8_t *c_desc, const uint8_t *c_flags, int nc,
+                                  const int32_t *node_qstart, const int32_t *q_items, const int32_t *node_cstart,
+                                  const int32_t *c_items, int nnodes, const float *F12_9, float ex, float ey,
+                                  const float *scale_factors, const float *level_sigma2, int nlevels, int max_dist,
+                                  int check_orientation, int32_t *match_q, int *nmatches, int device);
+
 const char *orbx_last_error(void);      /* thread-local description of the last failure */
 const char *orbx_version(void);
 int orbx_device_count(void);            /* number of HIP devices visible (0 if none) */

@@ -150,6 +150,8 @@ def lib():
         L.oracle_voc_transform_one.argtypes = [vp, vp, i32, C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(i32)]
         L.oracle_voc_transform.restype = i32
         L.oracle_voc_transform.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, C.POINTER(i32)]
+        L.oracle_search_for_triangulation.restype = i32
+        L.oracle_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, f32, f32, vp, vp, i32, i32, vp]
         L.oracle_search_by_bow.restype = i32
         L.oracle_search_by_bow.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp]
         L.oracle_distinctive_descriptor.restype = i32
@@ -519,4 +521,18 @@ def search_by_bow(qd, qa, qv, cd, ca, cv, nqs, qit, ncs, cit, th_low, strict_lt,
     mq = np.zeros(len(qa), np.int32)
     n = lib().oracle_search_by_bow(_p(qd), _p(qa), _p(qv), len(qa), _p(cd), _p(ca), _p(cvv), len(ca), _p(nqs), _p(qit), _p(ncs),
                                    _p(cit), len(nqs) - 1, int(th_low), int(strict_lt), float(nnratio), int(check_ori), _p(mq))
+    return n, mq
+
+
+def search_for_triangulation(k1, qd, qf, k2, cd, cf, nqs, qit, ncs, cit, F12, ex, ey, sf, sigma2, th_low=50, check_ori=True):
+    k1 = np.ascontiguousarray(k1, KP_DTYPE); k2 = np.ascontiguousarray(k2, KP_DTYPE)
+    qd = np.ascontiguousarray(qd, np.uint8); cd = np.ascontiguousarray(cd, np.uint8)
+    qf = np.ascontiguousarray(qf, np.uint8); cf = np.ascontiguousarray(cf, np.uint8)
+    nqs = np.ascontiguousarray(nqs, np.int32); qit = np.ascontiguousarray(qit, np.int32)
+    ncs = np.ascontiguousarray(ncs, np.int32); cit = np.ascontiguousarray(cit, np.int32)
+    F = _f32(F12); sf = _f32(sf); s2 = _f32(sigma2)
+    mq = np.zeros(len(k1), np.int32)
+    n = lib().oracle_search_for_triangulation(_p(k1), _p(qd), _p(qf), len(k1), _p(k2), _p(cd), _p(cf), len(k2), _p(nqs), _p(qit),
+                                              _p(ncs), _p(cit), len(nqs) - 1, _p(F), float(ex), float(ey), _p(sf), _p(s2),
+                                              int(th_low), int(check_ori), _p(mq))
     return n, mq

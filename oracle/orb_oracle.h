@@ -226,6 +226,10 @@ void oracle_voc_transform_one(const oracle_voc_t *v, const uint8_t *feature, int
                               int32_t *nid);
 int oracle_voc_transform(const oracle_voc_t *v, const uint8_t *features, int n, int levelsup, int32_t *bow_word,
                          double *bow_value, int32_t *fv_node, int32_t *fv_start, int32_t *fv_items, int *nfv_out);
+int oracle_search_for_triangulation(const oracle_kp_t *k1, const uint8_t *qd, const uint8_t *qf, int nq, const oracle_kp_t *k2,
+                                    const uint8_t *cd, const uint8_t *cf, int nc, const int32_t *nqs, const int32_t *qit,
+                                    const int32_t *ncs, const int32_t *cit, int nnodes, const float *F12, float ex, float ey,
+                                    const float *sf, const float *sigma2, int th_low, int check_ori, int32_t *match_q);
 int oracle_search_by_bow(const uint8_t *qd, const float *qa, const uint8_t *qv, int nq, const uint8_t *cd, const float *ca,
                          const uint8_t *cv, int nc, const int32_t *nqs, const int32_t *qit, const int32_t *ncs,
                          const int32_t *cit, int nnodes, int th_low, int strict_lt, float nnratio, int check_ori,

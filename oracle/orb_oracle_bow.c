@@ -180,3 +180,69 @@ int oracle_search_by_bow(const uint8_t *qd, const float *qa, const uint8_t *qv, 
     free(taken); free(hist);
     return nmatches;
 }
+
+/* ORBmatcher::CheckDistEpipolarLine (src/ORBmatcher.cc:140-157) */
+static int check_dist_epipolar_line(const oracle_kp_t *kp1, const oracle_kp_t *kp2, const float *F12, const float *sigma2) {
+    const float a = kp1->x * F12[0] + kp1->y * F12[3] + F12[6];
+    const float b = kp1->x * F12[1] + kp1->y * F12[4] + F12[7];
+    const float c = kp1->x * F12[2] + kp1->y * F12[5] + F12[8];
+    const float num = a * kp2->x + b * kp2->y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2[kp2->octave];
+}
+
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-825) on the intersected node lists.
+ * qf / cf: bit 0 usable (no map point, stereo rule of bOnlyStereo applied by the caller), bit 1 mvuRight >= 0. */
+int oracle_search_for_triangulation(const oracle_kp_t *k1, const uint8_t *qd, const uint8_t *qf, int nq, const oracle_kp_t *k2,
+                                    const uint8_t *cd, const uint8_t *cf, int nc, const int32_t *nqs, const int32_t *qit,
+                                    const int32_t *ncs, const int32_t *cit, int nnodes, const float *F12, float ex, float ey,
+                                    const float *sf, const float *sigma2, int th_low, int check_ori, int32_t *match_q) {
+    int nmatches = 0;
+    uint8_t *matched2 = (uint8_t *)calloc(nc > 0 ? nc : 1, 1);
+    int32_t *hist = (int32_t *)malloc(sizeof(int32_t) * HISTO_LENGTH * (size_t)(nq > 0 ? nq : 1));
+    int32_t hn[HISTO_LENGTH] = {0};
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < nq; i++) match_q[i] = -1;
+    for (int j = 0; j < nnodes; j++)
+        for (int q = nqs[j]; q < nqs[j + 1]; q++) {
+            const int idx1 = qit[q];
+            if (!(qf[idx1] & 1)) continue;
+            const int bStereo1 = (qf[idx1] & 2) != 0;
+            int bestDist = th_low, bestIdx2 = -1;
+            for (int p = ncs[j]; p < ncs[j + 1]; p++) {
+                const int idx2 = cit[p];
+                if (matched2[idx2] || !(cf[idx2] & 1)) continue;
+                const int bStereo2 = (cf[idx2] & 2) != 0;
+                const int dist = oracle_hamming(qd + 32 * (size_t)idx1, cd + 32 * (size_t)idx2);
+                if (dist > th_low || dist > bestDist) continue;
+                if (!bStereo1 && !bStereo2) {
+                    const float distex = ex - k2[idx2].x, distey = ey - k2[idx2].y;
+                    if (distex * distex + distey * distey < 100 * sf[k2[idx2].octave]) continue;
+                }
+                if (check_dist_epipolar_line(&k1[idx1], &k2[idx2], F12, sigma2)) { bestIdx2 = idx2; bestDist = dist; }
+            }
+            if (bestIdx2 >= 0) {
+                match_q[idx1] = bestIdx2;
+                matched2[bestIdx2] = 1;
+                nmatches++;
+                if (check_ori) {
+                    float rot = k1[idx1].angle - k2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    hist[(size_t)bin * nq + hn[bin]++] = idx1;
+                }
+            }
+        }
+    if (check_ori) {
+        int ind1, ind2, ind3;
+        oracle_three_maxima(hn, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int t = 0; t < hn[i]; t++) { match_q[hist[(size_t)i * nq + t]] = -1; nmatches--; }
+    }
+    free(matched2); free(hist);
+    return nmatches;
+}

@@ -40,7 +40,7 @@ EXPORTS = [
     "orbm_stereo", "orbm_search_for_initialization", "orbm_search_by_projection_mp",
     "orbm_search_by_projection_frame", "orbm_match_windows", "orbm_best_in_windows", "orbm_distinctive_descriptors", "orbm_predict_scale_thresholds", "orbm_is_in_frustum",
     "orbm_search_local_points", "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_transform",
-    "orbm_search_by_bow", "orbx_last_error", "orbx_version", "orbx_device_count",
+    "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
 ]
 
 
@@ -147,6 +147,8 @@ def lib():
     L.orbv_destroy.restype = None
     L.orbv_info.argtypes = [vp] + [C.POINTER(i32)] * 6
     L.orbv_transform.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    L.orbm_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, f32, f32, vp, vp, i32, i32, i32, vp,
+                                                C.POINTER(i32), i32]
     L.orbm_search_by_bow.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, f32, i32, vp, C.POINTER(i32), i32]
     L.orbm_is_in_frustum.argtypes = [vp, i32, vp, C.POINTER(Camera), C.POINTER(GridGeom), f32, vp, i32, vp, i32]
     L.orbm_search_local_points.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp, i32, vp, vp, i32, vp, C.POINTER(Camera), f32,
@@ -509,4 +511,22 @@ def search_by_bow(q_desc, q_angle, q_valid, c_desc, c_angle, c_valid, node_qstar
     _check(lib().orbm_search_by_bow(_p(qd), _p(qa), _p(qv), len(qa), _p(cd), _p(ca), _p(cv), len(ca), _p(nqs), _p(qi), _p(ncs),
                                     _p(ci), len(nqs) - 1, int(max_dist), float(nnratio), int(check_orientation), _p(mq),
                                     C.byref(n), int(device)))
+    return n.value, mq
+
+
+def search_for_triangulation(kp1, q_desc, q_flags, kp2, c_desc, c_flags, node_qstart, q_items, node_cstart, c_items, F12, ex, ey,
+                             scale_factors, level_sigma2, max_dist=50, check_orientation=True, device=0):
+    """orbm_search_for_triangulation -> (nmatches, match_q)"""
+    k1 = np.ascontiguousarray(kp1, KP_DTYPE); k2 = np.ascontiguousarray(kp2, KP_DTYPE)
+    qd = np.ascontiguousarray(q_desc, np.uint8); cd = np.ascontiguousarray(c_desc, np.uint8)
+    qf = np.ascontiguousarray(q_flags, np.uint8); cf = np.ascontiguousarray(c_flags, np.uint8)
+    nqs = np.ascontiguousarray(node_qstart, np.int32); qi = np.ascontiguousarray(q_items, np.int32)
+    ncs = np.ascontiguousarray(node_cstart, np.int32); ci = np.ascontiguousarray(c_items, np.int32)
+    F = np.ascontiguousarray(F12, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+    s2 = np.ascontiguousarray(level_sigma2, np.float32)
+    mq = np.zeros(len(k1), np.int32)
+    n = C.c_int(0)
+    _check(lib().orbm_search_for_triangulation(_p(k1), _p(qd), _p(qf), len(k1), _p(k2), _p(cd), _p(cf), len(k2), _p(nqs), _p(qi),
+                                               _p(ncs), _p(ci), len(nqs) - 1, _p(F), float(ex), float(ey), _p(sf), _p(s2), len(sf),
+                                               int(max_dist), int(check_orientation), _p(mq), C.byref(n), int(device)))
     return n.value, mq

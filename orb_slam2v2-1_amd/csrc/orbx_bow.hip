@@ -316,3 +316,126 @@ extern "C" int orbm_search_by_bow(const uint8_t *q_desc, const float *q_angle, c
     *nmatches = out[0];
     return ORBX_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-825): same node structure as SearchByBoW, but the best
+// candidate is the LAST one (in list order) of minimum distance among those that pass the two geometric tests,
+// which depend on the pair only: key = dist << 32 | ~position, one wave minimum.
+struct TriGeom { float F[9]; float ex, ey; float sf[ORBX_MAX_LEVELS], sig2[ORBX_MAX_LEVELS]; };
+__global__ __launch_bounds__(256) void k_tri_match(const orbx_keypoint_t *__restrict__ k1, const uint8_t *__restrict__ qd,
+                                                   const uint8_t *__restrict__ qf, const orbx_keypoint_t *__restrict__ k2,
+                                                   const uint8_t *__restrict__ cd, const uint8_t *__restrict__ cf,
+                                                   const int32_t *__restrict__ nqs, const int32_t *__restrict__ qit,
+                                                   const int32_t *__restrict__ ncs, const int32_t *__restrict__ cit,
+                                                   int nnodes, TriGeom G, int max_dist, int32_t *__restrict__ match_q,
+                                                   int32_t *__restrict__ overflow) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= nnodes) return;
+    const int q0 = nqs[j], q1 = nqs[j + 1], c0 = ncs[j], nc = ncs[j + 1] - c0;
+    if (nc > 64 * 64) { if (lane == 0) *overflow = 1; return; }
+    u64 taken = 0;
+    for (int q = q0; q < q1; q++) {
+        const int iq = qit[q];
+        const int fq = qf[iq];
+        if (!(fq & 1)) continue;
+        const bool stereo1 = (fq & 2) != 0;
+        const orbx_keypoint_t kp1 = k1[iq];
+        const Desc256 dq = load_desc(qd + (size_t)iq * 32);
+        // epipolar line in the second image l = x1'F12 = [a b c]   (:142-145)
+        const float a = kp1.x * G.F[0] + kp1.y * G.F[3] + G.F[6];
+        const float b = kp1.x * G.F[1] + kp1.y * G.F[4] + G.F[7];
+        const float c = kp1.x * G.F[2] + kp1.y * G.F[5] + G.F[8];
+        const float den = a * a + b * b;
+        u64 best = ~0ull;
+        for (int p = lane; p < nc; p += 64) {
+            if ((taken >> (p >> 6)) & 1ull) continue;                    // vbMatched2   (:724)
+            const int ic = cit[c0 + p];
+            const int fc = cf[ic];
+            if (!(fc & 1)) continue;
+            const int dist = ham(dq, load_desc(cd + (size_t)ic * 32));
+            if (dist > max_dist) continue;                               // :737 (dist > bestDist is implied by the minimum)
+            const orbx_keypoint_t kp2 = k2[ic];
+            const int oct = min(max(kp2.octave, 0), ORBX_MAX_LEVELS - 1);
+            if (!stereo1 && !(fc & 2)) {                                 // :742-748
+                const float distex = G.ex - kp2.x, distey = G.ey - kp2.y;
+                if (distex * distex + distey * distey < 100 * G.sf[oct]) continue;
+            }
+            const float num = a * kp2.x + b * kp2.y + c;                 // :147-156
+            if (den == 0) continue;
+            const float dsqr = num * num / den;
+            if (!((double)dsqr < 3.84 * (double)G.sig2[oct])) continue;
+            const u64 key = ((u64)dist << 32) | (u64)(0xFFFFFFFFu - (unsigned)p);
+            best = key < best ? key : best;
+        }
+        best = wave_min_u64(best);
+        if (best == ~0ull) continue;
+        const int p = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFu));
+        if (lane == (p & 63)) taken |= 1ull << (p >> 6);
+        if (lane == 0) match_q[iq] = cit[c0 + p];
+    }
+}
+__global__ __launch_bounds__(256) void k_kp_angles(const orbx_keypoint_t *__restrict__ k, int n, float *__restrict__ a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) a[i] = k[i].angle;
+}
+
+extern "C" int orbm_search_for_triangulation(const orbx_keypoint_t *kp1, const uint8_t *q_desc, const uint8_t *q_flags, int nq,
+                                             const orbx_keypoint_t *kp2, const uint8_t *c_desc, const uint8_t *c_flags, int nc,
+                                             const int32_t *node_qstart, const int32_t *q_items, const int32_t *node_cstart,
+                                             const int32_t *c_items, int nnodes, const float *F12_9, float ex, float ey,
+                                             const float *scale_factors, const float *level_sigma2, int nlevels, int max_dist,
+                                             int check_orientation, int32_t *match_q, int *nmatches, int device) {
+    if (nq < 0 || nc < 0 || nnodes < 0 || !nmatches || !F12_9 || !scale_factors || !level_sigma2 || nlevels < 1 || nlevels > ORBX_MAX_LEVELS ||
+        (nq > 0 && (!kp1 || !q_desc || !q_flags || !match_q)) || (nc > 0 && (!kp2 || !c_desc || !c_flags)) ||
+        (nnodes > 0 && (!node_qstart || !node_cstart))) {
+        orbx_set_error("orbm_search_for_triangulation: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    *nmatches = 0;
+    for (int i = 0; i < nq; i++) match_q[i] = -1;
+    if (nq == 0 || nc == 0 || nnodes == 0) return ORBX_OK;
+    const int tq = node_qstart[nnodes], tc = node_cstart[nnodes];
+    if (node_qstart[0] != 0 || node_cstart[0] != 0 || tq < 0 || tc < 0 || (tq > 0 && !q_items) || (tc > 0 && !c_items)) { orbx_set_error("orbm_search_for_triangulation: bad node lists"); return ORBX_ERR_ARG; }
+    for (int j = 0; j < nnodes; j++)
+        if (node_qstart[j + 1] < node_qstart[j] || node_cstart[j + 1] < node_cstart[j]) { orbx_set_error("orbm_search_for_triangulation: node lists not monotonic at %d", j); return ORBX_ERR_ARG; }
+    for (int i = 0; i < tq; i++) if (q_items[i] < 0 || q_items[i] >= nq) { orbx_set_error("q_items[%d] out of range", i); return ORBX_ERR_ARG; }
+    for (int i = 0; i < tc; i++) if (c_items[i] < 0 || c_items[i] >= nc) { orbx_set_error("c_items[%d] out of range", i); return ORBX_ERR_ARG; }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += ALN(bytes); return o; };
+    const size_t o_k1 = take((size_t)nq * sizeof(orbx_keypoint_t)), o_qd = take((size_t)nq * 32), o_qf = take(nq), o_qa = take((size_t)nq * 4),
+                 o_k2 = take((size_t)nc * sizeof(orbx_keypoint_t)), o_cd = take((size_t)nc * 32), o_cf = take(nc), o_ca = take((size_t)nc * 4),
+                 o_nqs = take((size_t)(nnodes + 1) * 4), o_ncs = take((size_t)(nnodes + 1) * 4), o_qi = take((size_t)(tq > 0 ? tq : 1) * 4),
+                 o_ci = take((size_t)(tc > 0 ? tc : 1) * 4), o_m = take((size_t)nq * 4), o_out = take(16);
+    uint8_t *base;
+    int rc = scratch(device, off, &base);
+    if (rc) return rc;
+    H2DB(o_k1, kp1, (size_t)nq * sizeof(orbx_keypoint_t)); H2DB(o_qd, q_desc, (size_t)nq * 32); H2DB(o_qf, q_flags, nq);
+    H2DB(o_k2, kp2, (size_t)nc * sizeof(orbx_keypoint_t)); H2DB(o_cd, c_desc, (size_t)nc * 32); H2DB(o_cf, c_flags, nc);
+    H2DB(o_nqs, node_qstart, (size_t)(nnodes + 1) * 4); H2DB(o_ncs, node_cstart, (size_t)(nnodes + 1) * 4);
+    if (tq > 0) H2DB(o_qi, q_items, (size_t)tq * 4);
+    if (tc > 0) H2DB(o_ci, c_items, (size_t)tc * 4);
+    ORBX_HIP(hipMemset(base + o_m, 0xFF, (size_t)nq * 4));
+    ORBX_HIP(hipMemset(base + o_out, 0, 16));
+    TriGeom G;
+    memcpy(G.F, F12_9, sizeof(G.F));
+    G.ex = ex; G.ey = ey;
+    for (int l = 0; l < ORBX_MAX_LEVELS; l++) { G.sf[l] = scale_factors[l < nlevels ? l : nlevels - 1]; G.sig2[l] = level_sigma2[l < nlevels ? l : nlevels - 1]; }
+    (void)hipGetLastError();
+    int32_t *dout = (int32_t *)(base + o_out);
+    hipLaunchKernelGGL(k_kp_angles, dim3((nq + 255) / 256), dim3(256), 0, 0, (const orbx_keypoint_t *)(base + o_k1), nq, (float *)(base + o_qa));
+    hipLaunchKernelGGL(k_kp_angles, dim3((nc + 255) / 256), dim3(256), 0, 0, (const orbx_keypoint_t *)(base + o_k2), nc, (float *)(base + o_ca));
+    hipLaunchKernelGGL(k_tri_match, dim3((nnodes + 3) / 4), dim3(256), 0, 0, (const orbx_keypoint_t *)(base + o_k1), base + o_qd, base + o_qf,
+                       (const orbx_keypoint_t *)(base + o_k2), base + o_cd, base + o_cf, (const int32_t *)(base + o_nqs),
+                       (const int32_t *)(base + o_qi), (const int32_t *)(base + o_ncs), (const int32_t *)(base + o_ci), nnodes, G, max_dist,
+                       (int32_t *)(base + o_m), dout + 1);
+    hipLaunchKernelGGL(k_bow_orient, dim3(1), dim3(256), 0, 0, (const float *)(base + o_qa), (const float *)(base + o_ca), nq,
+                       (int32_t *)(base + o_m), check_orientation, dout);
+    ORBX_HIP(hipGetLastError());
+    int32_t out[2] = {0, 0};
+    ORBX_HIP(hipMemcpy(out, dout, 8, hipMemcpyDeviceToHost));
+    if (out[1]) { orbx_set_error("orbm_search_for_triangulation: a vocabulary node holds more than 4096 candidate features"); return ORBX_ERR_UNSUPPORTED; }
+    ORBX_HIP(hipMemcpy(match_q, base + o_m, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    *nmatches = out[0];
+    return ORBX_OK;
+}

@@ -550,6 +550,50 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint
     return nmatches;
 }
 
+int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12,
+                                       std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo) {
+    vMatchedPairs.clear();
+    const int nq = pKF1->N, nc = pKF2->N;
+    if (nq == 0 || nc == 0) return 0;
+    // epipole in the second image (:663-670): C2 = R2w*Cw + t2w is a gemm (double accumulation, one rounding)
+    cv::Mat Cw = pKF1->GetCameraCenter(), R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();
+    float C2[3];
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)R2w.at<float>(r, k) * (double)Cw.at<float>(k);
+        C2[r] = (float)(s + (double)t2w.at<float>(r));
+    }
+    const float invz = 1.0f / C2[2];
+    const float ex = pKF2->fx * C2[0] * invz + pKF2->cx;
+    const float ey = pKF2->fy * C2[1] * invz + pKF2->cy;
+    std::vector<int32_t> sq, iq, sc, ic;
+    intersect_feature_vectors(pKF1->mFeatVec, pKF2->mFeatVec, sq, iq, sc, ic);
+    std::vector<orbx_keypoint_t> k1, k2; gather_keypoints(pKF1->mvKeysUn, k1); gather_keypoints(pKF2->mvKeysUn, k2);
+    std::vector<uint8_t> qd, cd, qf(nq), cf(nc);
+    gather_descriptors(pKF1->mDescriptors, nq, qd); gather_descriptors(pKF2->mDescriptors, nc, cd);
+    for (int i = 0; i < nq; i++) {
+        const bool stereo = pKF1->mvuRight[i] >= 0;
+        qf[i] = (uint8_t)((!pKF1->GetMapPoint(i) && (!bOnlyStereo || stereo) ? 1 : 0) | (stereo ? 2 : 0));   // :700-710
+    }
+    for (int i = 0; i < nc; i++) {
+        const bool stereo = pKF2->mvuRight[i] >= 0;
+        cf[i] = (uint8_t)((!pKF2->GetMapPoint(i) && (!bOnlyStereo || stereo) ? 1 : 0) | (stereo ? 2 : 0));   // :721-731
+    }
+    float F[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) F[r * 3 + c] = F12.at<float>(r, c);
+    std::vector<int32_t> match(nq, -1);
+    int nmatches = 0;
+    if (orbm_search_for_triangulation(k1.data(), qd.data(), qf.data(), nq, k2.data(), cd.data(), cf.data(), nc, sq.data(), iq.data(),
+                                      sc.data(), ic.data(), (int)sq.size() - 1, F, ex, ey, pKF2->mvScaleFactors.data(),
+                                      pKF2->mvLevelSigma2.data(), (int)pKF2->mvScaleFactors.size(), TH_LOW,
+                                      mbCheckOrientation ? 1 : 0, match.data(), &nmatches, device) != ORBX_OK)
+        return fail("SearchForTriangulation");
+    vMatchedPairs.reserve(nmatches);
+    for (int i = 0; i < nq; i++)
+        if (match[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)match[i]));   // :812-822
+    return nmatches;
+}
+
 int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched,
                                         std::vector<int> &vnMatches12, int windowSize) {
     const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();

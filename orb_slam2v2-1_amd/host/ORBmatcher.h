@@ -1,10 +1,11 @@
 // ORBmatcher.h — the hot routines of the reference's include/ORBmatcher.h:37-102 with the
 // same names, signatures and constants, executed on an MI355X through include/orbx.h.
-// (SearchForTriangulation stays on the reference's CPU implementation.)
+// Every public matcher of the reference's ORBmatcher is covered.
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
 #include <set>
+#include <utility>
 #include <vector>
 #include "cv_shim.h"
 #include "frame_shim.h"
@@ -55,6 +56,10 @@ public:
     // Used in Relocalisation and Loop Detection                      (src/ORBmatcher.cc:159-288, 522-655)
     int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);
     int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12);
+
+    // Matching to triangulate new MapPoints. Check Epipolar Constraint.   (src/ORBmatcher.cc:657-825)
+    int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12,
+                               std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo);
 
     // Matching for the Map Initialization (only used in the monocular case) (src/ORBmatcher.cc:405-520)
     int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched,

@@ -152,7 +152,7 @@ public:
     cv::Mat mDescriptors;
     int mnScaleLevels = 0;
     float mfLogScaleFactor = 0.f;
-    std::vector<float> mvScaleFactors, mvInvLevelSigma2;
+    std::vector<float> mvScaleFactors, mvInvLevelSigma2, mvLevelSigma2;
     int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;   // ints: include/KeyFrame.h:199-202
     float mfGridElementWidthInv = 0.f, mfGridElementHeightInv = 0.f;
     std::vector<MapPoint *> mvpMapPoints;

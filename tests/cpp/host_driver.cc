@@ -334,6 +334,51 @@ static int bow_mode(int argc, char **argv) {
     return 0;
 }
 
+static int tri_mode(int argc, char **argv) {
+    // argv: tri voc.txt d1.bin k1.bin(orbx_keypoint_t[n1]) m1.bin(u8 has map point) ur1.bin(f32) d2.bin k2.bin m2.bin ur2.bin aux.bin onlyStereo out
+    // aux: F12[9], T1w[16], T2w[16], fx, fy, cx, cy (f32)
+    if (argc != 14) return 2;
+    ORBVocabulary voc;
+    if (!voc.loadFromTextFile(argv[2])) return 3;
+    std::vector<unsigned char> d1 = slurp(argv[3]), k1 = slurp(argv[4]), m1 = slurp(argv[5]), u1 = slurp(argv[6]), d2 = slurp(argv[7]),
+                               k2 = slurp(argv[8]), m2 = slurp(argv[9]), u2 = slurp(argv[10]), aux = slurp(argv[11]);
+    const bool onlyStereo = atoi(argv[12]) != 0;
+    const std::string out = argv[13];
+    const int n1 = (int)m1.size(), n2 = (int)m2.size();
+    const float *fa = (const float *)aux.data();
+    KeyFrame K[2];
+    std::vector<MapPoint> pts(n1 + n2);
+    for (int s = 0; s < 2; s++) {
+        const int n = s ? n2 : n1;
+        const orbx_keypoint_t *kp = (const orbx_keypoint_t *)(s ? k2.data() : k1.data());
+        K[s].mpORBvocabulary = &voc;
+        K[s].N = n;
+        K[s].mDescriptors = cv::Mat(n, 32, CV_8U, (s ? d2 : d1).data()).clone();
+        K[s].mvKeysUn.resize(n); K[s].mvpMapPoints.assign(n, (MapPoint *)NULL);
+        K[s].mvuRight.assign((const float *)(s ? u2 : u1).data(), (const float *)(s ? u2 : u1).data() + n);
+        for (int i = 0; i < n; i++) {
+            K[s].mvKeysUn[i].pt.x = kp[i].x; K[s].mvKeysUn[i].pt.y = kp[i].y; K[s].mvKeysUn[i].octave = kp[i].octave; K[s].mvKeysUn[i].angle = kp[i].angle;
+            if ((s ? m2 : m1)[i]) K[s].mvpMapPoints[i] = &pts[s * n1 + i];
+        }
+        K[s].mvScaleFactors.resize(8); K[s].mvLevelSigma2.resize(8);
+        K[s].mvScaleFactors[0] = 1.0f; K[s].mvLevelSigma2[0] = 1.0f;
+        for (int l = 1; l < 8; l++) { K[s].mvScaleFactors[l] = K[s].mvScaleFactors[l - 1] * 1.2f; K[s].mvLevelSigma2[l] = K[s].mvScaleFactors[l] * K[s].mvScaleFactors[l]; }   // src/ORBextractor.cc:417-424
+        K[s].fx = fa[41]; K[s].fy = fa[42]; K[s].cx = fa[43]; K[s].cy = fa[44];
+        K[s].SetPose(mat4(fa + 9 + 16 * s));
+        K[s].ComputeBoW();
+    }
+    cv::Mat F12(3, 3, CV_32F);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) F12.at<float>(r, c) = fa[r * 3 + c];
+    ORBmatcher matcher(0.6f, false);   // src/LocalMapping.cc:223
+    std::vector<std::pair<size_t, size_t> > pairs;
+    const int n = matcher.SearchForTriangulation(&K[0], &K[1], F12, pairs, onlyStereo);
+    std::vector<int> res;
+    for (size_t i = 0; i < pairs.size(); i++) { res.push_back((int)pairs[i].first); res.push_back((int)pairs[i].second); }
+    dump(out + ".i32", res.data(), res.size() * 4);
+    printf("%d %d %d\n", n1, n2, n);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) return 2;
     const std::string mode = argv[1];
@@ -342,6 +387,7 @@ int main(int argc, char **argv) {
     if (mode == "distinct") return distinct_mode(argc, argv);
     if (mode == "local") return local_mode(argc, argv);
     if (mode == "bow") return bow_mode(argc, argv);
+    if (mode == "tri") return tri_mode(argc, argv);
     if (mode == "extract" && argc == 7) {
         const int w = atoi(argv[3]), h = atoi(argv[4]), nf = atoi(argv[5]);
         const std::string out = argv[6];

@@ -421,3 +421,62 @@ def test_bow_classes(driver, oracle, tmp_path):
     onB, mB = oracle.search_by_bow(d1, a1, v1 == 1, d2, a2, v2 == 1, nqs, qit, ncs, cit, 50, 1, ratio, True)
     assert nB == onB > 80
     np.testing.assert_array_equal(res[n2:], mB)
+
+
+@pytest.mark.parametrize("only_stereo", [0, 1])
+def test_search_for_triangulation_class(driver, oracle, tmp_path, only_stereo):
+    """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-825) through the C++ class: epipole from the two
+    keyframe poses, flags from map points / mvuRight / bOnlyStereo, pairs in increasing first index."""
+    import bow_scene as bs
+    import kf_scene as ks
+    rng = np.random.default_rng(23 + only_stereo)
+    voc = bs.make_vocabulary(rng, k=9, L=5, early_leaf=0.03)
+    ov = oracle.Vocabulary(9, 5, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    bs.write_text(voc, tmp_path / "voc.txt")
+    base = bs.features_near_words(rng, voc, 900, noise_bits=4)
+    pos = np.stack([rng.uniform(20, 1220, len(base)), rng.uniform(20, 356, len(base))], 1)
+
+    def frame(n, dx):
+        nd = n // 6
+        src = np.concatenate([rng.permutation(len(base))[:n - nd], rng.integers(0, len(base), nd)])
+        rng.shuffle(src)
+        noise = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        for _ in range(4):
+            noise &= rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        k = np.zeros(n, oracle.KP_DTYPE)
+        k["x"] = pos[src, 0] + dx + rng.normal(0, 0.3, n); k["y"] = pos[src, 1] + rng.normal(0, 0.8, n)
+        k["octave"] = rng.integers(0, 8, n); k["angle"] = (src * 0.5 + rng.normal(0, 3, n)) % 360
+        has_mp = (rng.random(n) < 0.25).astype(np.uint8)
+        ur = np.where(rng.random(n) < 0.5, k["x"] - rng.uniform(1, 30, n), -1).astype(np.float32)
+        return base[src] ^ noise, k, has_mp, ur
+    d1, k1, m1, u1 = frame(800, 0.0)
+    d2, k2, m2, u2 = frame(820, -12.0)
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    T1 = ks.pose(rng); T2 = ks.pose(rng); T2[0, 3] += 0.4
+    cam = np.array([ks.FX, ks.FY, ks.CX, ks.CY], np.float32)
+    for name, arr in (("d1", d1), ("k1", k1), ("m1", m1), ("u1", u1), ("d2", d2), ("k2", k2), ("m2", m2), ("u2", u2)):
+        np.ascontiguousarray(arr).tofile(tmp_path / (name + ".bin"))
+    with open(tmp_path / "aux.bin", "wb") as f:
+        for a in (F12, T1, T2, cam):
+            f.write(np.ascontiguousarray(a, np.float32).tobytes())
+    n1, n2, n = _run(driver, "tri", tmp_path / "voc.txt", *[tmp_path / (x + ".bin") for x in ("d1", "k1", "m1", "u1", "d2", "k2", "m2", "u2")],
+                     tmp_path / "aux.bin", only_stereo, tmp_path / "o")
+    # the epipole exactly as :663-670 evaluates it
+    Cw = np.array([np.float32(-sum(np.float64(T1[k, i]) * np.float64(T1[k, 3]) for k in range(3))) for i in range(3)], np.float32)
+    C2 = np.array([np.float32(sum(np.float64(T2[r, k]) * np.float64(Cw[k]) for k in range(3)) + np.float64(T2[r, 3])) for r in range(3)], np.float32)
+    invz = np.float32(1.0) / C2[2]
+    ex = cam[0] * C2[0] * invz + cam[2]; ey = cam[1] * C2[1] * invz + cam[3]
+    st1, st2 = u1 >= 0, u2 >= 0
+    f1 = (((m1 == 0) & (st1 | (only_stereo == 0))).astype(np.uint8)) | (st1.astype(np.uint8) << 1)
+    f2 = (((m2 == 0) & (st2 | (only_stereo == 0))).astype(np.uint8)) | (st2.astype(np.uint8) << 1)
+    sf = np.ones(8, np.float32)
+    for l in range(1, 8):
+        sf[l] = sf[l - 1] * np.float32(1.2)
+    _, _, fv1 = ov.transform(d1, 4); _, _, fv2 = ov.transform(d2, 4)
+    nqs, qit, ncs, cit = bs.intersect(fv1, fv2)
+    on, om = oracle.search_for_triangulation(k1, d1, f1, k2, d2, f2, nqs, qit, ncs, cit, F12, ex, ey, sf, sf * sf, 50, False)
+    res = np.fromfile(str(tmp_path / "o.i32"), np.int32).reshape(-1, 2)
+    assert n == on > 40 and len(res) == on
+    idx = np.flatnonzero(om >= 0)
+    np.testing.assert_array_equal(res[:, 0], idx)
+    np.testing.assert_array_equal(res[:, 1], om[idx])

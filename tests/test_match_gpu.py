@@ -518,3 +518,46 @@ def test_search_by_bow(pkg, oracle, bow, variant):
         assert on > 150
         assert gn == on
         np.testing.assert_array_equal(gm, om)
+
+
+def test_search_for_triangulation(pkg, oracle, bow):
+    """orbm_search_for_triangulation vs ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:657-825): node-constrained
+    search, epipole and epipolar-line tests, LAST candidate of minimum distance wins, rotation consistency."""
+    bs, rng, voc, ov, gv = bow
+    n1, n2 = 1000, 1050
+    base = bs.features_near_words(rng, voc, 1100, noise_bits=4)
+    pos = np.stack([rng.uniform(20, 1220, len(base)), rng.uniform(20, 356, len(base))], 1)
+
+    def frame(n, dx):
+        nd = n // 6
+        src = np.concatenate([rng.permutation(len(base))[:n - nd], rng.integers(0, len(base), nd)])
+        rng.shuffle(src)
+        noise = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        for _ in range(4):
+            noise &= rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        k = np.zeros(n, oracle.KP_DTYPE)
+        k["x"] = pos[src, 0] + dx + rng.normal(0, 0.3, n)         # pure horizontal motion: epipolar lines are the rows
+        k["y"] = pos[src, 1] + rng.normal(0, 0.8, n)
+        k["octave"] = rng.integers(0, 8, n)
+        k["angle"] = (src * 0.5 + rng.normal(0, 3, n)) % 360
+        flags = (rng.random(n) > 0.2).astype(np.uint8) | ((rng.random(n) < 0.4).astype(np.uint8) << 1)
+        return base[src] ^ noise, k, flags
+    d1, k1, f1 = frame(n1, 0.0)
+    d2, k2, f2 = frame(n2, -12.0)
+    # fundamental matrix of a pure x-translation: l = x1'F12 = (0, -1, y1) up to scale
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    ex, ey = 600.0, 180.0                                         # an epipole inside the image: the distance test bites
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    sigma2 = (sf * sf).astype(np.float32)
+    _, _, fv1 = ov.transform(d1, 1)
+    _, _, fv2 = ov.transform(d2, 1)
+    nqs, qit, ncs, cit = bs.intersect(fv1, fv2)
+    for ori in (True, False):
+        on, om = oracle.search_for_triangulation(k1, d1, f1, k2, d2, f2, nqs, qit, ncs, cit, F12, ex, ey, sf, sigma2, 50, ori)
+        gn, gm = pkg.search_for_triangulation(k1, d1, f1, k2, d2, f2, nqs, qit, ncs, cit, F12, ex, ey, sf, sigma2, 50, ori)
+        assert on > 150
+        assert gn == on
+        np.testing.assert_array_equal(gm, om)
+    # without the epipolar gate (all-zero F12: den == 0) nothing may match
+    zn, zm = pkg.search_for_triangulation(k1, d1, f1, k2, d2, f2, nqs, qit, ncs, cit, np.zeros((3, 3), np.float32), ex, ey, sf, sigma2)
+    assert zn == 0 and (zm == -1).all()
