@@ -235,7 +235,8 @@ class ORBextractor:
         if image.size == 0:  # empty image: silent return (src/ORBextractor.cc:1046-1047)
             return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
         assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 expected (:1050)"
-        image = np.ascontiguousarray(image)
+        if image.strides[1] != 1 or image.strides[0] < image.shape[1]:
+            image = np.ascontiguousarray(image)   # a row-strided view (ROI of a wider image) is passed as it is
         h, w = image.shape
         cap = max(self.nfeatures + 8 * self.nlevels, 64) + 260
         kps = np.zeros(cap, KP_DTYPE)

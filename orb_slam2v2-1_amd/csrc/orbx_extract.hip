@@ -2114,15 +2114,18 @@ extern "C" int orbx_extract_batch(orbx_extractor_t *h, const uint8_t *const *img
     ORBX_HIP(hipSetDevice(h->device));
     int rc = ensure_plan(h, w, hgt, B);
     if (rc) return rc;
-    const size_t img_bytes = ((size_t)w * hgt + 255) & ~(size_t)255;
+    // One linear copy per image with the caller's row stride kept on the device (the kernels take a stride):
+    // a 2-D copy of rows whose width is not a multiple of 4 bytes (1241!) runs ~100x slower than a linear one.
+    const size_t span = (size_t)stride * (hgt - 1) + w;
+    const size_t img_bytes = (span + 255) & ~(size_t)255;
     rc = ensure_staging(h, img_bytes * B, B, cap);
     if (rc) return rc;
     const int dcap = h->out_cap;
     for (int b = 0; b < B; b++) {
         if (!imgs[b]) { orbx_set_error("imgs[%d] is NULL", b); return ORBX_ERR_ARG; }
-        ORBX_HIP(hipMemcpy2DAsync(h->d_in + img_bytes * b, w, imgs[b], stride, w, hgt, hipMemcpyHostToDevice, h->stream));
+        ORBX_HIP(hipMemcpyAsync(h->d_in + img_bytes * b, imgs[b], span, hipMemcpyHostToDevice, h->stream));
     }
-    rc = launch_pipeline(h, h->d_in, B, w, hgt, w, img_bytes, h->d_kps, h->d_desc, h->d_counts, dcap, h->stream);
+    rc = launch_pipeline(h, h->d_in, B, w, hgt, stride, img_bytes, h->d_kps, h->d_desc, h->d_counts, dcap, h->stream);
     if (rc) return rc;
     std::vector<int32_t> cnt(B);
     ORBX_HIP(hipMemcpyAsync(cnt.data(), h->d_counts, sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->stream));
@@ -2189,7 +2192,12 @@ extern "C" int orbx_pyramid_host(orbx_extractor_t *h, int b, int level, int padd
     if (h->last_stream) ORBX_HIP(hipStreamSynchronize(h->last_stream));
     const uint8_t *src = h->d_pyr + (size_t)b * h->pyrImgBytes + g.poff +
                          (padded ? 0 : (size_t)ORBX_EDGE * g.pstride + ORBX_EDGE);
-    ORBX_HIP(hipMemcpy2D(dst, dst_stride, src, g.pstride, ow, oh, hipMemcpyDeviceToHost));
+    // linear device-to-host copy of the row span, rows unpacked on the host (2-D copies of odd widths are very slow)
+    const size_t span = (size_t)g.pstride * (oh - 1) + ow;
+    static thread_local std::vector<uint8_t> tmp;
+    if (tmp.size() < span) tmp.resize(span);
+    ORBX_HIP(hipMemcpy(tmp.data(), src, span, hipMemcpyDeviceToHost));
+    for (int r = 0; r < oh; r++) memcpy(dst + (size_t)r * dst_stride, tmp.data() + (size_t)r * g.pstride, ow);
     return ORBX_OK;
 }
 

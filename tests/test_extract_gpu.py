@@ -241,3 +241,26 @@ def test_quadtree_pyramid_overflow_falls_back(pkg, oracle):
     img[200:280, 260:380] = rng.integers(0, 256, (80, 120), dtype=np.uint8)   # all corners in 2 % of the image
     k = _compare(pkg, oracle, img, 3000)
     assert len(k) > 0  # the reference stops early on clustered input (size == prevSize, :669)
+
+
+def test_host_api_latency_odd_width(pkg, synth):
+    """orbx_extract from host memory at 1241x376 (a width that is not a multiple of 4): the image goes up as ONE
+    linear copy with the caller's stride kept on the device — a 2-D copy of 1241-byte rows took 3 ms per image.
+    Generous bound (measured 0.22 ms)."""
+    import time
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    img = synth.frame(1241, 376, 90)
+    for _ in range(3):
+        ex(img)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        k, d = ex(img)
+    dt = (time.perf_counter() - t0) / 10
+    assert len(k) > 900
+    assert dt < 1.5e-3, "orbx_extract took %.3f ms per 1241x376 image" % (dt * 1e3)
+    # a strided source (ROI of a wider buffer) gives the same keypoints
+    wide = np.zeros((376, 1300), np.uint8)
+    wide[:, 13:13 + 1241] = img
+    k2, d2 = ex(wide[:, 13:13 + 1241])
+    np.testing.assert_array_equal(k2, k)
+    np.testing.assert_array_equal(d2, d)
