@@ -140,14 +140,42 @@ __device__ __forceinline__ bool chunk_conflict(int claim, int myBest, int mySeco
     return conflict;
 }
 
+// The same test through an LDS table (one byte per keypoint, 0 = unclaimed, else lane + 1): every claiming lane
+// settles the table entry of its keypoint on the SMALLEST claiming lane (a write / read-back round per
+// competitor, one or two in practice), every active lane looks its two keypoints up, claimants clear their
+// entry.  O(1) per round instead of 63 readlane steps — the resolver is a single wave, so this is its critical path.
+__device__ __forceinline__ bool chunk_conflict_lds(uint8_t *claimtab, int claim, int myBest, int mySecond, bool act) {
+    const int lane = threadIdx.x & 63;
+    const uint8_t me = (uint8_t)(lane + 1);
+    for (;;) {
+        bool wrote = false;
+        if (claim >= 0) {
+            const uint8_t cur = claimtab[claim];
+            if (cur == 0 || cur > me) { claimtab[claim] = me; wrote = true; }
+        }
+        wave_sync();
+        if (!__ballot(wrote)) break;
+    }
+    bool conflict = false;
+    if (act) {
+        const uint8_t c1 = myBest >= 0 ? claimtab[myBest] : (uint8_t)0, c2 = mySecond >= 0 ? claimtab[mySecond] : (uint8_t)0;
+        conflict = (c1 != 0 && c1 < me) || (c2 != 0 && c2 < me);
+    }
+    wave_sync();
+    if (claim >= 0) claimtab[claim] = 0;
+    wave_sync();
+    return conflict;
+}
+
 // ---- B1. SearchByProjection(Frame, MapPoints): resolution  (src/ORBmatcher.cc:98-125)
 __global__ __launch_bounds__(64) void k_resolve_mp(const u64 *__restrict__ keys, const int32_t *__restrict__ ncand,
                                                    const orbm_mappoint_t *__restrict__ mps, int m, int n,
                                                    int32_t *__restrict__ frame_mp, float nnratio,
                                                    int32_t *__restrict__ out /* [0] nmatches [1] overflow */) {
-    extern __shared__ uint8_t blocked[];  // [n] dynamic: keypoint got a holder with Observations() > 0
+    extern __shared__ uint8_t blocked[];  // [n] dynamic: keypoint got a holder with Observations() > 0; then the claim table [n]
+    uint8_t *claimtab = blocked + ((n + 15) & ~15);
     const int lane = threadIdx.x;
-    for (int j = lane; j < n; j += 64) blocked[j] = 0;
+    for (int j = lane; j < n; j += 64) { blocked[j] = 0; claimtab[j] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     int nm = 0;
@@ -185,7 +213,7 @@ __global__ __launch_bounds__(64) void k_resolve_mp(const u64 *__restrict__ keys,
             }
             const bool accept = act && best >= 0 && bestDist <= TH_HIGH &&
                                 !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
-            const bool conflict = chunk_conflict(accept ? best : -1, best, second, pending) && act;
+            const bool conflict = chunk_conflict_lds(claimtab, accept ? best : -1, best, second, act);
             const u64 cm = __ballot(conflict);
             const u64 commit = cm ? (pending & ((1ull << __builtin_ctzll(cm)) - 1ull)) : pending;
             const bool mineCommits = (commit >> lane) & 1ull;
@@ -211,12 +239,13 @@ __global__ __launch_bounds__(64) void k_resolve_init(const u64 *__restrict__ key
                                                      int n1, int n2, float *__restrict__ prev, int32_t *__restrict__ m12,
                                                      int32_t *__restrict__ bin1, float nnratio, int check_ori,
                                                      int32_t *__restrict__ out) {
-    extern __shared__ int32_t sm[];  // vmd[n2], m21[n2]
+    extern __shared__ int32_t sm[];  // vmd[n2], m21[n2], claim table [n2] bytes
     int32_t *vmd = sm, *m21 = sm + n2;
+    uint8_t *claimtab = (uint8_t *)(sm + 2 * n2);
     __shared__ int hn[HISTO_LENGTH];
     __shared__ int ind[3];
     const int lane = threadIdx.x;
-    for (int j = lane; j < n2; j += 64) { vmd[j] = INT_MAX; m21[j] = -1; }
+    for (int j = lane; j < n2; j += 64) { vmd[j] = INT_MAX; m21[j] = -1; claimtab[j] = 0; }
     for (int i = lane; i < n1; i += 64) { m12[i] = -1; bin1[i] = -1; }
     if (lane < HISTO_LENGTH) hn[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -250,7 +279,7 @@ __global__ __launch_bounds__(64) void k_resolve_init(const u64 *__restrict__ key
             }
             const bool ranout = false;
             const bool accept = act && best >= 0 && bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * nnratio;
-            const bool conflict = chunk_conflict(accept ? best : -1, best, second, pending) && act;
+            const bool conflict = chunk_conflict_lds(claimtab, accept ? best : -1, best, second, act);
             const u64 cm = __ballot(conflict);
             const u64 commit = cm ? (pending & ((1ull << __builtin_ctzll(cm)) - 1ull)) : pending;
             const bool mineCommits = (commit >> lane) & 1ull;
@@ -298,11 +327,12 @@ __global__ __launch_bounds__(64) void k_resolve_frame(const u64 *__restrict__ ke
                                                       int32_t *__restrict__ cur_mp, int32_t *__restrict__ hist_idx,
                                                       int32_t *__restrict__ hist_bin, int check_ori,
                                                       int32_t *__restrict__ out) {
-    extern __shared__ uint8_t blocked[];
+    extern __shared__ uint8_t blocked[];   // [n], then the claim table [n]
+    uint8_t *claimtab = blocked + ((n + 15) & ~15);
     __shared__ int hn[HISTO_LENGTH];
     __shared__ int ind[3];
     const int lane = threadIdx.x;
-    for (int j = lane; j < n; j += 64) blocked[j] = 0;
+    for (int j = lane; j < n; j += 64) { blocked[j] = 0; claimtab[j] = 0; }
     if (lane < HISTO_LENGTH) hn[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -334,7 +364,7 @@ __global__ __launch_bounds__(64) void k_resolve_frame(const u64 *__restrict__ ke
                 ranout = best < 0 && nc > QK;
             }
             const bool accept = act && best >= 0 && bestDist <= TH_HIGH;
-            const bool conflict = chunk_conflict(accept ? best : -1, best, -1, pending) && act;
+            const bool conflict = chunk_conflict_lds(claimtab, accept ? best : -1, best, -1, act);
             const u64 cm = __ballot(conflict);
             const u64 commit = cm ? (pending & ((1ull << __builtin_ctzll(cm)) - 1ull)) : pending;
             const bool mineCommits = (commit >> lane) & 1ull;
@@ -383,11 +413,12 @@ __global__ __launch_bounds__(64) void k_resolve_windows(const u64 *__restrict__ 
                                                         int32_t *__restrict__ holder, int32_t *__restrict__ hist_idx,
                                                         int32_t *__restrict__ hist_bin, int max_dist, int check_ori,
                                                         int32_t *__restrict__ out) {
-    extern __shared__ uint8_t blocked[];
+    extern __shared__ uint8_t blocked[];   // [n], then the claim table [n]
+    uint8_t *claimtab = blocked + ((n + 15) & ~15);
     __shared__ int hn[HISTO_LENGTH];
     __shared__ int ind[3];
     const int lane = threadIdx.x;
-    for (int j = lane; j < n; j += 64) blocked[j] = 0;
+    for (int j = lane; j < n; j += 64) { blocked[j] = 0; claimtab[j] = 0; }
     if (lane < HISTO_LENGTH) hn[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -419,7 +450,7 @@ __global__ __launch_bounds__(64) void k_resolve_windows(const u64 *__restrict__ 
                 ranout = best < 0 && nc > QK;
             }
             const bool accept = act && best >= 0 && bestDist <= max_dist;
-            const bool conflict = chunk_conflict(accept ? best : -1, best, -1, pending) && act;
+            const bool conflict = chunk_conflict_lds(claimtab, accept ? best : -1, best, -1, act);
             const u64 cm = __ballot(conflict);
             const u64 commit = cm ? (pending & ((1ull << __builtin_ctzll(cm)) - 1ull)) : pending;
             const bool mineCommits = (commit >> lane) & 1ull;
@@ -624,15 +655,19 @@ static void frustum_pose(const float *T, FrustumPose &P) {   // mRcw, mtcw, mOw 
     }
 }
 
-// ---- host side: one grow-only device arena per host thread (no hipMalloc per call)
+// ---- host side: one grow-only device arena per host thread (no hipMalloc per call) with a PINNED host mirror of
+// the same layout: every input is memcpy'd into the mirror and the whole used range goes up in ONE
+// hipMemcpyAsync (UP ... FLUSH_UP); results come down into the mirror in one or two copies and ONE stream
+// synchronisation (DOWN ... after the sync, copy out).  A call used to issue 8-10 pageable copies and 2 syncs.
 struct Arena {
-    uint8_t *base = nullptr; size_t cap = 0, off = 0; int device = -1; hipStream_t st = nullptr;
+    uint8_t *base = nullptr, *hbase = nullptr; size_t cap = 0, off = 0, up_lo = 0, up_hi = 0; int device = -1; hipStream_t st = nullptr;
 };
 static thread_local Arena g_ar;
 static int arena_begin(int device, size_t need) {
     ORBX_HIP(hipSetDevice(device));
     if (g_ar.device != device || g_ar.cap < need) {
         if (g_ar.base) { hipSetDevice(g_ar.device >= 0 ? g_ar.device : device); hipFree(g_ar.base); hipSetDevice(device); }
+        if (g_ar.hbase) { hipHostFree(g_ar.hbase); g_ar.hbase = nullptr; }
         if (!g_ar.st || g_ar.device != device) {
             if (g_ar.st) hipStreamDestroy(g_ar.st);
             ORBX_HIP(hipStreamCreateWithFlags(&g_ar.st, hipStreamNonBlocking));
@@ -640,9 +675,11 @@ static int arena_begin(int device, size_t need) {
         g_ar.base = nullptr; g_ar.cap = 0;
         const size_t cap = std::max(need * 2, (size_t)4 << 20);
         ORBX_HIP(hipMalloc(&g_ar.base, cap));
+        ORBX_HIP(hipHostMalloc((void **)&g_ar.hbase, cap, hipHostMallocDefault));
         g_ar.cap = cap; g_ar.device = device;
     }
     g_ar.off = 0;
+    g_ar.up_lo = g_ar.cap; g_ar.up_hi = 0;
     return ORBX_OK;
 }
 template <typename T> static T *arena_get(size_t count) {
@@ -651,14 +688,32 @@ template <typename T> static T *arena_get(size_t count) {
     g_ar.off += bytes;
     return p;
 }
-#define UP(dst, src, count) ORBX_HIP(hipMemcpyAsync((dst), (src), sizeof(*(dst)) * (size_t)(count), hipMemcpyHostToDevice, st))
+static inline void arena_stage(void *dst, const void *src, size_t bytes) {
+    const size_t o = (size_t)((uint8_t *)dst - g_ar.base);
+    memcpy(g_ar.hbase + o, src, bytes);
+    g_ar.up_lo = std::min(g_ar.up_lo, o);
+    g_ar.up_hi = std::max(g_ar.up_hi, o + bytes);
+}
+#define UP(dst, src, count) arena_stage((dst), (src), sizeof(*(dst)) * (size_t)(count))
+// everything staged since the last flush goes up in one copy (call before the first kernel that reads it)
+#define FLUSH_UP()                                                                                                        \
+    do {                                                                                                                  \
+        if (g_ar.up_hi > g_ar.up_lo)                                                                                      \
+            ORBX_HIP(hipMemcpyAsync(g_ar.base + g_ar.up_lo, g_ar.hbase + g_ar.up_lo, g_ar.up_hi - g_ar.up_lo,              \
+                                    hipMemcpyHostToDevice, st));                                                          \
+        g_ar.up_lo = g_ar.cap; g_ar.up_hi = 0;                                                                            \
+        (void)hipGetLastError();                                                                                          \
+    } while (0)
+// device -> pinned mirror (same offset); valid after the stream is synchronised
+template <typename T> static const T *arena_host(const T *dev) { return (const T *)(g_ar.hbase + ((const uint8_t *)dev - g_ar.base)); }
+#define DOWN(dev, count) ORBX_HIP(hipMemcpyAsync((void *)arena_host(dev), (dev), sizeof(*(dev)) * (size_t)(count), hipMemcpyDeviceToHost, st))
 #define ORBX_FAST_FALLBACK 1  // positive: not an error, the caller runs the exact legacy kernel
 
 // Returns ORBX_OK (results written), ORBX_FAST_FALLBACK, or a negative error.
 int fast_search_for_initialization(const orbx_keypoint_t *k1, const uint8_t *d1, int n1, const orbx_keypoint_t *k2,
                                    const uint8_t *d2, int n2, const orbm_grid_geom_t *g2, float *prev, int32_t *m12,
                                    int window, float nnratio, int check_ori, int device, int *nmatches) {
-    if (n2 > 8000 || n1 > 65535) return ORBX_FAST_FALLBACK;  // LDS plan of k_resolve_init (8 B per F2 keypoint)
+    if (n2 > 7000 || n1 > 65535) return ORBX_FAST_FALLBACK;  // LDS plan of k_resolve_init (9 B per F2 keypoint, 64 KB)
     const size_t need = (size_t)(n1 + n2) * (28 + 32 + 64) + (size_t)n1 * (CAND_CAP * 8 + 64) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
@@ -671,21 +726,20 @@ int fast_search_for_initialization(const orbx_keypoint_t *k1, const uint8_t *d1,
     GQuery *dq = arena_get<GQuery>(n1);
     u64 *dkeys = arena_get<u64>((size_t)n1 * CAND_CAP);
     UP(dk1, k1, n1); UP(dk2, k2, n2); UP(dd1, d1, (size_t)32 * n1); UP(dd2, d2, (size_t)32 * n2); UP(dprev, prev, 2 * (size_t)n1);
-    (void)hipGetLastError();
+    FLUSH_UP();
     hipLaunchKernelGGL(k_cell_codes, dim3((n2 + 255) / 256), dim3(256), 0, st, dk2, n2, *g2, dcode);
     hipLaunchKernelGGL(k_queries_init, dim3((n1 + 255) / 256), dim3(256), 0, st, dk1, dprev, n1, window, dq);
     hipLaunchKernelGGL(k_cand<true>, dim3((n1 + 3) / 4), dim3(256), 0, st, dq, dd1, n1, dk2, dd2, (const float *)nullptr,
                        (const uint8_t *)nullptr, dcode, n2, *g2, dkeys, dnc);
-    hipLaunchKernelGGL(k_resolve_init, dim3(1), dim3(64), sizeof(int32_t) * 2 * (size_t)n2, st, dkeys, dnc, dk1, dk2, n1, n2,
+    hipLaunchKernelGGL(k_resolve_init, dim3(1), dim3(64), sizeof(int32_t) * 2 * (size_t)n2 + (size_t)((n2 + 15) & ~15), st, dkeys, dnc, dk1, dk2, n1, n2,
                        dprev, dm12, dbin, nnratio, check_ori, dout);
     ORBX_HIP(hipGetLastError());
-    int32_t out[2] = {0, 0};
-    ORBX_HIP(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, st));
+    DOWN(dout, 2); DOWN(dprev, 2 * (size_t)n1); DOWN(dm12, n1);
     ORBX_HIP(hipStreamSynchronize(st));
+    const int32_t *out = arena_host(dout);
     if (out[1]) return ORBX_FAST_FALLBACK;
-    ORBX_HIP(hipMemcpyAsync(prev, dprev, sizeof(float) * 2 * (size_t)n1, hipMemcpyDeviceToHost, st));
-    ORBX_HIP(hipMemcpyAsync(m12, dm12, sizeof(int32_t) * (size_t)n1, hipMemcpyDeviceToHost, st));
-    ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(prev, arena_host(dprev), sizeof(float) * 2 * (size_t)n1);
+    memcpy(m12, arena_host(dm12), sizeof(int32_t) * (size_t)n1);
     *nmatches = out[0];
     return ORBX_OK;
 }
@@ -703,11 +757,12 @@ int fast_is_in_frustum(const orbm_worldpoint_t *pts, int m, const float *Tcw16, 
     if (nlevels > 1) UP(dthr, thr, nlevels - 1);
     FrustumPose P;
     frustum_pose(Tcw16, P);
-    (void)hipGetLastError();
+    FLUSH_UP();
     hipLaunchKernelGGL(k_frustum, dim3((m + 255) / 256), dim3(256), 0, st, dw, m, P, *cam, *g, viewCosLimit, dthr, nlevels, dmp);
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipMemcpyAsync(out, dmp, sizeof(orbm_mappoint_t) * (size_t)m, hipMemcpyDeviceToHost, st));
+    DOWN(dmp, m);
     ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(out, arena_host(dmp), sizeof(orbm_mappoint_t) * (size_t)m);
     return ORBX_OK;
 }
 
@@ -717,7 +772,7 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
                                  const orbm_grid_geom_t *g, const float *sf, int nlevels, const orbm_mappoint_t *mps,
                                  const uint8_t *mp_desc, int m, int32_t *frame_mp, const int32_t *ext_obs, float th,
                                  float nnratio, int device, int *nmatches, const FrustumArgs *world, orbm_mappoint_t *proj_out) {
-    if (n > 60000 && !world) return ORBX_FAST_FALLBACK;
+    if (n > 30000 && !world) return ORBX_FAST_FALLBACK;
     const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)m * (28 + 32 + QK * 8 + 64 + sizeof(orbm_worldpoint_t)) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
@@ -733,7 +788,6 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
     UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(du, uright, n); UP(dsf, sf, nlevels);
     UP(dmd, mp_desc, (size_t)32 * m); UP(dfm, frame_mp, n);
     if (ext_obs) UP(deo, ext_obs, n);
-    (void)hipGetLastError();
     if (world) {
         orbm_worldpoint_t *dw = arena_get<orbm_worldpoint_t>(m);
         float *dthr = arena_get<float>(nlevels);
@@ -741,24 +795,29 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
         if (nlevels > 1) UP(dthr, world->thr, nlevels - 1);
         FrustumPose P;
         frustum_pose(world->Tcw16, P);
+        FLUSH_UP();
         hipLaunchKernelGGL(k_frustum, dim3((m + 255) / 256), dim3(256), 0, st, dw, m, P, *world->cam, *g, world->viewCosLimit, dthr,
                            nlevels, dmp);
-        if (proj_out) ORBX_HIP(hipMemcpyAsync(proj_out, dmp, sizeof(orbm_mappoint_t) * (size_t)m, hipMemcpyDeviceToHost, st));
-        if (n > 60000) { ORBX_HIP(hipStreamSynchronize(st)); return ORBX_FAST_FALLBACK; }
-    } else UP(dmp, mps, m);
+        if (proj_out) DOWN(dmp, m);
+        if (n > 30000) {
+            ORBX_HIP(hipStreamSynchronize(st));
+            if (proj_out) memcpy(proj_out, arena_host(dmp), sizeof(orbm_mappoint_t) * (size_t)m);
+            return ORBX_FAST_FALLBACK;
+        }
+    } else { UP(dmp, mps, m); FLUSH_UP(); }
     const int mx = std::max(n, m);
     hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *g, dcode);
     hipLaunchKernelGGL(k_queries_mp, dim3((mx + 255) / 256), dim3(256), 0, st, dmp, m, dsf, th, dq, dfm,
                        ext_obs ? deo : (const int32_t *)nullptr, n, dsb);
     hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dmd, m, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
-    hipLaunchKernelGGL(k_resolve_mp, dim3(1), dim3(64), (size_t)((n + 15) & ~15), st, dkeys, dnc, dmp, m, n, dfm, nnratio, dout);
+    hipLaunchKernelGGL(k_resolve_mp, dim3(1), dim3(64), 2 * (size_t)((n + 15) & ~15), st, dkeys, dnc, dmp, m, n, dfm, nnratio, dout);
     ORBX_HIP(hipGetLastError());
-    int32_t out[2] = {0, 0};
-    ORBX_HIP(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, st));
+    DOWN(dout, 2); DOWN(dfm, n);
     ORBX_HIP(hipStreamSynchronize(st));
+    if (world && proj_out) memcpy(proj_out, arena_host(dmp), sizeof(orbm_mappoint_t) * (size_t)m);
+    const int32_t *out = arena_host(dout);
     if (out[1]) return ORBX_FAST_FALLBACK;
-    ORBX_HIP(hipMemcpyAsync(frame_mp, dfm, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-    ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(frame_mp, arena_host(dfm), sizeof(int32_t) * (size_t)n);
     *nmatches = out[0];
     return ORBX_OK;
 }
@@ -768,7 +827,7 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
                                     const float *Tc16, const float *Tl16, const orbm_lastpoint_t *last,
                                     const uint8_t *last_desc, int nlast, int32_t *cur_mp, const int32_t *ext_obs,
                                     float th, int mono, int check_ori, int device, int *nmatches) {
-    if (n > 60000) return ORBX_FAST_FALLBACK;
+    if (n > 30000) return ORBX_FAST_FALLBACK;
     const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)nlast * (28 + 32 + QK * 8 + 64) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
@@ -787,22 +846,20 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
     UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(du, uright, n); UP(dsf, sf, nlevels); UP(dl, last, nlast);
     UP(dld, last_desc, (size_t)32 * nlast); UP(dcm, cur_mp, n); UP(dT, T2, 32);
     if (ext_obs) UP(deo, ext_obs, n);
-    ORBX_HIP(hipStreamSynchronize(st));  // T2 lives on this stack frame
-    (void)hipGetLastError();
+    FLUSH_UP();
     const int mx = std::max(n, nlast);
     hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *g, dcode);
     hipLaunchKernelGGL(k_queries_frame, dim3((mx + 255) / 256), dim3(256), 0, st, dl, nlast, dsf, *cam, *g, dT, dT + 16, th,
                        mono, dq, dcm, ext_obs ? deo : (const int32_t *)nullptr, n, dsb);
     hipLaunchKernelGGL(k_cand<false>, dim3((nlast + 3) / 4), dim3(256), 0, st, dq, dld, nlast, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
-    hipLaunchKernelGGL(k_resolve_frame, dim3(1), dim3(64), (size_t)((n + 15) & ~15), st, dkeys, dnc, dl, dk, nlast, n, dcm,
+    hipLaunchKernelGGL(k_resolve_frame, dim3(1), dim3(64), 2 * (size_t)((n + 15) & ~15), st, dkeys, dnc, dl, dk, nlast, n, dcm,
                        dhi, dhb, check_ori, dout);
     ORBX_HIP(hipGetLastError());
-    int32_t out[2] = {0, 0};
-    ORBX_HIP(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, st));
+    DOWN(dout, 2); DOWN(dcm, n);
     ORBX_HIP(hipStreamSynchronize(st));
+    const int32_t *out = arena_host(dout);
     if (out[1]) return ORBX_FAST_FALLBACK;
-    ORBX_HIP(hipMemcpyAsync(cur_mp, dcm, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-    ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(cur_mp, arena_host(dcm), sizeof(int32_t) * (size_t)n);
     *nmatches = out[0];
     return ORBX_OK;
 }
@@ -811,7 +868,7 @@ int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const fl
                        const orbm_grid_geom_t *g, const orbm_grid_geom_t *ga, const orbm_window_query_t *q,
                        const uint8_t *qdesc, int m,
                        int32_t *holder, const int32_t *ext_blocks, int max_dist, int check_ori, int device, int *nmatches) {
-    if (n > 60000) return ORBX_FAST_FALLBACK;
+    if (n > 30000) return ORBX_FAST_FALLBACK;
     const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)m * (40 + 32 + QK * 8 + 96) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
@@ -827,23 +884,26 @@ int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const fl
     u64 *dkeys = arena_get<u64>((size_t)m * QK);
     UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(dw, q, m); UP(dqd, qdesc, (size_t)32 * m); UP(dh, holder, n);
     if (uright) UP(du, uright, n);
-    else ORBX_HIP(hipMemsetAsync(du, 0, sizeof(float) * (size_t)n, st));  // 0: no stereo coordinate, never gated
+    else {   // 0: no stereo coordinate, never gated (staged like the other inputs: the flush covers the whole range)
+        const size_t o = (size_t)((uint8_t *)du - g_ar.base);
+        memset(g_ar.hbase + o, 0, sizeof(float) * (size_t)n);
+        g_ar.up_lo = std::min(g_ar.up_lo, o); g_ar.up_hi = std::max(g_ar.up_hi, o + sizeof(float) * (size_t)n);
+    }
     if (ext_blocks) UP(deb, ext_blocks, n);
-    (void)hipGetLastError();
+    FLUSH_UP();
     const int mx = std::max(n, m);
     hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *ga, dcode);
     hipLaunchKernelGGL(k_queries_windows, dim3((mx + 255) / 256), dim3(256), 0, st, dw, m, dq, dh,
                        ext_blocks ? deb : (const int32_t *)nullptr, n, dsb);
     hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dqd, m, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
-    hipLaunchKernelGGL(k_resolve_windows, dim3(1), dim3(64), (size_t)((n + 15) & ~15), st, dkeys, dnc, dw, dk, m, n, dh, dhi,
+    hipLaunchKernelGGL(k_resolve_windows, dim3(1), dim3(64), 2 * (size_t)((n + 15) & ~15), st, dkeys, dnc, dw, dk, m, n, dh, dhi,
                        dhb, max_dist, check_ori, dout);
     ORBX_HIP(hipGetLastError());
-    int32_t out[2] = {0, 0};
-    ORBX_HIP(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, st));
+    DOWN(dout, 2); DOWN(dh, n);
     ORBX_HIP(hipStreamSynchronize(st));
+    const int32_t *out = arena_host(dout);
     if (out[1]) return ORBX_FAST_FALLBACK;
-    ORBX_HIP(hipMemcpyAsync(holder, dh, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-    ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(holder, arena_host(dh), sizeof(int32_t) * (size_t)n);
     *nmatches = out[0];
     return ORBX_OK;
 }
@@ -915,7 +975,7 @@ int fast_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const 
     UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(dw, q, m); UP(dqd, qdesc, (size_t)32 * m);
     if (uright) UP(du, uright, n);
     if (inv_sigma2) UP(dis, inv_sigma2, nlevels);
-    (void)hipGetLastError();
+    FLUSH_UP();
     hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *ga, dcode);
     if (inv_sigma2)
         hipLaunchKernelGGL(k_best<true>, dim3((m + 3) / 4), dim3(256), 0, st, dw, dqd, m, dk, dd,
@@ -924,9 +984,10 @@ int fast_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const 
         hipLaunchKernelGGL(k_best<false>, dim3((m + 3) / 4), dim3(256), 0, st, dw, dqd, m, dk, dd, (const float *)nullptr,
                            (const float *)nullptr, nlevels, dcode, n, *g, dbi, dbd);
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipMemcpyAsync(best_idx, dbi, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, st));
-    ORBX_HIP(hipMemcpyAsync(best_dist, dbd, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, st));
+    DOWN(dbi, m); DOWN(dbd, m);
     ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(best_idx, arena_host(dbi), sizeof(int32_t) * (size_t)m);
+    memcpy(best_dist, arena_host(dbd), sizeof(int32_t) * (size_t)m);
     return ORBX_OK;
 }
 
@@ -992,11 +1053,13 @@ int fast_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
     int32_t *doff = arena_get<int32_t>(npoints + 1), *dbr = arena_get<int32_t>(npoints), *dbm = arena_get<int32_t>(npoints);
     if (total > 0) UP(dd, desc, (size_t)32 * total);
     UP(doff, offsets, npoints + 1);
-    (void)hipGetLastError();
+    FLUSH_UP();
     hipLaunchKernelGGL(k_distinctive, dim3((npoints + 3) / 4), dim3(256), 0, st, dd, doff, npoints, dbr, dbm);
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipMemcpyAsync(best_row, dbr, sizeof(int32_t) * (size_t)npoints, hipMemcpyDeviceToHost, st));
-    if (best_median) ORBX_HIP(hipMemcpyAsync(best_median, dbm, sizeof(int32_t) * (size_t)npoints, hipMemcpyDeviceToHost, st));
+    DOWN(dbr, npoints);
+    if (best_median) DOWN(dbm, npoints);
     ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(best_row, arena_host(dbr), sizeof(int32_t) * (size_t)npoints);
+    if (best_median) memcpy(best_median, arena_host(dbm), sizeof(int32_t) * (size_t)npoints);
     return ORBX_OK;
 }
