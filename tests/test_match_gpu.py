@@ -561,3 +561,37 @@ def test_search_for_triangulation(pkg, oracle, bow):
     # without the epipolar gate (all-zero F12: den == 0) nothing may match
     zn, zm = pkg.search_for_triangulation(k1, d1, f1, k2, d2, f2, nqs, qit, ncs, cit, np.zeros((3, 3), np.float32), ex, ey, sf, sigma2)
     assert zn == 0 and (zm == -1).all()
+
+
+def test_degenerate_sizes_and_bad_arguments(pkg, oracle):
+    """Empty inputs are answers, not errors; malformed inputs are ORBX_ERR_ARG with a message (no crash)."""
+    g = pkg.grid_geom(640, 480)
+    k0 = np.zeros(0, pkg.KP_DTYPE); d0 = np.zeros((0, 32), np.uint8)
+    k3 = np.zeros(3, pkg.KP_DTYPE); k3["x"] = [10, 20, 30]; k3["y"] = [10, 20, 30]
+    d3 = np.zeros((3, 32), np.uint8)
+    q0 = np.zeros(0, pkg.WINDOW_DTYPE)
+    bi, bd = pkg.best_in_windows(k3, d3, None, g, q0, d0)
+    assert len(bi) == 0
+    q2 = np.zeros(2, pkg.WINDOW_DTYPE)                      # invalid queries only
+    bi, bd = pkg.best_in_windows(k3, d3, None, g, q2, np.zeros((2, 32), np.uint8))
+    assert list(bi) == [-1, -1] and list(bd) == [256, 256]
+    bi, bd = pkg.best_in_windows(k0, d0, None, g, q2, np.zeros((2, 32), np.uint8))
+    assert list(bi) == [-1, -1]
+    n, h = pkg.match_windows(k3, d3, None, g, q0, d0, np.full(3, -1, np.int32))
+    assert n == 0 and list(h) == [-1, -1, -1]
+    br, bm = pkg.distinctive_descriptors(d0, [0, 0, 0])
+    assert list(br) == [-1, -1]
+    n, mq = pkg.search_by_bow(d3, np.zeros(3, np.float32), np.ones(3, np.uint8), d3, np.zeros(3, np.float32), None,
+                              [0], np.zeros(0, np.int32), [0], np.zeros(0, np.int32), 50, 0.7)
+    assert n == 0 and list(mq) == [-1, -1, -1]
+    with pytest.raises(pkg.OrbxError):                      # item index out of range
+        pkg.search_by_bow(d3, np.zeros(3, np.float32), np.ones(3, np.uint8), d3, np.zeros(3, np.float32), None,
+                          [0, 1], [7], [0, 1], [0], 50, 0.7)
+    with pytest.raises(pkg.OrbxError):                      # offsets not monotonic
+        pkg.distinctive_descriptors(d3, [0, 2, 1])
+    with pytest.raises(pkg.OrbxError):                      # a node whose parent does not precede it
+        pkg.Vocabulary(2, 1, 0, 0, [0, 2, 1], [0, 1, 1], np.zeros((3, 32), np.uint8), [0, 1.0, 1.0])
+    thr = pkg.predict_scale_thresholds(np.float32(np.log(np.float32(1.2))), 8)
+    cam = pkg.Camera(500, 500, 320, 240, 40, 0.08)
+    out = pkg.is_in_frustum(np.zeros(0, pkg.WORLDPOINT_DTYPE), np.eye(4, dtype=np.float32), cam, g, 0.5, thr, 8)
+    assert len(out) == 0
