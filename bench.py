@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the result all-gather when N > 1")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="S > 1: consecutive steps alternate over S extractor handles on S streams (independent steps overlap; "
+                         "the default 1 keeps every kernel alone on the GPU so that its measured duration is its own)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N > 1 on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -180,14 +183,16 @@ def main():
             dist.init_process_group("gloo")
     d_imgs = torch.from_numpy(imgs).to(dev)
 
-    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=dev_index)
-    cap = ex.max_keypoints()
-    ex(imgs[0])                     # plan for this image size; cap is now exact
+    S = max(1, args.streams)
+    exs = [pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=dev_index) for _ in range(S)]
+    ex = exs[0]
+    for e in exs:
+        e(imgs[0])                  # plan for this image size; cap is now exact
     cap = ex.max_keypoints()
     mbf = KITTI_BF
     mb = float(np.float32(KITTI_BF) / np.float32(KITTI_FX))
 
-    nbuf = 2
+    nbuf = max(2, S)
     kps = [torch.zeros((nimg, cap, 7), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     desc = [torch.zeros((nimg, cap, 32), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     cnt = [torch.zeros(nimg, dtype=torch.int32, device=dev) for _ in range(nbuf)]
@@ -201,22 +206,23 @@ def main():
         pack = [torch.zeros((B, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         gath = [torch.zeros((world * B, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         works = [None] * nbuf
-    stream = torch.cuda.current_stream()
-    st = stream.cuda_stream
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(S - 1)]
     ev_m0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_m1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(i, timed_idx=None):
         j = i % nbuf
+        exi, stream = exs[i % S], streams[i % S]
+        st = stream.cuda_stream
         if gather and works[j] is not None:
             works[j].wait()         # buffer j is free again (its all-gather finished)
             works[j] = None
-        ex.extract_batch_device(d_imgs.data_ptr(), nimg, w, h, w, w * h, kps[j].data_ptr(), desc[j].data_ptr(),
-                                cnt[j].data_ptr(), cap, st)
+        exi.extract_batch_device(d_imgs.data_ptr(), nimg, w, h, w, w * h, kps[j].data_ptr(), desc[j].data_ptr(),
+                                 cnt[j].data_ptr(), cap, st)
         if stereo:
             if timed_idx is not None:
                 ev_m0[timed_idx].record(stream)
-            pkg.stereo_batch_device(ex, ex, B, 0, B,
+            pkg.stereo_batch_device(exi, exi, B, 0, B,
                                     kps[j].data_ptr(), desc[j].data_ptr(), cnt[j].data_ptr(),
                                     kps[j][B:].data_ptr(), desc[j][B:].data_ptr(), cnt[j][B:].data_ptr(),
                                     cap, mbf, mb, ur[j].data_ptr(), dp[j].data_ptr(), nm[j].data_ptr(), st)
