@@ -369,7 +369,17 @@ __global__ __launch_bounds__(256) void k_pyr_pad(const uint8_t *__restrict__ img
 // else {S >= minTh}; this equals running cv::FAST(iniTh) and, if empty, cv::FAST(minTh).
 // Output: row-major ordered candidates (x | y<<12 | score<<24, relative to minBorder) in
 // the cell's slot block + count.
+// first global cell number of every level, passed BY VALUE (kernel arguments sit in SGPRs): finding a cell's level
+// must not start a chain of dependent loads at the head of every wave
+struct CellBases { int v[ORBX_MAX_LEVELS + 1]; };
+__device__ __forceinline__ int level_of_cell(const CellBases &cb, int nlevels, int gc) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < ORBX_MAX_LEVELS; i++) l += (i < nlevels && gc >= cb.v[i]) ? 1 : 0;
+    return l;
+}
 #define FAST_WAVES 4
+#define FAST_STG 8     // window dword pairs per lane fetched in one go (8 x 64 >= a 36x38 window's 456 items)
 typedef short short2v __attribute__((ext_vector_type(2)));
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -452,13 +462,12 @@ __device__ __forceinline__ void fast_nms_pair(const uint8_t *Sc, int SS, int cw,
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
     int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ slots, size_t slotsPerImg,
-    int iniTh, int minTh, int ES, int SS, int tileRows, int ldsPerWave, int phaseLimit) {
+    int iniTh, int minTh, int ES, int SS, int tileRows, int ldsPerWave, int phaseLimit, CellBases cb) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int gc = blockIdx.x * FAST_WAVES + wave, b = blockIdx.y;
     if (gc >= totalCells) return;  // wave-uniform; the kernel uses no block barrier
-    int l = 0;
-    while (l + 1 < nlevels && gc >= geom[l + 1].cellBase) l++;
+    const int l = level_of_cell(cb, nlevels, gc);
     const LevelGeom g = geom[l];
     const int c = gc - g.cellBase;
     const int ci = c / g.nCols, cj = c - ci * g.nCols;
@@ -489,18 +498,31 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
         const int nd = (sh + tw + 3) >> 2, pstr4 = g.pstride >> 2, items = nd * th;
         // E column index = byte offset inside the aligned row (window column + sh): every item
         // is one aligned 16-byte LDS write, no bounds checks
-        int r = 0, q = lane;
-        while (q >= nd) { q -= nd; r++; }
-        for (int i = lane; i < items; i += 64) {
-            const uint32_t d0 = src[(size_t)r * pstr4 + q], d1 = src[(size_t)r * pstr4 + q + 1];
-            uint4 e;  // bytes b0..b3 of d0 and b4 = first byte of d1 -> pairs (b0,b1) (b1,b2) (b2,b3) (b3,b4)
-            e.x = __builtin_amdgcn_perm(d1, d0, 0x0c010c00u);
-            e.y = __builtin_amdgcn_perm(d1, d0, 0x0c020c01u);
-            e.z = __builtin_amdgcn_perm(d1, d0, 0x0c030c02u);
-            e.w = __builtin_amdgcn_perm(d1, d0, 0x0c040c03u);
-            *(uint4 *)(E + r * ES + 4 * q) = e;
-            q += 64;
-            while (q >= nd) { q -= nd; r++; }
+        // ALL global loads of the window are issued before the first use (FAST_STG x 2 dwords per lane in flight):
+        // one memory latency per cell instead of one per 64 items — this phase was a third of the kernel.
+        const unsigned M = (1u << 20) / (unsigned)nd + 1u;   // floor(i / nd) == (i * M) >> 20 for i < 2^10, nd <= 2^6
+        for (int base = 0; base < items; base += 64 * FAST_STG) {
+            uint32_t d0[FAST_STG], d1[FAST_STG];
+            int rr[FAST_STG], qq[FAST_STG];
+#pragma unroll
+            for (int k = 0; k < FAST_STG; k++) {
+                const int i = min(base + lane + 64 * k, items - 1);
+                rr[k] = (int)(((unsigned)i * M) >> 20);
+                qq[k] = i - rr[k] * nd;
+                const uint32_t *p = src + (size_t)rr[k] * pstr4 + qq[k];
+                d0[k] = p[0]; d1[k] = p[1];
+            }
+#pragma unroll
+            for (int k = 0; k < FAST_STG; k++) {
+                if (base + lane + 64 * k < items) {
+                    uint4 e;  // bytes b0..b3 of d0 and b4 = first byte of d1 -> pairs (b0,b1) (b1,b2) (b2,b3) (b3,b4)
+                    e.x = __builtin_amdgcn_perm(d1[k], d0[k], 0x0c010c00u);
+                    e.y = __builtin_amdgcn_perm(d1[k], d0[k], 0x0c020c01u);
+                    e.z = __builtin_amdgcn_perm(d1[k], d0[k], 0x0c030c02u);
+                    e.w = __builtin_amdgcn_perm(d1[k], d0[k], 0x0c040c03u);
+                    *(uint4 *)(E + rr[k] * ES + 4 * qq[k]) = e;
+                }
+            }
         }
         const int nz = ((ch + 2) * SS) >> 2;  // zero the score tile (halo + odd tail columns)
         for (int i = lane; i < nz; i += 64) ((uint32_t *)Sc)[i] = 0;
@@ -625,17 +647,22 @@ __global__ __launch_bounds__(256) void k_cell_scan(const LevelGeom *__restrict__
 __global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ geom, int nlevels, int totalCells,
                                                 const uint32_t *__restrict__ cellCnt, const uint32_t *__restrict__ cellOff,
                                                 const uint32_t *__restrict__ slots, size_t slotsPerImg,
-                                                uint32_t *__restrict__ cand, size_t keysPerImg) {
+                                                uint32_t *__restrict__ cand, size_t keysPerImg, CellBases cb) {
     const int sub = threadIdx.x & 15;
     const int gc = blockIdx.x * GATHER_CELLS_PER_BLOCK + (threadIdx.x >> 4), b = blockIdx.y;
     if (gc >= totalCells) return;
-    int l = 0;
-    while (l + 1 < nlevels && gc >= geom[l + 1].cellBase) l++;
+    const int l = level_of_cell(cb, nlevels, gc);
     const int c = gc - geom[l].cellBase, capc = geom[l].capc;
     const int cn = (int)cellCnt[(size_t)b * totalCells + gc], off = (int)cellOff[(size_t)b * totalCells + gc];
     const uint32_t *src = slots + (size_t)b * slotsPerImg + geom[l].slotOff + (size_t)c * capc;
     uint32_t *dst = cand + (size_t)b * keysPerImg + geom[l].keyOff + off;
-    for (int j = sub; j < cn; j += 16) dst[j] = src[j];
+    for (int j0 = 0; j0 < cn; j0 += 64) {   // four loads in flight per lane before the stores
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = src[min(j0 + sub + 16 * k, cn - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (j0 + sub + 16 * k < cn) dst[j0 + sub + 16 * k] = v[k];
+    }
 }
 
 // K3: DistributeOctTree (:539-763), one workgroup per (level, image).
@@ -1479,9 +1506,18 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     const int sh = __builtin_amdgcn_readfirstlane((int)(a & 3));
     const uint32_t *src = (const uint32_t *)(lvl + (a - sh));
     const int pstr4 = g.pstride >> 2;
-    for (int i = lane; i < PROWS * 12; i += 64) {
-        const int r = i / 12, c = i - r * 12;
-        ((uint32_t *)P)[r * 12 + c] = src[(size_t)r * pstr4 + c];
+    {   // all (PROWS*12 + 63) / 64 loads of a lane are in flight before the first LDS write: one memory latency per keypoint
+        constexpr int NI = (PROWS * 12 + 63) / 64;
+        uint32_t v[NI];
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int i = min(lane + 64 * k, PROWS * 12 - 1);
+            const int r = i / 12, c = i - r * 12;
+            v[k] = src[(size_t)r * pstr4 + c];
+        }
+#pragma unroll
+        for (int k = 0; k < NI; k++)
+            if (lane + 64 * k < PROWS * 12) ((uint32_t *)P)[lane + 64 * k] = v[k];
     }
     wave_sync();
     // pixel (cx-21+c, cy-21+r) is byte P[r*48 + sh + c], r,c in [0,43)
@@ -1989,6 +2025,8 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
                            size_t img_stride, orbx_keypoint_t *d_kps, uint8_t *d_desc, int32_t *d_counts,
                            int cap, hipStream_t st) {
     const int nl = h->nlevels;
+    CellBases cb;
+    for (int l = 0; l <= ORBX_MAX_LEVELS; l++) cb.v[l] = l < nl ? h->geom[l].cellBase : h->totalCells;
     const bool prof = h->profiling != 0;
     (void)hipGetLastError();  // drop stale errors of other HIP users in this process
     hipEvent_t *ev = nullptr;
@@ -2024,7 +2062,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
         hipLaunchKernelGGL(k_fast_cells, grid, dim3(64 * FAST_WAVES), (size_t)h->fastLdsPerWave * FAST_WAVES, st,
                            h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_slots,
                            h->slotsPerImg, h->ini_th, h->min_th, h->fastTileStride, h->fastScoreStride,
-                           h->fastTileRows, h->fastLdsPerWave, g_debug[0]);
+                           h->fastTileRows, h->fastLdsPerWave, g_debug[0], cb);
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[2], st));
     {   // K3
@@ -2039,7 +2077,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
                            h->d_cellOff, h->d_candCnt);
         hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
                            dim3(256), 0, st, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_cellOff, h->d_slots,
-                           h->slotsPerImg, h->d_cand, h->keysPerImg);
+                           h->slotsPerImg, h->d_cand, h->keysPerImg, cb);
         const bool usePyr = g_debug[4] == 0;
         if (usePyr) {
             ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_pyr, hipFuncAttributeMaxDynamicSharedMemorySize,
