@@ -1478,17 +1478,20 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     const int o = blockIdx.x * DESC_WAVES + wave, b = blockIdx.y;
     // locate (level, k) of output ordinal o: level-major concatenation (:1076-1104)
     int l = 0, base = 0, total = 0;
-    {
-        int acc = 0;
-        bool found = false;
-        for (int i = 0; i < nlevels; i++) {
-            const int c = lvlCnt[b * nlevels + i];
-            if (!found && o < acc + c) { l = i; base = acc; found = true; }
-            acc += c;
+    {   // lane i < nlevels holds the count of level i: ONE load, a 4-step prefix sum, a ballot (not nlevels dependent loads)
+        const int c = lane < nlevels ? lvlCnt[b * nlevels + lane] : 0;
+        int inc = c;
+#pragma unroll
+        for (int d = 1; d < ORBX_MAX_LEVELS; d <<= 1) {
+            const int t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
         }
-        total = acc;
+        total = __builtin_amdgcn_readlane(inc, ORBX_MAX_LEVELS - 1);
         if (blockIdx.x == 0 && threadIdx.x == 0) counts[b] = min(total, cap);
-        if (!found || o >= cap) return;  // wave-uniform
+        const unsigned long long hit = __ballot(lane < nlevels && o < inc);
+        if (!hit || o >= cap) return;  // wave-uniform
+        l = __builtin_ctzll(hit);
+        base = __builtin_amdgcn_readlane(inc - c, l);
     }
     l = __builtin_amdgcn_readfirstlane(l);
     const LevelGeom g = geom[l];

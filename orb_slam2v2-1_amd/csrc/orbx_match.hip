@@ -85,6 +85,42 @@ __global__ __launch_bounds__(256) void k_stereo_prep(StereoLevels lv, const orbx
     o.y = __float_as_uint(kp.x);
     rc[(size_t)b * cap + i] = o;
 }
+// Row bins for the candidate search (the reference's vRowIndices, :495-508, at a coarser grain): bins of BH rows,
+// BH = a power of two >= the tallest row band, so a right keypoint's band touches at most two bins and a left
+// keypoint only looks at the right keypoints of ITS bin (a few hundred) instead of all of them.
+#define ST_MAX_BINS 512
+__global__ __launch_bounds__(256) void k_stereo_bins(const uint2 *__restrict__ rc, const int32_t *__restrict__ nr, int cap,
+                                                     int bhShift, int nbins, int32_t *__restrict__ binStart,
+                                                     int32_t *__restrict__ items) {
+    __shared__ int cnt[ST_MAX_BINS + 1], fill[ST_MAX_BINS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Nr = min(nr[b], cap);
+    const uint2 *rcb = rc + (size_t)b * cap;
+    for (int i = tid; i <= nbins; i += 256) cnt[i] = 0;
+    for (int i = tid; i < nbins; i += 256) fill[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < Nr; i += 256) {
+        const uint32_t x = rcb[i].x;
+        const int minr = (int)(x & 0xFFF), maxr = (int)((x >> 12) & 0xFFF);
+        if (maxr < minr) continue;
+        const int b0 = min(minr >> bhShift, nbins - 1), b1 = min(maxr >> bhShift, nbins - 1);
+        atomicAdd(&cnt[b0 + 1], 1);
+        if (b1 != b0) atomicAdd(&cnt[b1 + 1], 1);
+    }
+    __syncthreads();
+    if (tid == 0) for (int i = 0; i < nbins; i++) cnt[i + 1] += cnt[i];   // <= 512 steps, once per frame
+    __syncthreads();
+    int32_t *bs = binStart + (size_t)b * (ST_MAX_BINS + 1), *it = items + (size_t)b * 2 * cap;
+    for (int i = tid; i <= nbins; i += 256) bs[i] = cnt[i];
+    for (int i = tid; i < Nr; i += 256) {
+        const uint32_t x = rcb[i].x;
+        const int minr = (int)(x & 0xFFF), maxr = (int)((x >> 12) & 0xFFF);
+        if (maxr < minr) continue;
+        const int b0 = min(minr >> bhShift, nbins - 1), b1 = min(maxr >> bhShift, nbins - 1);
+        it[cnt[b0] + atomicAdd(&fill[b0], 1)] = i;
+        if (b1 != b0) it[cnt[b1] + atomicAdd(&fill[b1], 1)] = i;
+    }
+}
 // one wave per left keypoint: row-band candidate test (:498-508, :535), level and
 // disparity-range tests (:548-553), Hamming argmin (first minimum in iR order, :558-562),
 // then the 11x11 SAD over 11 shifts (:577-607), parabola (:613-620), disparity (:623-636).
@@ -93,20 +129,14 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
     size_t pyrImgR, const orbx_keypoint_t *__restrict__ kl, const uint8_t *__restrict__ dl,
     const int32_t *__restrict__ nl, const orbx_keypoint_t *__restrict__ kr, const uint8_t *__restrict__ dr,
     const int32_t *__restrict__ nr, int cap, float mbf, float mb, float *__restrict__ uright,
-    float *__restrict__ depth, int32_t *__restrict__ sad, const uint2 *__restrict__ rc) {
-    // The right keypoints' compact records are staged in LDS once per workgroup (ST_WAVES left keypoints of
-    // one frame share them): the candidate filter then never waits on global memory, and the few survivors
-    // are compacted (ballot prefix, increasing iR) so that their descriptors are fetched by all lanes at once.
-    extern __shared__ uint2 s_rc[];
+    float *__restrict__ depth, int32_t *__restrict__ sad, const uint2 *__restrict__ rc, const int32_t *__restrict__ binStart,
+    const int32_t *__restrict__ binItems, int bhShift, int nbins) {
+    // Candidates = the right keypoints of this keypoint's row bin; the survivors of the exact tests are compacted
+    // (ballot prefix) so that their descriptors are fetched by all lanes at once.
     __shared__ uint16_t s_cand[ST_WAVES][ST_CAND];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int iL = blockIdx.x * ST_WAVES + wave, b = blockIdx.y;
-    const int N = min(nl[b], cap), Nr = min(nr[b], cap);
-    {
-        const uint2 *rcb = rc + (size_t)b * cap;
-        for (int i = threadIdx.x; i < Nr; i += 64 * ST_WAVES) s_rc[i] = rcb[i];
-    }
-    __syncthreads();
+    const int N = min(nl[b], cap);
     if (iL >= cap) return;
     const size_t o = (size_t)b * cap + iL;
     if (iL >= N) {
@@ -129,11 +159,17 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
         const uint8_t *drb = dr + (size_t)b * cap * 32;
         uint16_t *cl = s_cand[wave];
         int cnt = 0;
-        for (int i0 = 0; i0 < Nr; i0 += 64) {
-            const int iR = i0 + lane;
+        const uint2 *rcb = rc + (size_t)b * cap;
+        const int32_t *bs = binStart + (size_t)b * (ST_MAX_BINS + 1), *bit = binItems + (size_t)b * 2 * cap;
+        const int bin = min(row >> bhShift, nbins - 1);
+        const int p0 = bs[bin], p1 = bs[bin + 1];
+        for (int i0 = p0; i0 < p1; i0 += 64) {
+            const int ip = i0 + lane;
+            int iR = 0;
             bool pass = false;
-            if (iR < Nr) {
-                const uint2 q = s_rc[iR];
+            if (ip < p1) {
+                iR = bit[ip];
+                const uint2 q = rcb[iR];
                 const int minr = (int)(q.x & 0xFFF), maxr = (int)((q.x >> 12) & 0xFFF), octR = (int)(q.x >> 24);
                 const float uR = __uint_as_float(q.y);
                 pass = row >= minr && row <= maxr && octR >= levelL - 1 && octR <= levelL + 1 && uR >= minU && uR <= maxU;
@@ -189,12 +225,21 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
                 const int av1 = (int)IL[(size_t)(cy + ay1) * sL + cxl + ax1] - cL;
                 float vDists[11];
                 int bestDistS = INT_MAX, bestincR = 0;
+                // the 33 right-image bytes of this lane (2 window pixels + the window centre, 11 shifts each) are all
+                // requested before the first sum: one memory latency instead of eleven
+                int rc0[11], rb0[11], rb1[11];
+#pragma unroll
+                for (int k = 0; k < 11; k++) {
+                    const int cxr = cxr0 + k - L;
+                    rc0[k] = IR[(size_t)cy * sR + cxr];
+                    rb0[k] = IR[(size_t)(cy + ay0) * sR + cxr + ax0];
+                    rb1[k] = IR[(size_t)(cy + ay1) * sR + cxr + ax1];
+                }
 #pragma unroll
                 for (int incR = -L; incR <= L; incR++) {
-                    const int cxr = cxr0 + incR;
-                    const int cR = IR[(size_t)cy * sR + cxr];
-                    const int bv0 = (int)IR[(size_t)(cy + ay0) * sR + cxr + ax0] - cR;
-                    const int bv1 = (int)IR[(size_t)(cy + ay1) * sR + cxr + ax1] - cR;
+                    const int cR = rc0[incR + L];
+                    const int bv0 = rb0[incR + L] - cR;
+                    const int bv1 = rb1[incR + L] - cR;
                     const int df0 = av0 - bv0, df1 = av1 - bv1;
                     int s = (df0 < 0 ? -df0 : df0) + (has1 ? (df1 < 0 ? -df1 : df1) : 0);
                     s = wave_sum_i32(s);
@@ -311,8 +356,8 @@ static int fill_stereo_levels(orbx_extractor *hl, orbx_extractor *hr, StereoLeve
 }
 
 // scratch for the SAD distances, grown on demand (per left extractor handle)
-struct StereoScratch { int32_t *d_sad; uint2 *d_rc; size_t n; int device; };
-static thread_local StereoScratch g_ss = {nullptr, nullptr, 0, -1};
+struct StereoScratch { int32_t *d_sad; uint2 *d_rc; int32_t *d_binStart, *d_items; size_t n; int nB; int device; };
+static thread_local StereoScratch g_ss = {nullptr, nullptr, nullptr, nullptr, 0, 0, -1};
 
 extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, int left_slot0,
                                         int right_slot0, const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
@@ -329,24 +374,32 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
     if (rc) return rc;
     ORBX_HIP(hipSetDevice(hl->device));
     const size_t need = (size_t)B * cap;
-    if (g_ss.n < need || g_ss.device != hl->device) {
+    if (g_ss.n < need || g_ss.nB < B || g_ss.device != hl->device) {
         if (g_ss.d_sad) hipFree(g_ss.d_sad);
         if (g_ss.d_rc) hipFree(g_ss.d_rc);
-        g_ss.d_sad = nullptr; g_ss.d_rc = nullptr; g_ss.n = 0;
+        if (g_ss.d_binStart) hipFree(g_ss.d_binStart);
+        if (g_ss.d_items) hipFree(g_ss.d_items);
+        g_ss.d_sad = nullptr; g_ss.d_rc = nullptr; g_ss.d_binStart = nullptr; g_ss.d_items = nullptr; g_ss.n = 0; g_ss.nB = 0;
         ORBX_HIP(hipMalloc(&g_ss.d_sad, sizeof(int32_t) * need));
         ORBX_HIP(hipMalloc(&g_ss.d_rc, sizeof(uint2) * need));
-        g_ss.n = need; g_ss.device = hl->device;
+        ORBX_HIP(hipMalloc(&g_ss.d_items, sizeof(int32_t) * 2 * need));
+        ORBX_HIP(hipMalloc(&g_ss.d_binStart, sizeof(int32_t) * (ST_MAX_BINS + 1) * (size_t)B));
+        g_ss.n = need; g_ss.nB = B; g_ss.device = hl->device;
     }
+    // bin height: a power of two >= the tallest row band (maxr - minr + 1 <= 2r + 3, r = 2 * scale of the coarsest level)
+    int bhShift = 3;
+    while ((1 << bhShift) < (int)(4.0f * lv.sf[lv.nlevels - 1]) + 4) bhShift++;
+    while (((lv.nRows + (1 << bhShift) - 1) >> bhShift) > ST_MAX_BINS) bhShift++;
+    const int nbins = std::max(1, (lv.nRows + (1 << bhShift) - 1) >> bhShift);
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream
     dim3 grid((cap + ST_WAVES - 1) / ST_WAVES, B);
     (void)hipGetLastError();
-    if (cap > 16000) { orbx_set_error("orbm_stereo: %d keypoints per image exceed the LDS plan (16000)", cap); return ORBX_ERR_UNSUPPORTED; }
-    if (sizeof(uint2) * (size_t)cap > 48 * 1024)
-        ORBX_HIP(hipFuncSetAttribute((const void *)k_stereo_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint2) * (size_t)cap)));
+    if (cap > 65535) { orbx_set_error("orbm_stereo: %d keypoints per image (limit 65535)", cap); return ORBX_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_stereo_prep, dim3((cap + 255) / 256, B), dim3(256), 0, st, lv, d_kr, d_nr, cap, g_ss.d_rc);
-    hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), sizeof(uint2) * (size_t)cap, st, lv, hl->d_pyr + (size_t)left_slot0 * hl->pyrImgBytes, hl->pyrImgBytes,
+    hipLaunchKernelGGL(k_stereo_bins, dim3(B), dim3(256), 0, st, g_ss.d_rc, d_nr, cap, bhShift, nbins, g_ss.d_binStart, g_ss.d_items);
+    hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), 0, st, lv, hl->d_pyr + (size_t)left_slot0 * hl->pyrImgBytes, hl->pyrImgBytes,
                        hr->d_pyr + (size_t)right_slot0 * hr->pyrImgBytes, hr->pyrImgBytes, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
-                       g_ss.d_sad, g_ss.d_rc);
+                       g_ss.d_sad, g_ss.d_rc, g_ss.d_binStart, g_ss.d_items, bhShift, nbins);
     hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(SM_T), sizeof(int32_t) * cap, st, d_nl, cap, d_uright,
                        d_depth, g_ss.d_sad, d_nmatch);
     ORBX_HIP(hipGetLastError());

@@ -35,18 +35,38 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
     const unsigned lo = __shfl_xor((unsigned)v, m), hi = __shfl_xor((unsigned)(v >> 32), m);
     return (u64)lo | ((u64)hi << 32);
 }
-__device__ __forceinline__ u64 wave_min_u64(u64 v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const u64 t = shfl_xor_u64(v, o);
-        v = t < v ? t : v;
-    }
-    return v;
-}
+// Wave64 reductions on the DPP data path (row shifts + row broadcasts, ~7 VALU steps) instead of six
+// ds_bpermute round trips through the LDS crossbar: these sit on the critical path of one-wave-per-item kernels.
+// After the steps lane 63 holds the result; it is returned to every lane through an SGPR.
+#define ORBX_DPP_ROW_SHR(n) (0x110 + (n))
+#define ORBX_DPP_ROW_BCAST15 0x142
+#define ORBX_DPP_ROW_BCAST31 0x143
 __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, ORBX_DPP_ROW_SHR(1), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, ORBX_DPP_ROW_SHR(2), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, ORBX_DPP_ROW_SHR(4), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, ORBX_DPP_ROW_SHR(8), 0xf, 0xf, true);     // lane 15 of every row: row sum
+    v += __builtin_amdgcn_update_dpp(0, v, ORBX_DPP_ROW_BCAST15, 0xa, 0xf, true);   // rows 1, 3 += lane 15 of the row before
+    v += __builtin_amdgcn_update_dpp(0, v, ORBX_DPP_ROW_BCAST31, 0xc, 0xf, true);   // rows 2, 3 += lane 31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ u64 dpp_min_step(u64 v) {
+    // lanes that the masks disable or that read out of range see ~0 (the identity of min)
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(unsigned)v, CTRL, ROWMASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(unsigned)(v >> 32), CTRL, ROWMASK, 0xf, false);
+    const u64 t = (u64)lo | ((u64)hi << 32);
+    return t < v ? t : v;
+}
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+    v = dpp_min_step<ORBX_DPP_ROW_SHR(1), 0xf>(v);
+    v = dpp_min_step<ORBX_DPP_ROW_SHR(2), 0xf>(v);
+    v = dpp_min_step<ORBX_DPP_ROW_SHR(4), 0xf>(v);
+    v = dpp_min_step<ORBX_DPP_ROW_SHR(8), 0xf>(v);
+    v = dpp_min_step<ORBX_DPP_ROW_BCAST15, 0xa>(v);
+    v = dpp_min_step<ORBX_DPP_ROW_BCAST31, 0xc>(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return (u64)lo | ((u64)hi << 32);
 }
 
 
