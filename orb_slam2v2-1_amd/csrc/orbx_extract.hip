@@ -50,6 +50,19 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Wave64 inclusive prefix sum / total on the DPP data path (row shifts, then the two row broadcasts): ~6 VALU steps
+// instead of six ds_bpermute round trips — these scans sit on the critical path of single-wave code (quad-tree passes).
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ int wave_total_i32(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_i32(v), 63); }
+
 __device__ __forceinline__ int reflect101(int i, int n) {  // valid for -n < i < 2n-1
     if (i < 0) i = -i;
     if (i >= n) i = 2 * (n - 1) - i;
@@ -622,12 +635,7 @@ __global__ __launch_bounds__(256) void k_cell_scan(const LevelGeom *__restrict__
     const int beg = min(tid * chunk, g.ncells), end = min(beg + chunk, g.ncells);
     int s = 0;
     for (int c = beg; c < end; c++) s += (int)cc[c];
-    int inc = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
+    const int inc = wave_incl_scan_i32(s);
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
     int off = inc - s, tot = 0;
@@ -892,12 +900,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
                         const uint32_t cv = cnt[k];
                         s += ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) ? 1 : 0;
                     }
-                    int inc = s;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const int t = __shfl_up(inc, o);
-                        if (lane >= o) inc += t;
-                    }
+                    const int inc = wave_incl_scan_i32(s);
                     E = __builtin_amdgcn_readlane(inc, 63);
                     int off = inc - s;
                     for (int k = beg; k < end; k++) {
@@ -931,8 +934,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
                             }
                             wave_sync();
                         }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+                    e = wave_total_i32(e);
                     E = e;
                     for (int k = lane; k < E; k += 64) xlist[k] = (uint16_t)(skey[k] & 0xFFFFu);
                 }
@@ -947,12 +949,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
                         const int k = xlist[r];
                         s += (hist[4 * k] > 0) + (hist[4 * k + 1] > 0) + (hist[4 * k + 2] > 0) + (hist[4 * k + 3] > 0);
                     }
-                    int inc = s;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const int t = __shfl_up(inc, o);
-                        if (lane >= o) inc += t;
-                    }
+                    const int inc = wave_incl_scan_i32(s);
                     int off = inc - s;
                     int hit = 0x7FFFFFFF;
                     for (int r = beg; r < end; r++) {
@@ -996,20 +993,14 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
                         }
                     }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) nexp += __shfl_xor(nexp, o);
+                nexp = wave_total_i32(nexp);
                 wave_sync();
                 {   // survivors keep their relative order behind the new nodes
                     const int chunk = (L + 63) >> 6;
                     const int beg = min(lane * chunk, L), end = min(beg + chunk, L);
                     int s = 0;
                     for (int k = beg; k < end; k++) s += split[k] ? 0 : 1;
-                    int inc = s;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const int t = __shfl_up(inc, o);
-                        if (lane >= o) inc += t;
-                    }
+                    const int inc = wave_incl_scan_i32(s);
                     int off = inc - s;
                     for (int k = beg; k < end; k++)
                         if (!split[k]) {
@@ -1214,12 +1205,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
                     const uint32_t cv = cnt[k];
                     s += ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) ? 1 : 0;
                 }
-                int inc = s;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int t = __shfl_up(inc, o);
-                    if (lane >= o) inc += t;
-                }
+                const int inc = wave_incl_scan_i32(s);
                 E = __builtin_amdgcn_readlane(inc, 63);
                 int off = inc - s;
                 for (int k = beg; k < end; k++) {
@@ -1253,8 +1239,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
                         }
                         wave_sync();
                     }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+                e = wave_total_i32(e);
                 E = e;
                 for (int k = lane; k < E; k += 64) S.xlist[k] = (uint16_t)(S.skey[k] & 0xFFFFu);
             }
@@ -1269,12 +1254,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
                     const int k = S.xlist[r];
                     s += (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) + (S.hist[4 * k + 3] > 0);
                 }
-                int inc = s;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int t = __shfl_up(inc, o);
-                    if (lane >= o) inc += t;
-                }
+                const int inc = wave_incl_scan_i32(s);
                 int off = inc - s;
                 // 3. number of parents split: phase 2 stops at the first rank that reaches N (:730-731)
                 int hit = 0x7FFFFFFF;
@@ -1320,20 +1300,14 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
                     }
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) nexp += __shfl_xor(nexp, o);
+            nexp = wave_total_i32(nexp);
             wave_sync();
             {   // survivors keep their relative order behind the new nodes
                 const int chunk = (L + 63) >> 6;
                 const int beg = min(lane * chunk, L), end = min(beg + chunk, L);
                 int s = 0;
                 for (int k = beg; k < end; k++) s += S.split[k] ? 0 : 1;
-                int inc = s;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int t = __shfl_up(inc, o);
-                    if (lane >= o) inc += t;
-                }
+                const int inc = wave_incl_scan_i32(s);
                 int off = inc - s;
                 for (int k = beg; k < end; k++)
                     if (!S.split[k]) {
@@ -1550,11 +1524,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
         m10 = s1;
         m01 = v * s0;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        m10 += __shfl_xor(m10, off);
-        m01 += __shfl_xor(m01, off);
-    }
+    m10 = wave_total_i32(m10);
+    m01 = wave_total_i32(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // ---- horizontal 7-tap pass: 4 outputs per lane-iteration from one aligned b128 read
