@@ -453,15 +453,20 @@ __device__ __forceinline__ void fast_score_pair(const uint32_t *E, int ES, int s
 // strict 3x3 maximum test of the pair (px, px+1): scores v0/v1 and keep flags
 __device__ __forceinline__ void fast_nms_pair(const uint8_t *Sc, int SS, int cw, int py, int px, bool &k0, bool &k1,
                                               int &v0, int &v1) {
-    const uint8_t *sc = Sc + (py + 1) * SS + px;  // pixels px-2 .. px+3 are bytes sc[0..5]
+    // pixels px-1 .. px+2 of a row are bytes o .. o+3 of the two aligned dwords at (row + px) & ~3 (SS % 4 == 0, px even:
+    // o = 1 or 3): ONE 8-byte LDS read per row and three v_perm with lane-constant selectors
+    const int px4 = px & ~3;
+    const uint32_t o = (px & 2) ? 3u : 1u, osel = o * 0x00010001u;
+    const uint8_t *sc = Sc + (py + 1) * SS + px4;  // 4-byte aligned: pixel px4-2+k is byte k
     half2v l3[3], m3[3], r3[3];
 #pragma unroll
     for (int rw = 0; rw < 3; rw++) {
-        const uint8_t *q = sc + (rw - 1) * SS;
-        const uint32_t A = *(const uint16_t *)q, M = *(const uint16_t *)(q + 2), C = *(const uint16_t *)(q + 4);
-        l3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(M, A, 0x0c040c01u));  // (px-1, px)
-        m3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(M, M, 0x0c010c00u));  // (px, px+1)
-        r3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(C, M, 0x0c040c01u));  // (px+1, px+2)
+        const uint32_t *w32 = (const uint32_t *)(sc + (rw - 1) * SS);   // two dwords (ds_read2_b32: 4-byte alignment is enough)
+        uint2 w;
+        w.x = w32[0]; w.y = w32[1];
+        l3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(w.y, w.x, 0x0c010c00u + osel));  // (px-1, px)
+        m3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(w.y, w.x, 0x0c020c01u + osel));  // (px, px+1)
+        r3[rw] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(w.y, w.x, 0x0c030c02u + osel));  // (px+1, px+2)
     }
     const half2v nb = pk_max3(pk_max3(l3[0], m3[0], r3[0]), pk_max3(l3[2], m3[2], r3[2]),
                               __builtin_elementwise_maximum(l3[1], r3[1]));
