@@ -280,9 +280,9 @@ def gaussian_blur7(src):
 
 def distribute_octtree(cands, width, height, N):
     cands = np.ascontiguousarray(cands, CAND_DTYPE)
-    out = np.zeros(N + 8, CAND_DTYPE)
+    out = np.zeros(max(N + 8, 4 * int(round(width / height)) + 8), CAND_DTYPE)   # the first pass splits every root whatever N is
     n = lib().oracle_distribute_octtree(_p(cands), len(cands), width, height, N, _p(out), out.size)
-    if n < 0:
+    if n < 0 or n > out.size:
         raise RuntimeError("octtree failed")
     return out[:n].copy()
 

@@ -593,12 +593,15 @@ int oracle_extract(orb_oracle_t *o, const uint8_t *img, int w, int h, int stride
         }
         o->cand[l] = cd; o->ncand[l] = nc;
         double tb = now_s(); o->stage_s[1] += tb - ta;
+        /* the list holds at most max(N + 3, 4 * nIni) nodes: the first pass splits EVERY root before N is looked at (:606-672) */
+        const int nIniL = (int)roundf((float)(maxBorderX - minBorderX) / (float)(maxBorderY - minBorderY));
         int capk = o->nfeat[l] + 8;
+        if (capk < 4 * nIniL + 8) capk = 4 * nIniL + 8;
         o->sel[l] = (oracle_cand_t *)malloc(sizeof(oracle_cand_t) * capk);
         int ns = oracle_distribute_octtree(cd, nc, maxBorderX - minBorderX, maxBorderY - minBorderY,
                                            o->nfeat[l], o->sel[l], capk);
         if (ns < 0) return -1000;
-        if (ns > capk) ns = capk; /* cannot exceed N+3 */
+        if (ns > capk) return -1000; /* cannot happen: see capk */
         o->nsel[l] = ns;
         o->stage_s[2] += now_s() - tb;
     }

@@ -347,14 +347,16 @@ __global__ __launch_bounds__(256) void k_pyr_pad(const uint8_t *__restrict__ img
         return;
     }
     const int total = 2 * ORBX_EDGE * pw4 + G.h * side;
+    // floor(i / d) == (i * M) >> 24 with M = 2^24 / d + 1 for every i < 2^24 / d (frame items: < 2^14): no integer division
+    const unsigned Mp = (1u << 24) / (unsigned)pw4 + 1u, Ms = (1u << 24) / (unsigned)side + 1u;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         int py, p4;
         if (i < 2 * ORBX_EDGE * pw4) {
-            const int r = i / pw4;
+            const int r = (int)(((unsigned long long)(unsigned)i * Mp) >> 24);
             p4 = i - r * pw4;
             py = r < ORBX_EDGE ? r : G.h + r;           // top frame rows, then bottom frame rows
         } else {
-            const int j = i - 2 * ORBX_EDGE * pw4, r = j / side, k = j - r * side;
+            const int j = i - 2 * ORBX_EDGE * pw4, r = (int)(((unsigned long long)(unsigned)j * Ms) >> 24), k = j - r * side;
             py = ORBX_EDGE + r;
             p4 = k < LW ? k : R0 + (k - LW);
         }

@@ -217,6 +217,13 @@ def test_fused_pyramid_kernel(pkg, oracle, synth):
         pkg.lib().orbx_debug_set(5, 0)
 
 
+def test_small_budget_many_roots(pkg, oracle, synth):
+    """The coarsest level of a 1229x497 image at scale 1.5 has 4 quad-tree roots and a budget of 5: the first pass splits all
+    roots (16 nodes) before N is looked at (src/ORBextractor.cc:606-672)."""
+    k = _compare(pkg, oracle, synth.frame(1229, 497, 672), 100, sf=1.5, nl=6)
+    assert (k["octave"] == 5).sum() == 16
+
+
 def test_large_scale_factor(pkg, oracle, synth):
     """scaleFactor 2.6 and 3.4: source columns of a lane's pixel pair up to 4 apart (3.4 takes the fused kernel)."""
     _compare(pkg, oracle, synth.frame(1920, 1080, 84), 500, sf=2.6, nl=3)
