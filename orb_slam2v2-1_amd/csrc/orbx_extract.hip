@@ -1487,9 +1487,29 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     // ---- stage the 43x43 patch with aligned dword loads (pstride is a multiple of 64)
     const uint8_t *lvl = pyr + (size_t)b * pyrImgBytes + g.poff;
     const size_t a = (size_t)(cy + ORBX_EDGE - PR) * g.pstride + (size_t)(cx + ORBX_EDGE - PR);
-    const int sh = __builtin_amdgcn_readfirstlane((int)(a & 3));
+    int sh = __builtin_amdgcn_readfirstlane((int)(a & 3));
     const uint32_t *src = (const uint32_t *)(lvl + (a - sh));
     const int pstr4 = g.pstride >> 2;
+    // The 19-px REFLECT_101 frame of the levels >= 1 is only ever read HERE, by the few keypoints closer than PR to a
+    // level's edge (the frame of level 0 comes with the copy of the input).  Those keypoints mirror the coordinates
+    // themselves, so the pipeline never writes the frames of levels >= 1 (orbx_pyramid_host writes them on demand).
+    const bool edge = l > 0 && (cx < PR || cy < PR || cx + PR >= g.w || cy + PR >= g.h);   // wave-uniform
+    if (edge) {
+        sh = 0;
+        const uint8_t *inner = lvl + (size_t)ORBX_EDGE * g.pstride + ORBX_EDGE;
+        for (int base0 = 0; base0 < PROWS * PSTRIDE; base0 += 64 * 8) {
+            uint8_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = min(base0 + lane + 64 * k, PROWS * PSTRIDE - 1);
+                const int r = i / PSTRIDE, c = i - r * PSTRIDE;
+                v[k] = inner[(size_t)reflect101c(cy - PR + r, g.h) * g.pstride + reflect101c(cx - PR + c, g.w)];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (base0 + lane + 64 * k < PROWS * PSTRIDE) P[base0 + lane + 64 * k] = v[k];
+        }
+    } else
     {   // all (PROWS*12 + 63) / 64 loads of a lane are in flight before the first LDS write: one memory latency per keypoint
         constexpr int NI = (PROWS * 12 + 63) / 64;
         uint32_t v[NI];
@@ -2026,13 +2046,9 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
             hipLaunchKernelGGL(k_pyr_level, dim3((nxc * nbands + 3) / 4, B), dim3(256), 0, st, h->d_pyr, h->pyrImgBytes,
                                h->d_geom, l, h->d_tab, nxc, nbands);
         }
-        if (nl > 1) {
-            const LevelGeom &g1 = h->geom[1];
-            const int p1 = (g1.w + 2 * ORBX_EDGE + 3) >> 2, tot1 = 2 * ORBX_EDGE * p1 + g1.h * 12;
-            hipLaunchKernelGGL(k_pyr_pad<false>, dim3((tot1 + 255) / 256, nl - 1, B), dim3(256), 0, st, d_imgs, stride,
-                               img_stride, h->d_pyr, h->pyrImgBytes, h->d_geom, 1);
-        }
-    } else {   // K1, fused form (orbx_debug_set(5, 1))
+        h->framesStale = nl > 1 ? B : 0;   // frames of levels >= 1: written on demand (ensure_frames)
+    } else {   // K1, fused form (orbx_debug_set(5, 1)): writes every frame itself
+        h->framesStale = 0;
         hipLaunchKernelGGL(k_pyramid_fused, dim3(h->pyrTilesX * h->pyrTilesY, B), dim3(256), h->pyrLdsBytes, st, d_imgs,
                            stride, img_stride, h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->d_tab, h->pyrXSpanOff,
                            h->pyrYSpanOff, h->pyrTilesX, h->pyrTilesY, h->pyrBufBytes, h->pyrMaxPar);
@@ -2181,11 +2197,31 @@ int orbx_internal_level(const orbx_extractor *h, int level, int *w, int *hgt, in
     return ORBX_OK;
 }
 
+// copyMakeBorder of the levels >= 1 of the last batch, for callers that look at the padded buffers
+static int ensure_frames(orbx_extractor *h) {
+    if (h->framesStale <= 0) return ORBX_OK;
+    const int nl = h->nlevels, B = h->framesStale;
+    hipStream_t st = h->last_stream;
+    const LevelGeom &g1 = h->geom[1];
+    const int p1 = (g1.w + 2 * ORBX_EDGE + 3) >> 2, tot1 = 2 * ORBX_EDGE * p1 + g1.h * 12;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_pyr_pad<false>, dim3((tot1 + 255) / 256, nl - 1, B), dim3(256), 0, st, (const uint8_t *)nullptr, 0, (size_t)0,
+                       h->d_pyr, h->pyrImgBytes, h->d_geom, 1);
+    ORBX_HIP(hipGetLastError());
+    h->framesStale = 0;
+    return ORBX_OK;
+}
+
 extern "C" int orbx_pyramid_device(orbx_extractor_t *h, int b, int level, const uint8_t **d_ptr, int *w, int *hgt,
                                    int *stride) {
     if (!h || !d_ptr || level < 0 || level >= h->nlevels || h->pw == 0 || b < 0 || b >= h->pB) {
         orbx_set_error("orbx_pyramid_device: bad arguments or no frame extracted yet");
         return ORBX_ERR_ARG;
+    }
+    if (level > 0) {   // the caller may walk into the 19-px frame around the ROI, as with the reference's padded cv::Mat
+        ORBX_HIP(hipSetDevice(h->device));
+        const int rc = ensure_frames(h);
+        if (rc) return rc;
     }
     const LevelGeom &g = h->geom[level];
     *d_ptr = h->d_pyr + (size_t)b * h->pyrImgBytes + g.poff + (size_t)ORBX_EDGE * g.pstride + ORBX_EDGE;
@@ -2208,6 +2244,7 @@ extern "C" int orbx_pyramid_host(orbx_extractor_t *h, int b, int level, int padd
     if (!dst) return ORBX_OK;
     if (dst_stride < ow) { orbx_set_error("dst_stride < width"); return ORBX_ERR_ARG; }
     ORBX_HIP(hipSetDevice(h->device));
+    if (padded && level > 0) { const int rc = ensure_frames(h); if (rc) return rc; }
     if (h->last_stream) ORBX_HIP(hipStreamSynchronize(h->last_stream));
     const uint8_t *src = h->d_pyr + (size_t)b * h->pyrImgBytes + g.poff +
                          (padded ? 0 : (size_t)ORBX_EDGE * g.pstride + ORBX_EDGE);

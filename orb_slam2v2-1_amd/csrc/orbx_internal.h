@@ -87,6 +87,7 @@ struct orbx_extractor {
     hipStream_t stream;      // own stream
     hipStream_t last_stream; // stream of the last batch call
     int lastB;
+    int framesStale;         // > 0: the frames of levels >= 1 of that many images have not been written (see ensure_frames)
     // per-stage HIP-event timing: a ring of event sets so that timing never forces a sync
     int profiling;
     hipEvent_t ev[ORBX_EV_RING][ORBX_NUM_STAGES];
