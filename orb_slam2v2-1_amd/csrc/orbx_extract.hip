@@ -1450,6 +1450,25 @@ __device__ __forceinline__ void sincos_0_2pi(float af, float &sn, float &cs) {
     cs = (float)(((q + 1) & 2) ? -cq : cq);
 }
 
+// IC_Angle weights per lane (lane = 2 * (v + 15) + half: row v of the radius-15 disc, u = -15..0 or u = 1..16), as bytes for
+// v_dot4_u32_u8: m = 1 inside the disc (|u| <= umax[|v|], u <= 15), w = |u| inside.  Built at compile time.
+struct IcTab { uint32_t m[64][4], w[64][4]; };
+constexpr IcTab make_ic_tab() {
+    IcTab t{};
+    constexpr int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    for (int lane = 0; lane < 62; lane++) {
+        const int v = (lane >> 1) - 15, half = lane & 1, d = um[v < 0 ? -v : v];
+        for (int k = 0; k < 16; k++) {
+            const int u = half ? k + 1 : k - 15, au = u < 0 ? -u : u;
+            const bool in = au <= d && u <= 15;
+            t.m[lane][k >> 2] |= (in ? 1u : 0u) << (8 * (k & 3));
+            t.w[lane][k >> 2] |= (in ? (uint32_t)au : 0u) << (8 * (k & 3));
+        }
+    }
+    return t;
+}
+__constant__ const IcTab c_ic = make_ic_tab();
+
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
     const uint32_t *__restrict__ lvlKp, int lvlKpCap, const int32_t *__restrict__ lvlCnt,
@@ -1539,17 +1558,16 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
         for (int k = 0; k < 5; k++) w[k] = row[k];
 #pragma unroll
         for (int k = 0; k < 4; k++) wa[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sa8);  // 16 bytes from o0
-        int s0 = 0, s1 = 0;
+        // sum of the pixels and of |u| * pixel over this lane's 16 columns: 8 byte dot products with the table weights
+        uint32_t s0 = 0, s1 = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int val = (int)((wa[k >> 2] >> (8 * (k & 3))) & 0xFF);
-            const int u = half ? k + 1 : k - 15;
-            const bool in = (u < 0 ? -u : u) <= d && u <= 15;
-            s0 += in ? val : 0;
-            s1 += in ? u * val : 0;
+        for (int j = 0; j < 4; j++) {
+            s0 = __builtin_amdgcn_udot4(wa[j], c_ic.m[lane][j], s0, false);
+            s1 = __builtin_amdgcn_udot4(wa[j], c_ic.w[lane][j], s1, false);
         }
-        m10 = s1;
-        m01 = v * s0;
+        m10 = half ? (int)s1 : -(int)s1;   // u <= 0 in half 0
+        m01 = v * (int)s0;
+        (void)d;
     }
     m10 = wave_total_i32(m10);
     m01 = wave_total_i32(m01);
