@@ -1744,6 +1744,7 @@ extern "C" int orbx_destroy(orbx_extractor_t *h) {
     if (h->last_stream) hipStreamSynchronize(h->last_stream);
     free_plan(h);
     hipFree(h->d_in); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts);
+    if (h->h_kps) { hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); }
     for (int r = 0; r < ORBX_EV_RING; r++)
         for (int i = 0; i < ORBX_NUM_STAGES; i++) hipEventDestroy(h->ev[r][i]);
     hipStreamDestroy(h->stream);
@@ -2148,6 +2149,11 @@ static int ensure_staging(orbx_extractor *h, size_t in_bytes, int B, int cap) {
         ORBX_HIP(hipMalloc(&h->d_kps, sizeof(orbx_keypoint_t) * (size_t)nb * nc));
         ORBX_HIP(hipMalloc(&h->d_desc, (size_t)32 * nb * nc));
         ORBX_HIP(hipMalloc(&h->d_counts, sizeof(int32_t) * nb));
+        // pinned mirrors: the results of a host-API call come down in three copies and ONE synchronisation
+        if (h->h_kps) { hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); h->h_kps = nullptr; h->h_desc = nullptr; h->h_counts = nullptr; }
+        ORBX_HIP(hipHostMalloc((void **)&h->h_kps, sizeof(orbx_keypoint_t) * (size_t)nb * nc, hipHostMallocDefault));
+        ORBX_HIP(hipHostMalloc((void **)&h->h_desc, (size_t)32 * nb * nc, hipHostMallocDefault));
+        ORBX_HIP(hipHostMalloc((void **)&h->h_counts, sizeof(int32_t) * nb, hipHostMallocDefault));
         h->out_cap = nc; h->out_B = nb;
     }
     return ORBX_OK;
@@ -2180,22 +2186,20 @@ extern "C" int orbx_extract_batch(orbx_extractor_t *h, const uint8_t *const *img
     }
     rc = launch_pipeline(h, h->d_in, B, w, hgt, stride, img_bytes, h->d_kps, h->d_desc, h->d_counts, dcap, h->stream);
     if (rc) return rc;
-    std::vector<int32_t> cnt(B);
-    ORBX_HIP(hipMemcpyAsync(cnt.data(), h->d_counts, sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->stream));
+    ORBX_HIP(hipMemcpyAsync(h->h_counts, h->d_counts, sizeof(int32_t) * B, hipMemcpyDeviceToHost, h->stream));
+    ORBX_HIP(hipMemcpyAsync(h->h_kps, h->d_kps, sizeof(orbx_keypoint_t) * (size_t)B * dcap, hipMemcpyDeviceToHost, h->stream));
+    ORBX_HIP(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)32 * B * dcap, hipMemcpyDeviceToHost, h->stream));
     ORBX_HIP(hipStreamSynchronize(h->stream));
     int status = ORBX_OK;
     for (int b = 0; b < B; b++) {
-        int n = cnt[b];
-        if (n > cap) { n = cap; status = ORBX_ERR_CAPACITY; orbx_set_error("frame %d produced %d keypoints, cap %d", b, cnt[b], cap); }
+        int n = h->h_counts[b];
+        if (n > cap) { n = cap; status = ORBX_ERR_CAPACITY; orbx_set_error("frame %d produced %d keypoints, cap %d", b, h->h_counts[b], cap); }
         n_out[b] = n;
         if (n > 0) {
-            ORBX_HIP(hipMemcpyAsync(kps + (size_t)b * cap, h->d_kps + (size_t)b * dcap, sizeof(orbx_keypoint_t) * n,
-                                    hipMemcpyDeviceToHost, h->stream));
-            ORBX_HIP(hipMemcpyAsync(desc + (size_t)b * cap * 32, h->d_desc + (size_t)b * dcap * 32, (size_t)32 * n,
-                                    hipMemcpyDeviceToHost, h->stream));
+            memcpy(kps + (size_t)b * cap, h->h_kps + (size_t)b * dcap, sizeof(orbx_keypoint_t) * n);
+            memcpy(desc + (size_t)b * cap * 32, h->h_desc + (size_t)b * dcap * 32, (size_t)32 * n);
         }
     }
-    ORBX_HIP(hipStreamSynchronize(h->stream));
     return status;
 }
 

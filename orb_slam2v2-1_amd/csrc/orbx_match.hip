@@ -415,6 +415,20 @@ struct DevBuf {
 #define DEV_ALLOC(buf, bytes) do { if ((buf).alloc(bytes)) { orbx_set_error("hipMalloc(%zu) failed", (size_t)(bytes)); return ORBX_ERR_HIP; } } while (0)
 #define H2D(buf, src, bytes) ORBX_HIP(hipMemcpy((buf).p, (src), (bytes), hipMemcpyHostToDevice))
 
+// thread-local device scratch with a pinned host mirror of the same layout: the host-array entry points below move their
+// inputs with ONE upload and their results with ONE download + ONE synchronisation (no hipMalloc per call)
+struct StagePair { uint8_t *d = nullptr, *h = nullptr; size_t cap = 0; int device = -1; };
+static thread_local StagePair g_sp;
+static int stage_reserve(int device, size_t need) {
+    if (g_sp.device == device && g_sp.cap >= need) return ORBX_OK;
+    if (g_sp.d) { hipSetDevice(g_sp.device); hipFree(g_sp.d); hipHostFree(g_sp.h); g_sp.d = nullptr; g_sp.h = nullptr; g_sp.cap = 0; hipSetDevice(device); }
+    const size_t cap = std::max(need * 2, (size_t)1 << 20);
+    ORBX_HIP(hipMalloc(&g_sp.d, cap));
+    ORBX_HIP(hipHostMalloc((void **)&g_sp.h, cap, hipHostMallocDefault));
+    g_sp.cap = cap; g_sp.device = device;
+    return ORBX_OK;
+}
+
 extern "C" int orbm_stereo(orbx_extractor_t *hl, orbx_extractor_t *hr, const orbx_keypoint_t *kl,
                            const uint8_t *dl, int nl, const orbx_keypoint_t *kr, const uint8_t *dr, int nr,
                            float mbf, float mb, float *uright, float *depth, int *nmatch) {
@@ -426,25 +440,28 @@ extern "C" int orbm_stereo(orbx_extractor_t *hl, orbx_extractor_t *hr, const orb
     if (nl == 0) return ORBX_OK;
     ORBX_HIP(hipSetDevice(hl->device));
     const int cap = std::max(std::max(nl, nr), 1);
-    DevBuf bkl, bdl, bkr, bdr, bn, bu, bd, bm;
-    DEV_ALLOC(bkl, sizeof(orbx_keypoint_t) * cap); DEV_ALLOC(bdl, (size_t)32 * cap);
-    DEV_ALLOC(bkr, sizeof(orbx_keypoint_t) * cap); DEV_ALLOC(bdr, (size_t)32 * cap);
-    DEV_ALLOC(bn, sizeof(int32_t) * 3); DEV_ALLOC(bu, sizeof(float) * cap); DEV_ALLOC(bd, sizeof(float) * cap);
-    H2D(bkl, kl, sizeof(orbx_keypoint_t) * nl); H2D(bdl, dl, (size_t)32 * nl);
-    if (nr) { H2D(bkr, kr, sizeof(orbx_keypoint_t) * nr); H2D(bdr, dr, (size_t)32 * nr); }
-    int32_t cnt[3] = {nl, nr, 0};
-    H2D(bn, cnt, sizeof(cnt));
-    int32_t *dn = (int32_t *)bn.p;
-    int rc = orbm_stereo_batch_device(hl, hr, 1, 0, 0, (orbx_keypoint_t *)bkl.p, (uint8_t *)bdl.p, dn,
-                                      (orbx_keypoint_t *)bkr.p, (uint8_t *)bdr.p, dn + 1, cap, mbf, mb,
-                                      (float *)bu.p, (float *)bd.p, dn + 2, hl->stream);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_kl = 0, o_dl = o_kl + al(sizeof(orbx_keypoint_t) * cap), o_kr = o_dl + al((size_t)32 * cap),
+                 o_dr = o_kr + al(sizeof(orbx_keypoint_t) * cap), o_n = o_dr + al((size_t)32 * cap), o_in_end = o_n + 256,
+                 o_u = o_in_end, o_d = o_u + al(sizeof(float) * cap), o_end = o_d + al(sizeof(float) * cap);
+    int rc = stage_reserve(hl->device, o_end);
     if (rc) return rc;
-    ORBX_HIP(hipStreamSynchronize(hl->stream));
-    ORBX_HIP(hipMemcpy(uright, bu.p, sizeof(float) * nl, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(depth, bd.p, sizeof(float) * nl, hipMemcpyDeviceToHost));
-    int32_t nm = 0;
-    ORBX_HIP(hipMemcpy(&nm, dn + 2, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (nmatch) *nmatch = nm;
+    memcpy(g_sp.h + o_kl, kl, sizeof(orbx_keypoint_t) * nl); memcpy(g_sp.h + o_dl, dl, (size_t)32 * nl);
+    if (nr) { memcpy(g_sp.h + o_kr, kr, sizeof(orbx_keypoint_t) * nr); memcpy(g_sp.h + o_dr, dr, (size_t)32 * nr); }
+    int32_t cnt[3] = {nl, nr, 0};
+    memcpy(g_sp.h + o_n, cnt, sizeof(cnt));
+    hipStream_t st = hl->stream;
+    ORBX_HIP(hipMemcpyAsync(g_sp.d, g_sp.h, o_in_end, hipMemcpyHostToDevice, st));
+    int32_t *dn = (int32_t *)(g_sp.d + o_n);
+    rc = orbm_stereo_batch_device(hl, hr, 1, 0, 0, (orbx_keypoint_t *)(g_sp.d + o_kl), g_sp.d + o_dl, dn,
+                                  (orbx_keypoint_t *)(g_sp.d + o_kr), g_sp.d + o_dr, dn + 1, cap, mbf, mb,
+                                  (float *)(g_sp.d + o_u), (float *)(g_sp.d + o_d), dn + 2, st);
+    if (rc) return rc;
+    ORBX_HIP(hipMemcpyAsync(g_sp.h + o_n, g_sp.d + o_n, o_end - o_n, hipMemcpyDeviceToHost, st));   // counts | uright | depth
+    ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(uright, g_sp.h + o_u, sizeof(float) * nl);
+    memcpy(depth, g_sp.h + o_d, sizeof(float) * nl);
+    if (nmatch) *nmatch = ((const int32_t *)(g_sp.h + o_n))[2];
     return ORBX_OK;
 }
 
