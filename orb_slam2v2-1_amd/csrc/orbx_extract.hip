@@ -225,12 +225,14 @@ __device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b) {
 __global__ __launch_bounds__(256) void k_pyr_level(uint8_t *__restrict__ pyr, size_t pyrImgBytes,
                                                    const LevelGeom *__restrict__ geom, int l,
                                                    const int32_t *__restrict__ tab, int nxc, int nbands) {
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    int bx, b;
+    xcd_block_map(bx, b);
+    const int wave = __builtin_amdgcn_readfirstlane(bx * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (wave >= nxc * nbands) return;
     const int band = wave / nxc, xc = wave - band * nxc;
     const LevelGeom G = geom[l];
     const int sw = geom[l - 1].w, sh = geom[l - 1].h, sps = geom[l - 1].pstride;
-    uint8_t *base = pyr + (size_t)blockIdx.y * pyrImgBytes;
+    uint8_t *base = pyr + (size_t)b * pyrImgBytes;
     const uint8_t *srow0 = base + geom[l - 1].poff + (size_t)ORBX_EDGE * sps;   // padded row of source row 0
     uint8_t *drow0 = base + G.poff + (size_t)ORBX_EDGE * G.pstride + ORBX_EDGE;
     const int x0 = xc * 128 + 2 * lane - 1, x1 = x0 + 1;
@@ -485,7 +487,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     int iniTh, int minTh, int ES, int SS, int tileRows, int ldsPerWave, int phaseLimit, CellBases cb) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int gc = blockIdx.x * FAST_WAVES + wave, b = blockIdx.y;
+    int bx, b;
+    xcd_block_map(bx, b);
+    const int gc = bx * FAST_WAVES + wave;
     if (gc >= totalCells) return;  // wave-uniform; the kernel uses no block barrier
     const int l = level_of_cell(cb, nlevels, gc);
     const LevelGeom g = geom[l];
@@ -664,7 +668,9 @@ __global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ ge
                                                 const uint32_t *__restrict__ slots, size_t slotsPerImg,
                                                 uint32_t *__restrict__ cand, size_t keysPerImg, CellBases cb) {
     const int sub = threadIdx.x & 15;
-    const int gc = blockIdx.x * GATHER_CELLS_PER_BLOCK + (threadIdx.x >> 4), b = blockIdx.y;
+    int bx, b;
+    xcd_block_map(bx, b);
+    const int gc = bx * GATHER_CELLS_PER_BLOCK + (threadIdx.x >> 4);
     if (gc >= totalCells) return;
     const int l = level_of_cell(cb, nlevels, gc);
     const int c = gc - geom[l].cellBase, capc = geom[l].capc;
@@ -1475,7 +1481,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     orbx_keypoint_t *__restrict__ kps, uint8_t *__restrict__ desc, int32_t *__restrict__ counts, int cap) {
     __shared__ __align__(16) uint8_t smem[DESC_WAVES * DESC_LDS_PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int o = blockIdx.x * DESC_WAVES + wave, b = blockIdx.y;
+    int bx, b;
+    xcd_block_map(bx, b);   // all patches of an image are read through ONE L2
+    const int o = bx * DESC_WAVES + wave;
     // locate (level, k) of output ordinal o: level-major concatenation (:1076-1104)
     int l = 0, base = 0, total = 0;
     {   // lane i < nlevels holds the count of level i: ONE load, a 4-step prefix sum, a ballot (not nlevels dependent loads)
@@ -1487,7 +1495,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
             if (lane >= d) inc += t;
         }
         total = __builtin_amdgcn_readlane(inc, ORBX_MAX_LEVELS - 1);
-        if (blockIdx.x == 0 && threadIdx.x == 0) counts[b] = min(total, cap);
+        if (bx == 0 && threadIdx.x == 0) counts[b] = min(total, cap);
         const unsigned long long hit = __ballot(lane < nlevels && o < inc);
         if (!hit || o >= cap) return;  // wave-uniform
         l = __builtin_ctzll(hit);

@@ -132,3 +132,16 @@ int fast_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const 
 int fast_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, int npoints, int32_t *best_row,
                                  int32_t *best_median, int device);
 extern int g_debug[8];  // developer knobs (orbx_debug_set); [2] != 0 forces the exact one-workgroup matcher kernels
+
+// XCD-aware block -> (image, block-in-image) map for grids of (blocks per image, images).  Workgroups are dealt round-robin
+// to the 8 XCDs in linear-id order and every XCD has its own L2, so with the identity map neighbouring blocks - which
+// share 128-byte lines of the same pyramid rows - land in different L2s and each line crosses the fabric several times
+// (measured on k_fast_cells: FETCH_SIZE 2.0x the algorithmic bytes).  With this map XCD x works through a contiguous
+// eighth of the (image, block) list, i.e. whole images.  A bijection for any grid size.
+__device__ __forceinline__ void xcd_block_map(int &bx, int &b) {
+    const unsigned nbx = gridDim.x, total = nbx * gridDim.y, lin = blockIdx.y * nbx + blockIdx.x;
+    const unsigned xcd = lin & 7u, idx = lin >> 3, q = total >> 3, r = total & 7u;
+    const unsigned pos = xcd * q + min(xcd, r) + idx;   // XCD x owns q (+1 if x < r) consecutive positions
+    b = (int)(pos / nbx);
+    bx = (int)(pos - (unsigned)b * nbx);
+}

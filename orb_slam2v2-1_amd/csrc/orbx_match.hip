@@ -135,7 +135,9 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
     // (ballot prefix) so that their descriptors are fetched by all lanes at once.
     __shared__ uint16_t s_cand[ST_WAVES][ST_CAND];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int iL = blockIdx.x * ST_WAVES + wave, b = blockIdx.y;
+    int bx, b;
+    xcd_block_map(bx, b);   // both pyramids of a frame are read through ONE L2
+    const int iL = bx * ST_WAVES + wave;
     const int N = min(nl[b], cap);
     if (iL >= cap) return;
     const size_t o = (size_t)b * cap + iL;

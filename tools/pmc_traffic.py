@@ -4,9 +4,9 @@ profiles/pmc_traffic.json: HBM bytes per launch of every kernel of the bench ste
 
 Units / corrections (MI355X_MICROARCH.md, "HBM"): the counters are in KiB; on gfx950 FETCH_SIZE
 reports exactly half of the bytes of wide coalesced streaming reads (128-B requests tallied at
-64 B), so the read side is doubled; WRITE_SIZE is exact for wide stores.  These kernels also do
-narrow (byte / dword-gather) accesses for which the factor is uncalibrated — both the raw and
-the corrected figure are kept.  Only full-batch launches (the most frequent grid size) count."""
+64 B), so the read side is doubled; WRITE_SIZE is exact for wide stores.  tools/pmc_calibrate.hip
+calibrates the patterns these kernels use (dword loads, 32/64-byte row segments): the read side is 1/2
+for all of them, a lone dword store is tallied as 32 B — both the raw and the corrected figure are kept.  Only full-batch launches (the most frequent grid size) count."""
 import collections, csv, glob, json, sys
 
 

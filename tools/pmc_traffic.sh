@@ -4,6 +4,11 @@
 # each with --kernel-trace only, as MI355X_MICROARCH.md "HBM" prescribes.
 set -e
 out=$GRAFT_REPO_ROOT/gpurun_out
+if [ -z "$PMC_NO_HEARTBEAT" ]; then   # PMC passes are slow and silent; gpurun kills silent runs
+    ( while sleep 45; do date >> $out/heartbeat.log; done ) &
+    hb=$!
+    trap "kill $hb 2>/dev/null" EXIT
+fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf $out/pmc_fetch $out/pmc_write
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
