@@ -292,8 +292,9 @@ def main():
         if os.path.exists(pmc_path):
             try:
                 pm = json.load(open(pmc_path))
-                if pm.get("workload") == args.workload and pm.get("batch") == B and dom in pm.get("kernels", {}):
-                    traffic = pm["kernels"][dom]["hbm_bytes_per_launch"]
+                inst = [k for k in pm.get("kernels", {}) if k.split("<")[0] == dom]   # template instances: k_fast_cells<44>
+                if pm.get("workload") == args.workload and pm.get("batch") == B and inst:
+                    traffic = max(pm["kernels"][k]["hbm_bytes_per_launch"] for k in inst)
             except Exception:
                 traffic = None
         out = {

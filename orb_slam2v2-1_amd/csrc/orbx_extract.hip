@@ -481,10 +481,15 @@ __device__ __forceinline__ void fast_nms_pair(const uint8_t *Sc, int SS, int cw,
     k1 = gt.y > 0 && px + 1 < cw;
 }
 
+// ES_T != 0: the tile strides are compile-time constants (pair tile ES_T dwords, score tile ES_T - 8 bytes), so every LDS
+// address of the ring / NMS reads is ONE base register + an immediate offset; with run-time strides the score loop spent
+// 21 of its 150 VALU instructions per pixel pair on address arithmetic.  ES_T == 0: run-time strides (any configuration).
+template <int ES_T>
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
     int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ slots, size_t slotsPerImg,
-    int iniTh, int minTh, int ES, int SS, int tileRows, int ldsPerWave, int phaseLimit, CellBases cb) {
+    int iniTh, int minTh, int ESrt, int SSrt, int tileRows, int ldsPerWave, int phaseLimit, CellBases cb) {
+    const int ES = ES_T ? ES_T : ESrt, SS = ES_T ? ES_T - 8 : SSrt;
     extern __shared__ __align__(16) uint8_t smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int bx, b;
@@ -580,28 +585,62 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     uint32_t *Lst = E;
     bool anyIni = false;
     int nL = 0;
-    {
-        const bool grid16 = pw2 <= 16;
-        const int npairs = grid16 ? ((ch + 3) & ~3) * 16 : pw2 * ch;
-        int py = grid16 ? (lane >> 4) : 0, j = grid16 ? (lane & 15) : lane;
-        if (!grid16) while (j >= pw2) { j -= pw2; py++; }
+    if (pw2 <= 16) {
+        // fixed lane -> (row mod 4, pair) map as in the score phase: column, byte selectors and the keep-mask of the odd
+        // pixel are loop invariants, a row step is one address add, and the iniTh test is ONE ballot after the loop
+        const int j = lane & 15, px = 2 * j, r4 = lane >> 4;
+        const bool colOk = j < pw2, k1ok = px + 1 < cw;
+        const uint32_t osel = ((px & 2) ? 3u : 1u) * 0x00010001u;
+        const uint32_t selL = 0x0c010c00u + osel, selM = 0x0c020c01u + osel, selR = 0x0c030c02u + osel;
+        const uint8_t *col = Sc + (px & ~3);   // pixels px-1 .. px+2 of a row = bytes of the two aligned dwords here
+        bool ini = false;
+        for (int r0 = 0; r0 < ch; r0 += 4) {
+            const int py = r0 + r4;
+            const bool act = colOk && py < ch;
+            const uint32_t *top = (const uint32_t *)(col + min(py, ch - 1) * SS);   // tile rows py, py+1, py+2
+            const uint32_t a0 = top[0], a1 = top[1], b0 = top[SS / 4], b1 = top[SS / 4 + 1], c0 = top[SS / 2],
+                           c1 = top[SS / 2 + 1];
+            const half2v lt = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(a1, a0, selL)),
+                         mt = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(a1, a0, selM)),
+                         rt = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(a1, a0, selR)),
+                         lm = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(b1, b0, selL)),
+                         mm = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(b1, b0, selM)),
+                         rm = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(b1, b0, selR)),
+                         lb = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(c1, c0, selL)),
+                         mb = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(c1, c0, selM)),
+                         rb = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(c1, c0, selR));
+            const half2v nb = pk_max3(pk_max3(lt, mt, rt), pk_max3(lb, mb, rb), __builtin_elementwise_maximum(lm, rm));
+            const short2v gt = __builtin_bit_cast(short2v, mm - nb);   // > 0 iff strictly greater than all 8 neighbours
+            const uint32_t cv = __builtin_bit_cast(uint32_t, mm);
+            const int v0 = (int)(cv & 0xFFFFu), v1 = (int)(cv >> 16);
+            const bool k0 = act && gt.x > 0, k1 = act && k1ok && gt.y > 0;
+            ini |= (k0 && v0 >= iniTh) || (k1 && v1 >= iniTh);
+            const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+            const int pos = nL + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u)) +
+                            (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+            const uint32_t w0 = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)v0 << 16);
+            if (k0) Lst[pos] = w0;
+            if (k1) Lst[pos + (k0 ? 1 : 0)] = (uint32_t)(px + 1) | ((uint32_t)py << 8) | ((uint32_t)v1 << 16);
+            nL += __popcll(m0) + __popcll(m1);
+        }
+        anyIni = __ballot(ini) != 0ull;
+    } else {
+        const int npairs = pw2 * ch;
+        int py = 0, j = lane;
+        while (j >= pw2) { j -= pw2; py++; }
         for (int base = 0; base < npairs; base += 64) {
             bool k0 = false, k1 = false;
             int v0 = 0, v1 = 0;
             const int px = 2 * j;
-            const bool act = grid16 ? (j < pw2 && py < ch) : (base + lane < npairs);
-            if (act) fast_nms_pair(Sc, SS, cw, py, px, k0, k1, v0, v1);
+            if (base + lane < npairs) fast_nms_pair(Sc, SS, cw, py, px, k0, k1, v0, v1);
             anyIni |= (__ballot((k0 && v0 >= iniTh) || (k1 && v1 >= iniTh)) != 0ull);
             const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1), lt = (1ull << lane) - 1ull;
             int pos = nL + __popcll(m0 & lt) + __popcll(m1 & lt);
             if (k0) Lst[pos++] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)v0 << 16);
             if (k1) Lst[pos] = (uint32_t)(px + 1) | ((uint32_t)py << 8) | ((uint32_t)v1 << 16);
             nL += __popcll(m0) + __popcll(m1);
-            if (grid16) py += 4;
-            else {
-                j += 64;
-                while (j >= pw2) { j -= pw2; py++; }
-            }
+            j += 64;
+            while (j >= pw2) { j -= pw2; py++; }
         }
     }
     wave_sync();
@@ -2083,10 +2122,19 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
     if (prof) ORBX_HIP(hipEventRecord(ev[1], st));
     {   // K2
         dim3 grid((h->totalCells + FAST_WAVES - 1) / FAST_WAVES, B);
-        hipLaunchKernelGGL(k_fast_cells, grid, dim3(64 * FAST_WAVES), (size_t)h->fastLdsPerWave * FAST_WAVES, st,
-                           h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_slots,
-                           h->slotsPerImg, h->ini_th, h->min_th, h->fastTileStride, h->fastScoreStride,
-                           h->fastTileRows, h->fastLdsPerWave, g_debug[0], cb);
+#define ORBX_LAUNCH_FAST(EST)                                                                                         \
+    hipLaunchKernelGGL(k_fast_cells<EST>, grid, dim3(64 * FAST_WAVES), (size_t)h->fastLdsPerWave * FAST_WAVES, st,  \
+                       h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_slots,            \
+                       h->slotsPerImg, h->ini_th, h->min_th, h->fastTileStride, h->fastScoreStride, h->fastTileRows, \
+                       h->fastLdsPerWave, g_debug[0], cb)
+        const int es = (h->fastScoreStride == h->fastTileStride - 8 && g_debug[6] == 0) ? h->fastTileStride : 0;
+        switch (es) {   // the strides of the usual 30-px cell grids; anything else takes the run-time-stride instance
+        case 44: ORBX_LAUNCH_FAST(44); break;
+        case 48: ORBX_LAUNCH_FAST(48); break;
+        case 52: ORBX_LAUNCH_FAST(52); break;
+        default: ORBX_LAUNCH_FAST(0); break;
+        }
+#undef ORBX_LAUNCH_FAST
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[2], st));
     {   // K3

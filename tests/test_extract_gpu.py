@@ -240,6 +240,20 @@ def test_quadtree_sweep_kernel_alone(pkg, oracle, synth):
         pkg.lib().orbx_debug_set(4, 0)
 
 
+def test_fast_runtime_stride_instance(pkg, oracle, synth):
+    """k_fast_cells<0> (run-time tile strides) serves every configuration whose stride has no compile-time
+    instance (44/48/52 dwords); forced here on configurations that normally take an instance, and reached
+    naturally by 60-px-tall single-cell levels (stride 60)."""
+    pkg.lib().orbx_debug_set(6, 1)
+    try:
+        _compare(pkg, oracle, synth.frame(752, 480, 85), 1000)
+        _compare(pkg, oracle, synth.frame(1241, 376, 86), 1000)
+    finally:
+        pkg.lib().orbx_debug_set(6, 0)
+    _compare(pkg, oracle, synth.frame(1241, 376, 86), 1000)
+    _compare(pkg, oracle, synth.frame(333, 211, 87), 300, sf=1.3, nl=5)
+
+
 def test_quadtree_pyramid_overflow_falls_back(pkg, oracle):
     """Clustered candidates: the tree gets deeper than the count pyramid in a few levels, which
     are then redone by k_octree; a large budget on a small textured patch forces it."""
