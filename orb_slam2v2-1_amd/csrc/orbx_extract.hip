@@ -221,6 +221,9 @@ typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b), 0u, false);
 }
+__device__ __forceinline__ uint32_t udot2_u16_acc(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b), c, false);
+}
 
 __global__ __launch_bounds__(256) void k_pyr_level(uint8_t *__restrict__ pyr, size_t pyrImgBytes,
                                                    const LevelGeom *__restrict__ geom, int l,
@@ -1647,32 +1650,33 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     }
     wave_sync();
 
-    // ---- vertical pass: lane = (column pair, row segment); 7-row sliding window in registers
+    // ---- vertical pass: lane = (column pair, row segment of 13 output rows).  A dword of the intermediate holds the u16
+    // values of two columns; v_perm re-pairs two consecutive ROWS of one column, so that one v_dot2_u32_u16 applies two
+    // taps: out[r] = (18,34).pair[r] + (49,55).pair[r+2] + (49,34).pair[r+4] + (0,18).pair[r+5] + 2^15, and the rounded bytes of
+    // both columns leave through one more v_perm (byte 2 of the sums clamped to 2^24 - 1).
     if (lane < 60) {
         const int cp = lane % 20, seg = lane / 20;
         const int r0 = seg * 13, nr = seg == 2 ? 11 : 13;
         const uint32_t *col = Tm + r0 * TSTRIDE4 + cp;
-        int lo[7], hi[7];
+        uint32_t T[19];   // rows r0 .. r0+18; for the last segment rows 43, 44 lie in Bl: read, never used by a stored output
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const uint32_t t = col[j * TSTRIDE4];
-            lo[j] = (int)(t & 0xFFFF);
-            hi[j] = (int)(t >> 16);
-        }
+        for (int k = 0; k < 19; k++) T[k] = col[k * TSTRIDE4];
+        const uint32_t W01 = 18u | (34u << 16), W23 = 49u | (55u << 16), W45 = 49u | (34u << 16);
 #pragma unroll
         for (int rr = 0; rr < 13; rr++) {
-            if (rr < nr) {
-                const uint32_t t = col[(rr + 6) * TSTRIDE4];
-                lo[(rr + 6) % 7] = (int)(t & 0xFFFF);
-                hi[(rr + 6) % 7] = (int)(t >> 16);
-                int a0 = 18 * (lo[rr % 7] + lo[(rr + 6) % 7]) + 34 * (lo[(rr + 1) % 7] + lo[(rr + 5) % 7]) +
-                         49 * (lo[(rr + 2) % 7] + lo[(rr + 4) % 7]) + 55 * lo[(rr + 3) % 7];
-                int a1 = 18 * (hi[rr % 7] + hi[(rr + 6) % 7]) + 34 * (hi[(rr + 1) % 7] + hi[(rr + 5) % 7]) +
-                         49 * (hi[(rr + 2) % 7] + hi[(rr + 4) % 7]) + 55 * hi[(rr + 3) % 7];
-                a0 = min((a0 + (1 << 15)) >> 16, 255);
-                a1 = min((a1 + (1 << 15)) >> 16, 255);
-                *(uint16_t *)(Bl + (r0 + rr) * BSTRIDE + 2 * cp) = (uint16_t)(a0 | (a1 << 8));
+            uint32_t a0 = 1u << 15, a1 = 1u << 15;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint32_t w = k == 0 ? W01 : k == 1 ? W23 : W45;
+                a0 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 2 * k + 1], T[rr + 2 * k], 0x05040100u), w, a0);
+                a1 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 2 * k + 1], T[rr + 2 * k], 0x07060302u), w, a1);
             }
+            // 7th tap = high half of pair[rr+5] = (row rr+5, row rr+6), a pair the next output row needs anyway
+            a0 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 6], T[rr + 5], 0x05040100u), 18u << 16, a0);
+            a1 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 6], T[rr + 5], 0x07060302u), 18u << 16, a1);
+            a0 = min(a0, 0xFFFFFFu);   // the taps sum to 257: a saturated patch reaches 257 * 65535 + 2^15 > 2^24 (-> 255)
+            a1 = min(a1, 0xFFFFFFu);
+            if (rr < nr) *(uint16_t *)(Bl + (r0 + rr) * BSTRIDE + 2 * cp) = (uint16_t)__builtin_amdgcn_perm(a1, a0, 0x0c0c0602u);
         }
     }
     wave_sync();
