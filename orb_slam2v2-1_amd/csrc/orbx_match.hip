@@ -71,11 +71,7 @@ struct StereoLevels {
 #define ST_CAND 256   // candidates of one left keypoint kept in LDS before the Hamming step
 // right keypoints in the compact form the candidate loop needs (8 B, coalesced):
 // x = minr | maxr << 12 | octave << 24 (row band floor(y-r)..ceil(y+r), r = 2*scale, :498-508), y = bits of pt.x
-__global__ __launch_bounds__(256) void k_stereo_prep(StereoLevels lv, const orbx_keypoint_t *__restrict__ kr,
-                                                     const int32_t *__restrict__ nr, int cap, uint2 *__restrict__ rc) {
-    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (i >= min(nr[b], cap)) return;
-    const orbx_keypoint_t kp = kr[(size_t)b * cap + i];
+__device__ __forceinline__ uint2 stereo_right_record(const StereoLevels &lv, const orbx_keypoint_t &kp) {
     const float r = 2.0f * lv.sf[kp.octave];
     int maxr = (int)ceilf(kp.y + r), minr = (int)floorf(kp.y - r);
     minr = max(minr, 0);
@@ -83,24 +79,27 @@ __global__ __launch_bounds__(256) void k_stereo_prep(StereoLevels lv, const orbx
     uint2 o;
     o.x = maxr < minr ? 0xFFFu : ((uint32_t)minr | ((uint32_t)maxr << 12) | ((uint32_t)kp.octave << 24));  // empty band: min > max
     o.y = __float_as_uint(kp.x);
-    rc[(size_t)b * cap + i] = o;
+    return o;
 }
 // Row bins for the candidate search (the reference's vRowIndices, :495-508, at a coarser grain): bins of BH rows,
 // BH = a power of two >= the tallest row band, so a right keypoint's band touches at most two bins and a left
 // keypoint only looks at the right keypoints of ITS bin (a few hundred) instead of all of them.
 #define ST_MAX_BINS 512
-__global__ __launch_bounds__(256) void k_stereo_bins(const uint2 *__restrict__ rc, const int32_t *__restrict__ nr, int cap,
+__global__ __launch_bounds__(256) void k_stereo_bins(StereoLevels lv, const orbx_keypoint_t *__restrict__ kr,
+                                                     uint2 *__restrict__ rc, const int32_t *__restrict__ nr, int cap,
                                                      int bhShift, int nbins, int32_t *__restrict__ binStart,
                                                      int32_t *__restrict__ items) {
     __shared__ int cnt[ST_MAX_BINS + 1], fill[ST_MAX_BINS];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int Nr = min(nr[b], cap);
-    const uint2 *rcb = rc + (size_t)b * cap;
+    uint2 *rcb = rc + (size_t)b * cap;
     for (int i = tid; i <= nbins; i += 256) cnt[i] = 0;
     for (int i = tid; i < nbins; i += 256) fill[i] = 0;
     __syncthreads();
-    for (int i = tid; i < Nr; i += 256) {
-        const uint32_t x = rcb[i].x;
+    for (int i = tid; i < Nr; i += 256) {   // the compact records are made here (each thread re-reads only its own below)
+        const uint2 rec = stereo_right_record(lv, kr[(size_t)b * cap + i]);
+        rcb[i] = rec;
+        const uint32_t x = rec.x;
         const int minr = (int)(x & 0xFFF), maxr = (int)((x >> 12) & 0xFFF);
         if (maxr < minr) continue;
         const int b0 = min(minr >> bhShift, nbins - 1), b1 = min(maxr >> bhShift, nbins - 1);
@@ -281,11 +280,11 @@ __global__ __launch_bounds__(SM_T) void k_stereo_median(const int32_t *__restric
                                                         const int32_t *__restrict__ sad,
                                                         int32_t *__restrict__ nmatch) {
     extern __shared__ int32_t sd[];  // [cap] sad (or -1)
-    __shared__ int sh_nd, sh_med, sh_keep;
+    __shared__ int sh_nd, sh_keep;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int N = min(nl[b], cap);
     const size_t o = (size_t)b * cap;
-    if (tid == 0) { sh_nd = 0; sh_med = -1; sh_keep = 0; }
+    if (tid == 0) { sh_nd = 0; sh_keep = 0; }
     __syncthreads();
     int c = 0;
     for (int i = tid; i < N; i += SM_T) {
@@ -303,30 +302,22 @@ __global__ __launch_bounds__(SM_T) void k_stereo_median(const int32_t *__restric
     // median = element of rank nd/2 of the sorted SAD distances (values < 2^16: 121*510 max):
     // two-level radix select on (high byte, low byte) histograms
     __shared__ int hist[256];
-    __shared__ int sh_hi, sh_rank;
+    __shared__ int sh_hi, sh_rank, sh_lo, sh_rest;
     const int target = nd / 2;
     hist[tid] = 0;
     __syncthreads();
     for (int i = tid; i < N; i += SM_T) { const int s = sd[i]; if (s >= 0) atomicAdd(&hist[(s >> 8) & 0xFF], 1); }
     __syncthreads();
-    if (tid == 0) {
-        int acc = 0, h = 0;
-        for (; h < 256; h++) { if (acc + hist[h] > target) break; acc += hist[h]; }
-        sh_hi = h; sh_rank = target - acc;
-    }
+    if (tid < 64) hist256_select(hist, target, tid, &sh_hi, &sh_rank);   // (a serial 256-step scan by one thread cost 5 us)
     __syncthreads();
     const int hi8 = sh_hi;
     hist[tid] = 0;
     __syncthreads();
     for (int i = tid; i < N; i += SM_T) { const int s = sd[i]; if (s >= 0 && ((s >> 8) & 0xFF) == hi8) atomicAdd(&hist[s & 0xFF], 1); }
     __syncthreads();
-    if (tid == 0) {
-        int acc = 0, lo = 0;
-        for (; lo < 256; lo++) { if (acc + hist[lo] > sh_rank) break; acc += hist[lo]; }
-        sh_med = (hi8 << 8) | lo;
-    }
+    if (tid < 64) hist256_select(hist, sh_rank, tid, &sh_lo, &sh_rest);
     __syncthreads();
-    const float median = (float)sh_med;
+    const float median = (float)((hi8 << 8) | sh_lo);
     const float thDist = 1.5f * 1.4f * median;
     int keep = 0;
     for (int i = tid; i < N; i += SM_T) {
@@ -397,8 +388,7 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
     dim3 grid((cap + ST_WAVES - 1) / ST_WAVES, B);
     (void)hipGetLastError();
     if (cap > 65535) { orbx_set_error("orbm_stereo: %d keypoints per image (limit 65535)", cap); return ORBX_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(k_stereo_prep, dim3((cap + 255) / 256, B), dim3(256), 0, st, lv, d_kr, d_nr, cap, g_ss.d_rc);
-    hipLaunchKernelGGL(k_stereo_bins, dim3(B), dim3(256), 0, st, g_ss.d_rc, d_nr, cap, bhShift, nbins, g_ss.d_binStart, g_ss.d_items);
+    hipLaunchKernelGGL(k_stereo_bins, dim3(B), dim3(256), 0, st, lv, d_kr, g_ss.d_rc, d_nr, cap, bhShift, nbins, g_ss.d_binStart, g_ss.d_items);
     hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), 0, st, lv, hl->d_pyr + (size_t)left_slot0 * hl->pyrImgBytes, hl->pyrImgBytes,
                        hr->d_pyr + (size_t)right_slot0 * hr->pyrImgBytes, hr->pyrImgBytes, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
                        g_ss.d_sad, g_ss.d_rc, g_ss.d_binStart, g_ss.d_items, bhShift, nbins);

@@ -50,6 +50,32 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, ORBX_DPP_ROW_BCAST31, 0xc, 0xf, true);   // rows 2, 3 += lane 31
     return __builtin_amdgcn_readlane(v, 63);
 }
+// Wave64 inclusive prefix sum on the DPP data path (row shifts, then the two row broadcasts)
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2, 3
+    return v;
+}
+// Rank select in a 256-bin histogram (LDS), run by ONE full wave: the first bin h with sum(hist[0..h]) > target and the
+// rank left inside it.  Lane i owns bins 4i..4i+3.  Requires target < sum(hist).
+__device__ __forceinline__ void hist256_select(const int *hist, int target, int lane, int *bin, int *rank) {
+    const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+    const int s = h0 + h1 + h2 + h3, inc = wave_incl_scan_dpp(s);
+    const unsigned long long hit = __ballot(inc > target);
+    if (hit && lane == __builtin_ctzll(hit)) {
+        int acc = inc - s, k = 0;
+        if (acc + h0 <= target) { acc += h0; k = 1;
+            if (acc + h1 <= target) { acc += h1; k = 2;
+                if (acc + h2 <= target) { acc += h2; k = 3; } } }
+        *bin = 4 * lane + k;
+        *rank = target - acc;
+    }
+}
+
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ u64 dpp_min_step(u64 v) {
     // lanes that the masks disable or that read out of range see ~0 (the identity of min)
