@@ -207,8 +207,8 @@ def main():
         gath = [torch.zeros((world * B, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         works = [None] * nbuf
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(S - 1)]
-    ev_m0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev_m1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_m0 = [torch.cuda.Event(enable_timing=True) for _ in range(max(1, min(args.steps, 10)))]
+    ev_m1 = [torch.cuda.Event(enable_timing=True) for _ in range(max(1, min(args.steps, 10)))]
 
     def step(i, timed_idx=None):
         j = i % nbuf
@@ -247,13 +247,15 @@ def main():
     for i in range(args.warmup):
         step(i)
     drain()
-    ex.set_profiling(True)
+    # Timed region: only the dominant kernel (k_fast_cells) is bracketed by HIP events on its launch stream.  Every
+    # recorded event idles the GPU for ~4.5 us, so the full stage breakdown is taken in a separate untimed pass below.
+    ex.set_profiling(2)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i, i)
+        step(args.warmup + i)
     drain()
     if world > 1:
         dist.barrier()
@@ -263,9 +265,15 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    fast_timed_ms = float(ex.stage_ms()[0][1])        # k_fast_cells, averaged over the K timed steps
+    nprof = max(1, min(args.steps, 10))               # untimed pass: events at every stage boundary
+    ex.set_profiling(1)
+    for i in range(nprof):
+        step(args.warmup + args.steps + i, i)
+    drain()
     stage_ms, ncalls = ex.stage_ms()
-    ex.set_profiling(False)
-    match_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_m0, ev_m1)])) if stereo else 0.0
+    ex.set_profiling(0)
+    match_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_m0[:nprof], ev_m1[:nprof])])) if stereo else 0.0
 
     if rank == 0:
         frames = world * B * args.steps
@@ -280,7 +288,7 @@ def main():
         # timed region).  Algorithmic bytes per image: FAST+NMS reads every level once = P;
         # quad-tree reads its candidates; describe reads P + writes 60 N (SURVEY §8(d) split).
         kern = {
-            "k_fast_cells": (float(stage_ms[1]), P * nimg),
+            "k_fast_cells": (fast_timed_ms, P * nimg),
             "k_octree": (float(stage_ms[2]), 8.0 * ncand_img * nimg),   # 4 B key + 2 B node index read, 2 B written
             "k_describe": (float(stage_ms[3]), (P + 60 * navg) * nimg),
         }
@@ -318,7 +326,10 @@ def main():
             "stage_ms_per_call": {"pyramid": round(float(stage_ms[0]), 4), "fast": round(float(stage_ms[1]), 4),
                                   "quadtree": round(float(stage_ms[2]), 4), "describe": round(float(stage_ms[3]), 4),
                                   "extract_total": round(float(stage_ms[4]), 4), "stereo_match": round(match_ms, 4),
-                                  "images_per_call": nimg, "calls_averaged": ncalls},
+                                  "images_per_call": nimg, "calls_averaged": ncalls,
+                                  "fast_timed_region": round(fast_timed_ms, 4),
+                                  "note": "stage breakdown from an untimed pass of %d steps after the timed region; "
+                                          "roofline.kernel_ms is k_fast_cells over the %d timed steps" % (nprof, args.steps)},
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu

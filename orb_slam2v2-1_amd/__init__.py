@@ -291,8 +291,9 @@ class ORBextractor:
             _check(self._L.orbx_debug_level_points(self._h, b, level, stage, _p(out), n.value, C.byref(n)))
         return out[:n.value]
 
-    def set_profiling(self, on=True):
-        _check(self._L.orbx_set_profiling(self._h, int(on)))
+    def set_profiling(self, mode=1):
+        """0/False off, 1/True events at every stage boundary, 2 only around k_fast_cells (see orbx.h)."""
+        _check(self._L.orbx_set_profiling(self._h, int(mode)))
 
     def stage_ms(self):
         """(average ms per call [pyramid, FAST, quad-tree, describe, total], calls averaged)"""
