@@ -126,6 +126,16 @@ int orbm_hamming(const uint8_t *a32, const uint8_t *b32);
 int orbm_hamming_matrix_device(const uint8_t *d_a, int na, const uint8_t *d_b, int nb,
                                uint16_t *d_out, void *stream);
 
+/* Multi-GPU result exchange: pack the device outputs of B frames into ONE fixed-capacity record per
+ * frame so that a step needs a single all-gather:
+ *   [ cap x 28 B keypoints | cap x 32 B descriptors | cap x 4 B mvuRight | cap x 4 B mvDepth | int32 count | 12 B zero ]
+ * record size = orbx_record_bytes(cap) = 68*cap + 16.  d_uright / d_depth may be NULL (monocular: zeros).  One kernel,
+ * asynchronous on stream.  orb_slam2v2-1_amd/batching.py holds the matching unpack. */
+int orbx_record_bytes(int cap);
+int orbx_pack_records_device(const orbx_keypoint_t *d_kps, const uint8_t *d_desc, const float *d_uright,
+                             const float *d_depth, const int32_t *d_counts, int B, int cap, uint8_t *d_records,
+                             void *stream);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:481-655) for B stereo frames.  Left/right
  * keypoints + descriptors + counts are the DEVICE outputs of two extractors (hl, hr) whose
  * pyramids of the same batch are still resident.  d_uright / d_depth: [B][cap] float

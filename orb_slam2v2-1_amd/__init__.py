@@ -41,6 +41,7 @@ EXPORTS = [
     "orbm_search_by_projection_frame", "orbm_match_windows", "orbm_best_in_windows", "orbm_distinctive_descriptors", "orbm_predict_scale_thresholds", "orbm_is_in_frustum",
     "orbm_search_local_points", "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_transform",
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
+    "orbx_record_bytes", "orbx_pack_records_device",
 ]
 
 
@@ -127,6 +128,8 @@ def lib():
     L.orbx_pyramid_device.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.orbx_debug_level_points.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
     L.orbx_set_profiling.argtypes = [vp, i32]
+    L.orbx_record_bytes.argtypes = [i32]
+    L.orbx_pack_records_device.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp]
     L.orbx_get_stage_ms.argtypes = [vp, vp, C.POINTER(i32)]
     L.orbm_hamming.argtypes = [vp, vp]
     L.orbm_hamming_matrix_device.argtypes = [vp, i32, vp, i32, vp, vp]
@@ -301,6 +304,11 @@ class ORBextractor:
         n = C.c_int(0)
         _check(self._L.orbx_get_stage_ms(self._h, _p(ms), C.byref(n)))
         return ms, n.value
+
+
+def pack_records_device(d_kps, d_desc, d_uright, d_depth, d_counts, B, cap, d_records, stream=0):
+    """One record per frame for the result all-gather (raw device pointers; layout in orbx.h / batching.py)."""
+    _check(lib().orbx_pack_records_device(d_kps, d_desc, d_uright, d_depth, d_counts, B, cap, d_records, stream))
 
 
 def stereo_batch_device(ex_left, ex_right, B, left_slot0, right_slot0, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap,

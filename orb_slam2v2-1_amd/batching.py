@@ -36,6 +36,13 @@ def pack_records(kps, desc, uright, depth, counts, out=None):
     rb = record_bytes(cap)
     if out is None:
         out = torch.zeros((B, rb), dtype=torch.uint8, device=kps.device)
+    if kps.is_cuda:   # ONE kernel of the HIP library on the current stream (the torch slicing below is five strided copies)
+        from . import pack_records_device
+        assert kps.is_contiguous() and desc.is_contiguous() and uright.is_contiguous() and depth.is_contiguous()
+        assert counts.dtype == torch.int32 and counts.is_contiguous() and out.is_contiguous() and out.shape == (B, rb)
+        pack_records_device(kps.data_ptr(), desc.data_ptr(), uright.data_ptr(), depth.data_ptr(), counts.data_ptr(), B, cap,
+                            out.data_ptr(), torch.cuda.current_stream(kps.device).cuda_stream)
+        return out
     o = 0
     for t, nb in ((kps, cap * KP_BYTES), (desc, cap * DESC_BYTES), (uright, cap * 4), (depth, cap * 4)):
         out[:, o:o + nb] = t.contiguous().reshape(B, -1).view(torch.uint8)

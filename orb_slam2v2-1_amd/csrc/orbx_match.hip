@@ -59,6 +59,37 @@ extern "C" int orbm_hamming_matrix_device(const uint8_t *d_a, int na, const uint
 }
 
 // ------------------------------------------------------------------------------------
+// one fixed-capacity record per frame for the result all-gather (layout: orbx.h); a thread moves one dword
+__global__ __launch_bounds__(256) void k_pack_records(const uint32_t *__restrict__ kps, const uint32_t *__restrict__ desc,
+                                                      const uint32_t *__restrict__ ur, const uint32_t *__restrict__ dp,
+                                                      const int32_t *__restrict__ counts, int cap, int recDwords,
+                                                      uint32_t *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= recDwords) return;
+    const size_t fb = (size_t)b * cap;
+    uint32_t v = 0;
+    if (i < 7 * cap) v = kps[fb * 7 + i];
+    else if (i < 15 * cap) v = desc[fb * 8 + (i - 7 * cap)];
+    else if (i < 16 * cap) v = ur ? ur[fb + (i - 15 * cap)] : 0u;
+    else if (i < 17 * cap) v = dp ? dp[fb + (i - 16 * cap)] : 0u;
+    else if (i == 17 * cap) v = (uint32_t)counts[b];
+    out[(size_t)b * recDwords + i] = v;
+}
+extern "C" int orbx_record_bytes(int cap) { return cap < 1 ? ORBX_ERR_ARG : 68 * cap + 16; }
+extern "C" int orbx_pack_records_device(const orbx_keypoint_t *d_kps, const uint8_t *d_desc, const float *d_uright,
+                                        const float *d_depth, const int32_t *d_counts, int B, int cap, uint8_t *d_records,
+                                        void *stream) {
+    if (!d_kps || !d_desc || !d_counts || !d_records || B < 1 || cap < 1) { orbx_set_error("orbx_pack_records_device: bad arguments"); return ORBX_ERR_ARG; }
+    const int recDwords = 17 * cap + 4;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_pack_records, dim3((recDwords + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)d_kps,
+                       (const uint32_t *)d_desc, (const uint32_t *)d_uright, (const uint32_t *)d_depth, d_counts, cap, recDwords,
+                       (uint32_t *)d_records);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+// ------------------------------------------------------------------------------------
 // Frame::ComputeStereoMatches (src/Frame.cc:481-655)
 struct StereoLevels {
     int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], pstrideL[ORBX_MAX_LEVELS], pstrideR[ORBX_MAX_LEVELS];
