@@ -194,6 +194,31 @@ def test_device_batch_on_a_torch_side_stream(pkg, oracle, synth):
     np.testing.assert_array_equal(ex.pyramid_level(5, b=3), _pyr(oracle, imgs[3], 800, 5))
 
 
+def test_stage_profiling_modes(pkg, synth):
+    """orbx_set_profiling: mode 1 brackets every stage, mode 2 only k_fast_cells; results do not depend on the mode."""
+    imgs = synth.batch(640, 480, 4, k0=90)
+    ex = pkg.ORBextractor(500, 1.2, 8, 20, 7)
+    base = ex.extract_batch(imgs)
+    ex.set_profiling(1)
+    for _ in range(3):
+        r1 = ex.extract_batch(imgs)
+    ms, n = ex.stage_ms()
+    assert n == 3 and (ms[:4] > 0).all() and abs(ms[:4].sum() - ms[4]) < 0.2 * ms[4]
+    ex.set_profiling(2)
+    for _ in range(40):          # more calls than the event ring holds
+        r2 = ex.extract_batch(imgs)
+    ms2, n2 = ex.stage_ms()
+    assert n2 == 40 and ms2[1] > 0 and ms2[0] == 0 and ms2[2] == 0 and ms2[3] == 0 and ms2[4] == 0
+    assert 0.3 * ms[1] < ms2[1] < 3 * ms[1]
+    ex.set_profiling(0)
+    for r in (r1, r2):
+        for (k, d), (k0, d0) in zip(r, base):
+            np.testing.assert_array_equal(d, d0)
+            np.testing.assert_array_equal(k.view(np.uint8), k0.view(np.uint8))
+    with pytest.raises(pkg.OrbxError):
+        ex.set_profiling(3)
+
+
 def _pyr(oracle, img, nf, level):
     o = oracle.Extractor(nf, 1.2, 8, 20, 7)
     o.extract(img)
