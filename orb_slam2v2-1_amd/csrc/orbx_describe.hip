@@ -1,0 +1,289 @@
+// orbx_describe.hip — IC_Angle + GaussianBlur + steered BRIEF (src/ORBextractor.cc:77-147, :1085-1090): k_describe
+// (part of the ORB extractor, see orbx_extract.hip for the pipeline and the C ABI)
+#include "orbx_extract_dev.h"
+#include <math.h>
+#include <float.h>
+// ------------------------------------------------------------------------------------
+// constant tables
+__constant__ int8_t c_pattern[1024] = {
+#include "../../include/orb_pattern_31.inc"
+};
+// The other two tables of the path live in the code that uses them: umax (IC_Angle disc, :454-469) inside make_ic_tab,
+// the 7-tap sigma=2 Gaussian in 8-bit fixed point {18, 34, 49, 55, 49, 34, 18} (cvRound(k*256), sum 257) as the packed
+// weights of k_describe's two blur passes.
+
+// ------------------------------------------------------------------------------------
+// K4: one wave per kept keypoint: IC_Angle (:77-104) on the un-blurred level, 7x7 sigma=2
+// Gaussian (8-bit fixed point [18 34 49 55 49 34 18], (sum+2^15)>>16) of the 37x37
+// neighbourhood the 256 rotated test pairs can touch (|tap| <= 18), then the steered BRIEF
+// bits (:108-147) packed with one ballot per 64 pairs.  The blurred level is never written
+// to memory: blur is a pure function of the 43x43 source patch, which is staged in LDS from
+// the padded (BORDER_REFLECT_101) level, so border handling is identical to cv::GaussianBlur.
+// LDS traffic is kept to wide accesses (sub-dword LDS reads were the bottleneck of the first
+// version): the horizontal pass reads one b128 per 4 outputs and uses v_dot4_u32_u8 on
+// byte-aligned windows; the vertical pass slides a 7-row register window down a column pair.
+#define PR 21                    // source patch radius = 18 + 3
+#define PROWS (2 * PR + 1)       // 43
+#define PSTRIDE 48               // 12 dwords per patch row (16-byte aligned rows)
+#define PPAD 16                  // slack behind the patch: the last row's b128 read may run over
+#define TROWS PROWS
+#define TCOLS (2 * ORBX_DESC_R + 1)  // 37
+#define TGROUPS 10               // horizontal pass: 10 groups of 4 outputs per row (cols 0..39)
+#define TSTRIDE4 20              // dwords per row of the u16 intermediate (40 columns)
+#define BSTRIDE 40
+#define DESC_LDS_PER_WAVE (PROWS * PSTRIDE + PPAD + TROWS * TSTRIDE4 * 4 + TCOLS * BSTRIDE + 8)
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    // cv::fastAtan2 of OpenCV 2.4.11 / 3.2 (scalar path)
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// (float)cos((double)a), (float)sin((double)a) for a in [0, 2*pi] (src/ORBextractor.cc:112-113).
+// The generic double-precision library routines cost ~220 fp64 instructions per wave (two range
+// reductions with a Payne-Hanek path); here: one Cody-Waite reduction by k*pi/2 (k <= 4, exact
+// product with the 33-bit head of pi/2) and the fdlibm kernel polynomials on |r| <= pi/4, < 1 ulp
+// in double, so the value rounded to float is the library's (differences need a double result
+// within 1e-16 of a float rounding boundary).
+__device__ __forceinline__ void sincos_0_2pi(float af, float &sn, float &cs) {
+    const double a = (double)af;
+    const double k = rint(a * 6.36619772367581382433e-01);                       // 2/pi
+    const double r = (a - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+    const double z = r * r;
+    const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                      z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double s = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+    const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double c = w + (((1.0 - w) - hz) + z * pc);
+    const int q = (int)k & 3;
+    const double sq = (q & 1) ? c : s, cq = (q & 1) ? s : c;
+    sn = (float)((q & 2) ? -sq : sq);
+    cs = (float)(((q + 1) & 2) ? -cq : cq);
+}
+
+// IC_Angle weights per lane (lane = 2 * (v + 15) + half: row v of the radius-15 disc, u = -15..0 or u = 1..16), as bytes for
+// v_dot4_u32_u8: m = 1 inside the disc (|u| <= umax[|v|], u <= 15), w = |u| inside.  Built at compile time.
+struct IcTab { uint32_t m[64][4], w[64][4]; };
+constexpr IcTab make_ic_tab() {
+    IcTab t{};
+    constexpr int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    for (int lane = 0; lane < 62; lane++) {
+        const int v = (lane >> 1) - 15, half = lane & 1, d = um[v < 0 ? -v : v];
+        for (int k = 0; k < 16; k++) {
+            const int u = half ? k + 1 : k - 15, au = u < 0 ? -u : u;
+            const bool in = au <= d && u <= 15;
+            t.m[lane][k >> 2] |= (in ? 1u : 0u) << (8 * (k & 3));
+            t.w[lane][k >> 2] |= (in ? (uint32_t)au : 0u) << (8 * (k & 3));
+        }
+    }
+    return t;
+}
+__constant__ const IcTab c_ic = make_ic_tab();
+
+__global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
+    const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
+    const uint32_t *__restrict__ lvlKp, int lvlKpCap, const int32_t *__restrict__ lvlCnt,
+    orbx_keypoint_t *__restrict__ kps, uint8_t *__restrict__ desc, int32_t *__restrict__ counts, int cap) {
+    __shared__ __align__(16) uint8_t smem[DESC_WAVES * DESC_LDS_PER_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int bx, b;
+    xcd_block_map(bx, b);   // all patches of an image are read through ONE L2
+    const int o = bx * DESC_WAVES + wave;
+    // locate (level, k) of output ordinal o: level-major concatenation (:1076-1104)
+    int l = 0, base = 0, total = 0;
+    {   // lane i < nlevels holds the count of level i: ONE load, a 4-step prefix sum, a ballot (not nlevels dependent loads)
+        const int c = lane < nlevels ? lvlCnt[b * nlevels + lane] : 0;
+        int inc = c;
+#pragma unroll
+        for (int d = 1; d < ORBX_MAX_LEVELS; d <<= 1) {
+            const int t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
+        }
+        total = __builtin_amdgcn_readlane(inc, ORBX_MAX_LEVELS - 1);
+        if (bx == 0 && threadIdx.x == 0) counts[b] = min(total, cap);
+        const unsigned long long hit = __ballot(lane < nlevels && o < inc);
+        if (!hit || o >= cap) return;  // wave-uniform
+        l = __builtin_ctzll(hit);
+        base = __builtin_amdgcn_readlane(inc - c, l);
+    }
+    l = __builtin_amdgcn_readfirstlane(l);
+    const LevelGeom g = geom[l];
+    const uint32_t key = lvlKp[(size_t)b * lvlKpCap + g.lvlKpOff + (o - base)];
+    const int cx = (int)(key & 0xFFF) + ORBX_MINB, cy = (int)((key >> 12) & 0xFFF) + ORBX_MINB;
+    const int score = (int)(key >> 24);
+
+    uint8_t *P = smem + wave * DESC_LDS_PER_WAVE;                     // source patch [43][48] (+pad)
+    uint32_t *Tm = (uint32_t *)(P + PROWS * PSTRIDE + PPAD);          // horizontal pass, u16 [43][40]
+    uint8_t *Bl = (uint8_t *)(Tm + TROWS * TSTRIDE4);                 // blurred [37][40]
+
+    // ---- stage the 43x43 patch with aligned dword loads (pstride is a multiple of 64)
+    const uint8_t *lvl = pyr + (size_t)b * pyrImgBytes + g.poff;
+    const size_t a = (size_t)(cy + ORBX_EDGE - PR) * g.pstride + (size_t)(cx + ORBX_EDGE - PR);
+    int sh = __builtin_amdgcn_readfirstlane((int)(a & 3));
+    const uint32_t *src = (const uint32_t *)(lvl + (a - sh));
+    const int pstr4 = g.pstride >> 2;
+    // The 19-px REFLECT_101 frame of the levels >= 1 is only ever read HERE, by the few keypoints closer than PR to a
+    // level's edge (the frame of level 0 comes with the copy of the input).  Those keypoints mirror the coordinates
+    // themselves, so the pipeline never writes the frames of levels >= 1 (orbx_pyramid_host writes them on demand).
+    const bool edge = l > 0 && (cx < PR || cy < PR || cx + PR >= g.w || cy + PR >= g.h);   // wave-uniform
+    if (edge) {
+        sh = 0;
+        const uint8_t *inner = lvl + (size_t)ORBX_EDGE * g.pstride + ORBX_EDGE;
+        for (int base0 = 0; base0 < PROWS * PSTRIDE; base0 += 64 * 8) {
+            uint8_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = min(base0 + lane + 64 * k, PROWS * PSTRIDE - 1);
+                const int r = i / PSTRIDE, c = i - r * PSTRIDE;
+                v[k] = inner[(size_t)reflect101c(cy - PR + r, g.h) * g.pstride + reflect101c(cx - PR + c, g.w)];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (base0 + lane + 64 * k < PROWS * PSTRIDE) P[base0 + lane + 64 * k] = v[k];
+        }
+    } else
+    {   // all (PROWS*12 + 63) / 64 loads of a lane are in flight before the first LDS write: one memory latency per keypoint
+        constexpr int NI = (PROWS * 12 + 63) / 64;
+        uint32_t v[NI];
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int i = min(lane + 64 * k, PROWS * 12 - 1);
+            const int r = i / 12, c = i - r * 12;
+            v[k] = src[(size_t)r * pstr4 + c];
+        }
+#pragma unroll
+        for (int k = 0; k < NI; k++)
+            if (lane + 64 * k < PROWS * 12) ((uint32_t *)P)[lane + 64 * k] = v[k];
+    }
+    wave_sync();
+    // pixel (cx-21+c, cy-21+r) is byte P[r*48 + sh + c], r,c in [0,43)
+
+    // ---- IC_Angle: two lanes per row v of the radius-15 disc (u = -15..0 | 1..15)
+    int m10 = 0, m01 = 0;
+    if (lane < 62) {
+        const int v = (lane >> 1) - 15, half = lane & 1;
+        const int o0 = sh + PR - 15 + 16 * half;  // byte offset of u = -15 (half 0) / u = 1 (half 1)
+        const uint32_t *row = (const uint32_t *)(P + (PR + v) * PSTRIDE) + (o0 >> 2);
+        const int sa8 = o0 & 3;
+        uint32_t w[5], wa[4];
+#pragma unroll
+        for (int k = 0; k < 5; k++) w[k] = row[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) wa[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sa8);  // 16 bytes from o0
+        // sum of the pixels and of |u| * pixel over this lane's 16 columns: 8 byte dot products with the table weights
+        uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            s0 = __builtin_amdgcn_udot4(wa[j], c_ic.m[lane][j], s0, false);
+            s1 = __builtin_amdgcn_udot4(wa[j], c_ic.w[lane][j], s1, false);
+        }
+        m10 = half ? (int)s1 : -(int)s1;   // u <= 0 in half 0
+        m01 = v * (int)s0;
+    }
+    m10 = wave_total_i32(m10);
+    m01 = wave_total_i32(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- horizontal 7-tap pass: 4 outputs per lane-iteration from one aligned b128 read
+    const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), K1 = 49u | (34u << 8) | (18u << 16);
+    for (int i = lane; i < TROWS * TGROUPS; i += 64) {
+        const int r = i / TGROUPS, cg = i - r * TGROUPS;
+        const uint32_t *pr = (const uint32_t *)(P + r * PSTRIDE) + cg;  // dwords cg .. cg+3 hold bytes 4cg .. 4cg+15
+        const uint32_t d0 = pr[0], d1 = pr[1], d2 = pr[2], d3 = pr[3];
+        // w0..w2 = bytes (sh+4cg) .. +11 : source columns 4cg .. 4cg+11
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+                       w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+        uint32_t oo[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t lo = j ? __builtin_amdgcn_alignbyte(w1, w0, j) : w0;   // bytes j .. j+3
+            const uint32_t hi = j ? __builtin_amdgcn_alignbyte(w2, w1, j) : w1;   // bytes j+4 .. j+7
+            oo[j] = __builtin_amdgcn_udot4(hi, K1, __builtin_amdgcn_udot4(lo, K0, 0u, false), false);  // <= 65535
+        }
+        uint2 st;
+        st.x = oo[0] | (oo[1] << 16);
+        st.y = oo[2] | (oo[3] << 16);
+        *(uint2 *)(Tm + r * TSTRIDE4 + cg * 2) = st;
+    }
+    wave_sync();
+
+    // ---- vertical pass: lane = (column pair, row segment of 13 output rows).  A dword of the intermediate holds the u16
+    // values of two columns; v_perm re-pairs two consecutive ROWS of one column, so that one v_dot2_u32_u16 applies two
+    // taps: out[r] = (18,34).pair[r] + (49,55).pair[r+2] + (49,34).pair[r+4] + (0,18).pair[r+5] + 2^15, and the rounded bytes of
+    // both columns leave through one more v_perm (byte 2 of the sums clamped to 2^24 - 1).
+    if (lane < 60) {
+        const int cp = lane % 20, seg = lane / 20;
+        const int r0 = seg * 13, nr = seg == 2 ? 11 : 13;
+        const uint32_t *col = Tm + r0 * TSTRIDE4 + cp;
+        uint32_t T[19];   // rows r0 .. r0+18; for the last segment rows 43, 44 lie in Bl: read, never used by a stored output
+#pragma unroll
+        for (int k = 0; k < 19; k++) T[k] = col[k * TSTRIDE4];
+        const uint32_t W01 = 18u | (34u << 16), W23 = 49u | (55u << 16), W45 = 49u | (34u << 16);
+#pragma unroll
+        for (int rr = 0; rr < 13; rr++) {
+            uint32_t a0 = 1u << 15, a1 = 1u << 15;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint32_t w = k == 0 ? W01 : k == 1 ? W23 : W45;
+                a0 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 2 * k + 1], T[rr + 2 * k], 0x05040100u), w, a0);
+                a1 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 2 * k + 1], T[rr + 2 * k], 0x07060302u), w, a1);
+            }
+            // 7th tap = high half of pair[rr+5] = (row rr+5, row rr+6), a pair the next output row needs anyway
+            a0 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 6], T[rr + 5], 0x05040100u), 18u << 16, a0);
+            a1 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 6], T[rr + 5], 0x07060302u), 18u << 16, a1);
+            a0 = min(a0, 0xFFFFFFu);   // the taps sum to 257: a saturated patch reaches 257 * 65535 + 2^15 > 2^24 (-> 255)
+            a1 = min(a1, 0xFFFFFFu);
+            if (rr < nr) *(uint16_t *)(Bl + (r0 + rr) * BSTRIDE + 2 * cp) = (uint16_t)__builtin_amdgcn_perm(a1, a0, 0x0c0c0602u);
+        }
+    }
+    wave_sync();
+
+    // ---- steered BRIEF: 4 rounds x 64 pairs, one ballot = 8 descriptor bytes
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float ang = angle * factorPI;
+    float ca, sa;
+    sincos_0_2pi(ang, sa, ca);
+    const uint8_t *Bc = Bl + ORBX_DESC_R * BSTRIDE + ORBX_DESC_R;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int pair = r * 64 + lane;
+        const int8_t *q = c_pattern + 4 * pair;
+        const float x0 = (float)q[0], y0 = (float)q[1], x1 = (float)q[2], y1 = (float)q[3];
+        const int t0 = Bc[__float2int_rn(x0 * sa + y0 * ca) * BSTRIDE + __float2int_rn(x0 * ca - y0 * sa)];
+        const int t1 = Bc[__float2int_rn(x1 * sa + y1 * ca) * BSTRIDE + __float2int_rn(x1 * ca - y1 * sa)];
+        bits[r] = __ballot(t0 < t1);
+    }
+    const size_t oi = (size_t)b * cap + o;
+    if (lane < 4) ((unsigned long long *)(desc + oi * 32))[lane] = bits[lane];
+    if (lane == 0) {
+        orbx_keypoint_t kp;
+        kp.x = (float)cx;
+        kp.y = (float)cy;
+        if (l != 0) { kp.x *= g.scale; kp.y *= g.scale; }  // pt *= mvScaleFactor[level]  (:1095-1101)
+        kp.size = g.size;
+        kp.angle = angle;
+        kp.response = (float)score;
+        kp.octave = l;
+        kp.class_id = -1;
+        kps[oi] = kp;
+    }
+}

@@ -1,0 +1,86 @@
+// Device-side helpers and kernel declarations shared by the extractor's translation units
+// (orbx_pyramid.hip, orbx_fast.hip, orbx_octree.hip, orbx_describe.hip; launches in orbx_extract.hip).
+#pragma once
+#include "orbx_internal.h"
+
+// wave-synchronous LDS hand-off: all 64 lanes of a wave run in lock-step; drain the LDS
+// queue and forbid the compiler from moving LDS accesses across this point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Wave64 inclusive prefix sum / total on the DPP data path (row shifts, then the two row broadcasts): ~6 VALU steps
+// instead of six ds_bpermute round trips — these scans sit on the critical path of single-wave code (quad-tree passes).
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ int wave_total_i32(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_i32(v), 63); }
+
+__device__ __forceinline__ int reflect101(int i, int n) {  // valid for -n < i < 2n-1
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+__device__ __forceinline__ int reflect101c(int p, int n) {   // reflect101 + clamp (dword tails past the frame)
+    p = p < 0 ? -p : p;
+    p = p >= n ? 2 * (n - 1) - p : p;
+    return min(max(p, 0), n - 1);
+}
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b), 0u, false);
+}
+__device__ __forceinline__ uint32_t udot2_u16_acc(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b), c, false);
+}
+
+// ---- launch geometry the host side needs
+struct PyrSpan { short o0, o1, c0, c1; };  // owned [o0,o1) and computed [c0,c1) range along one axis
+#define PYR_RW 8   // output rows per wave
+#define PYR_SR 12  // source rows fetched up front: covers PYR_RW rows at scale factors up to ~1.4
+#define FAST_WAVES 4
+#define GATHER_CELLS_PER_BLOCK 16
+#define OCT_T 512   // 1024-thread workgroups are resident one per CU only; 512 packs 2x better at batch 128 and costs 6 us on a single frame
+#define DESC_WAVES 4
+struct CellBases { int v[ORBX_MAX_LEVELS + 1]; };
+__device__ __forceinline__ int level_of_cell(const CellBases &cb, int nlevels, int gc) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < ORBX_MAX_LEVELS; i++) l += (i < nlevels && gc >= cb.v[i]) ? 1 : 0;
+    return l;
+}
+
+// ---- kernels (definitions: see the file named on the right)
+__global__ void k_pyramid_fused(const uint8_t *src, int sstride, size_t simg, uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom,
+                                int nlevels, const int32_t *tab, int xSpanOff, int ySpanOff, int tilesX, int tilesY, int bufBytes,
+                                int maxPar);                                                                     // orbx_pyramid.hip
+__global__ void k_pyr_level(uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int l, const int32_t *tab, int nxc,
+                            int nbands);                                                                         // orbx_pyramid.hip
+template <bool FULL>
+__global__ void k_pyr_pad(const uint8_t *img, int sstride, size_t simg, uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom,
+                          int l0);                                                                               // orbx_pyramid.hip
+template <int ES_T>
+__global__ void k_fast_cells(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalCells,
+                             uint32_t *cellCnt, uint32_t *slots, size_t slotsPerImg, int iniTh, int minTh, int ESrt, int SSrt,
+                             int tileRows, int ldsPerWave, int phaseLimit, CellBases cb);                        // orbx_fast.hip
+__global__ void k_cell_scan(const LevelGeom *geom, int nlevels, int totalCells, const uint32_t *cellCnt, uint32_t *cellOff,
+                            int32_t *candCnt);                                                                   // orbx_fast.hip
+__global__ void k_gather(const LevelGeom *geom, int nlevels, int totalCells, const uint32_t *cellCnt, const uint32_t *cellOff,
+                         const uint32_t *slots, size_t slotsPerImg, uint32_t *cand, size_t keysPerImg, CellBases cb);  // orbx_fast.hip
+__global__ void k_octree_pyr(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
+                             uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
+                             int pyrWords, int32_t *fallback);                                                   // orbx_octree.hip
+__global__ void k_octree(const LevelGeom *geom, int nlevels, int totalCells, const uint32_t *cellCnt, const uint32_t *slots,
+                         size_t slotsPerImg, uint32_t *cand, uint16_t *nodeOf, size_t keysPerImg, const int32_t *candCnt,
+                         uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
+                         int scratchInts, int dbgStop, const int32_t *fallback);                                 // orbx_octree.hip
+__global__ void k_describe(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, const uint32_t *lvlKp,
+                           int lvlKpCap, const int32_t *lvlCnt, orbx_keypoint_t *kps, uint8_t *desc, int32_t *counts,
+                           int cap);                                                                             // orbx_describe.hip

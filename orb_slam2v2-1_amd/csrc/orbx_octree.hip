@@ -1,0 +1,704 @@
+// orbx_octree.hip — ORBextractor::DistributeOctTree (src/ORBextractor.cc:539-763): k_octree_pyr and its exact fallback k_octree
+// (part of the ORB extractor, see orbx_extract.hip for the pipeline and the C ABI)
+#include "orbx_extract_dev.h"
+
+// K3: DistributeOctTree (:539-763), one workgroup per (level, image).
+//
+// Parallel restatement of the reference's std::list surgery (validated against the literal
+// CPU oracle).  Facts it relies on:
+//  * every insertion is push_front, so the list is always ordered by DESCENDING creation
+//    time; the node array here IS the list (index 0 = front);
+//  * a pass visits expandable nodes (created in the previous pass, >1 key) in an order O,
+//    creates the non-empty children n1..n4 of each and erases the parent:
+//       new list = reverse(created sequence) ++ (old list minus the split parents);
+//  * phase 1 (:594-665): O = list order, all expandable nodes are split;
+//    phase 2 (:673-737): O = sort by (size desc, tie), split until size >= N.
+//    Tie-break of equal sizes: the reference compares heap pointers (:684); this build
+//    fixes "later-created first" == smaller list index first.
+//  * a key's child is a pure function of (x, y, parent box): keys never move in memory,
+//    only their 16-bit node index is rewritten.
+
+struct OctLds {
+    short4 *box[2];
+    uint32_t *cnt[2];   // bit31 = fresh (created in the previous pass)
+    uint32_t *hist;     // [4*cap] children key counts, also scratch
+    uint16_t *childIdx; // [4*cap]
+    uint16_t *survIdx;  // [cap]
+    uint16_t *xlist;    // [cap] expandable nodes in visiting order
+    int *pn, *pg;       // [cap] inclusive prefix of created children / gain by rank
+    uint8_t *split;     // [cap]
+    unsigned long long *skey;  // [pow2(cap)]
+};
+
+__device__ __forceinline__ int child_of(int x, int y, short4 bx) {
+    const int mx = bx.x + ((bx.y - bx.x + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)   (:483)
+    const int my = bx.z + ((bx.w - bx.z + 1) >> 1);  // UL.y + ceil((BR.y-UL.y)/2)   (:484)
+    return (x < mx ? 0 : 1) | (y < my ? 0 : 2);      // n1,n2,n3,n4                   (:513-525)
+}
+__device__ __forceinline__ short4 child_box(short4 bx, int q) {
+    const short mx = (short)(bx.x + ((bx.y - bx.x + 1) >> 1));
+    const short my = (short)(bx.z + ((bx.w - bx.z + 1) >> 1));
+    short4 r;
+    r.x = (q & 1) ? mx : bx.x;
+    r.y = (q & 1) ? bx.y : mx;
+    r.z = (q & 2) ? my : bx.z;
+    r.w = (q & 2) ? bx.w : my;
+    return r;
+}
+
+// four consecutive keys / node indices of one thread (16-B / 8-B accesses; the level's key block is 16-B aligned)
+__device__ __forceinline__ void load_keys4(const uint32_t *keys, int i0, int n, uint32_t key[4]) {
+    if (i0 + 3 < n) {
+        const uint4 v = *(const uint4 *)(keys + i0);
+        key[0] = v.x; key[1] = v.y; key[2] = v.z; key[3] = v.w;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) key[u] = i0 + u < n ? keys[i0 + u] : 0u;
+    }
+}
+__device__ __forceinline__ void load_nof4(const uint16_t *nof, int i0, int n, int kk[4]) {
+    if (i0 + 3 < n) {
+        const ushort4 v = *(const ushort4 *)(nof + i0);
+        kk[0] = v.x; kk[1] = v.y; kk[2] = v.z; kk[3] = v.w;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) kk[u] = i0 + u < n ? (int)nof[i0 + u] : 0;
+    }
+}
+__device__ __forceinline__ void store_nof4(uint16_t *nof, int i0, int n, const int kk[4]) {
+    if (i0 + 3 < n) {
+        ushort4 v;
+        v.x = (unsigned short)kk[0]; v.y = (unsigned short)kk[1]; v.z = (unsigned short)kk[2]; v.w = (unsigned short)kk[3];
+        *(ushort4 *)(nof + i0) = v;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (i0 + u < n) nof[i0 + u] = (uint16_t)kk[u];
+    }
+}
+
+// exclusive scan of one int per thread across the block; returns the exclusive prefix and
+// writes the block total to *total (all threads).  wsum: LDS int[OCT_T/64 + 1].
+__device__ __forceinline__ int block_scan_excl(int v, int *wsum, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();  // protect wsum reuse
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < OCT_T / 64; w++) {
+        const int s = wsum[w];
+        if (w < wave) woff += s;
+        tot += s;
+    }
+    *total = tot;
+    return woff + inc - v;
+}
+
+// in-place exclusive scan of an LDS int array a[0..m) (m arbitrary); returns total
+__device__ int array_scan_excl(int *a, int m, int *wsum) {
+    const int chunk = (m + OCT_T - 1) / OCT_T;
+    const int beg = min((int)threadIdx.x * chunk, m), end = min(beg + chunk, m);
+    int s = 0;
+    for (int i = beg; i < end; i++) s += a[i];
+    int total;
+    int off = block_scan_excl(s, wsum, &total);
+    for (int i = beg; i < end; i++) {
+        const int t = a[i];
+        a[i] = off;
+        off += t;
+    }
+    __syncthreads();
+    return total;
+}
+
+// K3 (main path): DistributeOctTree from a COUNT PYRAMID.  A key's path through the quad-tree
+// is a pure function of its coordinates (root by tabulated x/hX, then ceil-halved boxes), so
+// ONE sweep over the keys histograms them at a fixed depth Dm and the key count of every node
+// of every shallower depth follows by summing children.  All the list surgery of the passes
+// (which nodes are split, in which order, where the break falls) then runs on node counts only
+// — no further key sweep — and one final sweep walks every key down to its leaf to elect the
+// best response per node.  Two sweeps over the keys instead of one per pass.  If a pass would
+// need counts deeper than Dm (sparse, clustered candidates) the level is flagged and redone by
+// the sweep-per-pass kernel k_octree below: results never depend on the path taken.
+__device__ __forceinline__ uint32_t pyr_count(const uint32_t *pyr, int nIni, int Dm, int d, uint32_t c) {
+    const uint32_t off = (uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u);
+    if (d == Dm) return (pyr[off + (c >> 1)] >> (16 * (c & 1))) & 0xFFFFu;
+    return pyr[off + c];
+}
+
+__global__ __launch_bounds__(OCT_T) void k_octree_pyr(
+    const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand, size_t keysPerImg,
+    const int32_t *__restrict__ candCnt, uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
+    const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;  // level-major: large levels start first
+    const LevelGeom g = geom[l];
+    const int Dm = g.pyrDepth, nIni = g.nIni, N = g.N;
+    uint8_t *sp = smem;
+    unsigned long long *skey = (unsigned long long *)sp; sp += sizeof(unsigned long long) * pow2cap;
+    uint32_t *cntA = (uint32_t *)sp; sp += 4 * 2 * capMax;   // [2][cap] key count, bit31 = fresh
+    uint32_t *nidA = (uint32_t *)sp; sp += 4 * 2 * capMax;   // [2][cap] depth << 28 | cell
+    uint32_t *hist = (uint32_t *)sp; sp += 4 * 4 * capMax;   // children counts of list node k; later best[]
+    int *pn = (int *)sp; sp += 4 * capMax;
+    uint32_t *pyr = (uint32_t *)sp; sp += 4 * (size_t)pyrWords;
+    uint16_t *xlist = (uint16_t *)sp; sp += 2 * capMax;
+    uint8_t *split = sp; sp += capMax;
+    __shared__ int sh_L, sh_Lnew, sh_finish, sh_phase, sh_abort;
+
+    const uint32_t *keys = cand + (size_t)b * keysPerImg + g.keyOff;
+    const int n = candCnt[b * nlevels + l];
+    const int32_t *xPath = tab + g.xPathOff, *yPath = tab + g.yPathOff;
+    const uint32_t offDeep = (uint32_t)nIni * (((1u << (2 * Dm)) - 1u) / 3u);
+
+    // ---- 1. histogram of the keys at depth Dm (two 16-bit counters per word)
+    for (int i = tid; i < pyrWords; i += OCT_T) pyr[i] = 0;
+    if (tid == 0) sh_abort = 0;
+    __syncthreads();
+    for (int i0 = 4 * tid; i0 < n; i0 += 4 * OCT_T) {
+        uint32_t key[4], c[4];
+        load_keys4(keys, i0, n, key);
+#pragma unroll
+        for (int u = 0; u < 4; u++)   // unconditional (a missing key is 0): all 8 lookups in flight at once
+            c[u] = (uint32_t)xPath[key[u] & 0xFFF] | (uint32_t)yPath[(key[u] >> 12) & 0xFFF];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + u < n) atomicAdd(&pyr[offDeep + (c[u] >> 1)], 1u << (16 * (c[u] & 1)));
+    }
+    __syncthreads();
+    // ---- 2. counts of the shallower depths
+    for (int d = Dm - 1; d >= 0; d--) {
+        const uint32_t off = (uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u);
+        const int ne = nIni << (2 * d);
+        for (int e = tid; e < ne; e += OCT_T) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) s += pyr_count(pyr, nIni, Dm, d + 1, 4u * e + q);
+            pyr[off + e] = s;
+        }
+        __syncthreads();
+    }
+    // ---- 3. root nodes (:543-592)
+    if (tid == 0) {
+        int L0 = 0;
+        for (int r = 0; r < nIni; r++) {
+            const uint32_t c = pyr[r];
+            if (c > 0) { cntA[L0] = c | 0x80000000u; nidA[L0] = (uint32_t)r; L0++; }
+        }
+        sh_L = L0;
+    }
+    __syncthreads();
+    int L = sh_L, cur = 0, phase = 1;
+
+    // ---- 4. passes: list bookkeeping on node counts only, by wave 0
+    while (true) {
+        uint32_t *cnt = cntA + cur * capMax, *ncnt = cntA + (cur ^ 1) * capMax;
+        uint32_t *nid = nidA + cur * capMax, *nnid = nidA + (cur ^ 1) * capMax;
+        if (tid < 64) {
+            const int lane = tid;
+            // children counts of every expandable node from the pyramid
+            bool deep = false;
+            for (int k = lane; k < L; k += 64) {
+                const uint32_t cv = cnt[k];
+                if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) {
+                    const int d = (int)(nid[k] >> 28);
+                    const uint32_t c = nid[k] & 0x0FFFFFFFu;
+                    if (d + 1 > Dm) deep = true;
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) hist[4 * k + q] = pyr_count(pyr, nIni, Dm, d + 1, 4u * c + q);
+                    }
+                }
+            }
+            if (__ballot(deep)) { if (lane == 0) sh_abort = 1; }
+            wave_sync();
+            if (!sh_abort) {
+                // visiting order of the expandable (fresh, >1 key) nodes
+                int E;
+                if (phase == 1) {   // list order
+                    const int chunk = (L + 63) >> 6;
+                    const int beg = min(lane * chunk, L), end = min(beg + chunk, L);
+                    int s = 0;
+                    for (int k = beg; k < end; k++) {
+                        const uint32_t cv = cnt[k];
+                        s += ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) ? 1 : 0;
+                    }
+                    const int inc = wave_incl_scan_i32(s);
+                    E = __builtin_amdgcn_readlane(inc, 63);
+                    int off = inc - s;
+                    for (int k = beg; k < end; k++) {
+                        const uint32_t cv = cnt[k];
+                        if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) xlist[off++] = (uint16_t)k;
+                    }
+                } else {            // (size desc, later-created first): bitonic sort of (~size, list index)
+                    int P = 1;
+                    while (P < L) P <<= 1;
+                    int e = 0;
+                    for (int k = lane; k < P; k += 64) {
+                        unsigned long long key = ~0ull;
+                        if (k < L) {
+                            const uint32_t cv = cnt[k];
+                            if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) {
+                                key = ((unsigned long long)(0x7FFFFFFFu - (cv & 0x7FFFFFFFu)) << 32) | (unsigned)k;
+                                e++;
+                            }
+                        }
+                        skey[k] = key;
+                    }
+                    wave_sync();
+                    for (int kk2 = 2; kk2 <= P; kk2 <<= 1)
+                        for (int j = kk2 >> 1; j > 0; j >>= 1) {
+                            for (int i = lane; i < P; i += 64) {
+                                const int ixj = i ^ j;
+                                if (ixj > i) {
+                                    const unsigned long long a = skey[i], c2 = skey[ixj];
+                                    if ((a > c2) == ((i & kk2) == 0)) { skey[i] = c2; skey[ixj] = a; }
+                                }
+                            }
+                            wave_sync();
+                        }
+                    e = wave_total_i32(e);
+                    E = e;
+                    for (int k = lane; k < E; k += 64) xlist[k] = (uint16_t)(skey[k] & 0xFFFFu);
+                }
+                wave_sync();
+                // children created per rank -> exclusive prefix by rank; number of parents split
+                int Sp = E, C = 0;
+                {
+                    const int chunk = (E + 63) >> 6;
+                    const int beg = min(lane * chunk, E), end = min(beg + chunk, E);
+                    int s = 0;
+                    for (int r = beg; r < end; r++) {
+                        const int k = xlist[r];
+                        s += (hist[4 * k] > 0) + (hist[4 * k + 1] > 0) + (hist[4 * k + 2] > 0) + (hist[4 * k + 3] > 0);
+                    }
+                    const int inc = wave_incl_scan_i32(s);
+                    int off = inc - s;
+                    int hit = 0x7FFFFFFF;
+                    for (int r = beg; r < end; r++) {
+                        const int k = xlist[r];
+                        const int nz = (hist[4 * k] > 0) + (hist[4 * k + 1] > 0) + (hist[4 * k + 2] > 0) + (hist[4 * k + 3] > 0);
+                        pn[r] = off;
+                        if (phase == 2) {
+                            const int after = L + off + nz - (r + 1), before = L + off - r;
+                            if (after >= N && before < N) hit = r + 1;   // the break at :730-731
+                        }
+                        off += nz;
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) hit = min(hit, __shfl_xor(hit, o));
+                    if (phase == 2 && hit != 0x7FFFFFFF) Sp = hit;
+                    wave_sync();
+                    if (Sp > 0) {
+                        const int k = xlist[Sp - 1];
+                        C = pn[Sp - 1] + (hist[4 * k] > 0) + (hist[4 * k + 1] > 0) + (hist[4 * k + 2] > 0) + (hist[4 * k + 3] > 0);
+                    }
+                }
+                const int Lnew = L - Sp + C;
+                for (int k = lane; k < L; k += 64) split[k] = 0;
+                wave_sync();
+                // create children: creation sequence s -> list index C-1-s (every insertion is push_front)
+                int nexp = 0;
+                for (int r = lane; r < Sp; r += 64) {
+                    const int k = xlist[r];
+                    split[k] = 1;
+                    int s = pn[r];
+                    const uint32_t pd = nid[k] >> 28, pc = nid[k] & 0x0FFFFFFFu;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t hc = hist[4 * k + q];
+                        if (hc > 0) {
+                            const int ni = C - 1 - s;
+                            ncnt[ni] = hc | 0x80000000u;
+                            nnid[ni] = ((pd + 1) << 28) | (4u * pc + q);
+                            if (hc > 1) nexp++;
+                            s++;
+                        }
+                    }
+                }
+                nexp = wave_total_i32(nexp);
+                wave_sync();
+                {   // survivors keep their relative order behind the new nodes
+                    const int chunk = (L + 63) >> 6;
+                    const int beg = min(lane * chunk, L), end = min(beg + chunk, L);
+                    int s = 0;
+                    for (int k = beg; k < end; k++) s += split[k] ? 0 : 1;
+                    const int inc = wave_incl_scan_i32(s);
+                    int off = inc - s;
+                    for (int k = beg; k < end; k++)
+                        if (!split[k]) {
+                            const int ni = C + off++;
+                            ncnt[ni] = cnt[k] & 0x7FFFFFFFu;  // no longer fresh
+                            nnid[ni] = nid[k];
+                        }
+                }
+                const bool fin = (Lnew >= N || Lnew == L);   // :669-672, :733-734
+                if (lane == 0) {
+                    sh_Lnew = Lnew;
+                    sh_finish = fin ? 1 : 0;
+                    sh_phase = (!fin && phase == 1 && Lnew + 3 * nexp > N) ? 2 : phase;
+                }
+            }
+        }
+        __syncthreads();
+        if (sh_abort) {   // counts deeper than the pyramid are needed: hand the level to k_octree
+            if (tid == 0) fallback[b * nlevels + l] = 1;
+            return;
+        }
+        L = sh_Lnew;
+        phase = sh_phase;
+        cur ^= 1;
+        if (sh_finish) break;
+        __syncthreads();
+    }
+
+    // ---- 5. leaf map (depth, cell) -> list index, in place of the counts
+    {
+        const uint32_t *nid = nidA + cur * capMax;
+        __syncthreads();
+        for (int i = tid; i < pyrWords; i += OCT_T) pyr[i] = 0xFFFFFFFFu;
+        for (int i = tid; i < L; i += OCT_T) hist[i] = 0;  // best[]
+        __syncthreads();
+        for (int k = tid; k < L; k += OCT_T) {
+            const int d = (int)(nid[k] >> 28);
+            const uint32_t c = nid[k] & 0x0FFFFFFFu;
+            const uint32_t off = (uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u);
+            if (d == Dm) ((uint16_t *)(pyr + off))[c] = (uint16_t)k;
+            else pyr[off + c] = (uint32_t)k;
+        }
+        __syncthreads();
+    }
+    // ---- 6. every key walks down to its leaf; best key of the node, first maximum wins (:744-760)
+    for (int i0 = 4 * tid; i0 < n; i0 += 4 * OCT_T) {
+        uint32_t key[4], cd[4], node[4];
+        load_keys4(keys, i0, n, key);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            cd[u] = (uint32_t)xPath[key[u] & 0xFFF] | (uint32_t)yPath[(key[u] >> 12) & 0xFFF];
+            node[u] = 0xFFFFFFFFu;
+        }
+        // the leaves partition the region: exactly one cell on a key's path is in the map, so the depths
+        // are probed independently (4 keys x 1 depth in flight) instead of as a dependent descent
+        for (int d = 0; d < Dm; d++) {
+            const uint32_t off = (uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u);
+            const int sh = 2 * (Dm - d);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t v = pyr[off + (cd[u] >> sh)];
+                node[u] = v != 0xFFFFFFFFu ? v : node[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t v = ((const uint16_t *)(pyr + offDeep))[cd[u]];
+            node[u] = v != 0xFFFFu ? v : node[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + u < n && node[u] != 0xFFFFFFFFu)
+                atomicMax(&hist[node[u]], ((key[u] >> 24) << 20) | (0xFFFFFu - (uint32_t)(i0 + u)));
+    }
+    __syncthreads();
+    // ---- 7. output in list order
+    uint32_t *okp = lvlKp + (size_t)b * lvlKpCap + g.lvlKpOff;
+    const int Lout = min(L, g.nodeCap);
+    for (int k = tid; k < Lout; k += OCT_T) okp[k] = keys[0xFFFFFu - (hist[k] & 0xFFFFFu)];
+    if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; fallback[b * nlevels + l] = 0; }
+}
+
+// K3 (fallback): one sweep over the keys per pass; runs only for levels k_octree_pyr flagged
+__global__ __launch_bounds__(OCT_T) void k_octree(
+    const LevelGeom *__restrict__ geom, int nlevels, int totalCells, const uint32_t *__restrict__ cellCnt,
+    const uint32_t *__restrict__ slots, size_t slotsPerImg, uint32_t *__restrict__ cand,
+    uint16_t *__restrict__ nodeOf, size_t keysPerImg, const int32_t *__restrict__ candCnt,
+    uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
+    const int32_t *__restrict__ tab, int capMax, int pow2cap, int scratchInts, int dbgStop,
+    const int32_t *__restrict__ fallback) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    // level-major block order: the large levels start first and the small ones fill the gaps
+    const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+    if (fallback && !fallback[b * nlevels + l]) return;  // done by k_octree_pyr
+    const LevelGeom g = geom[l];
+    // ---- carve LDS
+    uint8_t *sp = smem;
+    OctLds S;
+    S.skey = (unsigned long long *)sp; sp += sizeof(unsigned long long) * pow2cap;
+    S.box[0] = (short4 *)sp; sp += sizeof(short4) * capMax;
+    S.box[1] = (short4 *)sp; sp += sizeof(short4) * capMax;
+    S.cnt[0] = (uint32_t *)sp; sp += 4 * capMax;
+    S.cnt[1] = (uint32_t *)sp; sp += 4 * capMax;
+    S.hist = (uint32_t *)sp; sp += 4 * (size_t)scratchInts;  // >= max(4*cap, ncells+1)
+    S.pn = (int *)sp; sp += 4 * capMax;
+    S.pg = (int *)sp; sp += 4 * capMax;
+    S.childIdx = (uint16_t *)sp; sp += 2 * 4 * capMax;
+    S.survIdx = (uint16_t *)sp; sp += 2 * capMax;
+    S.xlist = (uint16_t *)sp; sp += 2 * capMax;
+    S.split = sp; sp += capMax;
+    __shared__ int rootCnt[ORBX_MAX_ROOTS], rootMap[ORBX_MAX_ROOTS];
+
+    uint32_t *keys = cand + (size_t)b * keysPerImg + g.keyOff;
+    uint16_t *nof = nodeOf + (size_t)b * keysPerImg + g.keyOff;
+
+    // ---- A/B. keys were gathered in vToDistributeKeys order by k_cell_scan + k_gather
+    const int n = candCnt[b * nlevels + l];
+    const uint8_t *rootOf = (const uint8_t *)tab + g.rootTabOff;
+    if (tid < ORBX_MAX_ROOTS) rootCnt[tid] = 0;
+    __syncthreads();
+    {   // keys per root (:569): per-wave ballot counts, one LDS atomic per wave and root
+        const int lane = tid & 63;
+        for (int b0 = 0; b0 < n; b0 += 4 * OCT_T) {
+            const int i0 = b0 + 4 * tid;
+            uint32_t key[4];
+            load_keys4(keys, i0, n, key);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int r = i0 + u < n ? (int)rootOf[key[u] & 0xFFF] : -1;
+                for (int q = 0; q < g.nIni; q++) {
+                    const unsigned long long m = __ballot(r == q);
+                    if (lane == 0 && m) atomicAdd(&rootCnt[q], (int)__popcll(m));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (dbgStop == 2) return;
+    __shared__ int sh_L;
+    if (tid == 0) {
+        int L0 = 0;
+        for (int r = 0; r < g.nIni; r++) {
+            if (rootCnt[r] > 0) {
+                short4 bx;
+                bx.x = (short)tab[g.rootBoxOff + r];
+                bx.y = (short)tab[g.rootBoxOff + r + 1];
+                bx.z = 0;
+                bx.w = (short)g.regH;
+                S.box[0][L0] = bx;
+                S.cnt[0][L0] = (uint32_t)rootCnt[r] | 0x80000000u;
+                rootMap[r] = L0++;
+            }
+        }
+        sh_L = L0;
+    }
+    __syncthreads();
+    int L = sh_L;
+    int cur = 0, phase = 1;
+    const int N = g.N;
+    for (int i = tid; i < 4 * L; i += OCT_T) S.hist[i] = 0;  // coff is dead from here on
+    __syncthreads();
+    // first sweep: list index of the root + children histogram of the expandable roots
+    for (int b0 = 0; b0 < n; b0 += 4 * OCT_T) {
+        const int i0 = b0 + 4 * tid;
+        uint32_t key[4];
+        int kk[4];
+        load_keys4(keys, i0, n, key);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = rootMap[rootOf[key[u] & 0xFFF]];
+            kk[u] = k;
+            int bin = -1;
+            if (i0 + u < n) {
+                const uint32_t cv = S.cnt[0][k];
+                if ((cv & 0x7FFFFFFFu) > 1) bin = 4 * k + child_of(key[u] & 0xFFF, (key[u] >> 12) & 0xFFF, S.box[0][k]);
+            }
+            if (bin >= 0) atomicAdd(&S.hist[bin], 1u);
+        }
+        store_nof4(nof, i0, n, kk);
+    }
+    __syncthreads();
+
+    if (dbgStop == 3) return;
+    int npass = 0;
+    // ---- C. passes.  On entry S.hist holds the children key counts of every expandable node.
+    // The list bookkeeping of a pass touches only O(list size) entries: it is done by wave 0
+    // alone with wave-synchronous LDS hand-offs (no workgroup barriers); the other waves wait.
+    __shared__ int sh_Lnew, sh_finish, sh_phase;
+    while (true) {
+        // plain offsets (no runtime-indexed pointer arrays): keeps the accesses in the LDS address space
+        short4 *box = S.box[0] + cur * capMax, *nbox = S.box[0] + (cur ^ 1) * capMax;
+        uint32_t *cnt = S.cnt[0] + cur * capMax, *ncnt = S.cnt[0] + (cur ^ 1) * capMax;
+        if (tid < 64) {
+            const int lane = tid;
+            // 1. visiting order of the expandable (fresh, >1 key) nodes
+            int E;
+            if (phase == 1) {   // list order
+                const int chunk = (L + 63) >> 6;
+                const int beg = min(lane * chunk, L), end = min(beg + chunk, L);
+                int s = 0;
+                for (int k = beg; k < end; k++) {
+                    const uint32_t cv = cnt[k];
+                    s += ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) ? 1 : 0;
+                }
+                const int inc = wave_incl_scan_i32(s);
+                E = __builtin_amdgcn_readlane(inc, 63);
+                int off = inc - s;
+                for (int k = beg; k < end; k++) {
+                    const uint32_t cv = cnt[k];
+                    if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) S.xlist[off++] = (uint16_t)k;
+                }
+            } else {            // (size desc, later-created first): bitonic sort of (~size, list index)
+                int P = 1;
+                while (P < L) P <<= 1;
+                int e = 0;
+                for (int k = lane; k < P; k += 64) {
+                    unsigned long long key = ~0ull;
+                    if (k < L) {
+                        const uint32_t cv = cnt[k];
+                        if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) {
+                            key = ((unsigned long long)(0x7FFFFFFFu - (cv & 0x7FFFFFFFu)) << 32) | (unsigned)k;
+                            e++;
+                        }
+                    }
+                    S.skey[k] = key;
+                }
+                wave_sync();
+                for (int kk2 = 2; kk2 <= P; kk2 <<= 1)
+                    for (int j = kk2 >> 1; j > 0; j >>= 1) {
+                        for (int i = lane; i < P; i += 64) {
+                            const int ixj = i ^ j;
+                            if (ixj > i) {
+                                const unsigned long long a = S.skey[i], c2 = S.skey[ixj];
+                                if ((a > c2) == ((i & kk2) == 0)) { S.skey[i] = c2; S.skey[ixj] = a; }
+                            }
+                        }
+                        wave_sync();
+                    }
+                e = wave_total_i32(e);
+                E = e;
+                for (int k = lane; k < E; k += 64) S.xlist[k] = (uint16_t)(S.skey[k] & 0xFFFFu);
+            }
+            wave_sync();
+            // 2. children created per rank -> exclusive prefix by rank (in S.pn)
+            int Sp = E, C = 0;
+            {
+                const int chunk = (E + 63) >> 6;
+                const int beg = min(lane * chunk, E), end = min(beg + chunk, E);
+                int s = 0;
+                for (int r = beg; r < end; r++) {
+                    const int k = S.xlist[r];
+                    s += (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) + (S.hist[4 * k + 3] > 0);
+                }
+                const int inc = wave_incl_scan_i32(s);
+                int off = inc - s;
+                // 3. number of parents split: phase 2 stops at the first rank that reaches N (:730-731)
+                int hit = 0x7FFFFFFF;
+                for (int r = beg; r < end; r++) {
+                    const int k = S.xlist[r];
+                    const int nz = (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) + (S.hist[4 * k + 3] > 0);
+                    S.pn[r] = off;
+                    if (phase == 2) {
+                        const int after = L + off + nz - (r + 1), before = L + off - r;
+                        if (after >= N && before < N) hit = r + 1;
+                    }
+                    off += nz;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) hit = min(hit, __shfl_xor(hit, o));
+                if (phase == 2 && hit != 0x7FFFFFFF) Sp = hit;
+                wave_sync();
+                if (Sp > 0) {
+                    const int k = S.xlist[Sp - 1];
+                    C = S.pn[Sp - 1] + (S.hist[4 * k] > 0) + (S.hist[4 * k + 1] > 0) + (S.hist[4 * k + 2] > 0) + (S.hist[4 * k + 3] > 0);
+                }
+            }
+            const int Lnew = L - Sp + C;
+            for (int k = lane; k < L; k += 64) S.split[k] = 0;
+            wave_sync();
+            // 4. create children: creation sequence s -> list index C-1-s (every insertion is push_front)
+            int nexp = 0;
+            for (int r = lane; r < Sp; r += 64) {
+                const int k = S.xlist[r];
+                S.split[k] = 1;
+                int s = S.pn[r];
+                const short4 pb = box[k];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t hc = S.hist[4 * k + q];
+                    if (hc > 0) {
+                        const int ni = C - 1 - s;
+                        nbox[ni] = child_box(pb, q);
+                        ncnt[ni] = hc | 0x80000000u;
+                        S.childIdx[4 * k + q] = (uint16_t)ni;
+                        if (hc > 1) nexp++;
+                        s++;
+                    }
+                }
+            }
+            nexp = wave_total_i32(nexp);
+            wave_sync();
+            {   // survivors keep their relative order behind the new nodes
+                const int chunk = (L + 63) >> 6;
+                const int beg = min(lane * chunk, L), end = min(beg + chunk, L);
+                int s = 0;
+                for (int k = beg; k < end; k++) s += S.split[k] ? 0 : 1;
+                const int inc = wave_incl_scan_i32(s);
+                int off = inc - s;
+                for (int k = beg; k < end; k++)
+                    if (!S.split[k]) {
+                        const int ni = C + off++;
+                        nbox[ni] = box[k];
+                        ncnt[ni] = cnt[k] & 0x7FFFFFFFu;  // no longer fresh
+                        S.survIdx[k] = (uint16_t)ni;
+                    }
+            }
+            // 5. termination (:669-672, :733-734)
+            const bool fin = (Lnew >= N || Lnew == L);
+            if (lane == 0) {
+                sh_Lnew = Lnew;
+                sh_finish = fin ? 1 : 0;
+                sh_phase = (!fin && phase == 1 && Lnew + 3 * nexp > N) ? 2 : phase;
+            }
+        }
+        __syncthreads();
+        const int Lnew = sh_Lnew;
+        const bool finish = sh_finish != 0;
+        phase = sh_phase;
+        // 6. one sweep over the keys: new node index + (children histogram of the next pass |
+        //    best key of every node, first maximum wins (:744-760))
+        const int nz = finish ? Lnew : 4 * Lnew;
+        for (int i = tid; i < nz; i += OCT_T) S.hist[i] = 0;
+        __syncthreads();
+        for (int b0 = 0; b0 < n; b0 += 4 * OCT_T) {
+            const int i0 = b0 + 4 * tid;
+            uint32_t key[4];
+            int kk[4];
+            load_keys4(keys, i0, n, key);
+            load_nof4(nof, i0, n, kk);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u;
+                int bin = -1;
+                if (i < n) {
+                    const int ko = kk[u];
+                    const int x = key[u] & 0xFFF, y = (key[u] >> 12) & 0xFFF;
+                    const int k = S.split[ko] ? (int)S.childIdx[4 * ko + child_of(x, y, box[ko])] : (int)S.survIdx[ko];
+                    kk[u] = k;
+                    if (finish) {
+                        atomicMax(&S.hist[k], ((key[u] >> 24) << 20) | (0xFFFFFu - (uint32_t)i));
+                    } else {
+                        const uint32_t cv = ncnt[k];
+                        if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) bin = 4 * k + child_of(x, y, nbox[k]);
+                    }
+                }
+                if (bin >= 0) atomicAdd(&S.hist[bin], 1u);
+            }
+            if (!finish) store_nof4(nof, i0, n, kk);
+        }
+        __syncthreads();
+        L = Lnew;
+        cur ^= 1;
+        if (finish) break;
+        if (dbgStop >= 4 && ++npass >= dbgStop - 3) return;
+    }
+
+    // ---- D. output in list order
+    const uint32_t *best = S.hist;
+    uint32_t *okp = lvlKp + (size_t)b * lvlKpCap + g.lvlKpOff;
+    const int Lout = min(L, g.nodeCap);
+    for (int k = tid; k < Lout; k += OCT_T) okp[k] = keys[0xFFFFFu - (best[k] & 0xFFFFFu)];
+    if (tid == 0) lvlCnt[b * nlevels + l] = Lout;
+}
