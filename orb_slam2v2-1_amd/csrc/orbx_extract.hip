@@ -498,7 +498,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
                                          (int)h->octPyrLdsBytes));
             hipLaunchKernelGGL(k_octree_pyr, dim3(B, nl), dim3(OCT_T), h->octPyrLdsBytes, st, h->d_geom, nl, h->d_cand,
                                h->keysPerImg, h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap,
-                               pow2, h->octPyrWords, h->d_octFallback);
+                               pow2, h->octPyrWords, h->d_octFallback, g_debug[7]);
         }
         hipLaunchKernelGGL(k_octree, dim3(B, nl), dim3(OCT_T), h->octLdsBytes, st, h->d_geom, nl, h->totalCells,
                            h->d_cellCnt, h->d_slots, h->slotsPerImg, h->d_cand, h->d_nodeOf, h->keysPerImg,

@@ -135,7 +135,7 @@ __device__ __forceinline__ uint32_t pyr_count(const uint32_t *pyr, int nIni, int
 __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
     const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand, size_t keysPerImg,
     const int32_t *__restrict__ candCnt, uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
-    const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback) {
+    const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback, int dbgStop) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;  // level-major: large levels start first
     const LevelGeom g = geom[l];
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
             if (i0 + u < n) atomicAdd(&pyr[offDeep + (c[u] >> 1)], 1u << (16 * (c[u] & 1)));
     }
     __syncthreads();
+    if (dbgStop == 1) return;
     // ---- 2. counts of the shallower depths
     for (int d = Dm - 1; d >= 0; d--) {
         const uint32_t off = (uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u);
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
         }
         __syncthreads();
     }
+    if (dbgStop == 2) return;
     // ---- 3. root nodes (:543-592)
     if (tid == 0) {
         int L0 = 0;
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
         __syncthreads();
     }
 
+    if (dbgStop == 3) return;
     // ---- 5. leaf map (depth, cell) -> list index, in place of the counts
     {
         const uint32_t *nid = nidA + cur * capMax;
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
                 atomicMax(&hist[node[u]], ((key[u] >> 24) << 20) | (0xFFFFFu - (uint32_t)(i0 + u)));
     }
     __syncthreads();
+    if (dbgStop == 4) return;
     // ---- 7. output in list order
     uint32_t *okp = lvlKp + (size_t)b * lvlKpCap + g.lvlKpOff;
     const int Lout = min(L, g.nodeCap);
