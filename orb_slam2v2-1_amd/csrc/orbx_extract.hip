@@ -200,8 +200,8 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
         slotOff += (size_t)g.ncells * g.capc;
         g.keyOff = keyOff;
         g.keyCap = g.ncells * g.capc;
-        if (g.keyCap > 0xFFFFF) {
-            orbx_set_error("level %d can hold %d FAST candidates (> 2^20): unsupported", l, g.keyCap);
+        if (g.keyCap > 0xFFFFFF) {   // best-key election packs (response << 24 | ~index) in one LDS word
+            orbx_set_error("level %d can hold %d FAST candidates (> 2^24): unsupported", l, g.keyCap);
             return ORBX_ERR_UNSUPPORTED;
         }
         keyOff += ((size_t)g.keyCap + 7) & ~(size_t)7;  // 16-B aligned key blocks (uint4 / ushort4 sweeps)

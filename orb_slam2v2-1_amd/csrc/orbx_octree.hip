@@ -404,14 +404,14 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
 #pragma unroll
         for (int u = 0; u < 4; u++)
             if (i0 + u < n && node[u] != 0xFFFFFFFFu)
-                atomicMax(&hist[node[u]], ((key[u] >> 24) << 20) | (0xFFFFFu - (uint32_t)(i0 + u)));
+                atomicMax(&hist[node[u]], ((key[u] >> 24) << 24) | (0xFFFFFFu - (uint32_t)(i0 + u)));
     }
     __syncthreads();
     if (dbgStop == 4) return;
     // ---- 7. output in list order
     uint32_t *okp = lvlKp + (size_t)b * lvlKpCap + g.lvlKpOff;
     const int Lout = min(L, g.nodeCap);
-    for (int k = tid; k < Lout; k += OCT_T) okp[k] = keys[0xFFFFFu - (hist[k] & 0xFFFFFu)];
+    for (int k = tid; k < Lout; k += OCT_T) okp[k] = keys[0xFFFFFFu - (hist[k] & 0xFFFFFFu)];
     if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; fallback[b * nlevels + l] = 0; }
 }
 
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
                     const int k = S.split[ko] ? (int)S.childIdx[4 * ko + child_of(x, y, box[ko])] : (int)S.survIdx[ko];
                     kk[u] = k;
                     if (finish) {
-                        atomicMax(&S.hist[k], ((key[u] >> 24) << 20) | (0xFFFFFu - (uint32_t)i));
+                        atomicMax(&S.hist[k], ((key[u] >> 24) << 24) | (0xFFFFFFu - (uint32_t)i));
                     } else {
                         const uint32_t cv = ncnt[k];
                         if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) bin = 4 * k + child_of(x, y, nbox[k]);
@@ -703,6 +703,6 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
     const uint32_t *best = S.hist;
     uint32_t *okp = lvlKp + (size_t)b * lvlKpCap + g.lvlKpOff;
     const int Lout = min(L, g.nodeCap);
-    for (int k = tid; k < Lout; k += OCT_T) okp[k] = keys[0xFFFFFu - (best[k] & 0xFFFFFu)];
+    for (int k = tid; k < Lout; k += OCT_T) okp[k] = keys[0xFFFFFFu - (best[k] & 0xFFFFFFu)];
     if (tid == 0) lvlCnt[b * nlevels + l] = Lout;
 }

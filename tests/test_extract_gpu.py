@@ -75,6 +75,17 @@ def test_full_hd_4000_features(pkg, oracle, synth):
     assert len(k) >= 3900
 
 
+def test_4k_image_and_size_limits(pkg, oracle, synth):
+    """3840x2160: level 0 can hold 2.2 M candidates (the best-key election packs response << 24 | ~index);
+    sides above 4095 px and portrait images whose level has no quad-tree root are refused with an error."""
+    k = _compare(pkg, oracle, synth.frame(3840, 2160, 33), 5000)
+    assert len(k) >= 5000
+    with pytest.raises(pkg.OrbxError):
+        pkg.ORBextractor(500, 1.2, 8, 20, 7)(np.zeros((1000, 4096), np.uint8))
+    with pytest.raises(pkg.OrbxError):       # round(w/h) = 0 roots: the reference divides by zero (src/ORBextractor.cc:543-545)
+        pkg.ORBextractor(500, 1.2, 4, 20, 7)(np.zeros((2000, 900), np.uint8))
+
+
 def test_ragged_size_and_small_budget(pkg, oracle, synth):
     _compare(pkg, oracle, synth.frame(641, 479, 31), 300)
     _compare(pkg, oracle, synth.frame(333, 257, 32), 50)
