@@ -119,7 +119,7 @@ __device__ __forceinline__ uint2 stereo_right_record(const StereoLevels &lv, con
 __global__ __launch_bounds__(256) void k_stereo_bins(StereoLevels lv, const orbx_keypoint_t *__restrict__ kr,
                                                      uint2 *__restrict__ rc, const int32_t *__restrict__ nr, int cap,
                                                      int bhShift, int nbins, int32_t *__restrict__ binStart,
-                                                     int32_t *__restrict__ items) {
+                                                     uint4 *__restrict__ items) {
     __shared__ int cnt[ST_MAX_BINS + 1], fill[ST_MAX_BINS];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int Nr = min(nr[b], cap);
@@ -140,15 +140,18 @@ __global__ __launch_bounds__(256) void k_stereo_bins(StereoLevels lv, const orbx
     __syncthreads();
     if (tid == 0) for (int i = 0; i < nbins; i++) cnt[i + 1] += cnt[i];   // <= 512 steps, once per frame
     __syncthreads();
-    int32_t *bs = binStart + (size_t)b * (ST_MAX_BINS + 1), *it = items + (size_t)b * 2 * cap;
+    int32_t *bs = binStart + (size_t)b * (ST_MAX_BINS + 1);
+    uint4 *it = items + (size_t)b * 2 * cap;   // a bin entry is the whole record + the keypoint index: ONE load per candidate
     for (int i = tid; i <= nbins; i += 256) bs[i] = cnt[i];
     for (int i = tid; i < Nr; i += 256) {
-        const uint32_t x = rcb[i].x;
+        const uint2 rec = rcb[i];
+        const uint32_t x = rec.x;
         const int minr = (int)(x & 0xFFF), maxr = (int)((x >> 12) & 0xFFF);
         if (maxr < minr) continue;
         const int b0 = min(minr >> bhShift, nbins - 1), b1 = min(maxr >> bhShift, nbins - 1);
-        it[cnt[b0] + atomicAdd(&fill[b0], 1)] = i;
-        if (b1 != b0) it[cnt[b1] + atomicAdd(&fill[b1], 1)] = i;
+        const uint4 e = make_uint4(rec.x, rec.y, (uint32_t)i, 0u);
+        it[cnt[b0] + atomicAdd(&fill[b0], 1)] = e;
+        if (b1 != b0) it[cnt[b1] + atomicAdd(&fill[b1], 1)] = e;
     }
 }
 // one wave per left keypoint: row-band candidate test (:498-508, :535), level and
@@ -160,10 +163,11 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
     const int32_t *__restrict__ nl, const orbx_keypoint_t *__restrict__ kr, const uint8_t *__restrict__ dr,
     const int32_t *__restrict__ nr, int cap, float mbf, float mb, float *__restrict__ uright,
     float *__restrict__ depth, int32_t *__restrict__ sad, const uint2 *__restrict__ rc, const int32_t *__restrict__ binStart,
-    const int32_t *__restrict__ binItems, int bhShift, int nbins) {
+    const uint4 *__restrict__ binItems, int bhShift, int nbins) {
     // Candidates = the right keypoints of this keypoint's row bin; the survivors of the exact tests are compacted
     // (ballot prefix) so that their descriptors are fetched by all lanes at once.
     __shared__ uint16_t s_cand[ST_WAVES][ST_CAND];
+    __shared__ float s_candU[ST_WAVES][ST_CAND];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int bx, b;
     xcd_block_map(bx, b);   // both pyramids of a frame are read through ONE L2
@@ -187,23 +191,25 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
     if (ok) {
         const Desc256 dL = load_desc(dl + o * 32);
         u64 best = ~0ull;
-        const orbx_keypoint_t *krb = kr + (size_t)b * cap;
         const uint8_t *drb = dr + (size_t)b * cap * 32;
         uint16_t *cl = s_cand[wave];
+        float *cu = s_candU[wave];
         int cnt = 0;
-        const uint2 *rcb = rc + (size_t)b * cap;
-        const int32_t *bs = binStart + (size_t)b * (ST_MAX_BINS + 1), *bit = binItems + (size_t)b * 2 * cap;
+        float bestU = 0.f;   // pt.x of this lane's best candidate (the winner's is broadcast after the argmin)
+        const int32_t *bs = binStart + (size_t)b * (ST_MAX_BINS + 1);
+        const uint4 *bit = binItems + (size_t)b * 2 * cap;
         const int bin = min(row >> bhShift, nbins - 1);
         const int p0 = bs[bin], p1 = bs[bin + 1];
         for (int i0 = p0; i0 < p1; i0 += 64) {
             const int ip = i0 + lane;
             int iR = 0;
+            float uR = 0.f;
             bool pass = false;
             if (ip < p1) {
-                iR = bit[ip];
-                const uint2 q = rcb[iR];
+                const uint4 q = bit[ip];
+                iR = (int)q.z;
                 const int minr = (int)(q.x & 0xFFF), maxr = (int)((q.x >> 12) & 0xFFF), octR = (int)(q.x >> 24);
-                const float uR = __uint_as_float(q.y);
+                uR = __uint_as_float(q.y);
                 pass = row >= minr && row <= maxr && octR >= levelL - 1 && octR <= levelL + 1 && uR >= minU && uR <= maxU;
             }
             const u64 m = __ballot(pass);
@@ -213,12 +219,16 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
                     for (int c = lane; c < cnt; c += 64) {
                         const int jR = cl[c];
                         const int dist = ham(dL, load_desc(drb + (size_t)jR * 32));
-                        if (dist < TH_HIGH) { const u64 key = ((u64)dist << 32) | (unsigned)jR; best = key < best ? key : best; }
+                        if (dist < TH_HIGH) { const u64 key = ((u64)dist << 32) | (unsigned)jR; if (key < best) { best = key; bestU = cu[c]; } }
                     }
                     wave_sync();
                     cnt = 0;
                 }
-                if (pass) cl[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)iR;
+                if (pass) {
+                    const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                    cl[pos] = (uint16_t)iR;
+                    cu[pos] = uR;
+                }
                 cnt += __popcll(m);
             }
         }
@@ -226,14 +236,15 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
         for (int c = lane; c < cnt; c += 64) {
             const int jR = cl[c];
             const int dist = ham(dL, load_desc(drb + (size_t)jR * 32));
-            if (dist < TH_HIGH) { const u64 key = ((u64)dist << 32) | (unsigned)jR; best = key < best ? key : best; }
+            if (dist < TH_HIGH) { const u64 key = ((u64)dist << 32) | (unsigned)jR; if (key < best) { best = key; bestU = cu[c]; } }
         }
+        const u64 mine = best;
         best = wave_min_u64(best);
         const int bestDist = best == ~0ull ? TH_HIGH : (int)(best >> 32);
-        const int bestIdxR = best == ~0ull ? 0 : (int)(best & 0xFFFFFFFFu);
         const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
         if (bestDist < thOrbDist) {
-            const float uR0 = krb[bestIdxR].x;
+            // pt.x of the winner from the lane that holds it (keys are unique: the index is part of the key)
+            const float uR0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(bestU), (int)__builtin_ctzll(__ballot(mine == best))));
             const float scaleFactor = lv.isf[levelL];
             const float scaleduL = roundf(kpL.x * scaleFactor);
             const float scaledvL = roundf(kpL.y * scaleFactor);
@@ -247,29 +258,29 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
                                     (size_t)ORBX_EDGE * lv.pstrideR[levelL] + ORBX_EDGE;
                 const int sL = lv.pstrideL[levelL], sR = lv.pstrideR[levelL];
                 const int cy = (int)scaledvL, cxl = (int)scaleduL, cxr0 = (int)scaleduR0;
-                const int cL = IL[(size_t)cy * sL + cxl];
-                // this lane's two pixels of the 11x11 window (p = lane, lane + 64 < 121)
+                // this lane's two pixels of the 11x11 window (p = lane, lane + 64 < 121); the window centre is pixel 60, i.e.
+                // the first pixel of lane 60: it is taken from that lane's load, not fetched separately
                 const int p0 = lane, p1 = lane + 64;
                 const bool has1 = p1 < 121;
                 const int ay0 = p0 / 11 - w, ax0 = p0 % 11 - w;
                 const int ay1 = has1 ? p1 / 11 - w : 0, ax1 = has1 ? p1 % 11 - w : 0;
-                const int av0 = (int)IL[(size_t)(cy + ay0) * sL + cxl + ax0] - cL;
-                const int av1 = (int)IL[(size_t)(cy + ay1) * sL + cxl + ax1] - cL;
+                const int raw0 = IL[(size_t)(cy + ay0) * sL + cxl + ax0], raw1 = IL[(size_t)(cy + ay1) * sL + cxl + ax1];
                 float vDists[11];
                 int bestDistS = INT_MAX, bestincR = 0;
                 // the 33 right-image bytes of this lane (2 window pixels + the window centre, 11 shifts each) are all
                 // requested before the first sum: one memory latency instead of eleven
-                int rc0[11], rb0[11], rb1[11];
+                int rb0[11], rb1[11];
 #pragma unroll
                 for (int k = 0; k < 11; k++) {
                     const int cxr = cxr0 + k - L;
-                    rc0[k] = IR[(size_t)cy * sR + cxr];
                     rb0[k] = IR[(size_t)(cy + ay0) * sR + cxr + ax0];
                     rb1[k] = IR[(size_t)(cy + ay1) * sR + cxr + ax1];
                 }
+                const int cL = __builtin_amdgcn_readlane(raw0, 60);
+                const int av0 = raw0 - cL, av1 = raw1 - cL;
 #pragma unroll
                 for (int incR = -L; incR <= L; incR++) {
-                    const int cR = rc0[incR + L];
+                    const int cR = __builtin_amdgcn_readlane(rb0[incR + L], 60);
                     const int bv0 = rb0[incR + L] - cR;
                     const int bv1 = rb1[incR + L] - cR;
                     const int df0 = av0 - bv0, df1 = av1 - bv1;
@@ -380,7 +391,7 @@ static int fill_stereo_levels(orbx_extractor *hl, orbx_extractor *hr, StereoLeve
 }
 
 // scratch for the SAD distances, grown on demand (per left extractor handle)
-struct StereoScratch { int32_t *d_sad; uint2 *d_rc; int32_t *d_binStart, *d_items; size_t n; int nB; int device; };
+struct StereoScratch { int32_t *d_sad; uint2 *d_rc; int32_t *d_binStart; uint4 *d_items; size_t n; int nB; int device; };
 static thread_local StereoScratch g_ss = {nullptr, nullptr, nullptr, nullptr, 0, 0, -1};
 
 extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, int left_slot0,
@@ -406,7 +417,7 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
         g_ss.d_sad = nullptr; g_ss.d_rc = nullptr; g_ss.d_binStart = nullptr; g_ss.d_items = nullptr; g_ss.n = 0; g_ss.nB = 0;
         ORBX_HIP(hipMalloc(&g_ss.d_sad, sizeof(int32_t) * need));
         ORBX_HIP(hipMalloc(&g_ss.d_rc, sizeof(uint2) * need));
-        ORBX_HIP(hipMalloc(&g_ss.d_items, sizeof(int32_t) * 2 * need));
+        ORBX_HIP(hipMalloc(&g_ss.d_items, sizeof(uint4) * 2 * need));
         ORBX_HIP(hipMalloc(&g_ss.d_binStart, sizeof(int32_t) * (ST_MAX_BINS + 1) * (size_t)B));
         g_ss.n = need; g_ss.nB = B; g_ss.device = hl->device;
     }
