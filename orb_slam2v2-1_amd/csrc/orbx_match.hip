@@ -172,16 +172,16 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
     int bx, b;
     xcd_block_map(bx, b);   // both pyramids of a frame are read through ONE L2
     const int iL = bx * ST_WAVES + wave;
-    const int N = min(nl[b], cap);
     if (iL >= cap) return;
     const size_t o = (size_t)b * cap + iL;
+    const orbx_keypoint_t kpL = kl[o];      // requested together with the count (slot o exists even when iL >= N)
+    const int N = min(nl[b], cap);
     if (iL >= N) {
         if (lane == 0) { uright[o] = -1.0f; depth[o] = -1.0f; sad[o] = -1; }
         return;
     }
     float out_u = -1.0f, out_d = -1.0f;
     int out_s = -1;
-    const orbx_keypoint_t kpL = kl[o];
     const int levelL = kpL.octave;
     const float vL = kpL.y, uL = kpL.x;
     const int row = (int)vL;
