@@ -115,6 +115,48 @@ def cpu_baseline(w, h, nf, stereo, budget_s=20.0):
     # frame generation happens inside the workers too; remove its share of the wall time
     wall_work = wall * work / max(work + gen, 1e-9)
     st = np.sum([r[2] for r in res], 0)
+    # (i) one thread, mono extract; (ii) two threads, stereo extract + ComputeStereoMatches, the way
+    # the reference runs its two extractors (src/Frame.cc:78-81; ctypes releases the GIL during the oracle calls)
+    import threading
+    synth = importlib.import_module("orb_slam2v2-1_amd.synth")
+    one_thread_mono = two_thread_stereo = None
+    try:
+        reps = 3
+        img = synth.frame(w, h, 7)
+        e1 = oracle.Extractor(nf, 1.2, 8, 20, 7)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            e1.extract(img)
+        one_thread_mono = reps / (time.perf_counter() - t0)
+        if stereo:
+            l, r = synth.stereo_pair_blocky(w, h, 7)
+            exs = [oracle.Extractor(nf, 1.2, 8, 20, 7) for _ in range(2)]
+            out = [None, None]
+
+            def _work(i, im):
+                out[i] = exs[i].extract(im)
+            mb = np.float32(KITTI_BF) / np.float32(KITTI_FX)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ts = [threading.Thread(target=_work, args=(i, im)) for i, im in enumerate((l, r))]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
+                oracle.stereo_match(out[0][0], out[0][1], out[1][0], out[1][1], [exs[0].pyramid_level(i) for i in range(8)],
+                                    [exs[1].pyramid_level(i) for i in range(8)], exs[0].scale_factors, exs[0].inv_scale_factors,
+                                    KITTI_BF, mb)
+            two_thread_stereo = reps / (time.perf_counter() - t0)
+    except Exception:
+        pass
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "value": round(nframes / wall_work, 3), "unit": "frames/s", "cores": cores, "kind": "port",
         "sample": "%d synthetic %s frames %dx%d, %d features, CPU oracle (restated CPU path, gcc -O3 -march=native, "
@@ -122,6 +164,9 @@ def cpu_baseline(w, h, nf, stereo, budget_s=20.0):
                       nframes, "stereo" if stereo else "mono", w, h, nf, cores, t1),
         "stage_share": {k: round(float(v / max(st.sum(), 1e-9)), 3) for k, v in
                         zip(["pyramid", "fast", "quadtree", "orientation", "blur", "descriptor"], st)},
+        "cpu_model": model, "host_cores_visible": os.cpu_count(),
+        "one_thread_mono_images_per_s": None if one_thread_mono is None else round(one_thread_mono, 2),
+        "two_thread_stereo_frames_per_s": None if two_thread_stereo is None else round(two_thread_stereo, 2),
     }
 
 
