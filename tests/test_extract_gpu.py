@@ -117,6 +117,30 @@ def test_dense_random_texture(pkg, oracle):
     _compare(pkg, oracle, img, 2000)
 
 
+def test_extreme_images(pkg, oracle):
+    """Saturated 0/255 blocks (the 7-tap blur sums reach their clamp, FAST scores their maximum), a one-pixel
+    checkerboard (every pixel a candidate before NMS) and corners hugging the image border."""
+    rng = np.random.default_rng(21)
+    h, w = 480, 640
+    sat = np.zeros((h, w), np.uint8)
+    for _ in range(400):
+        x, y = rng.integers(0, w - 4), rng.integers(0, h - 4)
+        sat[y:y + rng.integers(2, 40), x:x + rng.integers(2, 40)] = 255 if rng.random() < 0.5 else 0
+    _compare(pkg, oracle, sat, 1000)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for pitch in (1, 2, 5):
+        chk = (((xx // pitch + yy // pitch) % 2) * 255).astype(np.uint8)
+        chk[160:200] = 128
+        _compare(pkg, oracle, chk, 1500)
+    frame = np.full((h, w), 20, np.uint8)
+    frame[:17] = 240; frame[-17:] = 240; frame[:, :17] = 240; frame[:, -17:] = 240
+    for _ in range(200):
+        frame[rng.integers(0, h), rng.integers(0, w)] = 255
+    _compare(pkg, oracle, frame, 500)
+    _compare(pkg, oracle, sat, 1)          # a budget of one feature
+    _compare(pkg, oracle, sat, 7, nl=1)    # a single level
+
+
 def test_batch_with_empty_and_flat_frames(pkg, oracle, synth):
     w, h = 640, 480
     imgs = np.stack([synth.frame(w, h, 40), np.full((h, w), 50, np.uint8), synth.frame(w, h, 41)])

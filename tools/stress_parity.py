@@ -13,14 +13,14 @@ bad = 0
 t0 = time.time()
 for it in range(N):
     w = int(rng.integers(300, 1400)); h = int(rng.integers(240, 800))
-    nf = int(rng.choice([100, 300, 500, 1000, 2000, 3000]))
+    nf = int(rng.choice([1, 7, 100, 300, 500, 1000, 2000, 3000]))
     sf = float(rng.choice([1.2, 1.2, 1.2, 1.1, 1.3, 1.5]))
     nl = int(rng.choice([8, 8, 8, 4, 6, 10]))
     ini, mn = int(rng.choice([20, 20, 15, 30, 8])), int(rng.choice([7, 7, 5, 12]))
     # level sizes must keep >= 62 px
     if min(w, h) / (sf ** (nl - 1)) < 64:
         nl = max(1, int(np.log(min(w, h) / 64.0) / np.log(sf)) + 1)
-    kind = it % 4
+    kind = it % 7
     if kind == 0:
         img = synth.frame(w, h, 500 + it)
     elif kind == 1:
@@ -31,8 +31,24 @@ for it in range(N):
         for _ in range(30):
             x, y = rng.integers(20, w - 30), rng.integers(20, h - 30)
             img[y:y + rng.integers(3, 12), x:x + rng.integers(3, 12)] = rng.integers(0, 256)
-    else:             # low-contrast texture: only minThFAST corners
+    elif kind == 3:   # low-contrast texture: only minThFAST corners
         img = (120 + rng.integers(-9, 10, (h, w))).astype(np.uint8)
+    elif kind == 4:   # saturated blocks: 0 / 255 rectangles (blur sums at the clamp, maximal FAST scores)
+        img = np.zeros((h, w), np.uint8)
+        for _ in range(400):
+            x, y = rng.integers(0, w - 4), rng.integers(0, h - 4)
+            img[y:y + rng.integers(2, 40), x:x + rng.integers(2, 40)] = 255 if rng.random() < 0.5 else 0
+    elif kind == 5:   # checkerboard of random pitch 1..6 with full contrast, plus a few flat bands
+        p = int(rng.integers(1, 7))
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = (((xx // p + yy // p) % 2) * 255).astype(np.uint8)
+        img[h // 3:h // 3 + 40] = 128
+    else:             # one bright frame of varying thickness around a dark image + sparse dots: corners hug the borders
+        img = np.full((h, w), 20, np.uint8)
+        t = int(rng.integers(1, 30))
+        img[:t] = 240; img[-t:] = 240; img[:, :t] = 240; img[:, -t:] = 240
+        for _ in range(200):
+            img[rng.integers(0, h), rng.integers(0, w)] = 255
     try:
         ok, od = oracle.Extractor(nf, sf, nl, ini, mn).extract(img)
     except RuntimeError:
