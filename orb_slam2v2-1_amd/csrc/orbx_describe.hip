@@ -130,6 +130,14 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     const int cx = (int)(key & 0xFFF) + ORBX_MINB, cy = (int)((key >> 12) & 0xFFF) + ORBX_MINB;
     const int score = (int)(key >> 24);
 
+    // table entries of this lane, requested before the patch so that their latency is hidden behind the staging
+    // (the 4 x 64 pattern pairs of the four ballot rounds, IC_Angle byte weights)
+    uint32_t pat[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) pat[r] = ((const uint32_t *)c_pattern)[r * 64 + lane];
+    uint32_t icm[4], icw[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { icm[j] = c_ic.m[lane][j]; icw[j] = c_ic.w[lane][j]; }
     uint8_t *P = smem + wave * DESC_LDS_PER_WAVE;                     // source patch [43][48] (+pad)
     uint32_t *Tm = (uint32_t *)(P + PROWS * PSTRIDE + PPAD);          // horizontal pass, u16 [43][40]
     uint8_t *Bl = (uint8_t *)(Tm + TROWS * TSTRIDE4);                 // blurred [37][40]
@@ -169,16 +177,17 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
             const int r = i / 12, c = i - r * 12;
             v[k] = src[(size_t)r * pstr4 + c];
         }
+        // unconditional writes to the clamped slot (lanes past the end rewrite the last dword with its own value): a store
+        // under a lane condition lets the compiler sink the last load behind a divergent branch = one more memory latency
 #pragma unroll
-        for (int k = 0; k < NI; k++)
-            if (lane + 64 * k < PROWS * 12) ((uint32_t *)P)[lane + 64 * k] = v[k];
+        for (int k = 0; k < NI; k++) ((uint32_t *)P)[min(lane + 64 * k, PROWS * 12 - 1)] = v[k];
     }
     wave_sync();
     // pixel (cx-21+c, cy-21+r) is byte P[r*48 + sh + c], r,c in [0,43)
 
     // ---- IC_Angle: two lanes per row v of the radius-15 disc (u = -15..0 | 1..15)
     int m10 = 0, m01 = 0;
-    if (lane < 62) {
+    {   // all 64 lanes: the table weights of lanes 62, 63 are zero (their row, v = 16, lies inside the patch)
         const int v = (lane >> 1) - 15, half = lane & 1;
         const int o0 = sh + PR - 15 + 16 * half;  // byte offset of u = -15 (half 0) / u = 1 (half 1)
         const uint32_t *row = (const uint32_t *)(P + (PR + v) * PSTRIDE) + (o0 >> 2);
@@ -192,8 +201,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
         uint32_t s0 = 0, s1 = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            s0 = __builtin_amdgcn_udot4(wa[j], c_ic.m[lane][j], s0, false);
-            s1 = __builtin_amdgcn_udot4(wa[j], c_ic.w[lane][j], s1, false);
+            s0 = __builtin_amdgcn_udot4(wa[j], icm[j], s0, false);
+            s1 = __builtin_amdgcn_udot4(wa[j], icw[j], s1, false);
         }
         m10 = half ? (int)s1 : -(int)s1;   // u <= 0 in half 0
         m01 = v * (int)s0;
@@ -265,9 +274,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     unsigned long long bits[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int pair = r * 64 + lane;
-        const int8_t *q = c_pattern + 4 * pair;
-        const float x0 = (float)q[0], y0 = (float)q[1], x1 = (float)q[2], y1 = (float)q[3];
+        const uint32_t pq = pat[r];   // (x0, y0, x1, y1) as signed bytes
+        const float x0 = (float)(int8_t)(pq & 0xFF), y0 = (float)(int8_t)((pq >> 8) & 0xFF), x1 = (float)(int8_t)((pq >> 16) & 0xFF),
+                    y1 = (float)(int8_t)(pq >> 24);
         const int t0 = Bc[__float2int_rn(x0 * sa + y0 * ca) * BSTRIDE + __float2int_rn(x0 * ca - y0 * sa)];
         const int t1 = Bc[__float2int_rn(x1 * sa + y1 * ca) * BSTRIDE + __float2int_rn(x1 * ca - y1 * sa)];
         bits[r] = __ballot(t0 < t1);
