@@ -170,14 +170,14 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
             }
 #pragma unroll
             for (int k = 0; k < FAST_STG; k++) {
-                if (base + lane + 64 * k < items) {
-                    uint4 e;  // bytes b0..b3 of d0 and b4 = first byte of d1 -> pairs (b0,b1) (b1,b2) (b2,b3) (b3,b4)
-                    e.x = __builtin_amdgcn_perm(d1[k], d0[k], 0x0c010c00u);
-                    e.y = __builtin_amdgcn_perm(d1[k], d0[k], 0x0c020c01u);
-                    e.z = __builtin_amdgcn_perm(d1[k], d0[k], 0x0c030c02u);
-                    e.w = __builtin_amdgcn_perm(d1[k], d0[k], 0x0c040c03u);
-                    *(uint4 *)(E + rr[k] * ES + 4 * qq[k]) = e;
-                }
+                // unconditional: lanes past the end hold the clamped LAST item and rewrite it with the same value (a store
+                // under a lane condition lets the compiler sink that slot's load behind a divergent branch: one more latency)
+                uint4 e;  // bytes b0..b3 of d0 and b4 = first byte of d1 -> pairs (b0,b1) (b1,b2) (b2,b3) (b3,b4)
+                e.x = __builtin_amdgcn_perm(d1[k], d0[k], 0x0c010c00u);
+                e.y = __builtin_amdgcn_perm(d1[k], d0[k], 0x0c020c01u);
+                e.z = __builtin_amdgcn_perm(d1[k], d0[k], 0x0c030c02u);
+                e.w = __builtin_amdgcn_perm(d1[k], d0[k], 0x0c040c03u);
+                *(uint4 *)(E + rr[k] * ES + 4 * qq[k]) = e;
             }
         }
         const int nz = ((ch + 2) * SS) >> 2;  // zero the score tile (halo + odd tail columns)
