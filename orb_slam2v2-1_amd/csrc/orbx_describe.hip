@@ -164,8 +164,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
                 v[k] = inner[(size_t)reflect101c(cy - PR + r, g.h) * g.pstride + reflect101c(cx - PR + c, g.w)];
             }
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (base0 + lane + 64 * k < PROWS * PSTRIDE) P[base0 + lane + 64 * k] = v[k];
+            for (int k = 0; k < 8; k++) P[min(base0 + lane + 64 * k, PROWS * PSTRIDE - 1)] = v[k];   // unconditional, clamped (see below)
         }
     } else
     {   // all (PROWS*12 + 63) / 64 loads of a lane are in flight before the first LDS write: one memory latency per keypoint

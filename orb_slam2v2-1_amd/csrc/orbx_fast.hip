@@ -346,8 +346,10 @@ __global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ ge
         uint32_t v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) v[k] = src[min(j0 + sub + 16 * k, cn - 1)];
+        // unconditional stores to the clamped slot (lanes past the end rewrite the last key with itself): under a lane
+        // condition the compiler sinks the load next to its store, behind a divergent branch
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (j0 + sub + 16 * k < cn) dst[j0 + sub + 16 * k] = v[k];
+        for (int k = 0; k < 4; k++) dst[min(j0 + sub + 16 * k, cn - 1)] = v[k];
     }
 }
 

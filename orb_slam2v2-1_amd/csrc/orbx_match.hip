@@ -200,18 +200,20 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
         const uint4 *bit = binItems + (size_t)b * 2 * cap;
         const int bin = min(row >> bhShift, nbins - 1);
         const int p0 = bs[bin], p1 = bs[bin + 1];
-        for (int i0 = p0; i0 < p1; i0 += 64) {
-            const int ip = i0 + lane;
-            int iR = 0;
-            float uR = 0.f;
-            bool pass = false;
-            if (ip < p1) {
-                const uint4 q = bit[ip];
-                iR = (int)q.z;
-                const int minr = (int)(q.x & 0xFFF), maxr = (int)((q.x >> 12) & 0xFFF), octR = (int)(q.x >> 24);
-                uR = __uint_as_float(q.y);
-                pass = row >= minr && row <= maxr && octR >= levelL - 1 && octR <= levelL + 1 && uR >= minU && uR <= maxU;
-            }
+        // two bin chunks per round, their entries requested together and unconditionally from clamped slots (a load under
+        // `if (ip < p1)` sits behind a divergent branch: one memory latency per 64 entries)
+        for (int i0 = p0; i0 < p1; i0 += 128) {
+          uint4 q2[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; hh++) q2[hh] = bit[min(i0 + 64 * hh + lane, p1 - 1)];
+#pragma unroll
+          for (int hh = 0; hh < 2; hh++) {
+            const int ip = i0 + 64 * hh + lane;
+            const uint4 q = q2[hh];
+            const int iR = (int)q.z;
+            const int minr = (int)(q.x & 0xFFF), maxr = (int)((q.x >> 12) & 0xFFF), octR = (int)(q.x >> 24);
+            const float uR = __uint_as_float(q.y);
+            const bool pass = ip < p1 && row >= minr && row <= maxr && octR >= levelL - 1 && octR <= levelL + 1 && uR >= minU && uR <= maxU;
             const u64 m = __ballot(pass);
             if (m) {
                 if (cnt + __popcll(m) > ST_CAND) {   // list full (wave-uniform): score what is staged, start over
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
                 }
                 cnt += __popcll(m);
             }
+          }
         }
         wave_sync();
         for (int c = lane; c < cnt; c += 64) {
