@@ -249,9 +249,23 @@ __global__ __launch_bounds__(256) void k_pyr_pad(const uint8_t *__restrict__ img
     const int pw4 = (G.w + 2 * ORBX_EDGE + 3) >> 2, rows = G.h + 2 * ORBX_EDGE;
     const int LW = (ORBX_EDGE >> 2) + 1, R0 = (ORBX_EDGE + G.w) >> 2, side = LW + (pw4 - R0);
     if (FULL) {   // 16-byte chunks of the padded rows; interior chunks are one (unaligned) 16-byte load
+        // Chunk order: first every chunk that lies inside the image row (one 16-byte load), then the few per row that touch
+        // the frame (byte gathers) - in row-major order each of those sat in a different wave and made nearly EVERY wave run
+        // both paths (213 VALU instructions per wave for a copy).
         const int pc = G.pstride >> 4, totalc = pc * rows;
+        const int cI0 = (ORBX_EDGE + 15) >> 4, cI1 = max((G.w + ORBX_EDGE) >> 4, cI0);   // interior chunks: cI0 <= c < cI1
+        const int nI = cI1 - cI0, nE = pc - nI, totalI = nI * rows;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < totalc; i += gridDim.x * 256) {
-            const int py = i / pc, c = i - py * pc;
+            int py, c;
+            if (i < totalI) {
+                py = i / nI;
+                c = cI0 + (i - py * nI);
+            } else {
+                const int j = i - totalI;
+                py = j / nE;
+                const int k = j - py * nE;
+                c = k < cI0 ? k : cI1 + (k - cI0);
+            }
             const uint8_t *srow = src + (size_t)reflect101c(py - ORBX_EDGE, G.h) * ss;
             const int px = c * 16 - ORBX_EDGE;
             uint4 v;
