@@ -31,7 +31,9 @@ __constant__ int8_t c_pattern[1024] = {
 #define TGROUPS 10               // horizontal pass: 10 groups of 4 outputs per row (cols 0..39)
 #define TSTRIDE4 20              // dwords per row of the u16 intermediate (40 columns)
 #define BSTRIDE 40
-#define DESC_LDS_PER_WAVE (PROWS * PSTRIDE + PPAD + TROWS * TSTRIDE4 * 4 + TCOLS * BSTRIDE + 8)
+// patch | pad | horizontal-pass intermediate (+ 2 rows of slack: the vertical pass of the last row segment reads rows 43, 44
+// and ignores them).  The blurred 37x40 block OVERLAYS the patch, which nobody reads after the horizontal pass.
+#define DESC_LDS_PER_WAVE (PROWS * PSTRIDE + PPAD + (TROWS + 2) * TSTRIDE4 * 4)
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     // cv::fastAtan2 of OpenCV 2.4.11 / 3.2 (scalar path)
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     for (int j = 0; j < 4; j++) { icm[j] = c_ic.m[lane][j]; icw[j] = c_ic.w[lane][j]; }
     uint8_t *P = smem + wave * DESC_LDS_PER_WAVE;                     // source patch [43][48] (+pad)
     uint32_t *Tm = (uint32_t *)(P + PROWS * PSTRIDE + PPAD);          // horizontal pass, u16 [43][40]
-    uint8_t *Bl = (uint8_t *)(Tm + TROWS * TSTRIDE4);                 // blurred [37][40]
+    uint8_t *Bl = P;                                                  // blurred [37][40], in place of the patch (TCOLS * BSTRIDE <= PROWS * PSTRIDE)
 
     // ---- stage the 43x43 patch with aligned dword loads (pstride is a multiple of 64)
     const uint8_t *lvl = pyr + (size_t)b * pyrImgBytes + g.poff;
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
         const int cp = lane % 20, seg = lane / 20;
         const int r0 = seg * 13, nr = seg == 2 ? 11 : 13;
         const uint32_t *col = Tm + r0 * TSTRIDE4 + cp;
-        uint32_t T[19];   // rows r0 .. r0+18; for the last segment rows 43, 44 lie in Bl: read, never used by a stored output
+        uint32_t T[19];   // rows r0 .. r0+18; for the last segment rows 43, 44 are the slack rows: read, never used by a stored output
 #pragma unroll
         for (int k = 0; k < 19; k++) T[k] = col[k * TSTRIDE4];
         const uint32_t W01 = 18u | (34u << 16), W23 = 49u | (55u << 16), W45 = 49u | (34u << 16);
