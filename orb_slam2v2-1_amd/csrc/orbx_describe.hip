@@ -212,21 +212,33 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     m01 = wave_total_i32(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- horizontal 7-tap pass: 4 outputs per lane-iteration from one aligned b128 read
-    const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), K1 = 49u | (34u << 8) | (18u << 16);
+    // ---- horizontal 7-tap pass: 4 outputs per lane-iteration from one aligned b128 read.  Output j of a group is the
+    // 7-tap sum over bytes o .. o+6 of those 16 bytes, o = sh + j.  Instead of realigning the DATA (9 v_alignbyte per
+    // group) the WEIGHTS are shifted: W[j] = taps << 8*o as a 128-bit constant, wave-uniform (scalar registers), and the
+    // sum is a v_dot4_u32_u8 per dword the window can touch - 13 dot products per group, no alignment instructions.
+    uint32_t Wt[4][4];
+    {
+        const unsigned __int128 K7 = (unsigned __int128)(18ull | (34ull << 8) | (49ull << 16) | (55ull << 24) | (49ull << 32) |
+                                                         (34ull << 40) | (18ull << 48));
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const unsigned __int128 v = K7 << (8 * (sh + jj));
+#pragma unroll
+            for (int m = 0; m < 4; m++) Wt[jj][m] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> (32 * m)));
+        }
+    }
     for (int i = lane; i < TROWS * TGROUPS; i += 64) {
         const int r = i / TGROUPS, cg = i - r * TGROUPS;
         const uint32_t *pr = (const uint32_t *)(P + r * PSTRIDE) + cg;  // dwords cg .. cg+3 hold bytes 4cg .. 4cg+15
         const uint32_t d0 = pr[0], d1 = pr[1], d2 = pr[2], d3 = pr[3];
-        // w0..w2 = bytes (sh+4cg) .. +11 : source columns 4cg .. 4cg+11
-        const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
-                       w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
         uint32_t oo[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t lo = j ? __builtin_amdgcn_alignbyte(w1, w0, j) : w0;   // bytes j .. j+3
-            const uint32_t hi = j ? __builtin_amdgcn_alignbyte(w2, w1, j) : w1;   // bytes j+4 .. j+7
-            oo[j] = __builtin_amdgcn_udot4(hi, K1, __builtin_amdgcn_udot4(lo, K0, 0u, false), false);  // <= 65535
+        for (int jj = 0; jj < 4; jj++) {   // window bytes sh+jj .. sh+jj+6 <= 12: dword 3 only for jj = 3 (<= 65535 in total)
+            uint32_t acc = __builtin_amdgcn_udot4(d0, Wt[jj][0], 0u, false);
+            acc = __builtin_amdgcn_udot4(d1, Wt[jj][1], acc, false);
+            acc = __builtin_amdgcn_udot4(d2, Wt[jj][2], acc, false);
+            if (jj == 3) acc = __builtin_amdgcn_udot4(d3, Wt[jj][3], acc, false);
+            oo[jj] = acc;
         }
         uint2 st;
         st.x = oo[0] | (oo[1] << 16);
