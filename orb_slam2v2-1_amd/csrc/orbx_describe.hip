@@ -290,8 +290,14 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
         const uint32_t pq = pat[r];   // (x0, y0, x1, y1) as signed bytes
         const float x0 = (float)(int8_t)(pq & 0xFF), y0 = (float)(int8_t)((pq >> 8) & 0xFF), x1 = (float)(int8_t)((pq >> 16) & 0xFF),
                     y1 = (float)(int8_t)(pq >> 24);
-        const int t0 = Bc[__float2int_rn(x0 * sa + y0 * ca) * BSTRIDE + __float2int_rn(x0 * ca - y0 * sa)];
-        const int t1 = Bc[__float2int_rn(x1 * sa + y1 * ca) * BSTRIDE + __float2int_rn(x1 * ca - y1 * sa)];
+        // (x*sa + y*ca, x*ca - y*sa) on the packed-f32 pipe: two multiplies and one add per point, each rounded on its own
+        // exactly like the scalar form (no contraction)
+        typedef float float2v __attribute__((ext_vector_type(2)));
+        const float2v sc = {sa, ca}, cs = {ca, -sa};
+        const float2v p0 = (float2v){x0, x0} * sc + (float2v){y0, y0} * cs;
+        const float2v p1 = (float2v){x1, x1} * sc + (float2v){y1, y1} * cs;
+        const int t0 = Bc[__float2int_rn(p0.x) * BSTRIDE + __float2int_rn(p0.y)];
+        const int t1 = Bc[__float2int_rn(p1.x) * BSTRIDE + __float2int_rn(p1.y)];
         bits[r] = __ballot(t0 < t1);
     }
     const size_t oi = (size_t)b * cap + o;
