@@ -227,9 +227,21 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
             for (int m = 0; m < 4; m++) Wt[jj][m] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> (32 * m)));
         }
     }
-    for (int i = lane; i < TROWS * TGROUPS; i += 64) {
-        const int r = i / TGROUPS, cg = i - r * TGROUPS;
-        const uint32_t *pr = (const uint32_t *)(P + r * PSTRIDE) + cg;  // dwords cg .. cg+3 hold bytes 4cg .. 4cg+15
+    // item i = lane + 64 * it is group cg = i % 10 of row r = i / 10: the store address is linear in i (a row of the
+    // intermediate is 10 groups x 8 B), the load address advances by 6 rows + 4 groups per step with a carry into the row
+    int hcg = lane % TGROUPS;
+    const uint8_t *hlp = P + (lane / TGROUPS) * PSTRIDE + 4 * hcg;
+    constexpr int H_ITERS = (TROWS * TGROUPS + 63) / 64;
+#pragma unroll
+    for (int it = 0; it < H_ITERS; it++) {
+        const uint32_t *pr = (const uint32_t *)hlp;                      // dwords cg .. cg+3 hold bytes 4cg .. 4cg+15
+        {   // next item of this lane: +64 = 6 rows + 4 groups
+            hcg += 64 % TGROUPS;
+            const bool carry = hcg >= TGROUPS;
+            hcg -= carry ? TGROUPS : 0;
+            hlp += (64 / TGROUPS) * PSTRIDE + 4 * (64 % TGROUPS) + (carry ? PSTRIDE - 4 * TGROUPS : 0);
+        }
+        if ((it + 1) * 64 > TROWS * TGROUPS && it * 64 + lane >= TROWS * TGROUPS) continue;   // tail of the last step
         const uint32_t d0 = pr[0], d1 = pr[1], d2 = pr[2], d3 = pr[3];
         uint32_t oo[4];
 #pragma unroll
@@ -243,8 +255,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
         uint2 st;
         st.x = oo[0] | (oo[1] << 16);
         st.y = oo[2] | (oo[3] << 16);
-        *(uint2 *)(Tm + r * TSTRIDE4 + cg * 2) = st;
+        *(uint2 *)((uint8_t *)Tm + 8 * (it * 64 + lane)) = st;   // = Tm + r * TSTRIDE4 + cg * 2 (TSTRIDE4 = 2 * TGROUPS)
     }
+    static_assert(TSTRIDE4 == 2 * TGROUPS, "the horizontal pass stores at a linear address");
     wave_sync();
 
     // ---- vertical pass: lane = (column pair, row segment of 13 output rows).  A dword of the intermediate holds the u16
