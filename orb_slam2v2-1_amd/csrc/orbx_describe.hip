@@ -146,8 +146,10 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
 
     // ---- stage the 43x43 patch with aligned dword loads (pstride is a multiple of 64)
     const uint8_t *lvl = pyr + (size_t)b * pyrImgBytes + g.poff;
-    const size_t a = (size_t)(cy + ORBX_EDGE - PR) * g.pstride + (size_t)(cx + ORBX_EDGE - PR);
-    int sh = __builtin_amdgcn_readfirstlane((int)(a & 3));
+    // byte offset of the patch origin inside the level: the same in every lane (one keypoint per wave) - made scalar so that
+    // the staging loads are "scalar base + 32-bit lane offset" (a padded level is far smaller than 4 GiB)
+    const size_t a = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((cy + ORBX_EDGE - PR) * g.pstride + (cx + ORBX_EDGE - PR));
+    int sh = (int)(a & 3);
     const uint32_t *src = (const uint32_t *)(lvl + (a - sh));
     const int pstr4 = g.pstride >> 2;
     // The 19-px REFLECT_101 frame of the levels >= 1 is only ever read HERE, by the few keypoints closer than PR to a
@@ -172,11 +174,24 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     {   // all (PROWS*12 + 63) / 64 loads of a lane are in flight before the first LDS write: one memory latency per keypoint
         constexpr int NI = (PROWS * 12 + 63) / 64;
         uint32_t v[NI];
+        // item i = lane + 64 * k is dword c = i % 12 of row r = i / 12: +64 items = 5 rows + 4 dwords with a carry into the
+        // row.  The patch origin is wave-uniform (scalar base), so a lane only keeps a 32-bit byte offset.
+        const uint8_t *sbase = (const uint8_t *)src;
+        int c = lane % 12;
+        uint32_t off = (uint32_t)((lane / 12) * pstr4 + c) * 4u;
+        const uint32_t step = (uint32_t)(5 * pstr4 + 4) * 4u, stepCarry = (uint32_t)(6 * pstr4 + 4 - 12) * 4u;
 #pragma unroll
-        for (int k = 0; k < NI; k++) {
-            const int i = min(lane + 64 * k, PROWS * 12 - 1);
-            const int r = i / 12, c = i - r * 12;
-            v[k] = src[(size_t)r * pstr4 + c];
+        for (int k = 0; k < NI - 1; k++) {           // items < 512 <= PROWS * 12: no clamping
+            v[k] = *(const uint32_t *)(sbase + off);
+            c += 4;
+            const bool carry = c >= 12;
+            c -= carry ? 12 : 0;
+            off += carry ? stepCarry : step;
+        }
+        {   // last step: items 512 .. 575, clamped to the last dword of the patch
+            static_assert(NI == 9 && PROWS * 12 == 516, "tail of the patch staging");
+            const int i = min(lane + 64 * (NI - 1), PROWS * 12 - 1), r = i / 12, cc = i - r * 12;
+            v[NI - 1] = *(const uint32_t *)(sbase + (uint32_t)(r * pstr4 + cc) * 4u);
         }
         // unconditional writes to the clamped slot (lanes past the end rewrite the last dword with its own value): a store
         // under a lane condition lets the compiler sink the last load behind a divergent branch = one more memory latency
