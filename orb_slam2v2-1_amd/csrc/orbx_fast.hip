@@ -165,7 +165,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
                 const int i = min(base + lane + 64 * k, items - 1);
                 rr[k] = (int)(((unsigned)i * M) >> 20);
                 qq[k] = i - rr[k] * nd;
-                const uint32_t *p = src + (size_t)rr[k] * pstr4 + qq[k];
+                // scalar window origin + 32-bit lane offset (a padded level is far smaller than 4 GiB)
+                const uint32_t *p = (const uint32_t *)((const uint8_t *)src + (uint32_t)(rr[k] * pstr4 + qq[k]) * 4u);
                 d0[k] = p[0]; d1[k] = p[1];
             }
 #pragma unroll
