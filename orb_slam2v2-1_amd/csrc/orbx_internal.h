@@ -142,6 +142,8 @@ __device__ __forceinline__ void xcd_block_map(int &bx, int &b) {
     const unsigned nbx = gridDim.x, total = nbx * gridDim.y, lin = blockIdx.y * nbx + blockIdx.x;
     const unsigned xcd = lin & 7u, idx = lin >> 3, q = total >> 3, r = total & 7u;
     const unsigned pos = xcd * q + min(xcd, r) + idx;   // XCD x owns q (+1 if x < r) consecutive positions
-    b = (int)(pos / nbx);
-    bx = (int)(pos - (unsigned)b * nbx);
+    // the division runs on the vector ALU (no scalar float unit): hand the (uniform) results back to scalar registers so that
+    // everything derived from them - image base pointers above all - stays scalar
+    b = __builtin_amdgcn_readfirstlane((int)(pos / nbx));
+    bx = __builtin_amdgcn_readfirstlane((int)(pos - (unsigned)b * nbx));
 }

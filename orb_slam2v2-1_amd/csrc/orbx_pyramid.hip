@@ -184,10 +184,14 @@ __global__ __launch_bounds__(256) void k_pyr_level(uint8_t *__restrict__ pyr, si
         const uint32_t mask = __builtin_amdgcn_readfirstlane(m);
         uint2 q[PYR_SR];
 #pragma unroll
-        for (int k = 0; k < PYR_SR; k++) q[k] = *(const uint2 *)(srow0 + (size_t)min(rf + k, sh - 1) * sps + A);
+        for (int k = 0; k < PYR_SR; k++) {   // scalar row pointer + the lane's 32-bit column offset: no per-lane address arithmetic
+            const uint8_t *rowp = srow0 + (size_t)min(rf + k, sh - 1) * sps;
+            q[k] = *(const uint2 *)(rowp + (uint32_t)A);
+        }
         uint32_t tpa = 0, tpb = 0;
         int cnt = 0;
-        uint8_t *d = drow0 + (size_t)y0 * G.pstride + x0;
+        uint8_t *drow = drow0 + (size_t)y0 * G.pstride - 1;   // scalar; the lane's column x0 = xoff - 1 with xoff >= 0
+        const uint32_t xoff = (uint32_t)(x0 + 1);
 #pragma unroll
         for (int k = 0; k < PYR_SR; k++) {
             const uint32_t tca = udot2_u16(__builtin_amdgcn_perm(q[k].y, q[k].x, selA), aa) >> 4;
@@ -197,8 +201,8 @@ __global__ __launch_bounds__(256) void k_pyr_level(uint8_t *__restrict__ pyr, si
                 const uint32_t b0 = bb & 0xFFFFu, b1 = bb >> 16;
                 const uint32_t pa = (((b0 * tpa) >> 16) + ((b1 * tca) >> 16) + 2) >> 2;
                 const uint32_t pb = (((b0 * tpb) >> 16) + ((b1 * tcb) >> 16) + 2) >> 2;
-                if (vst) *(uint16_t *)d = (uint16_t)(pa | (pb << 8));
-                d += G.pstride;
+                if (vst) *(uint16_t *)(drow + xoff) = (uint16_t)(pa | (pb << 8));
+                drow += G.pstride;
                 cnt++;
             }
             tpa = tca; tpb = tcb;
