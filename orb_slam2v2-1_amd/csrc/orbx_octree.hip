@@ -401,10 +401,21 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
             const uint32_t v = ((const uint16_t *)(pyr + offDeep))[cd[u]];
             node[u] = v != 0xFFFFu ? v : node[u];
         }
+        // a thread's four keys are consecutive in cell-major order and mostly fall into the same node: merge equal
+        // neighbours first (the maximum of two packed values is what two atomicMax would leave) - LDS atomics on one
+        // address are serialised, and a level-0 node receives ~70 keys
+        uint32_t val[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            val[u] = ((key[u] >> 24) << 24) | (0xFFFFFFu - (uint32_t)(i0 + u));
+            if (i0 + u >= n) node[u] = 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            if (node[u] == node[u + 1]) { val[u + 1] = max(val[u], val[u + 1]); node[u] = 0xFFFFFFFFu; }
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (i0 + u < n && node[u] != 0xFFFFFFFFu)
-                atomicMax(&hist[node[u]], ((key[u] >> 24) << 24) | (0xFFFFFFu - (uint32_t)(i0 + u)));
+            if (node[u] != 0xFFFFFFFFu) atomicMax(&hist[node[u]], val[u]);
     }
     __syncthreads();
     if (dbgStop == 4) return;
