@@ -166,9 +166,16 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
 #pragma unroll
         for (int u = 0; u < 4; u++)   // unconditional (a missing key is 0): all 8 lookups in flight at once
             c[u] = (uint32_t)xPath[key[u] & 0xFFF] | (uint32_t)yPath[(key[u] >> 12) & 0xFFF];
+        // consecutive keys (row-major inside a FAST cell) mostly share the deep cell: count runs, one LDS atomic per run
+        uint32_t inc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) inc[u] = i0 + u < n ? 1u : 0u;
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            if (c[u] == c[u + 1]) { inc[u + 1] += inc[u]; inc[u] = 0; }
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (i0 + u < n) atomicAdd(&pyr[offDeep + (c[u] >> 1)], 1u << (16 * (c[u] & 1)));
+            if (inc[u]) atomicAdd(&pyr[offDeep + (c[u] >> 1)], inc[u] << (16 * (c[u] & 1)));
     }
     __syncthreads();
     if (dbgStop == 1) return;
