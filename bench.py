@@ -35,7 +35,10 @@ WORKLOADS = {
     "mono_640x480_1000feat": (640, 480, 1000, False),
     "mono_1920x1080_4000feat": (1920, 1080, 4000, False),
 }
-KITTI_FX, KITTI_BF = 718.856, 386.1448  # KITTI-00 calibration (fx, baseline*fx)
+# the other north-star sizes measured (briefly) after the headline: (workload, frames per step)
+OTHER_WORKLOADS = [("kitti_stereo_1241x376_2000feat", 64), ("euroc_stereo_752x480_1000feat", 64), ("mono_640x480_1000feat", 64),
+                   ("mono_1920x1080_4000feat", 32)]
+KITTI_FX, KITTI_BF = 718.856, 386.1448  # KITTI-00 calibration (fx, baseline*fx); same constants as pipeline.py
 
 
 def level_pixels(w, h, nlevels=8, sf=1.2):
@@ -170,6 +173,116 @@ def cpu_baseline(w, h, nf, stereo, budget_s=20.0):
     }
 
 
+def measure(fe, steps, warmup, ramp, world, dist, dev, torch):
+    """Ramp + warm-up + K timed steps of fe (barrier + synchronize on both sides, MAX over ranks) + an untimed
+    stage-profile pass.  Returns dict(dt, fast_ms, stage_ms, ncalls, match_ms, last_results)."""
+    ex = fe.ex
+    for i in range(ramp):               # clock ramp (untimed, not counted as warm-up steps)
+        fe.step(i)
+    fe.drain()
+    for i in range(warmup):
+        fe.step(i)
+    fe.drain()
+    # Timed region: only the dominant kernel (k_fast_cells) is bracketed by HIP events on its launch stream.  Every
+    # recorded event idles the GPU for ~4.5 us, so the full stage breakdown is taken in a separate untimed pass below.
+    ex.set_profiling(2)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fe.step(warmup + i)
+    fe.drain()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    fast_ms = float(ex.stage_ms()[0][1])            # k_fast_cells, averaged over the K timed steps
+    last = fe.results((warmup + steps - 1) % fe.ring.nbuf)   # outputs of the LAST TIMED step (host copies), checked later
+    nprof = max(1, min(steps, 10))                  # untimed pass: events at every stage boundary
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(nprof)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(nprof)]
+    ex.set_profiling(1)
+    for i in range(nprof):
+        fe.step(warmup + steps + i, ev0[i], ev1[i])
+    fe.drain()
+    stage_ms, ncalls = ex.stage_ms()
+    ex.set_profiling(0)
+    match_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)])) if fe.stereo else 0.0
+    return {"dt": dt, "fast_ms": fast_ms, "stage_ms": stage_ms, "ncalls": ncalls, "match_ms": match_ms, "last": last,
+            "nprof": nprof}
+
+
+def verify_against_oracle(fe, last, seeds, frames):
+    """Checker leg (outside every timed region): frames `frames` of the last timed step against the CPU oracle,
+    byte for byte (keypoints, descriptors, counts; mvuRight / mvDepth / match count for stereo)."""
+    import oracle
+    oracle.build()
+    ref = importlib.import_module("oracle.reference_frames")
+    imgs, st = last
+    bad = []
+    for b in frames:
+        if fe.stereo:
+            e = ref.stereo_frame((fe.w, fe.h, fe.nf, seeds[b], fe.mbf, fe.mb))
+            for side, k, d, gi in (("left", e["kl"], e["dl"], b), ("right", e["kr"], e["dr"], fe.B + b)):
+                m = ref.image_mismatch(imgs[gi][0], imgs[gi][1], k, d)
+                if m:
+                    bad.append("frame %d %s: %s" % (b, side, m))
+            m = ref.stereo_mismatch(st[b], e)
+            if m:
+                bad.append("frame %d stereo: %s" % (b, m))
+        else:
+            e = ref.mono_frame((fe.w, fe.h, fe.nf, seeds[b]))
+            m = ref.image_mismatch(imgs[b][0], imgs[b][1], e["k"], e["d"])
+            if m:
+                bad.append("frame %d: %s" % (b, m))
+    return bad
+
+
+def roofline_block(fe, m, workload, B, value, world, traffic_lookup=True):
+    """roofline of the dominant kernel + whole-step figures, from the SURVEY section 8(d) byte formula."""
+    w, h, stereo, nimg = fe.w, fe.h, fe.stereo, fe.nimg
+    P = level_pixels(w, h)
+    counts = np.array([len(k) for k, _ in m["last"][0]])
+    navg = float(counts.mean())
+    bytes_img = 3 * P + 60 * navg
+    ncand_img = sum(len(fe.ex.debug_level_points(l, 0, b=0)) for l in range(8))   # FAST candidates of image 0
+    bytes_frame = (2 * bytes_img + 64 * navg) if stereo else bytes_img
+    stage_ms = m["stage_ms"]
+    # dominant single kernel of the step (HIP events on the launch stream, averaged over the
+    # timed region).  Algorithmic bytes per image: FAST+NMS reads every level once = P;
+    # quad-tree reads its candidates; describe reads P + writes 60 N (SURVEY section 8(d) split).
+    kern = {
+        "k_fast_cells": (m["fast_ms"], P * nimg),
+        "k_octree": (float(stage_ms[2]), 8.0 * ncand_img * nimg),   # 4 B key + 2 B node index read, 2 B written
+        "k_describe": (float(stage_ms[3]), (P + 60 * navg) * nimg),
+    }
+    dom = max(kern, key=lambda k: kern[k][0])
+    dom_ms, dom_bytes = kern[dom]
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if traffic_lookup and os.path.exists(pmc_path):
+        try:
+            pm = json.load(open(pmc_path))
+            inst = [k for k in pm.get("kernels", {}) if k.split("<")[0] == dom]   # template instances: k_fast_cells<44>
+            if pm.get("workload") == workload and pm.get("batch") == B and inst:
+                traffic = max(pm["kernels"][k]["hbm_bytes_per_launch"] for k in inst)
+        except Exception:
+            traffic = None
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0,
+            "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+            "kernel_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
+            "pipeline_GBps": round(bytes_frame * value / world / 1e9, 2),
+            "pipeline_frac": round(bytes_frame * value / world / 1e9 / 8000.0, 5),
+            "algorithmic_bytes_per_frame": int(bytes_frame)}
+    return roof, navg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,9 +292,15 @@ def main():
                     help="untimed steps BEFORE the W warm-up steps: the GPU clocks need ~0.2 s of load to settle after the "
                          "CPU-only set-up phase (3 warm-up steps measured 2.5 %% low)")
     ap.add_argument("--workload", default="kitti_stereo_1241x376_1000feat", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU (weak scaling)")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="T > 0: ONE batch of T frames per step sharded over the ranks (batching.shard_range), i.e. strong "
+                         "scaling; BASELINE config 4 = --workload mono_1920x1080_4000feat --total-frames 512 --gpus 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the result all-gather when N > 1")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short untimed-by-the-driver runs of the other north-star sizes (other_workloads block)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step")
     ap.add_argument("--streams", type=int, default=1,
                     help="S > 1: consecutive steps alternate over S extractor handles on S streams (independent steps overlap; "
                          "the default 1 keeps every kernel alone on the GPU so that its measured duration is its own)")
@@ -202,19 +321,40 @@ def main():
                   "--nproc-per-node %d" % (args.gpus, world, args.gpus), file=sys.stderr)
         sys.exit(2)
 
+    batching = importlib.import_module("orb_slam2v2-1_amd.batching")
     w, h, nf, stereo = WORKLOADS[args.workload]
-    B = args.batch
-    nimg = 2 * B if stereo else B
+    strong = args.total_frames > 0
+    if strong:
+        f0, f1 = batching.shard_range(args.total_frames, rank, world)
+        B, seed0 = f1 - f0, f0
+        if B < 1:
+            print("bench.py: --total-frames %d leaves rank %d without frames" % (args.total_frames, rank), file=sys.stderr)
+            sys.exit(2)
+    else:
+        B, seed0 = args.batch, 1000 * rank
     # host-side work that forks worker processes happens BEFORE this process touches the GPU
     workers = max(1, min((os.cpu_count() or 1) // max(world, 1), 16))
-    left, right = make_frames(w, h, B, 1000 * rank, stereo, workers)
-    imgs = np.concatenate([left, right]) if stereo else left        # slots [0,B) left, [B,2B) right
+    left, right = make_frames(w, h, B, seed0, stereo, workers)
+    seeds = [seed0 + i for i in range(B)]
+    others = []
+    if world == 1 and not args.no_other_workloads and not strong and args.streams == 1:
+        for name, ob in OTHER_WORKLOADS:
+            if name == args.workload:
+                continue
+            ow, oh, onf, ost = WORKLOADS[name]
+            if (ow, oh, ost) == (w, h, stereo) and ob <= B:
+                ol, orr = left[:ob], (right[:ob] if stereo else None)      # same images, other feature budget
+                oseeds = seeds[:ob]
+            else:
+                ol, orr = make_frames(ow, oh, ob, 5000, ost, workers)
+                oseeds = [5000 + i for i in range(ob)]
+            others.append((name, ob, ol, orr, oseeds))
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, h, nf, stereo)
 
     pkg = importlib.import_module("orb_slam2v2-1_amd")
-    batching = importlib.import_module("orb_slam2v2-1_amd.batching")
+    pipeline = importlib.import_module("orb_slam2v2-1_amd.pipeline")
     pkg.lib()  # fails loudly if the HIP library is missing
     import torch
     import torch.distributed as dist
@@ -233,103 +373,21 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
-    d_imgs = torch.from_numpy(imgs).to(dev)
+    gather = world > 1 and not args.no_gather
+    if gather and strong:
+        # the all-gather is a fixed-shape collective: every rank contributes the same number of records
+        sizes = [batching.shard_range(args.total_frames, r, world) for r in range(world)]
+        if len({b - a for a, b in sizes}) != 1:
+            if rank == 0:
+                print("bench.py: --total-frames must be a multiple of the rank count when results are all-gathered", file=sys.stderr)
+            sys.exit(2)
 
     S = max(1, args.streams)
-    exs = [pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=dev_index) for _ in range(S)]
-    ex = exs[0]
-    for e in exs:
-        e(imgs[0])                  # plan for this image size; cap is now exact
-    cap = ex.max_keypoints()
-    mbf = KITTI_BF
-    mb = float(np.float32(KITTI_BF) / np.float32(KITTI_FX))
-
-    nbuf = max(3, S)          # >= 3: the overlapped pass below alternates over three streams
-    kps = [torch.zeros((nimg, cap, 7), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-    desc = [torch.zeros((nimg, cap, 32), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    cnt = [torch.zeros(nimg, dtype=torch.int32, device=dev) for _ in range(nbuf)]
-    ur = [torch.zeros((B, cap), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-    dp = [torch.zeros((B, cap), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-    nm = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(nbuf)]
-    gather = world > 1 and not args.no_gather
-    if gather:
-        # one packed record per frame so that a step is ONE all-gather: kps | desc | uright | depth | count
-        rec_bytes = batching.record_bytes(cap)
-        pack = [torch.zeros((B, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-        gath = [torch.zeros((world * B, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-        works = [None] * nbuf
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(S - 1)]
-    ev_m0 = [torch.cuda.Event(enable_timing=True) for _ in range(max(1, min(args.steps, 10)))]
-    ev_m1 = [torch.cuda.Event(enable_timing=True) for _ in range(max(1, min(args.steps, 10)))]
-
-    def step(i, timed_idx=None):
-        j = i % nbuf
-        exi, stream = exs[i % S], streams[i % S]
-        st = stream.cuda_stream
-        if gather and works[j] is not None:
-            works[j].wait()         # buffer j is free again (its all-gather finished)
-            works[j] = None
-        exi.extract_batch_device(d_imgs.data_ptr(), nimg, w, h, w, w * h, kps[j].data_ptr(), desc[j].data_ptr(),
-                                 cnt[j].data_ptr(), cap, st)
-        if stereo:
-            if timed_idx is not None:
-                ev_m0[timed_idx].record(stream)
-            pkg.stereo_batch_device(exi, exi, B, 0, B,
-                                    kps[j].data_ptr(), desc[j].data_ptr(), cnt[j].data_ptr(),
-                                    kps[j][B:].data_ptr(), desc[j][B:].data_ptr(), cnt[j][B:].data_ptr(),
-                                    cap, mbf, mb, ur[j].data_ptr(), dp[j].data_ptr(), nm[j].data_ptr(), st)
-            if timed_idx is not None:
-                ev_m1[timed_idx].record(stream)
-        if gather:
-            with torch.cuda.stream(stream):     # pack + collective are ordered behind this step's kernels
-                batching.pack_records(kps[j][:B], desc[j][:B], ur[j], dp[j], cnt[j][:B], out=pack[j])
-                if args.backend == "nccl":
-                    _, works[j] = batching.all_gather_records(pack[j], gath[j], async_op=True)
-                else:  # rehearsal: gloo moves host memory
-                    g, _ = batching.all_gather_records(pack[j].cpu())
-                    gath[j].copy_(g)
-
-    def drain():
-        if gather:
-            for j in range(nbuf):
-                if works[j] is not None:
-                    works[j].wait()
-                    works[j] = None
-        torch.cuda.synchronize()
-
-    for i in range(args.ramp_steps):    # clock ramp (untimed, not counted as warm-up steps)
-        step(i)
-    drain()
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    # Timed region: only the dominant kernel (k_fast_cells) is bracketed by HIP events on its launch stream.  Every
-    # recorded event idles the GPU for ~4.5 us, so the full stage breakdown is taken in a separate untimed pass below.
-    ex.set_profiling(2)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    drain()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    fast_timed_ms = float(ex.stage_ms()[0][1])        # k_fast_cells, averaged over the K timed steps
-    nprof = max(1, min(args.steps, 10))               # untimed pass: events at every stage boundary
-    ex.set_profiling(1)
-    for i in range(nprof):
-        step(args.warmup + args.steps + i, i)
-    drain()
-    stage_ms, ncalls = ex.stage_ms()
-    ex.set_profiling(0)
-    match_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_m0[:nprof], ev_m1[:nprof])])) if stereo else 0.0
+    fe = pipeline.FrontEnd(w, h, nf, stereo, B, device_index=dev_index, nbuf=3, streams=S, world=world, gather=gather,
+                           gather_via_host=(args.backend != "nccl"))
+    fe.upload(left, right)
+    m = measure(fe, args.steps, args.warmup, args.ramp_steps, world, dist, dev, torch)
+    dt, stage_ms = m["dt"], m["stage_ms"]
 
     # Extra pass (--overlap-pass, 1 GPU): the same K steps alternating over THREE extractor handles on three streams.
     # Steps are independent, so the latency-bound kernels of one step (upper pyramid levels, quad-tree, stereo bins /
@@ -337,89 +395,89 @@ def main():
     # GPU a kernel's own duration cannot be measured, and the roofline above is about kernels measured alone.
     overlapped = None
     if world == 1 and S == 1 and args.overlap_pass:
-        S3 = 3
-        exs3 = [ex] + [pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=dev_index) for _ in range(S3 - 1)]
-        for e in exs3[1:]:
-            e(imgs[0])
-        st3 = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(S3 - 1)]
-
-        def step3(i):
-            j, e, st = i % nbuf, exs3[i % S3], st3[i % S3].cuda_stream
-            e.extract_batch_device(d_imgs.data_ptr(), nimg, w, h, w, w * h, kps[j].data_ptr(), desc[j].data_ptr(),
-                                   cnt[j].data_ptr(), cap, st)
-            if stereo:
-                pkg.stereo_batch_device(e, e, B, 0, B, kps[j].data_ptr(), desc[j].data_ptr(), cnt[j].data_ptr(),
-                                        kps[j][B:].data_ptr(), desc[j][B:].data_ptr(), cnt[j][B:].data_ptr(),
-                                        cap, mbf, mb, ur[j].data_ptr(), dp[j].data_ptr(), nm[j].data_ptr(), st)
+        fe3 = pipeline.FrontEnd(w, h, nf, stereo, B, device_index=dev_index, nbuf=3, streams=3)
+        fe3.upload(left, right)
         for i in range(30):
-            step3(i)
-        torch.cuda.synchronize()
+            fe3.step(i)
+        fe3.drain()
         t3 = time.perf_counter()
         for i in range(args.steps):
-            step3(i)
-        torch.cuda.synchronize()
+            fe3.step(i)
+        fe3.drain()
         dt3 = time.perf_counter() - t3
-        overlapped = {"streams": S3, "value": round(B * args.steps / dt3, 2), "unit": "frames/s",
-                      "ms_per_step": round(dt3 / args.steps * 1e3, 4), "steps": args.steps,
+        bad3 = [] if args.no_verify else verify_against_oracle(fe3, fe3.results((args.steps - 1) % 3), seeds, [0, B - 1])
+        overlapped = {"streams": 3, "value": round(B * args.steps / dt3, 2), "unit": "frames/s",
+                      "ms_per_step": round(dt3 / args.steps * 1e3, 4), "steps": args.steps, "verified": (None if args.no_verify else not bad3),
                       "note": "independent steps alternate over 3 handles on 3 streams; kernels share the GPU, so "
                               "per-kernel durations are not isolated - informational, not the headline value"}
+        del fe3
+
+    # who took part: proves on a multi-GPU record that RCCL really saw N ranks on N devices
+    me = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device": torch.cuda.get_device_name(dev_index),
+          "frames_per_step": B, "first_seed": seed0}
+    ranks = [me]
+    world_seen = 1
+    if world > 1:
+        world_seen = dist.get_world_size()
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
 
     if rank == 0:
-        frames = world * B * args.steps
-        value = frames / dt
-        P = level_pixels(w, h)
-        counts = cnt[(args.warmup + args.steps - 1) % nbuf].cpu().numpy()
-        navg = float(counts.mean())
-        bytes_img = 3 * P + 60 * navg
-        ncand_img = sum(len(ex.debug_level_points(l, 0, b=0)) for l in range(8))   # FAST candidates of image 0
-        bytes_frame = (2 * bytes_img + 64 * navg) if stereo else bytes_img
-        # dominant single kernel of the step (HIP events on the launch stream, averaged over the
-        # timed region).  Algorithmic bytes per image: FAST+NMS reads every level once = P;
-        # quad-tree reads its candidates; describe reads P + writes 60 N (SURVEY §8(d) split).
-        kern = {
-            "k_fast_cells": (fast_timed_ms, P * nimg),
-            "k_octree": (float(stage_ms[2]), 8.0 * ncand_img * nimg),   # 4 B key + 2 B node index read, 2 B written
-            "k_describe": (float(stage_ms[3]), (P + 60 * navg) * nimg),
-        }
-        dom = max(kern, key=lambda k: kern[k][0])
-        dom_ms, dom_bytes = kern[dom]
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            try:
-                pm = json.load(open(pmc_path))
-                inst = [k for k in pm.get("kernels", {}) if k.split("<")[0] == dom]   # template instances: k_fast_cells<44>
-                if pm.get("workload") == args.workload and pm.get("batch") == B and inst:
-                    traffic = max(pm["kernels"][k]["hbm_bytes_per_launch"] for k in inst)
-            except Exception:
-                traffic = None
+        frames_per_step = args.total_frames if strong else world * B
+        value = frames_per_step * args.steps / dt
+        roof, navg = roofline_block(fe, m, args.workload, B, value, world)
+        verified, vnote = None, "skipped (--no-verify)"
+        if not args.no_verify:
+            vf = sorted({0, B // 2, B - 1})
+            bad = verify_against_oracle(fe, m["last"], seeds, vf)
+            verified = not bad
+            vnote = ("frames %s of the last timed step == CPU oracle, byte for byte (keypoints, descriptors, counts%s)"
+                     % (vf, ", mvuRight, mvDepth, match counts" if stereo else "")) if verified else "; ".join(bad[:5])
         out = {
             "metric": "frames/s ORB extract+match @1241x376 8-lvl 1000-feat" if args.workload.startswith("kitti_stereo_1241x376_1000")
             else "frames/s ORB extract+match (%s)" % args.workload,
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "verified": verified, "verified_note": vnote,
             "config": {"workload": args.workload, "frame": "stereo pair (2 images)" if stereo else "mono image",
                        "width": w, "height": h, "nlevels": 8, "scale_factor": 1.2, "nfeatures": nf,
                        "ini_th_fast": 20, "min_th_fast": 7, "frames_per_step_per_gpu": B, "clock_ramp_steps": args.ramp_steps,
+                       "total_frames_per_step": frames_per_step,
                        "match": "Frame::ComputeStereoMatches" if stereo else "none",
                        "parallelism": "frames sharded over %d GPU(s)%s" % (world, ", results all-gathered (%s)" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal") if gather else ""),
+                       "world_size_observed": world_seen, "ranks": ranks,
                        "avg_keypoints_per_image": round(navg, 1)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0,
-                         "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                         "kernel_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
-                         "pipeline_GBps": round(bytes_frame * value / world / 1e9, 2),
-                         "pipeline_frac": round(bytes_frame * value / world / 1e9 / 8000.0, 5),
-                         "algorithmic_bytes_per_frame": int(bytes_frame)},
+            "roofline": roof,
             "stage_ms_per_call": {"pyramid": round(float(stage_ms[0]), 4), "fast": round(float(stage_ms[1]), 4),
                                   "quadtree": round(float(stage_ms[2]), 4), "describe": round(float(stage_ms[3]), 4),
-                                  "extract_total": round(float(stage_ms[4]), 4), "stereo_match": round(match_ms, 4),
-                                  "images_per_call": nimg, "calls_averaged": ncalls,
-                                  "fast_timed_region": round(fast_timed_ms, 4),
+                                  "extract_total": round(float(stage_ms[4]), 4), "stereo_match": round(m["match_ms"], 4),
+                                  "images_per_call": fe.nimg, "calls_averaged": m["ncalls"],
+                                  "fast_timed_region": round(m["fast_ms"], 4),
                                   "note": "stage breakdown from an untimed pass of %d steps after the timed region; "
-                                          "roofline.kernel_ms is k_fast_cells over the %d timed steps" % (nprof, args.steps)},
+                                          "roofline.kernel_ms is k_fast_cells over the %d timed steps" % (m["nprof"], args.steps)},
         }
+        if others:
+            # the other north-star sizes, same definition of a step, short runs (not the headline; the driver times only `value`)
+            del fe
+            ow_out = {}
+            for name, ob, ol, orr, oseeds in others:
+                oww, ohh, onf, ost = WORKLOADS[name]
+                ofe = pipeline.FrontEnd(oww, ohh, onf, ost, ob, device_index=dev_index, nbuf=3)
+                ofe.upload(ol, orr)
+                osteps = 30
+                om = measure(ofe, osteps, 5, 60, 1, dist, dev, torch)
+                oval = ob * osteps / om["dt"]
+                oroof, onavg = roofline_block(ofe, om, name, ob, oval, 1, traffic_lookup=False)
+                obad = [] if args.no_verify else verify_against_oracle(ofe, om["last"], oseeds, [0, ob - 1])
+                ow_out[name] = {"value": round(oval, 2), "unit": "frames/s" if ost else "images/s", "frames_per_step": ob,
+                                "steps": osteps, "ms_per_step": round(om["dt"] / osteps * 1e3, 4),
+                                "dominant_kernel": oroof["kernel"], "dominant_kernel_ms": oroof["kernel_ms"],
+                                "roofline_frac": oroof["frac"], "pipeline_frac": oroof["pipeline_frac"],
+                                "avg_keypoints_per_image": round(onavg, 1),
+                                "verified": None if args.no_verify else not obad}
+                del ofe
+            out["other_workloads"] = ow_out
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if overlapped is not None:

@@ -360,6 +360,12 @@ int orbm_search_for_triangulation(const orbx_keypoint_t *kp1, const uint8_t *q_d
                                   const float *scale_factors, const float *level_sigma2, int nlevels, int max_dist,
                                   int check_orientation, int32_t *match_q, int *nmatches, int device);
 
+/* The host-array matcher entry points keep grow-only device scratch, a pinned mirror and one non-blocking stream
+ * PER HOST THREAD (re-entrant without locks: the reference calls matchers from Tracking, LocalMapping and LoopClosing
+ * threads at once, src/LocalMapping.cc:223, src/LoopClosing.cc:249).  Nothing is freed implicitly; a thread calls
+ * this before it exits or to hand the memory back.  Safe to call at any time, any number of times. */
+int orbx_thread_release_scratch(void);
+
 const char *orbx_last_error(void);      /* thread-local description of the last failure */
 const char *orbx_version(void);
 int orbx_device_count(void);            /* number of HIP devices visible (0 if none) */

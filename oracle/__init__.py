@@ -17,7 +17,7 @@ def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("orb_oracle_extract.c", "orb_oracle_match.c", "orb_oracle.h")):
+            for f in os.listdir(_HERE) if f.endswith((".c", ".h")) or f == "Makefile"):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B" if force else "-s"])
     return _LIB_PATH
 

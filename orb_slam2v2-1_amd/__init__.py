@@ -41,7 +41,7 @@ EXPORTS = [
     "orbm_search_by_projection_frame", "orbm_match_windows", "orbm_best_in_windows", "orbm_distinctive_descriptors", "orbm_predict_scale_thresholds", "orbm_is_in_frustum",
     "orbm_search_local_points", "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_transform",
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
-    "orbx_record_bytes", "orbx_pack_records_device",
+    "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch",
 ]
 
 

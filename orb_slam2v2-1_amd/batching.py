@@ -75,3 +75,62 @@ def all_gather_records(rec, gathered=None, group=None, async_op=False):
         gathered = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=torch.uint8, device=rec.device)
     work = dist.all_gather_into_tensor(gathered, rec, group=group, async_op=async_op)
     return gathered, work
+
+
+class ResultRing:
+    """The result buffers of the batched mode and their life cycle, shared by bench.py, the GPU tests and the gloo CPU tests.
+
+    `nbuf` buffer sets; step i uses set j = i % nbuf:
+        j = ring.acquire(i)      # waits until set j's previous all-gather (step i - nbuf) has finished: its pack[j] /
+                                 # gath[j] may be overwritten only then
+        ... the caller's kernels fill ring.kps[j], desc[j], cnt[j] (nimg images) and ur[j], dp[j], nm[j] (B frames) ...
+        ring.publish(j)          # N > 1: ONE pack kernel + ONE all-gather of fixed-capacity records, asynchronous, so that
+                                 # it overlaps the next step's kernels (on CPU tensors / gloo: torch slicing + gloo)
+        ring.drain()             # wait for every outstanding all-gather
+    Frames are the first B images of a set (a stereo pair's right image sits at slot B + b and is not exchanged)."""
+
+    def __init__(self, nbuf, B, nimg, cap, device, world=1, gather=False, blocking_via_host=False):
+        self.nbuf, self.B, self.nimg, self.cap, self.world = nbuf, B, nimg, cap, world
+        self.gather = gather and world > 1
+        self.via_host = blocking_via_host   # rehearsal on a box with fewer GPUs than ranks: gloo moves host memory
+        z = lambda shape, dt: [torch.zeros(shape, dtype=dt, device=device) for _ in range(nbuf)]
+        self.kps, self.desc, self.cnt = z((nimg, cap, 7), torch.float32), z((nimg, cap, 32), torch.uint8), z((nimg,), torch.int32)
+        self.ur, self.dp, self.nm = z((B, cap), torch.float32), z((B, cap), torch.float32), z((B,), torch.int32)
+        self.works = [None] * nbuf
+        self.gathered_steps = [None] * nbuf     # step whose records gath[j] holds (set by acquire / drain once complete)
+        self._pending = [None] * nbuf
+        if self.gather:
+            rb = record_bytes(cap)
+            self.pack = z((B, rb), torch.uint8)
+            self.gath = z((world * B, rb), torch.uint8)
+
+    def acquire(self, i):
+        j = i % self.nbuf
+        self._finish(j)
+        return j
+
+    def _finish(self, j):
+        if self.works[j] is not None:
+            self.works[j].wait()
+            self.works[j] = None
+        if self._pending[j] is not None:
+            self.gathered_steps[j], self._pending[j] = self._pending[j], None
+
+    def publish(self, j, step=None):
+        if not self.gather:
+            return
+        pack_records(self.kps[j][:self.B], self.desc[j][:self.B], self.ur[j], self.dp[j], self.cnt[j][:self.B], out=self.pack[j])
+        if self.via_host:
+            g, _ = all_gather_records(self.pack[j].cpu())
+            self.gath[j].copy_(g)
+        else:
+            _, self.works[j] = all_gather_records(self.pack[j], self.gath[j], async_op=True)
+        self._pending[j] = step
+
+    def drain(self):
+        for j in range(self.nbuf):
+            self._finish(j)
+
+    def gathered(self, j):
+        """dict(kps, desc, uright, depth, counts) of ALL ranks' frames of the step held by set j (after acquire/drain)."""
+        return unpack_records(self.gath[j], self.cap)

@@ -159,6 +159,10 @@ static int scratch(int device, size_t need, uint8_t **p) {
     *p = g_bs.d;
     return ORBX_OK;
 }
+void orbx_internal_release_bow_scratch() {
+    if (g_bs.d) { hipSetDevice(g_bs.device); hipFree(g_bs.d); }
+    g_bs.d = nullptr; g_bs.cap = 0; g_bs.device = -1;
+}
 #define ALN(x) (((x) + 255) & ~(size_t)255)
 
 extern "C" int orbv_transform(const orbv_vocabulary_t *v, const uint8_t *desc, int n, int levelsup, int32_t *word_id,

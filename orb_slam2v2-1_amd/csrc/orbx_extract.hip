@@ -31,6 +31,15 @@ extern "C" int orbx_device_count(void) {
     return n;
 }
 
+// The matcher entry points keep grow-only device scratch + pinned mirrors + one stream per HOST THREAD (so that they
+// are re-entrant without locks).  A thread that is about to exit - or wants its memory back - calls this.
+extern "C" int orbx_thread_release_scratch(void) {
+    orbx_internal_release_match_scratch();
+    orbx_internal_release_arena();
+    orbx_internal_release_bow_scratch();
+    return ORBX_OK;
+}
+
 int g_debug[8] = {0};
 extern "C" int orbx_debug_set(int key, int value) { if (key < 0 || key >= 8) return ORBX_ERR_ARG; g_debug[key] = value; return ORBX_OK; }
 
@@ -120,6 +129,8 @@ extern "C" int orbx_destroy(orbx_extractor_t *h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     if (h->last_stream) hipStreamSynchronize(h->last_stream);
+    if (h->st_stream) hipStreamSynchronize(h->st_stream);
+    orbx_internal_free_stereo_scratch(h);
     free_plan(h);
     hipFree(h->d_in); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts);
     if (h->h_kps) { hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); }

@@ -89,6 +89,9 @@ struct orbx_extractor {
     hipStream_t last_stream; // stream of the last batch call
     int lastB;
     int framesStale;         // > 0: the frames of levels >= 1 of that many images have not been written (see ensure_frames)
+    // scratch of Frame::ComputeStereoMatches when this handle is the LEFT extractor (orbx_match.hip: stereo_scratch_reserve)
+    int32_t *st_sad; uint2 *st_rc; int32_t *st_binStart; uint4 *st_items; size_t st_n; int st_nB;
+    hipStream_t st_stream;   // stream of the last stereo call on this handle
     // per-stage HIP-event timing: a ring of event sets so that timing never forces a sync
     int profiling;
     hipEvent_t ev[ORBX_EV_RING][ORBX_NUM_STAGES];
@@ -99,6 +102,10 @@ struct orbx_extractor {
 };
 
 // extractor internals used by the matcher side
+void orbx_internal_free_stereo_scratch(orbx_extractor *h);   // orbx_match.hip
+void orbx_internal_release_match_scratch();                  // orbx_match.hip      (thread-local staging pair)
+void orbx_internal_release_arena();                          // orbx_match_fast.hip (thread-local arena)
+void orbx_internal_release_bow_scratch();                    // orbx_bow.hip        (thread-local scratch)
 int orbx_internal_level(const orbx_extractor *h, int level, int *w, int *hgt, int *pstride,
                         unsigned long long *poff);
 

@@ -323,18 +323,19 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
 __global__ __launch_bounds__(SM_T) void k_stereo_median(const int32_t *__restrict__ nl, int cap,
                                                         float *__restrict__ uright, float *__restrict__ depth,
                                                         const int32_t *__restrict__ sad,
-                                                        int32_t *__restrict__ nmatch) {
-    extern __shared__ int32_t sd[];  // [cap] sad (or -1)
+                                                        int32_t *__restrict__ nmatch, int useLds) {
+    extern __shared__ int32_t sd_lds[];  // [cap] sad (or -1) when useLds; larger frames re-read the global array
     __shared__ int sh_nd, sh_keep;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int N = min(nl[b], cap);
     const size_t o = (size_t)b * cap;
     if (tid == 0) { sh_nd = 0; sh_keep = 0; }
     __syncthreads();
+    const int32_t *sd = useLds ? sd_lds : sad + o;
     int c = 0;
     for (int i = tid; i < N; i += SM_T) {
         const int s = sad[o + i];
-        sd[i] = s;
+        if (useLds) sd_lds[i] = s;
         c += s >= 0;
     }
     if (c) atomicAdd(&sh_nd, c);
@@ -393,10 +394,30 @@ static int fill_stereo_levels(orbx_extractor *hl, orbx_extractor *hr, StereoLeve
     return ORBX_OK;
 }
 
-// scratch for the SAD distances, grown on demand (per left extractor handle)
-struct StereoScratch { int32_t *d_sad; uint2 *d_rc; int32_t *d_binStart; uint4 *d_items; size_t n; int nB; int device; };
-static thread_local StereoScratch g_ss = {nullptr, nullptr, nullptr, nullptr, 0, 0, -1};
+// Scratch of one ComputeStereoMatches call (SAD distances, compact right-keypoint records, row bins): it belongs to the
+// LEFT extractor handle (orbx_extractor::st_*), like that handle's pyramid and candidate buffers, so two handles driven
+// on two streams - from one host thread or several - never share it.  Calls on ONE handle must be stream-ordered, the
+// same rule as for its extraction buffers.
+static int stereo_scratch_reserve(orbx_extractor *hl, int B, int cap) {
+    const size_t need = (size_t)B * cap;
+    if (hl->st_n >= need && hl->st_nB >= B) return ORBX_OK;
+    if (hl->last_stream) ORBX_HIP(hipStreamSynchronize(hl->last_stream));
+    if (hl->st_stream) ORBX_HIP(hipStreamSynchronize(hl->st_stream));
+    hipFree(hl->st_sad); hipFree(hl->st_rc); hipFree(hl->st_binStart); hipFree(hl->st_items);
+    hl->st_sad = nullptr; hl->st_rc = nullptr; hl->st_binStart = nullptr; hl->st_items = nullptr; hl->st_n = 0; hl->st_nB = 0;
+    ORBX_HIP(hipMalloc(&hl->st_sad, sizeof(int32_t) * need));
+    ORBX_HIP(hipMalloc(&hl->st_rc, sizeof(uint2) * need));
+    ORBX_HIP(hipMalloc(&hl->st_items, sizeof(uint4) * 2 * need));
+    ORBX_HIP(hipMalloc(&hl->st_binStart, sizeof(int32_t) * (ST_MAX_BINS + 1) * (size_t)B));
+    hl->st_n = need; hl->st_nB = B;
+    return ORBX_OK;
+}
+void orbx_internal_free_stereo_scratch(orbx_extractor *h) {
+    hipFree(h->st_sad); hipFree(h->st_rc); hipFree(h->st_binStart); hipFree(h->st_items);
+    h->st_sad = nullptr; h->st_rc = nullptr; h->st_binStart = nullptr; h->st_items = nullptr; h->st_n = 0; h->st_nB = 0;
+}
 
+#define SM_LDS_CAP 12288   // k_stereo_median keeps a frame's SAD values in LDS up to this many keypoints (48 KB), beyond: global memory
 extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, int left_slot0,
                                         int right_slot0, const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
                                         const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
@@ -407,23 +428,13 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
         orbx_set_error("orbm_stereo_batch_device: bad arguments");
         return ORBX_ERR_ARG;
     }
+    if (cap > 65535) { orbx_set_error("orbm_stereo: %d keypoints per image (limit 65535)", cap); return ORBX_ERR_UNSUPPORTED; }
     StereoLevels lv;
     int rc = fill_stereo_levels(hl, hr, &lv);
     if (rc) return rc;
     ORBX_HIP(hipSetDevice(hl->device));
-    const size_t need = (size_t)B * cap;
-    if (g_ss.n < need || g_ss.nB < B || g_ss.device != hl->device) {
-        if (g_ss.d_sad) hipFree(g_ss.d_sad);
-        if (g_ss.d_rc) hipFree(g_ss.d_rc);
-        if (g_ss.d_binStart) hipFree(g_ss.d_binStart);
-        if (g_ss.d_items) hipFree(g_ss.d_items);
-        g_ss.d_sad = nullptr; g_ss.d_rc = nullptr; g_ss.d_binStart = nullptr; g_ss.d_items = nullptr; g_ss.n = 0; g_ss.nB = 0;
-        ORBX_HIP(hipMalloc(&g_ss.d_sad, sizeof(int32_t) * need));
-        ORBX_HIP(hipMalloc(&g_ss.d_rc, sizeof(uint2) * need));
-        ORBX_HIP(hipMalloc(&g_ss.d_items, sizeof(uint4) * 2 * need));
-        ORBX_HIP(hipMalloc(&g_ss.d_binStart, sizeof(int32_t) * (ST_MAX_BINS + 1) * (size_t)B));
-        g_ss.n = need; g_ss.nB = B; g_ss.device = hl->device;
-    }
+    rc = stereo_scratch_reserve(hl, B, cap);
+    if (rc) return rc;
     // bin height: a power of two >= the tallest row band (maxr - minr + 1 <= 2r + 3, r = 2 * scale of the coarsest level)
     int bhShift = 3;
     while ((1 << bhShift) < (int)(4.0f * lv.sf[lv.nlevels - 1]) + 4) bhShift++;
@@ -432,39 +443,54 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream
     dim3 grid((cap + ST_WAVES - 1) / ST_WAVES, B);
     (void)hipGetLastError();
-    if (cap > 65535) { orbx_set_error("orbm_stereo: %d keypoints per image (limit 65535)", cap); return ORBX_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(k_stereo_bins, dim3(B), dim3(256), 0, st, lv, d_kr, g_ss.d_rc, d_nr, cap, bhShift, nbins, g_ss.d_binStart, g_ss.d_items);
+    hipLaunchKernelGGL(k_stereo_bins, dim3(B), dim3(256), 0, st, lv, d_kr, hl->st_rc, d_nr, cap, bhShift, nbins, hl->st_binStart, hl->st_items);
     hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), 0, st, lv, hl->d_pyr + (size_t)left_slot0 * hl->pyrImgBytes, hl->pyrImgBytes,
                        hr->d_pyr + (size_t)right_slot0 * hr->pyrImgBytes, hr->pyrImgBytes, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
-                       g_ss.d_sad, g_ss.d_rc, g_ss.d_binStart, g_ss.d_items, bhShift, nbins);
-    hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(SM_T), sizeof(int32_t) * cap, st, d_nl, cap, d_uright,
-                       d_depth, g_ss.d_sad, d_nmatch);
+                       hl->st_sad, hl->st_rc, hl->st_binStart, hl->st_items, bhShift, nbins);
+    const int useLds = cap <= SM_LDS_CAP;
+    hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(SM_T), useLds ? sizeof(int32_t) * cap : 0, st, d_nl, cap, d_uright,
+                       d_depth, hl->st_sad, d_nmatch, useLds);
     ORBX_HIP(hipGetLastError());
+    hl->st_stream = st;
     return ORBX_OK;
 }
 
-// tiny RAII helper for the host-array entry points
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    int alloc(size_t n) { return hipMalloc(&p, n ? n : 1) == hipSuccess ? 0 : -1; }
-};
-#define DEV_ALLOC(buf, bytes) do { if ((buf).alloc(bytes)) { orbx_set_error("hipMalloc(%zu) failed", (size_t)(bytes)); return ORBX_ERR_HIP; } } while (0)
-#define H2D(buf, src, bytes) ORBX_HIP(hipMemcpy((buf).p, (src), (bytes), hipMemcpyHostToDevice))
-
-// thread-local device scratch with a pinned host mirror of the same layout: the host-array entry points below move their
-// inputs with ONE upload and their results with ONE download + ONE synchronisation (no hipMalloc per call)
-struct StagePair { uint8_t *d = nullptr, *h = nullptr; size_t cap = 0; int device = -1; };
+// thread-local device scratch with a pinned host mirror of the same layout and a non-blocking stream of its own: the
+// host-array entry points below move their inputs with ONE upload and their results with ONE download + ONE
+// synchronisation of THAT stream (no hipMalloc per call, no device-wide synchronisation: other threads' extractors and
+// matchers keep running, as the reference's Tracking / LocalMapping / LoopClosing threads call matchers concurrently,
+// src/LocalMapping.cc:223, src/LoopClosing.cc:249)
+struct StagePair { uint8_t *d = nullptr, *h = nullptr; size_t cap = 0; int device = -1; hipStream_t st = nullptr; };
 static thread_local StagePair g_sp;
+static void stage_release() {
+    if (g_sp.device < 0) return;
+    hipSetDevice(g_sp.device);
+    if (g_sp.st) { hipStreamSynchronize(g_sp.st); hipStreamDestroy(g_sp.st); g_sp.st = nullptr; }
+    if (g_sp.d) hipFree(g_sp.d);
+    if (g_sp.h) hipHostFree(g_sp.h);
+    g_sp.d = nullptr; g_sp.h = nullptr; g_sp.cap = 0; g_sp.device = -1;
+}
 static int stage_reserve(int device, size_t need) {
     if (g_sp.device == device && g_sp.cap >= need) return ORBX_OK;
-    if (g_sp.d) { hipSetDevice(g_sp.device); hipFree(g_sp.d); hipHostFree(g_sp.h); g_sp.d = nullptr; g_sp.h = nullptr; g_sp.cap = 0; hipSetDevice(device); }
+    stage_release();
+    ORBX_HIP(hipSetDevice(device));
     const size_t cap = std::max(need * 2, (size_t)1 << 20);
     ORBX_HIP(hipMalloc(&g_sp.d, cap));
     ORBX_HIP(hipHostMalloc((void **)&g_sp.h, cap, hipHostMallocDefault));
+    ORBX_HIP(hipStreamCreateWithFlags(&g_sp.st, hipStreamNonBlocking));
     g_sp.cap = cap; g_sp.device = device;
     return ORBX_OK;
 }
+// layout of one call inside the StagePair: take() hands out 256-B aligned offsets; everything taken before mark_inputs()
+// is uploaded in one copy
+struct StagePlan {
+    size_t off = 0, in_end = 0;
+    size_t take(size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
+    void mark_inputs() { in_end = off; }
+};
+template <typename T> static inline T *stage_dev(size_t o) { return (T *)(g_sp.d + o); }
+static inline void stage_put(size_t o, const void *src, size_t bytes) { if (bytes) memcpy(g_sp.h + o, src, bytes); }
+void orbx_internal_release_match_scratch() { stage_release(); }
 
 extern "C" int orbm_stereo(orbx_extractor_t *hl, orbx_extractor_t *hr, const orbx_keypoint_t *kl,
                            const uint8_t *dl, int nl, const orbx_keypoint_t *kr, const uint8_t *dr, int nr,
@@ -636,28 +662,31 @@ extern "C" int orbm_search_for_initialization(const orbx_keypoint_t *k1, const u
                                                        check_orientation, device, nmatches);
         if (frc <= 0) return frc;  // done or error; > 0: exact fallback below
     }
+    StagePlan pl;
+    const size_t o_k1 = pl.take(sizeof(orbx_keypoint_t) * n1), o_d1 = pl.take((size_t)32 * n1), o_k2 = pl.take(sizeof(orbx_keypoint_t) * n2),
+                 o_d2 = pl.take((size_t)32 * n2), o_prev = pl.take(sizeof(float) * 2 * n1);
+    pl.mark_inputs();
+    const size_t o_m12 = pl.take(4 * (size_t)n1), o_nm = pl.take(4), o_m21 = pl.take(4 * (size_t)n2), o_vmd = pl.take(4 * (size_t)n2),
+                 o_code = pl.take(2 * (size_t)n2), o_bin = pl.take(4 * (size_t)n1);
+    int rc = stage_reserve(device, pl.off);
+    if (rc) return rc;
     ORBX_HIP(hipSetDevice(device));
-    DevBuf bk1, bd1, bk2, bd2, bprev, bm12, bm21, bvmd, bcode, bbin, bnm;
-    DEV_ALLOC(bk1, sizeof(orbx_keypoint_t) * n1); DEV_ALLOC(bd1, (size_t)32 * n1);
-    DEV_ALLOC(bk2, sizeof(orbx_keypoint_t) * n2); DEV_ALLOC(bd2, (size_t)32 * n2);
-    DEV_ALLOC(bprev, sizeof(float) * 2 * n1); DEV_ALLOC(bm12, 4 * (size_t)n1); DEV_ALLOC(bm21, 4 * (size_t)n2);
-    DEV_ALLOC(bvmd, 4 * (size_t)n2); DEV_ALLOC(bcode, 2 * (size_t)n2); DEV_ALLOC(bbin, 4 * (size_t)n1);
-    DEV_ALLOC(bnm, 4);
-    H2D(bk1, k1, sizeof(orbx_keypoint_t) * n1); H2D(bd1, d1, (size_t)32 * n1);
-    if (n2) { H2D(bk2, k2, sizeof(orbx_keypoint_t) * n2); H2D(bd2, d2, (size_t)32 * n2); }
-    H2D(bprev, prev_matched, sizeof(float) * 2 * n1);
+    hipStream_t st = g_sp.st;
+    stage_put(o_k1, k1, sizeof(orbx_keypoint_t) * n1); stage_put(o_d1, d1, (size_t)32 * n1);
+    stage_put(o_k2, k2, sizeof(orbx_keypoint_t) * n2); stage_put(o_d2, d2, (size_t)32 * n2);
+    stage_put(o_prev, prev_matched, sizeof(float) * 2 * n1);
+    ORBX_HIP(hipMemcpyAsync(g_sp.d, g_sp.h, pl.in_end, hipMemcpyHostToDevice, st));
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_search_init, dim3(1), dim3(SQ_T), 0, 0, (orbx_keypoint_t *)bk1.p, (uint8_t *)bd1.p, n1,
-                       (orbx_keypoint_t *)bk2.p, (uint8_t *)bd2.p, n2, *g2, (float *)bprev.p, (int32_t *)bm12.p,
-                       (int32_t *)bm21.p, (int32_t *)bvmd.p, (uint16_t *)bcode.p, (int32_t *)bbin.p, window,
-                       nnratio, check_orientation, (int32_t *)bnm.p);
+    hipLaunchKernelGGL(k_search_init, dim3(1), dim3(SQ_T), 0, st, stage_dev<orbx_keypoint_t>(o_k1), stage_dev<uint8_t>(o_d1), n1,
+                       stage_dev<orbx_keypoint_t>(o_k2), stage_dev<uint8_t>(o_d2), n2, *g2, stage_dev<float>(o_prev),
+                       stage_dev<int32_t>(o_m12), stage_dev<int32_t>(o_m21), stage_dev<int32_t>(o_vmd), stage_dev<uint16_t>(o_code),
+                       stage_dev<int32_t>(o_bin), window, nnratio, check_orientation, stage_dev<int32_t>(o_nm));
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipDeviceSynchronize());
-    ORBX_HIP(hipMemcpy(prev_matched, bprev.p, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost));
-    ORBX_HIP(hipMemcpy(matches12, bm12.p, 4 * (size_t)n1, hipMemcpyDeviceToHost));
-    int32_t nm = 0;
-    ORBX_HIP(hipMemcpy(&nm, bnm.p, 4, hipMemcpyDeviceToHost));
-    *nmatches = nm;
+    ORBX_HIP(hipMemcpyAsync(g_sp.h + o_prev, g_sp.d + o_prev, o_m21 - o_prev, hipMemcpyDeviceToHost, st));   // prev | m12 | nm
+    ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(prev_matched, g_sp.h + o_prev, sizeof(float) * 2 * n1);
+    memcpy(matches12, g_sp.h + o_m12, 4 * (size_t)n1);
+    *nmatches = *(const int32_t *)(g_sp.h + o_nm);
     return ORBX_OK;
 }
 
@@ -820,25 +849,31 @@ static int exact_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8
                                          const orbm_grid_geom_t *g, const float *scale_factors, int nlevels,
                                          const orbm_mappoint_t *mps, const uint8_t *mp_desc, int m, int32_t *frame_mp,
                                          const int32_t *ext_obs, float th, float nnratio, int device, int *nmatches) {
+    StagePlan pl;
+    const size_t o_k = pl.take(sizeof(orbx_keypoint_t) * n), o_d = pl.take((size_t)32 * n), o_u = pl.take(4 * (size_t)n),
+                 o_sf = pl.take(4 * (size_t)nlevels), o_mp = pl.take(sizeof(orbm_mappoint_t) * m), o_md = pl.take((size_t)32 * m),
+                 o_eo = pl.take(ext_obs ? 4 * (size_t)n : 0), o_fm = pl.take(4 * (size_t)n);
+    pl.mark_inputs();
+    const size_t o_nm = pl.take(4), o_code = pl.take(2 * (size_t)n);
+    int rc = stage_reserve(device, pl.off);
+    if (rc) return rc;
     ORBX_HIP(hipSetDevice(device));
-    DevBuf bk, bd, bu, bsf, bmp, bmd, bfm, beo, bcode, bnm;
-    DEV_ALLOC(bk, sizeof(orbx_keypoint_t) * n); DEV_ALLOC(bd, (size_t)32 * n); DEV_ALLOC(bu, 4 * (size_t)n);
-    DEV_ALLOC(bsf, 4 * (size_t)nlevels); DEV_ALLOC(bmp, sizeof(orbm_mappoint_t) * m); DEV_ALLOC(bmd, (size_t)32 * m);
-    DEV_ALLOC(bfm, 4 * (size_t)n); DEV_ALLOC(bcode, 2 * (size_t)n); DEV_ALLOC(bnm, 4);
-    H2D(bk, kun, sizeof(orbx_keypoint_t) * n); H2D(bd, desc, (size_t)32 * n); H2D(bu, uright, 4 * (size_t)n);
-    H2D(bsf, scale_factors, 4 * (size_t)nlevels); H2D(bmp, mps, sizeof(orbm_mappoint_t) * m);
-    H2D(bmd, mp_desc, (size_t)32 * m); H2D(bfm, frame_mp, 4 * (size_t)n);
-    if (ext_obs) { DEV_ALLOC(beo, 4 * (size_t)n); H2D(beo, ext_obs, 4 * (size_t)n); }
+    hipStream_t st = g_sp.st;
+    stage_put(o_k, kun, sizeof(orbx_keypoint_t) * n); stage_put(o_d, desc, (size_t)32 * n); stage_put(o_u, uright, 4 * (size_t)n);
+    stage_put(o_sf, scale_factors, 4 * (size_t)nlevels); stage_put(o_mp, mps, sizeof(orbm_mappoint_t) * m);
+    stage_put(o_md, mp_desc, (size_t)32 * m); stage_put(o_fm, frame_mp, 4 * (size_t)n);
+    if (ext_obs) stage_put(o_eo, ext_obs, 4 * (size_t)n);
+    ORBX_HIP(hipMemcpyAsync(g_sp.d, g_sp.h, pl.in_end, hipMemcpyHostToDevice, st));
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_search_proj_mp, dim3(1), dim3(SQ_T), 0, 0, (orbx_keypoint_t *)bk.p, (uint8_t *)bd.p,
-                       (float *)bu.p, n, *g, (float *)bsf.p, (orbm_mappoint_t *)bmp.p, (uint8_t *)bmd.p, m,
-                       (int32_t *)bfm.p, (int32_t *)beo.p, (uint16_t *)bcode.p, th, nnratio, (int32_t *)bnm.p);
+    hipLaunchKernelGGL(k_search_proj_mp, dim3(1), dim3(SQ_T), 0, st, stage_dev<orbx_keypoint_t>(o_k), stage_dev<uint8_t>(o_d),
+                       stage_dev<float>(o_u), n, *g, stage_dev<float>(o_sf), stage_dev<orbm_mappoint_t>(o_mp), stage_dev<uint8_t>(o_md), m,
+                       stage_dev<int32_t>(o_fm), ext_obs ? stage_dev<int32_t>(o_eo) : (int32_t *)nullptr, stage_dev<uint16_t>(o_code), th,
+                       nnratio, stage_dev<int32_t>(o_nm));
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipDeviceSynchronize());
-    ORBX_HIP(hipMemcpy(frame_mp, bfm.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
-    int32_t nm = 0;
-    ORBX_HIP(hipMemcpy(&nm, bnm.p, 4, hipMemcpyDeviceToHost));
-    *nmatches = nm;
+    ORBX_HIP(hipMemcpyAsync(g_sp.h + o_fm, g_sp.d + o_fm, o_code - o_fm, hipMemcpyDeviceToHost, st));   // frame_mp | nm
+    ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(frame_mp, g_sp.h + o_fm, 4 * (size_t)n);
+    *nmatches = *(const int32_t *)(g_sp.h + o_nm);
     return ORBX_OK;
 }
 
@@ -980,32 +1015,34 @@ extern "C" int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const
                                                         check_orientation, device, nmatches);
         if (frc <= 0) return frc;
     }
+    StagePlan pl;
+    const size_t o_k = pl.take(sizeof(orbx_keypoint_t) * n), o_d = pl.take((size_t)32 * n), o_u = pl.take(4 * (size_t)n),
+                 o_sf = pl.take(4 * (size_t)nlevels), o_T = pl.take(4 * 32), o_l = pl.take(sizeof(orbm_lastpoint_t) * nlast),
+                 o_ld = pl.take((size_t)32 * nlast), o_eo = pl.take(ext_obs ? 4 * (size_t)n : 0), o_cm = pl.take(4 * (size_t)n);
+    pl.mark_inputs();
+    const size_t o_nm = pl.take(4), o_code = pl.take(2 * (size_t)n), o_hi = pl.take(4 * (size_t)nlast), o_hb = pl.take(4 * (size_t)nlast);
+    int rc = stage_reserve(device, pl.off);
+    if (rc) return rc;
     ORBX_HIP(hipSetDevice(device));
-    DevBuf bk, bd, bu, bsf, bT, bl, bld, bcm, beo, bcode, bhi, bhb, bnm;
-    DEV_ALLOC(bk, sizeof(orbx_keypoint_t) * n); DEV_ALLOC(bd, (size_t)32 * n); DEV_ALLOC(bu, 4 * (size_t)n);
-    DEV_ALLOC(bsf, 4 * (size_t)nlevels); DEV_ALLOC(bT, 4 * 32); DEV_ALLOC(bl, sizeof(orbm_lastpoint_t) * nlast);
-    DEV_ALLOC(bld, (size_t)32 * nlast); DEV_ALLOC(bcm, 4 * (size_t)n); DEV_ALLOC(bcode, 2 * (size_t)n);
-    DEV_ALLOC(bhi, 4 * (size_t)nlast); DEV_ALLOC(bhb, 4 * (size_t)nlast); DEV_ALLOC(bnm, 4);
-    H2D(bk, kun, sizeof(orbx_keypoint_t) * n); H2D(bd, desc, (size_t)32 * n); H2D(bu, uright, 4 * (size_t)n);
-    H2D(bsf, scale_factors, 4 * (size_t)nlevels);
-    float T2[32];
-    memcpy(T2, Tcw_cur16, 64); memcpy(T2 + 16, Tcw_last16, 64);
-    H2D(bT, T2, sizeof(T2));
-    H2D(bl, last, sizeof(orbm_lastpoint_t) * nlast); H2D(bld, last_desc, (size_t)32 * nlast);
-    H2D(bcm, cur_mp, 4 * (size_t)n);
-    if (ext_obs) { DEV_ALLOC(beo, 4 * (size_t)n); H2D(beo, ext_obs, 4 * (size_t)n); }
+    hipStream_t st = g_sp.st;
+    stage_put(o_k, kun, sizeof(orbx_keypoint_t) * n); stage_put(o_d, desc, (size_t)32 * n); stage_put(o_u, uright, 4 * (size_t)n);
+    stage_put(o_sf, scale_factors, 4 * (size_t)nlevels);
+    stage_put(o_T, Tcw_cur16, 64); stage_put(o_T + 64, Tcw_last16, 64);
+    stage_put(o_l, last, sizeof(orbm_lastpoint_t) * nlast); stage_put(o_ld, last_desc, (size_t)32 * nlast);
+    stage_put(o_cm, cur_mp, 4 * (size_t)n);
+    if (ext_obs) stage_put(o_eo, ext_obs, 4 * (size_t)n);
+    ORBX_HIP(hipMemcpyAsync(g_sp.d, g_sp.h, pl.in_end, hipMemcpyHostToDevice, st));
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_search_proj_frame, dim3(1), dim3(SQ_T), 0, 0, (orbx_keypoint_t *)bk.p, (uint8_t *)bd.p,
-                       (float *)bu.p, n, *g, (float *)bsf.p, *cam, (float *)bT.p, (float *)bT.p + 16,
-                       (orbm_lastpoint_t *)bl.p, (uint8_t *)bld.p, nlast, (int32_t *)bcm.p, (int32_t *)beo.p,
-                       (uint16_t *)bcode.p, (int32_t *)bhi.p, (int32_t *)bhb.p, th, mono, check_orientation,
-                       (int32_t *)bnm.p);
+    hipLaunchKernelGGL(k_search_proj_frame, dim3(1), dim3(SQ_T), 0, st, stage_dev<orbx_keypoint_t>(o_k), stage_dev<uint8_t>(o_d),
+                       stage_dev<float>(o_u), n, *g, stage_dev<float>(o_sf), *cam, stage_dev<float>(o_T), stage_dev<float>(o_T) + 16,
+                       stage_dev<orbm_lastpoint_t>(o_l), stage_dev<uint8_t>(o_ld), nlast, stage_dev<int32_t>(o_cm),
+                       ext_obs ? stage_dev<int32_t>(o_eo) : (int32_t *)nullptr, stage_dev<uint16_t>(o_code), stage_dev<int32_t>(o_hi),
+                       stage_dev<int32_t>(o_hb), th, mono, check_orientation, stage_dev<int32_t>(o_nm));
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipDeviceSynchronize());
-    ORBX_HIP(hipMemcpy(cur_mp, bcm.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
-    int32_t nm = 0;
-    ORBX_HIP(hipMemcpy(&nm, bnm.p, 4, hipMemcpyDeviceToHost));
-    *nmatches = nm;
+    ORBX_HIP(hipMemcpyAsync(g_sp.h + o_cm, g_sp.d + o_cm, o_code - o_cm, hipMemcpyDeviceToHost, st));   // cur_mp | nm
+    ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(cur_mp, g_sp.h + o_cm, 4 * (size_t)n);
+    *nmatches = *(const int32_t *)(g_sp.h + o_nm);
     return ORBX_OK;
 }
 
@@ -1128,25 +1165,32 @@ extern "C" int orbm_match_windows(const orbx_keypoint_t *kun, const uint8_t *des
                                            check_orientation, device, nmatches);
         if (frc <= 0) return frc;
     }
+    StagePlan pl;
+    const size_t o_k = pl.take(sizeof(orbx_keypoint_t) * n), o_d = pl.take((size_t)32 * n), o_q = pl.take(sizeof(orbm_window_query_t) * m),
+                 o_qd = pl.take((size_t)32 * m), o_u = pl.take(uright ? 4 * (size_t)n : 0), o_eb = pl.take(ext_blocks ? 4 * (size_t)n : 0),
+                 o_h = pl.take(4 * (size_t)n);
+    pl.mark_inputs();
+    const size_t o_nm = pl.take(4), o_code = pl.take(2 * (size_t)n), o_hi = pl.take(4 * (size_t)m), o_hb = pl.take(4 * (size_t)m);
+    int rc = stage_reserve(device, pl.off);
+    if (rc) return rc;
     ORBX_HIP(hipSetDevice(device));
-    DevBuf bk, bd, bu, bq, bqd, bh, beb, bcode, bhi, bhb, bnm;
-    DEV_ALLOC(bk, sizeof(orbx_keypoint_t) * n); DEV_ALLOC(bd, (size_t)32 * n); DEV_ALLOC(bq, sizeof(orbm_window_query_t) * m);
-    DEV_ALLOC(bqd, (size_t)32 * m); DEV_ALLOC(bh, 4 * (size_t)n); DEV_ALLOC(bcode, 2 * (size_t)n); DEV_ALLOC(bhi, 4 * (size_t)m);
-    DEV_ALLOC(bhb, 4 * (size_t)m); DEV_ALLOC(bnm, 4);
-    H2D(bk, kun, sizeof(orbx_keypoint_t) * n); H2D(bd, desc, (size_t)32 * n); H2D(bq, queries, sizeof(orbm_window_query_t) * m);
-    H2D(bqd, query_desc, (size_t)32 * m); H2D(bh, holder, 4 * (size_t)n);
-    if (uright) { DEV_ALLOC(bu, 4 * (size_t)n); H2D(bu, uright, 4 * (size_t)n); }
-    if (ext_blocks) { DEV_ALLOC(beb, 4 * (size_t)n); H2D(beb, ext_blocks, 4 * (size_t)n); }
+    hipStream_t st = g_sp.st;
+    stage_put(o_k, kun, sizeof(orbx_keypoint_t) * n); stage_put(o_d, desc, (size_t)32 * n);
+    stage_put(o_q, queries, sizeof(orbm_window_query_t) * m); stage_put(o_qd, query_desc, (size_t)32 * m);
+    stage_put(o_h, holder, 4 * (size_t)n);
+    if (uright) stage_put(o_u, uright, 4 * (size_t)n);
+    if (ext_blocks) stage_put(o_eb, ext_blocks, 4 * (size_t)n);
+    ORBX_HIP(hipMemcpyAsync(g_sp.d, g_sp.h, pl.in_end, hipMemcpyHostToDevice, st));
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_match_windows_exact, dim3(1), dim3(SQ_T), 0, 0, (orbx_keypoint_t *)bk.p, (uint8_t *)bd.p,
-                       (float *)bu.p, n, *g, g_assign ? *g_assign : *g, (orbm_window_query_t *)bq.p, (uint8_t *)bqd.p, m, (int32_t *)bh.p,
-                       (int32_t *)beb.p, (uint16_t *)bcode.p, (int32_t *)bhi.p, (int32_t *)bhb.p, max_dist,
-                       check_orientation, (int32_t *)bnm.p);
+    hipLaunchKernelGGL(k_match_windows_exact, dim3(1), dim3(SQ_T), 0, st, stage_dev<orbx_keypoint_t>(o_k), stage_dev<uint8_t>(o_d),
+                       uright ? stage_dev<float>(o_u) : (float *)nullptr, n, *g, g_assign ? *g_assign : *g,
+                       stage_dev<orbm_window_query_t>(o_q), stage_dev<uint8_t>(o_qd), m, stage_dev<int32_t>(o_h),
+                       ext_blocks ? stage_dev<int32_t>(o_eb) : (int32_t *)nullptr, stage_dev<uint16_t>(o_code), stage_dev<int32_t>(o_hi),
+                       stage_dev<int32_t>(o_hb), max_dist, check_orientation, stage_dev<int32_t>(o_nm));
     ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipDeviceSynchronize());
-    ORBX_HIP(hipMemcpy(holder, bh.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
-    int32_t nm = 0;
-    ORBX_HIP(hipMemcpy(&nm, bnm.p, 4, hipMemcpyDeviceToHost));
-    *nmatches = nm;
+    ORBX_HIP(hipMemcpyAsync(g_sp.h + o_h, g_sp.d + o_h, o_code - o_h, hipMemcpyDeviceToHost, st));   // holder | nm
+    ORBX_HIP(hipStreamSynchronize(st));
+    memcpy(holder, g_sp.h + o_h, 4 * (size_t)n);
+    *nmatches = *(const int32_t *)(g_sp.h + o_nm);
     return ORBX_OK;
 }

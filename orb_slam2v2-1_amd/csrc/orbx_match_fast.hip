@@ -682,6 +682,14 @@ static int arena_begin(int device, size_t need) {
     g_ar.up_lo = g_ar.cap; g_ar.up_hi = 0;
     return ORBX_OK;
 }
+void orbx_internal_release_arena() {
+    if (g_ar.device < 0) return;
+    hipSetDevice(g_ar.device);
+    if (g_ar.st) { hipStreamSynchronize(g_ar.st); hipStreamDestroy(g_ar.st); g_ar.st = nullptr; }
+    if (g_ar.base) hipFree(g_ar.base);
+    if (g_ar.hbase) hipHostFree(g_ar.hbase);
+    g_ar.base = nullptr; g_ar.hbase = nullptr; g_ar.cap = 0; g_ar.device = -1;
+}
 template <typename T> static T *arena_get(size_t count) {
     const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
     T *p = (T *)(g_ar.base + g_ar.off);

@@ -1,0 +1,94 @@
+"""The batched many-frame step that bench.py times and tests/test_bench_step_gpu.py checks against the oracle:
+
+    B frames already resident in HBM  ->  ORBextractor::operator() on every image (ONE orbx_extract_batch_device call:
+    left images in slots [0,B), right images in [B,2B) of the same handle)  ->  Frame::ComputeStereoMatches for the B
+    pairs (orbm_stereo_batch_device with hl == hr)  ->  with N > 1 ranks: one packed record per frame, one all-gather.
+
+Reference call sites: src/Frame.cc:78-81 (two extractors), :84 ComputeStereoMatches, src/ORBextractor.cc:1043-1105.
+Host-side plumbing only (torch = device memory, streams, torch.distributed); every computation is a kernel of the HIP
+library, and there is no CPU fallback: constructing a FrontEnd without a GPU raises.
+"""
+import numpy as np
+import torch
+
+from . import KP_DTYPE, ORBextractor, stereo_batch_device
+from .batching import ResultRing
+
+KITTI_FX, KITTI_BF = 718.856, 386.1448  # KITTI-00 calibration (fx, baseline*fx)
+
+
+class FrontEnd:
+    def __init__(self, w, h, nfeatures, stereo, B, device_index=0, nbuf=3, streams=1, world=1, gather=False,
+                 gather_via_host=False, mbf=KITTI_BF, fx=KITTI_FX, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        if not torch.cuda.is_available():
+            raise RuntimeError("orb_slam2v2-1_amd.pipeline.FrontEnd needs a GPU: the HIP path has no CPU fallback")
+        self.w, self.h, self.nf, self.stereo, self.B = w, h, nfeatures, stereo, B
+        self.nimg = 2 * B if stereo else B
+        self.dev_index = device_index
+        self.dev = torch.device("cuda", device_index)
+        self.mbf = float(mbf)
+        self.mb = float(np.float32(mbf) / np.float32(fx))
+        self.S = max(1, streams)
+        self.exs = [ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th, device=device_index) for _ in range(self.S)]
+        self.ex = self.exs[0]
+        self.streams = [torch.cuda.current_stream(self.dev)] + [torch.cuda.Stream(self.dev) for _ in range(self.S - 1)]
+        self.d_imgs = None
+        self.cap = None
+        self.ring = None
+        self._ring_args = (max(nbuf, self.S), world, gather, gather_via_host)
+
+    def upload(self, left, right=None):
+        """left / right: uint8 [B, h, w] host arrays -> HBM (slots [0,B) left, [B,2B) right); plans every handle."""
+        imgs = np.concatenate([left, right]) if self.stereo else left
+        assert imgs.shape == (self.nimg, self.h, self.w) and imgs.dtype == np.uint8
+        for e in self.exs:
+            e(imgs[0])                  # plan for this image size; max_keypoints() is now exact
+        self.cap = self.ex.max_keypoints()
+        self.d_imgs = torch.from_numpy(np.ascontiguousarray(imgs)).to(self.dev)
+        nbuf, world, gather, via_host = self._ring_args
+        self.ring = ResultRing(nbuf, self.B, self.nimg, self.cap, self.dev, world=world, gather=gather,
+                               blocking_via_host=via_host)
+        return self
+
+    def step(self, i, ev_before_match=None, ev_after_match=None):
+        r = self.ring
+        j = r.acquire(i)
+        exi, stream = self.exs[i % self.S], self.streams[i % self.S]
+        st = stream.cuda_stream
+        B, cap, w, h = self.B, self.cap, self.w, self.h
+        exi.extract_batch_device(self.d_imgs.data_ptr(), self.nimg, w, h, w, w * h, r.kps[j].data_ptr(), r.desc[j].data_ptr(),
+                                 r.cnt[j].data_ptr(), cap, st)
+        if self.stereo:
+            if ev_before_match is not None:
+                ev_before_match.record(stream)
+            stereo_batch_device(exi, exi, B, 0, B, r.kps[j].data_ptr(), r.desc[j].data_ptr(), r.cnt[j].data_ptr(),
+                                r.kps[j][B:].data_ptr(), r.desc[j][B:].data_ptr(), r.cnt[j][B:].data_ptr(),
+                                cap, self.mbf, self.mb, r.ur[j].data_ptr(), r.dp[j].data_ptr(), r.nm[j].data_ptr(), st)
+            if ev_after_match is not None:
+                ev_after_match.record(stream)
+        if r.gather:
+            with torch.cuda.stream(stream):     # pack + collective are ordered behind this step's kernels
+                r.publish(j, i)
+        return j
+
+    def drain(self):
+        self.ring.drain()
+        torch.cuda.synchronize(self.dev)
+
+    def results(self, j):
+        """Host copies of buffer set j: list of per-image (keypoints, descriptors) + per-frame (uright, depth, nmatch)."""
+        r = self.ring
+        cnt = r.cnt[j].cpu().numpy()
+        kps = r.kps[j].cpu().numpy().view(np.uint8).reshape(self.nimg, self.cap, 28)
+        desc = r.desc[j].cpu().numpy()
+        ur, dp, nm = r.ur[j].cpu().numpy(), r.dp[j].cpu().numpy(), r.nm[j].cpu().numpy()
+        imgs = []
+        for b in range(self.nimg):
+            n = int(cnt[b])
+            imgs.append((np.frombuffer(kps[b, :n].tobytes(), KP_DTYPE).copy(), desc[b, :n].copy()))
+        frames = []
+        if self.stereo:
+            for b in range(self.B):
+                n = int(cnt[b])
+                frames.append((ur[b, :n].copy(), dp[b, :n].copy(), int(nm[b])))
+        return imgs, frames

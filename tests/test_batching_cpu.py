@@ -81,3 +81,71 @@ def test_allgather_world2_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert res == [(0, True, total), (1, True, total)]
+
+
+def _ring_fill(ring, j, rank, step, B, cap):
+    """What a step's kernels would leave in buffer set j: data that depends on (rank, step, frame)."""
+    ids = [10000 * step + 100 * rank + b for b in range(B)]
+    kps, desc, ur, dp, cnt = _fake(ids, cap)
+    ring.kps[j][:B].copy_(kps); ring.desc[j][:B].copy_(desc); ring.ur[j].copy_(ur); ring.dp[j].copy_(dp)
+    ring.cnt[j][:B].copy_(cnt)
+
+
+def _ring_expected(world, step, B, cap):
+    return _fake([10000 * step + 100 * r + b for r in range(world) for b in range(B)], cap)
+
+
+def _ring_check(ring, j, world, step, B, cap):
+    u = ring.gathered(j)
+    exp = _ring_expected(world, step, B, cap)
+    return ring.gathered_steps[j] == step and all(
+        torch.equal(a, b) for a, b in zip((u["kps"], u["desc"], u["uright"], u["depth"], u["counts"]), exp))
+
+
+def _ring_worker(rank, world, port, q):
+    """bench.py's step loop (pipeline.FrontEnd.step = acquire -> kernels -> publish) on CPU tensors over gloo: the
+    all-gather of step i is asynchronous and set j is refilled at step i + nbuf, so acquire() must have waited for it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, cap, nbuf, steps = 3, 19, 3, 8
+        ring = batching.ResultRing(nbuf, B, 2 * B, cap, torch.device("cpu"), world=world, gather=True)
+        ok = True
+        for i in range(steps):
+            j = ring.acquire(i)
+            if i >= nbuf:        # set j's previous exchange (step i - nbuf) is complete and intact at this point
+                ok = ok and _ring_check(ring, j, world, i - nbuf, B, cap)
+            _ring_fill(ring, j, rank, i, B, cap)
+            ring.publish(j, i)
+        ring.drain()
+        for i in range(steps - nbuf, steps):
+            ok = ok and _ring_check(ring, i % nbuf, world, i, B, cap)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_result_ring_double_buffering_world2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_result_ring_single_rank_is_a_no_op_exchange():
+    ring = batching.ResultRing(3, 2, 4, 11, torch.device("cpu"), world=1, gather=True)
+    assert not ring.gather
+    j = ring.acquire(5)
+    assert j == 2
+    ring.publish(j, 5)
+    ring.drain()

@@ -1,0 +1,116 @@
+"""The timed path IS the tested path: exactly the step bench.py times (orb_slam2v2-1_amd/pipeline.py: ONE handle,
+orbx_extract_batch_device on 2B images, orbm_stereo_batch_device(h, h, B, 0, B, ...)) against the CPU oracle, every
+frame of the batch byte for byte — keypoints, descriptors, counts, mvuRight, mvDepth, match counts.
+
+BASELINE configs covered here in their BATCHED form: 2 (KITTI 1241x376 stereo, 1000 and 2000 features), 3 (EuRoC 752x480
+stereo, 64-frame batch), 4's per-GPU share (32 frames of 1920x1080 / 4000 features).  Reference: src/Frame.cc:61-120,
+481-655; src/ORBextractor.cc:1043-1105."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+PKG = "orb_slam2v2-1_amd"
+
+
+def _pipeline():
+    return importlib.import_module(PKG + ".pipeline")
+
+
+def _ref():
+    import oracle  # noqa: F401  (builds the checker)
+    oracle.build()
+    return importlib.import_module("oracle.reference_frames")
+
+
+def _run_stereo(w, h, nf, B, seed0, streams=1, steps=1, fx=None, mbf=None):
+    pl, ref = _pipeline(), _ref()
+    kw = {}
+    if fx is not None:
+        kw = {"fx": fx, "mbf": mbf}
+    fe = pl.FrontEnd(w, h, nf, True, B, streams=streams, **kw)
+    exp = ref.run_pool(ref.stereo_frame, [(w, h, nf, seed0 + i, fe.mbf, fe.mb) for i in range(B)])
+    fe.upload(np.stack([e["left"] for e in exp]), np.stack([e["right"] for e in exp]))
+    bad = []
+    for i in range(steps):
+        j = fe.step(i)
+    fe.drain()
+    for i in range(max(0, steps - fe.ring.nbuf), steps):       # every buffer set still holding a step's results
+        imgs, frames = fe.results(i % fe.ring.nbuf)
+        for b in range(B):
+            e = exp[b]
+            for side, k, d, gi in (("left", e["kl"], e["dl"], b), ("right", e["kr"], e["dr"], B + b)):
+                m = ref.image_mismatch(imgs[gi][0], imgs[gi][1], k, d)
+                if m:
+                    bad.append("step %d frame %d %s: %s" % (i, b, side, m))
+            m = ref.stereo_mismatch(frames[b], e)
+            if m:
+                bad.append("step %d frame %d stereo: %s" % (i, b, m))
+    assert not bad, "\n".join(bad[:20])
+    return exp
+
+
+@pytest.mark.parametrize("w,h,nf,B", [(1241, 376, 1000, 64), (1241, 376, 2000, 64), (752, 480, 1000, 64)],
+                         ids=["kitti_1000feat_B64", "kitti_2000feat_B64", "euroc_B64"])
+def test_bench_step_stereo_batch(w, h, nf, B):
+    exp = _run_stereo(w, h, nf, B, seed0=0)
+    assert sum(e["nmatch"] for e in exp) > 50 * B        # the matcher really matched (not a batch of empty frames)
+
+
+def test_bench_step_three_handles_three_streams_one_thread():
+    """INTEGRATION.md's multi-handle mode: three handles on three streams driven from ONE host thread, 20 interleaved
+    steps with no join in between.  The stereo scratch lives in the left handle, so the steps cannot disturb each other;
+    every result still resident at the end (the last three steps, one per handle) equals the oracle."""
+    _run_stereo(1241, 376, 1000, 16, seed0=200, streams=3, steps=20)
+
+
+def test_bench_step_mono_full_hd_batch32():
+    """Config 4's per-GPU share: 32 frames of 1920x1080, 4000 features, one batched call."""
+    pl, ref = _pipeline(), _ref()
+    w, h, nf, B = 1920, 1080, 4000, 32
+    exp = ref.run_pool(ref.mono_frame, [(w, h, nf, 300 + i) for i in range(B)])
+    fe = pl.FrontEnd(w, h, nf, False, B)
+    fe.upload(np.stack([e["img"] for e in exp]))
+    j = fe.step(0)
+    fe.drain()
+    imgs, _ = fe.results(j)
+    bad = []
+    for b in range(B):
+        m = ref.image_mismatch(imgs[b][0], imgs[b][1], exp[b]["k"], exp[b]["d"])
+        if m:
+            bad.append("frame %d: %s" % (b, m))
+    assert not bad, "\n".join(bad[:20])
+    assert min(len(e["k"]) for e in exp) > 3800
+
+
+def test_stereo_scratch_regrows_and_large_cap():
+    """The per-handle stereo scratch grows with (B, cap); a cap above the LDS plan of k_stereo_median (12288) takes the
+    global-memory form of the median kernel - results identical to the small-cap call on the same frame."""
+    import torch
+    pkg = importlib.import_module(PKG)
+    ref = _ref()
+    w, h, nf = 752, 480, 800
+    e = ref.stereo_frame((w, h, nf, 77, 47.9, float(np.float32(47.9) / np.float32(435.2))))
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    imgs = np.stack([e["left"], e["right"]])
+    ex(imgs[0])
+    d_imgs = torch.from_numpy(imgs).cuda()
+    out = []
+    for cap in (ex.max_keypoints(), 20000):
+        kps = torch.zeros((2, cap, 7), dtype=torch.float32, device="cuda")
+        desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+        ur = torch.zeros((1, cap), dtype=torch.float32, device="cuda")
+        dp = torch.zeros((1, cap), dtype=torch.float32, device="cuda")
+        nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        ex.extract_batch_device(d_imgs.data_ptr(), 2, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)
+        pkg.stereo_batch_device(ex, ex, 1, 0, 1, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), kps[1:].data_ptr(),
+                                desc[1:].data_ptr(), cnt[1:].data_ptr(), cap, 47.9, float(np.float32(47.9) / np.float32(435.2)),
+                                ur.data_ptr(), dp.data_ptr(), nm.data_ptr(), st)
+        torch.cuda.synchronize()
+        n = int(cnt[0])
+        out.append((ur[0, :n].cpu().numpy(), dp[0, :n].cpu().numpy(), int(nm[0])))
+    for got in out:
+        assert ref.stereo_mismatch(got, e) is None, ref.stereo_mismatch(got, e)
