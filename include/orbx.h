@@ -305,6 +305,9 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  * Never set in production: keys 0, 1 and 7 leave outputs incomplete; 2, 4, 5, 6 select an alternative
  * kernel with identical results (tests use them to cover those kernels). */
 int orbx_debug_set(int key, int value);
+/* Test hook: the device's restatement of libm cosf / sinf (the float overloads src/ORBextractor.cc:113 resolves to) on n
+ * host angles in [0, 2 pi]; the descriptor kernel uses exactly this routine. */
+int orbx_debug_sincosf(const float *angles, int n, float *sin_out, float *cos_out, int device);
 
 /* ---- misc ---------------------------------------------------------------------------- */
 /* ---- DBoW2 vocabulary descent and the BoW-guided matchers.

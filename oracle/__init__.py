@@ -90,6 +90,9 @@ def lib():
         L.oracle_blurred_level.argtypes = [vp, i32]
         L.oracle_fast_atan2.restype = f32
         L.oracle_fast_atan2.argtypes = [f32, f32]
+        L.oracle_set_sincos_mode.argtypes = [i32]
+        L.oracle_sincosf.argtypes = [f32, C.POINTER(f32), C.POINTER(f32)]
+        L.oracle_sincosf_array.argtypes = [vp, i32, vp, vp]
         L.oracle_cv_round.restype = i32
         L.oracle_cv_round.argtypes = [C.c_double]
         L.oracle_fast_score.restype = i32
@@ -249,6 +252,24 @@ def imgs_from_levels(levels):
         keep.append(im)
         arr[l].ptr, arr[l].w, arr[l].h, arr[l].stride = im.ctypes.data, im.shape[1], im.shape[0], im.shape[1]
     return arr, keep
+
+
+def set_sincos_mode(mode):
+    """0 restated glibc cosf/sinf (default = the reference's float overloads), 1 host libm cosf/sinf, 2 double rounded."""
+    lib().oracle_set_sincos_mode(int(mode))
+
+
+def sincosf(angle):
+    s, c = C.c_float(), C.c_float()
+    lib().oracle_sincosf(float(angle), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def sincosf_array(angles):
+    a = np.ascontiguousarray(angles, np.float32)
+    s, c = np.zeros_like(a), np.zeros_like(a)
+    lib().oracle_sincosf_array(_p(a), len(a), _p(s), _p(c))
+    return s, c
 
 
 def hamming(a, b):

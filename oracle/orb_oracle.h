@@ -60,6 +60,11 @@ const double *oracle_stage_seconds(const orb_oracle_t *o);
 /* primitives exposed for unit tests */
 float oracle_fast_atan2(float y, float x);
 int oracle_cv_round(double v);
+/* cos / sin of the descriptor angle (src/ORBextractor.cc:113): mode 0 restated glibc cosf/sinf (default), 1 host libm
+ * cosf/sinf, 2 (float)cos((double)) - see orb_oracle_extract.c.  The mode is process-global: tests only. */
+void oracle_set_sincos_mode(int mode);
+void oracle_sincosf(float angle, float *s, float *c);
+void oracle_sincosf_array(const float *a, int n, float *s, float *c);
 int oracle_fast_score(const uint8_t *p, int stride, int threshold); /* cornerScore<16>; p = centre */
 int oracle_fast_is_corner(const uint8_t *p, int stride, int threshold);
 /* cv::FAST(img, thr, nms=true) on a w x h sub-image; writes up to cap (x,y,score), returns n */

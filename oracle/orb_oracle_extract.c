@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include "orb_oracle_sincosf.h"
 
 #define PATCH_SIZE 31
 #define HALF_PATCH_SIZE 15
@@ -506,10 +507,23 @@ static float ic_angle(const uint8_t *center, int step, const int32_t *umax) {
 }
 
 /* ------------------------------------------- computeOrbDescriptor (:108-147) */
+/* `cos(angle)` / `sin(angle)` with float angle under `using namespace std;` (:67) are the float overloads = libm's
+ * cosf / sinf.  Mode 0 (default): the restatement of glibc's algorithm (orb_oracle_sincosf.h, platform independent);
+ * mode 1: this host's libm cosf / sinf; mode 2: the double functions rounded to float (what round 1 assumed) - the
+ * last two exist so that tests can count what the choice changes. */
+static int g_sincos_mode = 0;
+void oracle_set_sincos_mode(int mode) { g_sincos_mode = mode; }
+void oracle_sincosf(float angle, float *s, float *c) {
+    if (g_sincos_mode == 1) { *c = cosf(angle); *s = sinf(angle); }
+    else if (g_sincos_mode == 2) { *c = (float)cos((double)angle); *s = (float)sin((double)angle); }
+    else { *c = rs_cosf(angle); *s = rs_sinf(angle); }
+}
+void oracle_sincosf_array(const float *a, int n, float *s, float *c) { for (int i = 0; i < n; i++) oracle_sincosf(a[i], &s[i], &c[i]); }
 static void orb_descriptor(float kp_angle, const uint8_t *center, int step, uint8_t *desc) {
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float angle = kp_angle * factorPI;
-    float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    float a, b;
+    oracle_sincosf(angle, &b, &a);
     const int8_t *pat = k_pattern;
     for (int i = 0; i < 32; ++i, pat += 32) {
         int val = 0;

@@ -41,7 +41,7 @@ EXPORTS = [
     "orbm_search_by_projection_frame", "orbm_match_windows", "orbm_best_in_windows", "orbm_distinctive_descriptors", "orbm_predict_scale_thresholds", "orbm_is_in_frustum",
     "orbm_search_local_points", "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_transform",
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
-    "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch",
+    "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch", "orbx_debug_sincosf",
 ]
 
 
@@ -157,6 +157,7 @@ def lib():
     L.orbm_search_local_points.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp, i32, vp, vp, i32, vp, C.POINTER(Camera), f32,
                                            vp, vp, vp, f32, f32, i32, C.POINTER(i32), vp]
     L.orbm_best_in_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, i32, vp, vp, i32]
+    L.orbx_debug_sincosf.argtypes = [vp, i32, vp, vp, i32]
     L.orbx_last_error.restype = C.c_char_p
     L.orbx_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -304,6 +305,14 @@ class ORBextractor:
         n = C.c_int(0)
         _check(self._L.orbx_get_stage_ms(self._h, _p(ms), C.byref(n)))
         return ms, n.value
+
+
+def debug_sincosf(angles, device=0):
+    """Test hook: the device's cosf / sinf restatement -> (sin, cos) float32 arrays."""
+    a = np.ascontiguousarray(angles, np.float32)
+    s, c = np.zeros_like(a), np.zeros_like(a)
+    _check(lib().orbx_debug_sincosf(_p(a), len(a), _p(s), _p(c), int(device)))
+    return s, c
 
 
 def pack_records_device(d_kps, d_desc, d_uright, d_depth, d_counts, B, cap, d_records, stream=0):

@@ -57,28 +57,37 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-// (float)cos((double)a), (float)sin((double)a) for a in [0, 2*pi] (src/ORBextractor.cc:112-113).
-// The generic double-precision library routines cost ~220 fp64 instructions per wave (two range
-// reductions with a Payne-Hanek path); here: one Cody-Waite reduction by k*pi/2 (k <= 4, exact
-// product with the 33-bit head of pi/2) and the fdlibm kernel polynomials on |r| <= pi/4, < 1 ulp
-// in double, so the value rounded to float is the library's (differences need a double result
-// within 1e-16 of a float rounding boundary).
-__device__ __forceinline__ void sincos_0_2pi(float af, float &sn, float &cs) {
-    const double a = (double)af;
-    const double k = rint(a * 6.36619772367581382433e-01);                       // 2/pi
-    const double r = (a - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
-    const double z = r * r;
-    const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
-                      z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-    const double s = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
-    const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
-                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
-    const double hz = 0.5 * z, w = 1.0 - hz;
-    const double c = w + (((1.0 - w) - hz) + z * pc);
-    const int q = (int)k & 3;
-    const double sq = (q & 1) ? c : s, cq = (q & 1) ? s : c;
-    sn = (float)((q & 2) ? -sq : sq);
-    cs = (float)(((q + 1) & 2) ? -cq : cq);
+// cos(angle), sin(angle) of src/ORBextractor.cc:113.  `angle` is a float and the file says `using namespace std;` (:67), so
+// these are std::cos(float) / std::sin(float) = the C library's cosf / sinf, not the double functions rounded to float (the
+// two differ for ~1 % of angles).  Restated: glibc >= 2.28 sinf / cosf (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c,
+// sincosf.h, sincosf_data.c) for |y| < 120: the argument in double, n = round(y * 2/pi) from a scaled double -> int32
+// truncation, x = y - n * pi/2, a degree-7 sine / degree-8 cosine polynomial in double evaluated in glibc's operation
+// order (no FMA contraction: the build uses -ffp-contract=off), one rounding to float.  The second coefficient table of
+// glibc (quadrants 2, 3) is the first with the cosine polynomial negated, i.e. the negated result.  The oracle's copy of
+// this algorithm equals the host libm for every float in [0, 6.2832] (oracle/orb_oracle_sincosf.h).
+__device__ __forceinline__ void sincosf_glibc(float y, float &sn, float &cs) {
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;          // abstop12
+    if (top < ((0x3a800000u >> 20) & 0x7ffu)) { sn = y; cs = 1.0f; return; }   // |y| < 2^-12
+    double x = (double)y;
+    int n = 0;
+    if (top >= ((0x3f490fdbu >> 20) & 0x7ffu)) {                       // |y| >= pi/4 (abstop12 of 0x1.921FB6p-1f): reduce_fast
+        const double r = x * 0x1.45F306DC9C883p+23;                    // 2/pi * 2^24
+        n = ((int)r + 0x800000) >> 24;
+        x = x - (double)n * 0x1.921FB54442D18p0;
+    }
+    const double sgn = ((n + 1) & 2) ? -1.0 : 1.0;                     // sign[n & 3] = {1, -1, -1, 1}
+    const double xs = x * sgn, x2 = x * x;
+    // sine polynomial (n even in sinf_poly)
+    const double x3 = xs * x2, s1 = 0x1.1107605230bc4p-7 + x2 * -0x1.994eb3774cf24p-13, x7 = x3 * x2,
+                 s = xs + x3 * -0x1.555545995a603p-3;
+    const float SP = (float)(s + x7 * s1);
+    // cosine polynomial (n odd), first table
+    const double x4 = x2 * x2, c2 = -0x1.6c087e89a359dp-10 + x2 * 0x1.99343027bf8c3p-16, c1 = 0x1p0 + x2 * -0x1.ffffffd0c621cp-2,
+                 x6 = x4 * x2, c = c1 + x4 * 0x1.55553e1068f19p-5;
+    float CP = (float)(c + x6 * c2);
+    if (n & 2) CP = -CP;
+    sn = (n & 1) ? CP : SP;
+    cs = (n & 1) ? SP : CP;
 }
 
 // IC_Angle weights per lane (lane = 2 * (v + 15) + half: row v of the radius-15 disc, u = -15..0 or u = 1..16), as bytes for
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ang = angle * factorPI;
     float ca, sa;
-    sincos_0_2pi(ang, sa, ca);
+    sincosf_glibc(ang, sa, ca);
     const uint8_t *Bc = Bl + ORBX_DESC_R * BSTRIDE + ORBX_DESC_R;
     unsigned long long bits[4];
 #pragma unroll
@@ -342,4 +351,31 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
         kp.class_id = -1;
         kps[oi] = kp;
     }
+}
+
+// ---- test hook: the device's cosf / sinf restatement on an array of angles (tests compare it with the oracle's and with
+// the host libm over the whole angle domain; a descriptor only ever exercises the angles its keypoints happen to have)
+__global__ __launch_bounds__(256) void k_debug_sincosf(const float *__restrict__ a, int n, float *__restrict__ s, float *__restrict__ c) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float sn, cs;
+    sincosf_glibc(a[i], sn, cs);
+    s[i] = sn; c[i] = cs;
+}
+extern "C" int orbx_debug_sincosf(const float *angles, int n, float *sin_out, float *cos_out, int device) {
+    if (!angles || !sin_out || !cos_out || n < 1) { orbx_set_error("orbx_debug_sincosf: bad arguments"); return ORBX_ERR_ARG; }
+    ORBX_HIP(hipSetDevice(device));
+    float *d = nullptr;
+    ORBX_HIP(hipMalloc(&d, sizeof(float) * 3 * (size_t)n));
+    hipError_t e = hipMemcpy(d, angles, sizeof(float) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_debug_sincosf, dim3((n + 255) / 256), dim3(256), 0, 0, d, n, d + n, d + 2 * (size_t)n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(sin_out, d + n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(cos_out, d + 2 * (size_t)n, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost);
+    hipFree(d);
+    ORBX_HIP(e);
+    return ORBX_OK;
 }

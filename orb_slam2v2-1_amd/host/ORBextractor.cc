@@ -37,14 +37,17 @@ ORBextractor::~ORBextractor() { orbx_destroy(mpHandle); }
 void ORBextractor::operator()(cv::InputArray image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint> &_keypoints,
                               cv::OutputArray _descriptors) {
     if (image.empty()) return;  // :1046-1047
-    assert(image.type() == CV_8UC1);  // :1050
+    // cv::_InputArray / cv::_OutputArray (real OpenCV) expose neither ptr() nor cols / rows / step: go through getMat(),
+    // as the reference does (`Mat image = _image.getMat();`, :1049); the shim's Mat has a trivial getMat()
+    const cv::Mat im = image.getMat();
+    assert(im.type() == CV_8UC1);  // :1050
     if (!mpHandle) { _keypoints.clear(); _descriptors.release(); return; }
 
     int cap = orbx_max_keypoints(mpHandle) + 256;
     mvKpBuf.resize(cap);
     cv::Mat desc(cap, 32, CV_8U);
     int n = 0;
-    int rc = orbx_extract(mpHandle, image.ptr(0), image.cols, image.rows, (int)image.step, mvKpBuf.data(),
+    int rc = orbx_extract(mpHandle, im.ptr(0), im.cols, im.rows, (int)im.step, mvKpBuf.data(),
                           desc.ptr(0), cap, &n);
     if (rc != ORBX_OK) {
         std::fprintf(stderr, "ORBextractor: %s\n", orbx_last_error());
@@ -56,7 +59,8 @@ void ORBextractor::operator()(cv::InputArray image, cv::InputArray /*mask*/, std
     if (n == 0) _descriptors.release();  // :1064-1065
     else {
         _descriptors.create(n, 32, CV_8U);  // :1068
-        for (int i = 0; i < n; i++) std::memcpy(_descriptors.ptr(i), desc.ptr(i), 32);
+        cv::Mat out = _descriptors.getMat();   // shares the buffer create() allocated (:1069)
+        for (int i = 0; i < n; i++) std::memcpy(out.ptr(i), desc.ptr(i), 32);
     }
     for (int i = 0; i < n; i++) {
         const orbx_keypoint_t &s = mvKpBuf[i];

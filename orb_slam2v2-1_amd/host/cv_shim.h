@@ -67,6 +67,9 @@ public:
     template <typename T> T &at(int r, int c = 0) { return ((T *)(data + (size_t)r * step))[c]; }
     template <typename T> const T &at(int r, int c = 0) const { return ((const T *)(data + (size_t)r * step))[c]; }
     Mat row(int r) const { Mat m(1, cols, type_, (void *)ptr(r), step); m.buf_ = buf_; return m; }
+    // cv::_InputArray / cv::_OutputArray hand out the matrix with getMat(); here InputArray / OutputArray ARE Mat
+    // references, so that the same source line (`cv::Mat im = image.getMat();`) compiles against both
+    Mat getMat() const { return *this; }
     static Mat zeros(int r, int c, int type) { Mat m(r, c, type); std::memset(m.data, 0, (size_t)r * m.step); return m; }
     static Mat eye(int r, int c, int type) {
         Mat m = zeros(r, c, type);

@@ -345,3 +345,22 @@ def test_host_api_latency_odd_width(pkg, synth):
     k2, d2 = ex(wide[:, 13:13 + 1241])
     np.testing.assert_array_equal(k2, k)
     np.testing.assert_array_equal(d2, d)
+
+
+def test_device_sincosf_equals_oracle_and_host_libm(pkg, oracle):
+    """src/ORBextractor.cc:113 calls the FLOAT overloads (cosf / sinf).  The descriptor kernel's restatement of glibc's
+    algorithm against the oracle's restatement (mode 0) AND this host's libm (mode 1), bit for bit, on 22 M floats of the
+    angle domain [0, 2 pi] (every 49th float + dense windows around the algorithm's branch points)."""
+    top = int(np.float32(6.2832).view(np.uint32))
+    us = [np.arange(0, top, 49, dtype=np.uint32)]
+    for centre in (0.0, 2.0 ** -12, 0.78539816, 1.5707964, 2.3561945, 3.1415927, 3.9269908, 4.712389, 5.4977871, 6.2831855):
+        u0 = int(np.float32(centre).view(np.uint32))
+        us.append(np.arange(max(u0 - 5000, 0), min(u0 + 5000, top), dtype=np.uint32))
+    ang = np.concatenate(us).view(np.float32)
+    gs, gc = pkg.debug_sincosf(ang)
+    for mode in (0, 1):
+        oracle.set_sincos_mode(mode)
+        os_, oc = oracle.sincosf_array(ang)
+        oracle.set_sincos_mode(0)
+        np.testing.assert_array_equal(gs.view(np.uint32), os_.view(np.uint32), err_msg="sin, oracle mode %d" % mode)
+        np.testing.assert_array_equal(gc.view(np.uint32), oc.view(np.uint32), err_msg="cos, oracle mode %d" % mode)
