@@ -67,7 +67,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 // this algorithm equals the host libm for every float in [0, 6.2832] (oracle/orb_oracle_sincosf.h).
 __device__ __forceinline__ void sincosf_glibc(float y, float &sn, float &cs) {
     const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;          // abstop12
-    if (top < ((0x3a800000u >> 20) & 0x7ffu)) { sn = y; cs = 1.0f; return; }   // |y| < 2^-12
+    if (top < ((0x39800000u >> 20) & 0x7ffu)) { sn = y; cs = 1.0f; return; }   // |y| < 2^-12
     double x = (double)y;
     int n = 0;
     if (top >= ((0x3f490fdbu >> 20) & 0x7ffu)) {                       // |y| >= pi/4 (abstop12 of 0x1.921FB6p-1f): reduce_fast

@@ -115,7 +115,7 @@ extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int i
 }
 
 static void free_plan(orbx_extractor *h) {
-    hipFree(h->d_cellOff); h->d_cellOff = nullptr;
+    hipFree(h->d_cellRaw); h->d_cellRaw = nullptr;
     hipFree(h->d_octFallback); h->d_octFallback = nullptr;
     hipFree(h->d_geom); hipFree(h->d_tab); hipFree(h->d_pyr); hipFree(h->d_cellCnt); hipFree(h->d_slots);
     hipFree(h->d_cand); hipFree(h->d_lvlKp); hipFree(h->d_nodeOf); hipFree(h->d_candCnt); hipFree(h->d_lvlCnt);
@@ -367,6 +367,18 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
         if (h->pyrLdsBytes > 150 * 1024) { orbx_set_error("pyramid tile needs %zu B of LDS", h->pyrLdsBytes); return ORBX_ERR_UNSUPPORTED; }
     }
     if (maxTw > 65 || maxTh > 65) { orbx_set_error("cell window %dx%d exceeds 65", maxTw, maxTh); return ORBX_ERR_UNSUPPORTED; }
+    {   // k_fast_strips takes the levels whose cells are at most 32 px wide (16 pixel pairs = one DPP row), k_fast_cells the rest
+        int nstrips = 0;
+        h->stripLevels = 0;
+        for (int l = 0; l <= ORBX_MAX_LEVELS; l++) {
+            h->stripBase[l] = nstrips;
+            if (l < h->nlevels && h->geom[l].wCell <= 32) {
+                nstrips += h->geom[l].nRows * ((h->geom[l].nCols + 3) / 4);
+                h->stripLevels |= 1u << l;
+            }
+        }
+        h->totalStrips = nstrips;
+    }
     h->max_kp = kpBound;
     h->totalCells = cellBase;
     h->maxNodeCap = maxNodeCap;
@@ -398,7 +410,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     ORBX_HIP(hipMalloc(&h->d_tab, sizeof(int32_t) * std::max<size_t>(tab.size(), 1)));
     ORBX_HIP(hipMalloc(&h->d_pyr, h->pyrImgBytes * Bz));
     ORBX_HIP(hipMalloc(&h->d_cellCnt, sizeof(uint32_t) * h->totalCells * Bz));
-    ORBX_HIP(hipMalloc(&h->d_cellOff, sizeof(uint32_t) * h->totalCells * Bz));
+    ORBX_HIP(hipMalloc(&h->d_cellRaw, sizeof(uint32_t) * h->totalCells * Bz));
     ORBX_HIP(hipMalloc(&h->d_slots, sizeof(uint32_t) * h->slotsPerImg * Bz));
     ORBX_HIP(hipMalloc(&h->d_cand, sizeof(uint32_t) * h->keysPerImg * Bz));
     ORBX_HIP(hipMalloc(&h->d_nodeOf, sizeof(uint16_t) * h->keysPerImg * Bz));
@@ -474,20 +486,32 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
     }
     if (profFast) ORBX_HIP(hipEventRecord(ev[1], st));
     {   // K2
-        dim3 grid((h->totalCells + FAST_WAVES - 1) / FAST_WAVES, B);
+        // developer knob 6: 1 = every level by k_fast_cells (compile-time tile strides), 2 = ... with run-time strides
+        const bool strips = h->totalStrips > 0 && g_debug[6] == 0;
+        const unsigned stripLevels = strips ? h->stripLevels : 0u;
+        if (strips) {
+            StripBases sb;
+            for (int l = 0; l <= ORBX_MAX_LEVELS; l++) sb.v[l] = h->stripBase[l];
+            hipLaunchKernelGGL(k_fast_strips, dim3((h->totalStrips + FAST_WAVES - 1) / FAST_WAVES, B), dim3(64 * FAST_WAVES), 0, st,
+                               h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->totalStrips, h->totalCells, h->d_cellCnt, h->d_cellRaw,
+                               h->d_slots, h->slotsPerImg, h->ini_th, h->min_th, sb);
+        }
+        if (stripLevels != (1u << nl) - 1u) {   // levels with wider cells (the coarsest ones of small images)
+            dim3 grid((h->totalCells + FAST_WAVES - 1) / FAST_WAVES, B);
 #define ORBX_LAUNCH_FAST(EST)                                                                                         \
     hipLaunchKernelGGL(k_fast_cells<EST>, grid, dim3(64 * FAST_WAVES), (size_t)h->fastLdsPerWave * FAST_WAVES, st,  \
-                       h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_slots,            \
+                       h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_cellRaw, h->d_slots, \
                        h->slotsPerImg, h->ini_th, h->min_th, h->fastTileStride, h->fastScoreStride, h->fastTileRows, \
-                       h->fastLdsPerWave, g_debug[0], cb)
-        const int es = (h->fastScoreStride == h->fastTileStride - 8 && g_debug[6] == 0) ? h->fastTileStride : 0;
-        switch (es) {   // the strides of the usual 30-px cell grids; anything else takes the run-time-stride instance
-        case 44: ORBX_LAUNCH_FAST(44); break;
-        case 48: ORBX_LAUNCH_FAST(48); break;
-        case 52: ORBX_LAUNCH_FAST(52); break;
-        default: ORBX_LAUNCH_FAST(0); break;
-        }
+                       h->fastLdsPerWave, g_debug[0], cb, stripLevels)
+            const int es = (h->fastScoreStride == h->fastTileStride - 8 && g_debug[6] != 2) ? h->fastTileStride : 0;
+            switch (es) {   // the strides of the usual 30-px cell grids; anything else takes the run-time-stride instance
+            case 44: ORBX_LAUNCH_FAST(44); break;
+            case 48: ORBX_LAUNCH_FAST(48); break;
+            case 52: ORBX_LAUNCH_FAST(52); break;
+            default: ORBX_LAUNCH_FAST(0); break;
+            }
 #undef ORBX_LAUNCH_FAST
+        }
     }
     if (profFast) ORBX_HIP(hipEventRecord(ev[2], st));
     {   // K3
@@ -498,11 +522,9 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
         const int scratch = std::max(4 * h->maxNodeCap, maxCells + 1);
         ORBX_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->octLdsBytes));
-        hipLaunchKernelGGL(k_cell_scan, dim3(nl, B), dim3(256), 0, st, h->d_geom, nl, h->totalCells, h->d_cellCnt,
-                           h->d_cellOff, h->d_candCnt);
         hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
-                           dim3(256), 0, st, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_cellOff, h->d_slots,
-                           h->slotsPerImg, h->d_cand, h->keysPerImg, cb);
+                           dim3(256), 0, st, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_cellRaw, h->d_slots,
+                           h->slotsPerImg, h->d_cand, h->keysPerImg, h->d_candCnt, h->ini_th, h->min_th, cb);
         const bool usePyr = g_debug[4] == 0;
         if (usePyr) {
             ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_pyr, hipFuncAttributeMaxDynamicSharedMemorySize,

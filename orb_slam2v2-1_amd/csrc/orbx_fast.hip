@@ -1,4 +1,4 @@
-// orbx_fast.hip — per-cell cv::FAST with threshold fallback (src/ORBextractor.cc:789-829): k_fast_cells, k_cell_scan, k_gather
+// orbx_fast.hip — per-cell cv::FAST with threshold fallback (src/ORBextractor.cc:789-829): k_fast_strips, k_fast_cells, k_gather
 // (part of the ORB extractor, see orbx_extract.hip for the pipeline and the C ABI)
 #include "orbx_extract_dev.h"
 // ------------------------------------------------------------------------------------
@@ -30,29 +30,23 @@ __device__ __forceinline__ half2v pk_max3(half2v a, half2v b, half2v c) {
     return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
 }
 
-// FAST-9/16 score of the pixel pair (px, px+1) of row py of the evaluated area -> score tile
-__device__ __forceinline__ void fast_score_pair(const uint32_t *E, int ES, int sh, uint8_t *Sc, int SS, int tlo, int cw,
-                                                int py, int px) {
-    const uint32_t *q = E + (py + 3) * ES + px + 3 + sh;
-    const uint32_t *qm3 = q - 3 * ES, *qm2 = q - 2 * ES, *qm1 = q - ES, *qp1 = q + ES, *qp2 = q + 2 * ES,
-                   *qp3 = q + 3 * ES;
-    const uint32_t vv = q[0];
-    uint32_t rr[16];
-    rr[0] = qp3[0];   rr[1] = qp3[1];   rr[2] = qp2[2];   rr[3] = qp1[3];
-    rr[4] = q[3];     rr[5] = qm1[3];   rr[6] = qm2[2];   rr[7] = qm3[1];
-    rr[8] = qm3[0];   rr[9] = qm3[-1];  rr[10] = qm2[-2]; rr[11] = qm1[-3];
-    rr[12] = q[-3];   rr[13] = qp1[-3]; rr[14] = qp2[-2]; rr[15] = qp3[-1];
-    // A 16-bit half holding the integer n in [0,255] IS the f16 denormal n*2^-24, so the
-    // pixel pairs can be fed to the packed f16 pipe unchanged: differences, 3-input
-    // minima/maxima (v_pk_minimum3_f16 / v_pk_maximum3_f16, gfx950) and negation are exact
-    // on these values, and a positive result's bit pattern is again the integer.
+// cornerScore<16> + 1 of a pixel PAIR from its centre dword vv and its 16 ring dwords (each holds the two pixels in 16-bit halves).
+// A 16-bit half holding the integer n in [0,255] IS the f16 denormal n*2^-24, so the pixel pairs can be fed to the packed
+// f16 pipe unchanged: 3-input minima/maxima (v_pk_minimum3_f16 / v_pk_maximum3_f16, gfx950), differences and negation are
+// exact on these values, and a positive result's bit pattern is again the integer.
+//
+// cornerScore + 1 = max(dark, bright), dark = max over the 16 nine-arcs of min_k (v - r[k]), bright = max over the arcs of
+// min_k (r[k] - v).  The centre is the same in every term, so it leaves the minima: dark = v - A, bright = B - v with
+//     A = min over arcs of (max of the arc's ring pixels),   B = max over arcs of (min of the arc's ring pixels)
+// computed on the ring values themselves: no per-position difference (16 packed subtractions per pair less).
+// Two neighbouring arcs share eight elements: min(max arc_2j, max arc_2j+1) = max(C_j, min(r[2j], r[2j+9])) with
+// C_j = max r[2j+1..2j+8], and C_j is two of the eight 4-windows q[t] = max r[2t+1..2t+4]: 36 packed ops per polarity.
+// Returns the two values as signed 16-bit halves (negative = far from a corner).
+__device__ __forceinline__ half2v fast_ring_score(uint32_t vv, const uint32_t (&rr)[16]) {
     const half2v v = __builtin_bit_cast(half2v, vv);
     half2v d[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - __builtin_bit_cast(half2v, rr[k]);
-    // score + 1 = max(max_k min(arc_k), max_k min(-arc_k)) over the 16 nine-arcs arc_k = d[k..k+8].  Two neighbouring arcs
-    // share eight elements: max(min arc_2j, min arc_2j+1) = min(C_j, max(d[2j], d[2j+9])) with C_j = min d[2j+1..2j+8],
-    // and C_j is two of the eight 4-windows q[t] = min d[2t+1..2t+4]: 36 packed ops per polarity instead of 40.
+    for (int k = 0; k < 16; k++) d[k] = __builtin_bit_cast(half2v, rr[k]);
     half2v pmn[8], pmx[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) {
@@ -65,16 +59,31 @@ __device__ __forceinline__ void fast_score_pair(const uint32_t *E, int ES, int s
         qmn[t] = __builtin_elementwise_minimum(pmn[t], pmn[(t + 1) & 7]);
         qmx[t] = __builtin_elementwise_maximum(pmx[t], pmx[(t + 1) & 7]);
     }
-    half2v dk[8], bt[8];
+    half2v lo[8], hi[8];   // per arc pair: the larger of the two arc minima / the smaller of the two arc maxima
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         const half2v e0 = d[2 * t], e1 = d[(2 * t + 9) & 15];
-        dk[t] = pk_min3(qmn[t], qmn[(t + 2) & 7], __builtin_elementwise_maximum(e0, e1));
-        bt[t] = pk_max3(qmx[t], qmx[(t + 2) & 7], __builtin_elementwise_minimum(e0, e1));
+        lo[t] = pk_min3(qmn[t], qmn[(t + 2) & 7], __builtin_elementwise_maximum(e0, e1));
+        hi[t] = pk_max3(qmx[t], qmx[(t + 2) & 7], __builtin_elementwise_minimum(e0, e1));
     }
-    const half2v dark = pk_max3(pk_max3(dk[0], dk[1], dk[2]), pk_max3(dk[3], dk[4], dk[5]), __builtin_elementwise_maximum(dk[6], dk[7]));
-    const half2v brt = pk_min3(pk_min3(bt[0], bt[1], bt[2]), pk_min3(bt[3], bt[4], bt[5]), __builtin_elementwise_minimum(bt[6], bt[7]));
-    const short2v best = __builtin_bit_cast(short2v, __builtin_elementwise_maximum(dark, -brt));
+    const half2v Bv = pk_max3(pk_max3(lo[0], lo[1], lo[2]), pk_max3(lo[3], lo[4], lo[5]), __builtin_elementwise_maximum(lo[6], lo[7]));
+    const half2v Av = pk_min3(pk_min3(hi[0], hi[1], hi[2]), pk_min3(hi[3], hi[4], hi[5]), __builtin_elementwise_minimum(hi[6], hi[7]));
+    return __builtin_elementwise_maximum(v - Av, Bv - v);
+}
+
+// FAST-9/16 score of the pixel pair (px, px+1) of row py of the evaluated area -> score tile
+__device__ __forceinline__ void fast_score_pair(const uint32_t *E, int ES, int sh, uint8_t *Sc, int SS, int tlo, int cw,
+                                                int py, int px) {
+    const uint32_t *q = E + (py + 3) * ES + px + 3 + sh;
+    const uint32_t *qm3 = q - 3 * ES, *qm2 = q - 2 * ES, *qm1 = q - ES, *qp1 = q + ES, *qp2 = q + 2 * ES,
+                   *qp3 = q + 3 * ES;
+    const uint32_t vv = q[0];
+    uint32_t rr[16];
+    rr[0] = qp3[0];   rr[1] = qp3[1];   rr[2] = qp2[2];   rr[3] = qp1[3];
+    rr[4] = q[3];     rr[5] = qm1[3];   rr[6] = qm2[2];   rr[7] = qm3[1];
+    rr[8] = qm3[0];   rr[9] = qm3[-1];  rr[10] = qm2[-2]; rr[11] = qm1[-3];
+    rr[12] = q[-3];   rr[13] = qp1[-3]; rr[14] = qp2[-2]; rr[15] = qp3[-1];
+    const short2v best = __builtin_bit_cast(short2v, fast_ring_score(vv, rr));
     const int s0 = best.x, s1 = best.y;
     const uint32_t o0 = s0 > tlo ? (uint32_t)(s0 - 1) : 0u;
     const uint32_t o1 = (s1 > tlo && px + 1 < cw) ? (uint32_t)(s1 - 1) : 0u;
@@ -114,8 +123,8 @@ __device__ __forceinline__ void fast_nms_pair(const uint8_t *Sc, int SS, int cw,
 template <int ES_T>
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
-    int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ slots, size_t slotsPerImg,
-    int iniTh, int minTh, int ESrt, int SSrt, int tileRows, int ldsPerWave, int phaseLimit, CellBases cb) {
+    int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ cellRaw, uint32_t *__restrict__ slots, size_t slotsPerImg,
+    int iniTh, int minTh, int ESrt, int SSrt, int tileRows, int ldsPerWave, int phaseLimit, CellBases cb, unsigned stripLevels) {
     const int ES = ES_T ? ES_T : ESrt, SS = ES_T ? ES_T - 8 : SSrt;
     extern __shared__ __align__(16) uint8_t smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -124,6 +133,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     const int gc = bx * FAST_WAVES + wave;
     if (gc >= totalCells) return;  // wave-uniform; the kernel uses no block barrier
     const int l = level_of_cell(cb, nlevels, gc);
+    if ((stripLevels >> l) & 1u) return;   // this level's cells are k_fast_strips' (cells up to 32 px wide)
     const LevelGeom g = geom[l];
     const int c = gc - g.cellBase;
     const int ci = c / g.nCols, cj = c - ci * g.nCols;
@@ -131,8 +141,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     const int iniY = ORBX_MINB + ci * g.hCell, iniX = ORBX_MINB + cj * g.wCell;
     int maxY = iniY + g.hCell + 6, maxX = iniX + g.wCell + 6;
     uint32_t *cnt = cellCnt + (size_t)b * totalCells + gc;
+    uint32_t *raw = cellRaw + (size_t)b * totalCells + gc;   // list length | threshold choice << 31 (see k_gather)
     if (iniY >= maxBY - 3 || iniX >= maxBX - 6) {  // skipped rows / columns (:794-795,803-804)
-        if (lane == 0) *cnt = 0;
+        if (lane == 0) { *cnt = 0; *raw = 0; }
         return;
     }
     if (maxY > maxBY) maxY = maxBY;
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     const int tw = maxX - iniX, th = maxY - iniY;  // FAST sub-image
     const int cw = tw - 6, ch = th - 6;            // evaluated area (rows/cols 3 .. dim-4)
     if (cw <= 0 || ch <= 0) {
-        if (lane == 0) *cnt = 0;
+        if (lane == 0) { *cnt = 0; *raw = 0; }
         return;
     }
     uint32_t *E = (uint32_t *)(smem + (size_t)wave * ldsPerWave);  // pair tile [th][ES] dwords
@@ -295,69 +306,219 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
         }
         total += __popcll(m);
     }
-    if (lane == 0) *cnt = (uint32_t)min(total, g.capc);
+    // this kernel's list is already filtered by the cell's threshold: k_gather's filter passes every entry
+    if (lane == 0) { *cnt = (uint32_t)min(total, g.capc); *raw = (uint32_t)min(total, g.capc) | (anyIni ? 0x80000000u : 0u); }
 }
 
 // ------------------------------------------------------------------------------------
-// K2b: per (level, image): exclusive scan of the cell counts = offsets of the cell lists in
-// the ordered concatenation (vToDistributeKeys order, :789-828).
-__global__ __launch_bounds__(256) void k_cell_scan(const LevelGeom *__restrict__ geom, int nlevels, int totalCells,
-                                                   const uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ cellOff,
-                                                   int32_t *__restrict__ candCnt) {
-    __shared__ int wsum[4];
-    const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const LevelGeom g = geom[l];
-    const uint32_t *cc = cellCnt + (size_t)b * totalCells + g.cellBase;
-    uint32_t *co = cellOff + (size_t)b * totalCells + g.cellBase;
-    const int chunk = (g.ncells + 255) / 256;
-    const int beg = min(tid * chunk, g.ncells), end = min(beg + chunk, g.ncells);
-    int s = 0;
-    for (int c = beg; c < end; c++) s += (int)cc[c];
-    const int inc = wave_incl_scan_i32(s);
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int off = inc - s, tot = 0;
-    for (int w = 0; w < 4; w++) {
-        if (w < wave) off += wsum[w];
-        tot += wsum[w];
-    }
-    for (int c = beg; c < end; c++) {
-        co[c] = (uint32_t)off;
-        off += (int)cc[c];
-    }
-    if (tid == 0) candCnt[b * nlevels + l] = tot;
-}
+// K2 for levels whose cells are at most 32 px wide (every level of the usual image sizes except the coarsest ones): ONE WAVE PER
+// STRIP OF FOUR horizontally adjacent cells, the window rows streamed through LDS.
+//   * lane = 16 * cell + pixel pair: a cell is one 16-lane DPP row, so the horizontal neighbours of the 3x3 non-maximum
+//     suppression come from row_shr:1 / row_shl:1 with zero fill at the row ends - exactly cv::FAST's "scores outside the
+//     evaluated area are 0" at a cell seam - and the vertical neighbours are the lane's own previous / next iteration: the
+//     scores never leave the registers (k_fast_cells: a byte tile in LDS, zeroed, written, read back with 9 v_perm per pair);
+//   * the iteration is one evaluated ROW of the four cells (30 rows x 16 lanes per cell instead of 8 x 64: no half-empty last
+//     iteration), reading the 7 window rows it needs from a ring of 8 rows in LDS; the next window row is in flight from global
+//     memory while a row is scored (k_fast_cells: the whole window first, a fifth of its time spent waiting for it).  Rows 0..5 of
+//     the ring are mirrored behind it, so that any 7 consecutive rows are contiguous: one base register + immediates;
+//   * the threshold is not applied before the suppression: a pixel that passes the threshold t beats every neighbour below t
+//     anyway, and one that does not is never emitted, so NMS on the raw scores keeps the same pixels;
+//   * survivors with score >= min(iniTh, minTh) go straight to the cell's slot list in row-major order (ballot prefix inside the
+//     cell's 16 lanes); the per-cell threshold fallback (:809-816) is decided at the end of the strip from per-lane counters
+//     (nA: survivors >= iniTh, nB: >= minTh) and applied by k_gather while it compacts: count = nA ? nA : nB.
+#define STRIP_ES 144      // dwords per tile row: 4 x 32 px + 6 px of window + alignment shift (<= 3) + the last pair's partner, 16-B rows
+#define STRIP_SLOTS 14    // ring of 8 rows + mirror of its rows 0..5
+__device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t dpp_row_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }
 
-// K2c: sixteen lanes per cell copy its candidate list to its place in the level's key array.
-__global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ geom, int nlevels, int totalCells,
-                                                const uint32_t *__restrict__ cellCnt, const uint32_t *__restrict__ cellOff,
-                                                const uint32_t *__restrict__ slots, size_t slotsPerImg,
-                                                uint32_t *__restrict__ cand, size_t keysPerImg, CellBases cb) {
-    const int sub = threadIdx.x & 15;
+__global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
+    const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels, int totalStrips,
+    int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ cellRaw, uint32_t *__restrict__ slots, size_t slotsPerImg,
+    int iniTh, int minTh, StripBases sb) {
+    __shared__ __align__(16) uint32_t smem[FAST_WAVES * STRIP_SLOTS * STRIP_ES];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int bx, b;
     xcd_block_map(bx, b);
-    const int gc = bx * GATHER_CELLS_PER_BLOCK + (threadIdx.x >> 4);
-    if (gc >= totalCells) return;
-    const int l = level_of_cell(cb, nlevels, gc);
-    const int c = gc - geom[l].cellBase, capc = geom[l].capc;
-    const int cn = (int)cellCnt[(size_t)b * totalCells + gc], off = (int)cellOff[(size_t)b * totalCells + gc];
-    const uint32_t *src = slots + (size_t)b * slotsPerImg + geom[l].slotOff + (size_t)c * capc;
-    uint32_t *dst = cand + (size_t)b * keysPerImg + geom[l].keyOff + off;
-    for (int j0 = 0; j0 < cn; j0 += 64) {   // four loads in flight per lane before the stores
+    const int strip = bx * FAST_WAVES + wave;
+    if (strip >= totalStrips) return;   // wave-uniform; no block barrier in this kernel
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < ORBX_MAX_LEVELS; i++) l += (i < nlevels && strip >= sb.v[i]) ? 1 : 0;
+    const LevelGeom g = geom[l];
+    const int s = strip - sb.v[l];
+    const int ng = (g.nCols + 3) >> 2;
+    const int ci = s / ng, cj0 = 4 * (s - ci * ng);
+    const int c = lane >> 4, j = lane & 15, cj = cj0 + c;
+    const bool exists = cj < g.nCols;
+    const int maxBX = g.w - ORBX_MINB, maxBY = g.h - ORBX_MINB;
+    const int iniY = ORBX_MINB + ci * g.hCell, Xs = ORBX_MINB + cj0 * g.wCell;
+    const int th = min(iniY + g.hCell + 6, maxBY) - iniY, ch = th - 6;          // FAST sub-image rows, evaluated rows
+    const int cw = exists ? min(g.wCell, maxBX - (ORBX_MINB + cj * g.wCell) - 6) : 0;   // evaluated columns of MY cell (<= 0: skipped, :803-804)
+    const int cw0 = min(g.wCell, maxBX - Xs - 6);                               // ... of the strip's first cell (wave-uniform)
+    const size_t cellIdx = (size_t)b * totalCells + g.cellBase + ci * g.nCols + cj;
+    if (iniY >= maxBY - 3 || ch <= 0 || cw0 <= 0) {   // skipped rows (:794-795) / nothing to evaluate
+        if (j == 0 && exists) { cellCnt[cellIdx] = 0; cellRaw[cellIdx] = 0; }
+        return;
+    }
+    const int cjL = min(cj0 + 3, g.nCols - 1);
+    const int tws = min(ORBX_MINB + cjL * g.wCell + g.wCell + 6, maxBX) - Xs;   // strip window width: its cells' windows overlap by 6 px
+
+    // ---- window rows: aligned dword pairs -> four pixel-PAIR dwords -> ring (pstride % 4 == 0: every row has the same misalignment)
+    uint32_t *E = smem + wave * (STRIP_SLOTS * STRIP_ES);
+    const size_t a = (size_t)(ORBX_EDGE + iniY) * g.pstride + ORBX_EDGE + Xs;
+    const int sh = (int)(a & 3);
+    const uint8_t *src = pyr + (size_t)b * pyrImgBytes + g.poff + (a - sh);
+    const int nd = (sh + tws + 3) >> 2;                       // aligned source dwords per window row (<= 36)
+    const int qi = min(lane, nd - 1);                         // lanes past the row repeat its last item (same value, same address)
+    const uint32_t loff = (uint32_t)qi * 4u;
+    auto load_row = [&](int r) -> uint2 {
+        const uint32_t *p = (const uint32_t *)(src + (size_t)min(r, th - 1) * g.pstride + loff);   // scalar row base + lane offset
+        uint2 d;
+        d.x = p[0]; d.y = p[1];
+        return d;
+    };
+    auto write_row = [&](int r, uint2 d) {
+        uint4 e;  // bytes b0..b3 of d.x and b4 = first byte of d.y -> pairs (b0,b1) (b1,b2) (b2,b3) (b3,b4)
+        e.x = __builtin_amdgcn_perm(d.y, d.x, 0x0c010c00u);
+        e.y = __builtin_amdgcn_perm(d.y, d.x, 0x0c020c01u);
+        e.z = __builtin_amdgcn_perm(d.y, d.x, 0x0c030c02u);
+        e.w = __builtin_amdgcn_perm(d.y, d.x, 0x0c040c03u);
+        const int slot = r & 7;
+        *(uint4 *)(E + slot * STRIP_ES + 4 * qi) = e;
+        if (slot < 6) *(uint4 *)(E + (slot + 8) * STRIP_ES + 4 * qi) = e;   // wave-uniform
+    };
+    {   // rows 0..6 (the first evaluated row's ring) + row 7 in flight: all eight loads issued before the first LDS write
+        uint2 d[7];
+#pragma unroll
+        for (int r = 0; r < 7; r++) d[r] = load_row(r);
+#pragma unroll
+        for (int r = 0; r < 7; r++) write_row(r, d[r]);
+    }
+    uint2 pre = load_row(7);
+    wave_sync();
+
+    const int tlo = max(min(iniTh, minTh), 0);
+    const int i0 = c * g.wCell + 3 + 2 * j;                   // strip column of my pair's first pixel
+    const uint32_t *q0 = E + sh + i0;
+    const uint32_t vmask = (2 * j < cw ? 0xFFFFu : 0u) | (2 * j + 1 < cw ? 0xFFFF0000u : 0u);
+    const uint32_t lt = (1u << j) - 1u;
+    const int cshift = 16 * (c & 1);
+    const uint32_t x0 = (uint32_t)(cj * g.wCell + 3 + 2 * j), ybase = (uint32_t)(ci * g.hCell + 3);
+    uint32_t *out = slots + (size_t)b * slotsPerImg + g.slotOff + (size_t)(ci * g.nCols + cj) * g.capc;
+    // NMS state: S1 = scores (+1) of row y-1, H1 / H2 = 3-wide horizontal maxima of rows y-1 / y-2, LR1 = max(left, right) of row y-1
+    uint32_t S1 = 0, H1 = 0, H2 = 0, LR1 = 0;
+    int nRaw = 0, nA = 0, nB = 0;
+    for (int y = 0; y <= ch; y++) {
+        uint32_t S = 0;
+        if (y < ch) {   // wave-uniform
+            const uint32_t *q = q0 + (y & 7) * STRIP_ES;       // window rows y .. y+6 are ring slots (y & 7) .. (y & 7) + 6
+            const uint32_t vv = q[3 * STRIP_ES];
+            uint32_t rr[16];
+            rr[0] = q[6 * STRIP_ES];       rr[1] = q[6 * STRIP_ES + 1];   rr[2] = q[5 * STRIP_ES + 2];   rr[3] = q[4 * STRIP_ES + 3];
+            rr[4] = q[3 * STRIP_ES + 3];   rr[5] = q[2 * STRIP_ES + 3];   rr[6] = q[1 * STRIP_ES + 2];   rr[7] = q[1];
+            rr[8] = q[0];                  rr[9] = q[-1];                 rr[10] = q[1 * STRIP_ES - 2];  rr[11] = q[2 * STRIP_ES - 3];
+            rr[12] = q[3 * STRIP_ES - 3];  rr[13] = q[4 * STRIP_ES - 3];  rr[14] = q[5 * STRIP_ES - 2];  rr[15] = q[6 * STRIP_ES - 1];
+            const half2v best = fast_ring_score(vv, rr);
+            // score + 1, clamped at 0, pixels outside the cell's evaluated area = 0
+            S = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(best, (half2v){(_Float16)0, (_Float16)0})) & vmask;
+        }
+        // row y: (left neighbour's second pixel, my first) and (my second, right neighbour's first); zero beyond the cell
+        const uint32_t Lp = __builtin_amdgcn_perm(S, dpp_row_shr1(S), 0x05040302u);   // bytes: shr.hi | S.lo << 16
+        const uint32_t Rp = __builtin_amdgcn_perm(dpp_row_shl1(S), S, 0x05040302u);   // bytes: S.hi | shl.lo << 16
+        const half2v Lh = __builtin_bit_cast(half2v, Lp), Rh = __builtin_bit_cast(half2v, Rp), Sh = __builtin_bit_cast(half2v, S);
+        const uint32_t H0 = __builtin_bit_cast(uint32_t, pk_max3(Lh, Sh, Rh));
+        const uint32_t LR0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(Lh, Rh));
+        // strict 3x3 maximum of row y-1: rows y-2 and y through their horizontal maxima
+        const half2v nb = pk_max3(__builtin_bit_cast(half2v, H2), __builtin_bit_cast(half2v, H0), __builtin_bit_cast(half2v, LR1));
+        const short2v gt = __builtin_bit_cast(short2v, __builtin_bit_cast(half2v, S1) - nb);   // > 0 iff strictly greater (exact on these values)
+        const int s0 = (int)(S1 & 0xFFFFu), s1 = (int)(S1 >> 16);
+        const bool k0 = gt.x > 0 && s0 > tlo, k1 = gt.y > 0 && s1 > tlo;
+        const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+        if (m0 | m1) {   // wave-uniform
+            nA += (k0 && s0 > iniTh ? 1 : 0) + (k1 && s1 > iniTh ? 1 : 0);
+            nB += (k0 && s0 > minTh ? 1 : 0) + (k1 && s1 > minTh ? 1 : 0);
+            // my cell's 16 lanes of the two ballots; row-major order inside the row = first, second pixel of pair 0, of pair 1, ...
+            const uint32_t w0 = (((c & 2) ? (uint32_t)(m0 >> 32) : (uint32_t)m0) >> cshift) & 0xFFFFu;
+            const uint32_t w1 = (((c & 2) ? (uint32_t)(m1 >> 32) : (uint32_t)m1) >> cshift) & 0xFFFFu;
+            const int pos = nRaw + __popc(w0 & lt) + __popc(w1 & lt);
+            const uint32_t yy = (ybase + (uint32_t)(y - 1)) << 12;
+            if (k0 && pos < g.capc) out[pos] = x0 | yy | ((uint32_t)(s0 - 1) << 24);
+            if (k1 && pos + (k0 ? 1 : 0) < g.capc) out[pos + (k0 ? 1 : 0)] = (x0 + 1u) | yy | ((uint32_t)(s1 - 1) << 24);
+            nRaw += __popc(w0) + __popc(w1);
+        }
+        S1 = S; H2 = H1; H1 = H0; LR1 = LR0;
+        // stream: window row y+7 (loaded during this iteration) replaces row y-1 in the ring; row y+8 goes in flight
+        if (y + 7 < th) write_row(y + 7, pre);   // wave-uniform
+        pre = load_row(y + 8);
+        wave_sync();
+    }
+    // per-cell totals: the 16 lanes of a cell
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { nA += __shfl_xor(nA, o); nB += __shfl_xor(nB, o); }
+    if (j == 0 && exists) {
+        cellCnt[cellIdx] = (uint32_t)min(nA ? nA : nB, g.capc);
+        cellRaw[cellIdx] = (uint32_t)min(nRaw, g.capc) | (nA ? 0x80000000u : 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K2c: the cell lists -> the level's key array in vToDistributeKeys order (:789-828), applying the per-cell threshold
+// (cellRaw bit 31: some survivor reached iniTh -> keep score >= iniTh, else score >= minTh).  A block = 16 consecutive cells,
+// 16 lanes per cell.  A cell's place in its level's array = number of kept keys of the level's earlier cells: the cells before
+// the block are summed by the whole block (<= a few hundred counts), the ones inside it by a 16-entry scan - no separate scan
+// kernel.  The cell that closes a level writes the level's total (candCnt).
+__global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ geom, int nlevels, int totalCells,
+                                                const uint32_t *__restrict__ cellCnt, const uint32_t *__restrict__ cellRaw,
+                                                const uint32_t *__restrict__ slots, size_t slotsPerImg,
+                                                uint32_t *__restrict__ cand, size_t keysPerImg, int32_t *__restrict__ candCnt,
+                                                int iniTh, int minTh, CellBases cb) {
+    __shared__ int wsum[4], ccnt[GATHER_CELLS_PER_BLOCK], clvl[GATHER_CELLS_PER_BLOCK];
+    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    int bx, b;
+    xcd_block_map(bx, b);
+    const int gc0 = bx * GATHER_CELLS_PER_BLOCK, gc = gc0 + grp;
+    const uint32_t *cc = cellCnt + (size_t)b * totalCells;
+    const int l0 = level_of_cell(cb, nlevels, gc0), base0 = cb.v[l0];
+    // kept keys of the cells [base0, gc0) of the block's first level
+    int part = 0;
+    for (int i = base0 + tid; i < gc0; i += 256) part += (int)cc[i];
+    part = wave_total_i32(part);
+    if ((tid & 63) == 0) wsum[tid >> 6] = part;
+    const bool live = gc < totalCells;
+    const int l = live ? level_of_cell(cb, nlevels, gc) : -1;
+    const int cn = live ? (int)cc[gc] : 0;
+    if (sub == 0) { ccnt[grp] = cn; clvl[grp] = l; }
+    __syncthreads();
+    if (!live) return;
+    int off = l == l0 ? wsum[0] + wsum[1] + wsum[2] + wsum[3] : 0;
+    for (int k = 0; k < grp; k++) off += clvl[k] == l ? ccnt[k] : 0;
+    const LevelGeom g = geom[l];
+    if (sub == 0 && gc == g.cellBase + g.ncells - 1) candCnt[b * nlevels + l] = off + cn;
+    const uint32_t rw = cellRaw[(size_t)b * totalCells + gc];
+    const int nraw = (int)(rw & 0x7FFFFFFFu);
+    const uint32_t thr = (rw >> 31) ? (uint32_t)iniTh : (uint32_t)minTh;
+    const uint32_t *src = slots + (size_t)b * slotsPerImg + g.slotOff + (size_t)(gc - g.cellBase) * g.capc;
+    uint32_t *dst = cand + (size_t)b * keysPerImg + g.keyOff + off;
+    const int gshift = (tid & 48);   // my group's 16 lanes inside the wave's ballot
+    int kept = 0;
+    for (int j0 = 0; j0 < nraw; j0 += 64) {   // four loads in flight per lane before the stores
         uint32_t v[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = src[min(j0 + sub + 16 * k, cn - 1)];
-        // unconditional stores to the clamped slot (lanes past the end rewrite the last key with itself): under a lane
-        // condition the compiler sinks the load next to its store, behind a divergent branch
+        for (int k = 0; k < 4; k++) v[k] = src[min(j0 + sub + 16 * k, nraw - 1)];
 #pragma unroll
-        for (int k = 0; k < 4; k++) dst[min(j0 + sub + 16 * k, cn - 1)] = v[k];
+        for (int k = 0; k < 4; k++) {
+            const bool keep = j0 + sub + 16 * k < nraw && (v[k] >> 24) >= thr;
+            const uint32_t m = (uint32_t)(__ballot(keep) >> gshift) & 0xFFFFu;
+            if (keep) dst[kept + __popc(m & ((1u << sub) - 1u))] = v[k];
+            kept += __popc(m);
+        }
     }
 }
 
 // the tile strides of the usual 30-px cell grids + the run-time-stride instance
 #define ORBX_FAST_INSTANCE(EST)                                                                                              \
     template __global__ void k_fast_cells<EST>(const uint8_t *, size_t, const LevelGeom *, int, int, uint32_t *, uint32_t *, \
-                                               size_t, int, int, int, int, int, int, int, CellBases)
+                                               uint32_t *, size_t, int, int, int, int, int, int, int, CellBases, unsigned)
 ORBX_FAST_INSTANCE(0);
 ORBX_FAST_INSTANCE(44);
 ORBX_FAST_INSTANCE(48);

@@ -69,6 +69,8 @@ struct orbx_extractor {
     int totalCells, maxNodeCap, lvlKpCap;
     size_t pyrImgBytes, slotsPerImg, keysPerImg;
     int fastTileStride, fastScoreStride, fastTileRows, fastLdsPerWave;
+    int stripBase[ORBX_MAX_LEVELS + 1], totalStrips;   // k_fast_strips: first strip of every level, strips per image
+    unsigned stripLevels;                              // bit l: level l is k_fast_strips' (cells <= 32 px wide), else k_fast_cells'
     size_t octLdsBytes, octPyrLdsBytes;
     int octPyrWords;
     int32_t *d_octFallback;
@@ -78,7 +80,7 @@ struct orbx_extractor {
     LevelGeom *d_geom;
     int32_t *d_tab;
     uint8_t *d_pyr;
-    uint32_t *d_cellCnt, *d_cellOff, *d_slots, *d_cand, *d_lvlKp;
+    uint32_t *d_cellCnt, *d_cellRaw, *d_slots, *d_cand, *d_lvlKp;
     uint16_t *d_nodeOf;
     int32_t *d_candCnt, *d_lvlCnt;
     // staging for the host API

@@ -300,18 +300,36 @@ def test_quadtree_sweep_kernel_alone(pkg, oracle, synth):
         pkg.lib().orbx_debug_set(4, 0)
 
 
-def test_fast_runtime_stride_instance(pkg, oracle, synth):
-    """k_fast_cells<0> (run-time tile strides) serves every configuration whose stride has no compile-time
-    instance (44/48/52 dwords); forced here on configurations that normally take an instance, and reached
-    naturally by 60-px-tall single-cell levels (stride 60)."""
-    pkg.lib().orbx_debug_set(6, 1)
-    try:
-        _compare(pkg, oracle, synth.frame(752, 480, 85), 1000)
-        _compare(pkg, oracle, synth.frame(1241, 376, 86), 1000)
-    finally:
-        pkg.lib().orbx_debug_set(6, 0)
+def test_fast_cell_kernel_instances(pkg, oracle, synth):
+    """FAST runs as k_fast_strips (one wave per strip of four cells) on levels whose cells are at most 32 px wide and as
+    k_fast_cells (one wave per cell) on the others.  Developer knob 6 forces k_fast_cells on every level: 1 = its instances
+    with compile-time tile strides (44/48/52 dwords), 2 = the run-time-stride instance that serves every other configuration
+    (reached naturally by 60-px-tall single-cell levels, stride 60)."""
+    for knob in (1, 2):
+        pkg.lib().orbx_debug_set(6, knob)
+        try:
+            _compare(pkg, oracle, synth.frame(752, 480, 85), 1000)
+            _compare(pkg, oracle, synth.frame(1241, 376, 86), 1000)
+        finally:
+            pkg.lib().orbx_debug_set(6, 0)
     _compare(pkg, oracle, synth.frame(1241, 376, 86), 1000)
     _compare(pkg, oracle, synth.frame(333, 211, 87), 300, sf=1.3, nl=5)
+
+
+def test_fast_strips_and_cells_mix(pkg, oracle, synth):
+    """Sizes whose pyramid mixes strip levels (cells <= 32 px) with wide-cell levels (640x480: levels 5 and 7 have 33- and
+    37-px cells), a last strip with one / two / three cells, a last column narrower than its neighbours, and thresholds that
+    make the per-cell fallback (src/ORBextractor.cc:809-816) decide differently from cell to cell."""
+    _compare(pkg, oracle, synth.frame(640, 480, 90), 1000)
+    for w in (406, 437, 468, 499, 531):          # nCols = 12 .. 16 at level 0: every remainder of nCols mod 4
+        _compare(pkg, oracle, synth.frame(w, 300, 91 + w), 600)
+    rng = np.random.default_rng(93)
+    img = np.full((376, 1241), 100, np.uint8)
+    for _ in range(300):                                # faint and strong squares: some cells only reach minTh
+        x, y, c = rng.integers(20, 1200), rng.integers(20, 340), int(rng.choice([9, 12, 15, 40, 90]))
+        img[y:y + 7, x:x + 7] = 100 + c
+    _compare(pkg, oracle, img, 1500)
+    _compare(pkg, oracle, img, 1500, ini=12, mn=30)     # iniTh < minTh
 
 
 def test_quadtree_pyramid_overflow_falls_back(pkg, oracle):
