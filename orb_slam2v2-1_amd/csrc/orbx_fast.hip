@@ -371,21 +371,26 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
     const int nd = (sh + tws + 3) >> 2;                       // aligned source dwords per window row (<= 36)
     const int qi = min(lane, nd - 1);                         // lanes past the row repeat its last item (same value, same address)
     const uint32_t loff = (uint32_t)qi * 4u;
+    const int chS = __builtin_amdgcn_readfirstlane(ch), thS = __builtin_amdgcn_readfirstlane(th), pstrideS = __builtin_amdgcn_readfirstlane(g.pstride);
+    // everything that depends on the row number alone is kept on the scalar unit (readfirstlane): the loop counter, the ring
+    // slot, the row's byte offset (a padded level is far smaller than 4 GiB) - the vector ALU is the kernel's bottleneck
     auto load_row = [&](int r) -> uint2 {
-        const uint32_t *p = (const uint32_t *)(src + (size_t)min(r, th - 1) * g.pstride + loff);   // scalar row base + lane offset
+        const uint32_t ro = (uint32_t)(min(r, thS - 1) * pstrideS);
+        const uint32_t *p = (const uint32_t *)(src + ro + loff);   // scalar row base + 32-bit lane offset
         uint2 d;
         d.x = p[0]; d.y = p[1];
         return d;
     };
+    uint32_t *Ew = E + 4 * qi;
     auto write_row = [&](int r, uint2 d) {
         uint4 e;  // bytes b0..b3 of d.x and b4 = first byte of d.y -> pairs (b0,b1) (b1,b2) (b2,b3) (b3,b4)
         e.x = __builtin_amdgcn_perm(d.y, d.x, 0x0c010c00u);
         e.y = __builtin_amdgcn_perm(d.y, d.x, 0x0c020c01u);
         e.z = __builtin_amdgcn_perm(d.y, d.x, 0x0c030c02u);
         e.w = __builtin_amdgcn_perm(d.y, d.x, 0x0c040c03u);
-        const int slot = r & 7;
-        *(uint4 *)(E + slot * STRIP_ES + 4 * qi) = e;
-        if (slot < 6) *(uint4 *)(E + (slot + 8) * STRIP_ES + 4 * qi) = e;   // wave-uniform
+        const int slot = __builtin_amdgcn_readfirstlane(r & 7);
+        *(uint4 *)(Ew + slot * STRIP_ES) = e;
+        if (slot < 6) *(uint4 *)(Ew + (slot + 8) * STRIP_ES) = e;   // wave-uniform
     };
     {   // rows 0..6 (the first evaluated row's ring) + row 7 in flight: all eight loads issued before the first LDS write
         uint2 d[7];
@@ -397,21 +402,26 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
     uint2 pre = load_row(7);
     wave_sync();
 
-    const int tlo = max(min(iniTh, minTh), 0);
+    const int tlo = max(min(iniTh, minTh), 0), thi = max(iniTh, minTh);
     const int i0 = c * g.wCell + 3 + 2 * j;                   // strip column of my pair's first pixel
     const uint32_t *q0 = E + sh + i0;
     const uint32_t vmask = (2 * j < cw ? 0xFFFFu : 0u) | (2 * j + 1 < cw ? 0xFFFF0000u : 0u);
-    const uint32_t lt = (1u << j) - 1u;
-    const int cshift = 16 * (c & 1);
+    // the lanes of my cell below me / up to me
+    const uint32_t ltc = (1u << j) - 1u;
+    const int cs = 16 * c;   // my cell's 16 lanes inside a ballot
+    const half2v tl2 = __builtin_bit_cast(half2v, (uint32_t)tlo * 0x00010001u);
     const uint32_t x0 = (uint32_t)(cj * g.wCell + 3 + 2 * j), ybase = (uint32_t)(ci * g.hCell + 3);
-    uint32_t *out = slots + (size_t)b * slotsPerImg + g.slotOff + (size_t)(ci * g.nCols + cj) * g.capc;
+    // slot list of my cell: scalar base of the level's slots + 32-bit lane offset
+    uint32_t *lvlSlots = slots + (size_t)b * slotsPerImg + g.slotOff;
+    const uint32_t cellOff = (uint32_t)((ci * g.nCols + cj) * g.capc);
     // NMS state: S1 = scores (+1) of row y-1, H1 / H2 = 3-wide horizontal maxima of rows y-1 / y-2, LR1 = max(left, right) of row y-1
     uint32_t S1 = 0, H1 = 0, H2 = 0, LR1 = 0;
-    int nRaw = 0, nA = 0, nB = 0;
-    for (int y = 0; y <= ch; y++) {
+    uint32_t nRaw = 0, nHi = 0;   // survivors >= min(iniTh, minTh) so far in my cell (same in its 16 lanes) / MY survivors >= max(iniTh, minTh)
+    for (int yv = 0; yv <= chS; yv++) {
+        const int y = __builtin_amdgcn_readfirstlane(yv);   // everything derived from the row number stays on the scalar unit
         uint32_t S = 0;
-        if (y < ch) {   // wave-uniform
-            const uint32_t *q = q0 + (y & 7) * STRIP_ES;       // window rows y .. y+6 are ring slots (y & 7) .. (y & 7) + 6
+        if (y < chS) {   // wave-uniform
+            const uint32_t *q = q0 + __builtin_amdgcn_readfirstlane((y & 7) * STRIP_ES);   // window rows y .. y+6 = ring slots (y & 7) .. + 6
             const uint32_t vv = q[3 * STRIP_ES];
             uint32_t rr[16];
             rr[0] = q[6 * STRIP_ES];       rr[1] = q[6 * STRIP_ES + 1];   rr[2] = q[5 * STRIP_ES + 2];   rr[3] = q[4 * STRIP_ES + 3];
@@ -427,37 +437,38 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
         const uint32_t Rp = __builtin_amdgcn_perm(dpp_row_shl1(S), S, 0x05040302u);   // bytes: S.hi | shl.lo << 16
         const half2v Lh = __builtin_bit_cast(half2v, Lp), Rh = __builtin_bit_cast(half2v, Rp), Sh = __builtin_bit_cast(half2v, S);
         const uint32_t H0 = __builtin_bit_cast(uint32_t, pk_max3(Lh, Sh, Rh));
-        const uint32_t LR0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(Lh, Rh));
-        // strict 3x3 maximum of row y-1: rows y-2 and y through their horizontal maxima
+        // max(left, right, tlo): the threshold min(iniTh, minTh) rides along as a third "neighbour" (score + 1 > tlo <=> score >= tlo)
+        const uint32_t LR0 = __builtin_bit_cast(uint32_t, pk_max3(Lh, Rh, tl2));
+        // strict 3x3 maximum of row y-1 (rows y-2 and y through their horizontal maxima) and score >= tlo: ONE sign test per
+        // pixel (exact on these values; a negative f16 is a negative int16)
         const half2v nb = pk_max3(__builtin_bit_cast(half2v, H2), __builtin_bit_cast(half2v, H0), __builtin_bit_cast(half2v, LR1));
-        const short2v gt = __builtin_bit_cast(short2v, __builtin_bit_cast(half2v, S1) - nb);   // > 0 iff strictly greater (exact on these values)
-        const int s0 = (int)(S1 & 0xFFFFu), s1 = (int)(S1 >> 16);
-        const bool k0 = gt.x > 0 && s0 > tlo, k1 = gt.y > 0 && s1 > tlo;
-        const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
-        if (m0 | m1) {   // wave-uniform
-            nA += (k0 && s0 > iniTh ? 1 : 0) + (k1 && s1 > iniTh ? 1 : 0);
-            nB += (k0 && s0 > minTh ? 1 : 0) + (k1 && s1 > minTh ? 1 : 0);
-            // my cell's 16 lanes of the two ballots; row-major order inside the row = first, second pixel of pair 0, of pair 1, ...
-            const uint32_t w0 = (((c & 2) ? (uint32_t)(m0 >> 32) : (uint32_t)m0) >> cshift) & 0xFFFFu;
-            const uint32_t w1 = (((c & 2) ? (uint32_t)(m1 >> 32) : (uint32_t)m1) >> cshift) & 0xFFFFu;
-            const int pos = nRaw + __popc(w0 & lt) + __popc(w1 & lt);
-            const uint32_t yy = (ybase + (uint32_t)(y - 1)) << 12;
-            if (k0 && pos < g.capc) out[pos] = x0 | yy | ((uint32_t)(s0 - 1) << 24);
-            if (k1 && pos + (k0 ? 1 : 0) < g.capc) out[pos + (k0 ? 1 : 0)] = (x0 + 1u) | yy | ((uint32_t)(s1 - 1) << 24);
-            nRaw += __popc(w0) + __popc(w1);
+        const short2v kp = __builtin_bit_cast(short2v, __builtin_bit_cast(half2v, S1) - nb);
+        // the two pixels of a pair are neighbours: at most ONE of them is a strict maximum, so a lane emits at most one key per row
+        const bool k0 = kp.x > 0, k1 = kp.y > 0;
+        const unsigned long long m = __ballot(k0 || k1);
+        if (m) {   // wave-uniform
+            const uint32_t a = (uint32_t)(m >> cs) & 0xFFFFu;                    // my cell's 16 lanes of the ballot (one 64-bit shift)
+            const uint32_t sc = k1 ? S1 >> 16 : S1 & 0xFFFFu;                    // score + 1 of my survivor
+            const uint32_t pos = cellOff + nRaw + __popc(a & ltc);               // row-major order: the survivors of my cell's lower lanes first
+            // (a cell cannot hold more than capc = ceil(w/2) * ceil(h/2) strict 3x3 maxima: no two of them are neighbours)
+            if (k0 || k1) lvlSlots[pos] = (sc << 24) + (k1 ? x0 + 1u : x0) + ((ybase + (uint32_t)(y - 1)) << 12) - (1u << 24);
+            nHi += (k0 || k1) && sc > (uint32_t)thi ? 1u : 0u;
+            nRaw += __popc(a);
         }
         S1 = S; H2 = H1; H1 = H0; LR1 = LR0;
         // stream: window row y+7 (loaded during this iteration) replaces row y-1 in the ring; row y+8 goes in flight
-        if (y + 7 < th) write_row(y + 7, pre);   // wave-uniform
+        if (y + 7 < thS) write_row(y + 7, pre);   // wave-uniform
         pre = load_row(y + 8);
         wave_sync();
     }
     // per-cell totals: the 16 lanes of a cell
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { nA += __shfl_xor(nA, o); nB += __shfl_xor(nB, o); }
+    for (int o = 8; o > 0; o >>= 1) nHi += __shfl_xor(nHi, o);
     if (j == 0 && exists) {
-        cellCnt[cellIdx] = (uint32_t)min(nA ? nA : nB, g.capc);
-        cellRaw[cellIdx] = (uint32_t)min(nRaw, g.capc) | (nA ? 0x80000000u : 0u);
+        // {>= iniTh} if non-empty else {>= minTh} (:809-816): one of the two sets is the whole list, the other the nHi entries
+        const uint32_t nA = iniTh >= minTh ? nHi : nRaw, nB = iniTh >= minTh ? nRaw : nHi;
+        cellCnt[cellIdx] = min(nA ? nA : nB, (uint32_t)g.capc);
+        cellRaw[cellIdx] = min(nRaw, (uint32_t)g.capc) | (nA ? 0x80000000u : 0u);
     }
 }
 
