@@ -301,7 +301,7 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  * key 1: stop k_octree early; key 2: force the exact one-workgroup matcher kernels;
  * key 3: pyramid tile size; key 4: quad-tree by k_octree alone, without the count pyramid;
  * key 5: pyramid by the one-launch fused kernel; key 6: 1 = every level's FAST by k_fast_cells (one wave per cell) instead of
- * k_fast_strips, 2 = ... with run-time tile strides;
+ * k_fast_strips, 2 = ... with run-time tile strides, 3 = k_fast_strips even for a small batch (default: by batch size);
  * key 7: stop k_octree_pyr after phase n).
  * Never set in production: keys 0, 1 and 7 leave outputs incomplete; 2, 4, 5, 6 select an alternative
  * kernel with identical results (tests use them to cover those kernels). */

@@ -487,7 +487,9 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
     if (profFast) ORBX_HIP(hipEventRecord(ev[1], st));
     {   // K2
         // developer knob 6: 1 = every level by k_fast_cells (compile-time tile strides), 2 = ... with run-time strides
-        const bool strips = h->totalStrips > 0 && g_debug[6] == 0;
+        // a strip is a longer job than a cell (a wave walks ~33 rows): with few images the one-wave-per-cell kernel finishes
+        // sooner (13 vs 29 us for one 1241x376 image); once the strips fill the GPU they win (2.5 vs 3.1 us per image).  Same results.
+        const bool strips = h->totalStrips > 0 && (g_debug[6] == 0 ? (size_t)h->totalStrips * B >= 4096 : g_debug[6] == 3);
         const unsigned stripLevels = strips ? h->stripLevels : 0u;
         if (strips) {
             StripBases sb;
@@ -520,23 +522,22 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
         int maxCells = 0;
         for (int l = 0; l < nl; l++) maxCells = std::max(maxCells, h->geom[l].ncells);
         const int scratch = std::max(4 * h->maxNodeCap, maxCells + 1);
-        ORBX_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)h->octLdsBytes));
         hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
                            dim3(256), 0, st, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_cellRaw, h->d_slots,
                            h->slotsPerImg, h->d_cand, h->keysPerImg, h->d_candCnt, h->ini_th, h->min_th, cb);
         const bool usePyr = g_debug[4] == 0;
-        if (usePyr) {
-            ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_pyr, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)h->octPyrLdsBytes));
-            hipLaunchKernelGGL(k_octree_pyr, dim3(B, nl), dim3(OCT_T), h->octPyrLdsBytes, st, h->d_geom, nl, h->d_cand,
+        if (usePyr) {   // a level whose tree outgrows the count pyramid is redone by the same block with the exact form: one launch
+            const size_t lds = std::max(h->octPyrLdsBytes, h->octLdsBytes);
+            ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_pyr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_octree_pyr, dim3(B, nl), dim3(OCT_T), lds, st, h->d_geom, nl, h->d_cand,
                                h->keysPerImg, h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap,
-                               pow2, h->octPyrWords, h->d_octFallback, g_debug[7]);
+                               pow2, h->octPyrWords, h->d_octFallback, g_debug[7], h->d_nodeOf, scratch, g_debug[1]);
+        } else {        // developer knob 4: the exact form alone
+            ORBX_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octLdsBytes));
+            hipLaunchKernelGGL(k_octree, dim3(B, nl), dim3(OCT_T), h->octLdsBytes, st, h->d_geom, nl, h->d_cand, h->d_nodeOf,
+                               h->keysPerImg, h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2,
+                               scratch, g_debug[1]);
         }
-        hipLaunchKernelGGL(k_octree, dim3(B, nl), dim3(OCT_T), h->octLdsBytes, st, h->d_geom, nl, h->totalCells,
-                           h->d_cellCnt, h->d_slots, h->slotsPerImg, h->d_cand, h->d_nodeOf, h->keysPerImg,
-                           h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2, scratch,
-                           g_debug[1], usePyr ? h->d_octFallback : (const int32_t *)nullptr);
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[3], st));
     {   // K4

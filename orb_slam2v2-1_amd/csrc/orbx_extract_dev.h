@@ -79,11 +79,10 @@ __global__ void k_gather(const LevelGeom *geom, int nlevels, int totalCells, con
                          int minTh, CellBases cb);                                                               // orbx_fast.hip
 __global__ void k_octree_pyr(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
                              uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
-                             int pyrWords, int32_t *fallback, int dbgStop);                                                   // orbx_octree.hip
-__global__ void k_octree(const LevelGeom *geom, int nlevels, int totalCells, const uint32_t *cellCnt, const uint32_t *slots,
-                         size_t slotsPerImg, uint32_t *cand, uint16_t *nodeOf, size_t keysPerImg, const int32_t *candCnt,
-                         uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
-                         int scratchInts, int dbgStop, const int32_t *fallback);                                 // orbx_octree.hip
+                             int pyrWords, int32_t *fallback, int dbgStop, uint16_t *nodeOf, int scratchInts, int dbgStopExact);  // orbx_octree.hip
+__global__ void k_octree(const LevelGeom *geom, int nlevels, const uint32_t *cand, uint16_t *nodeOf, size_t keysPerImg,
+                         const int32_t *candCnt, uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax,
+                         int pow2cap, int scratchInts, int dbgStop);                                             // orbx_octree.hip
 __global__ void k_describe(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, const uint32_t *lvlKp,
                            int lvlKpCap, const int32_t *lvlCnt, orbx_keypoint_t *kps, uint8_t *desc, int32_t *counts,
                            int cap);                                                                             // orbx_describe.hip

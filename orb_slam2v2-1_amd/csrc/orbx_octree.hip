@@ -132,10 +132,14 @@ __device__ __forceinline__ uint32_t pyr_count(const uint32_t *pyr, int nIni, int
     return pyr[off + c];
 }
 
+__device__ __noinline__ void octree_exact_level(const LevelGeom *geom, int nlevels, const uint32_t *cand, uint16_t *nodeOf, size_t keysPerImg,
+                                                const int32_t *candCnt, uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab,
+                                                int capMax, int pow2cap, int scratchInts, int dbgStop, int l, int b);
 __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
     const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand, size_t keysPerImg,
     const int32_t *__restrict__ candCnt, uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
-    const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback, int dbgStop) {
+    const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback, int dbgStop,
+    uint16_t *__restrict__ nodeOf, int scratchInts, int dbgStopExact) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;  // level-major: large levels start first
     const LevelGeom g = geom[l];
@@ -355,8 +359,11 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
             }
         }
         __syncthreads();
-        if (sh_abort) {   // counts deeper than the pyramid are needed: hand the level to k_octree
-            if (tid == 0) fallback[b * nlevels + l] = 1;
+        if (sh_abort) {   // counts deeper than the pyramid are needed: this block redoes its level with the exact form (same LDS, carved anew)
+            if (tid == 0) fallback[b * nlevels + l] = 1;   // (kept as a record: tests look at it)
+            __syncthreads();
+            octree_exact_level(geom, nlevels, cand, nodeOf, keysPerImg, candCnt, lvlKp, lvlKpCap, lvlCnt, tab, capMax, pow2cap, scratchInts,
+                               dbgStopExact, l, b);
             return;
         }
         L = sh_Lnew;
@@ -433,18 +440,15 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
     if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; fallback[b * nlevels + l] = 0; }
 }
 
-// K3 (fallback): one sweep over the keys per pass; runs only for levels k_octree_pyr flagged
-__global__ __launch_bounds__(OCT_T) void k_octree(
-    const LevelGeom *__restrict__ geom, int nlevels, int totalCells, const uint32_t *__restrict__ cellCnt,
-    const uint32_t *__restrict__ slots, size_t slotsPerImg, uint32_t *__restrict__ cand,
+// K3 (exact form): one sweep over the keys per pass.  Called by k_octree_pyr for the levels whose tree outgrows the count
+// pyramid (a block that finds out simply carries on here: no second launch), and launched on its own with developer knob 4.
+__device__ __noinline__ void octree_exact_level(
+    const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand,
     uint16_t *__restrict__ nodeOf, size_t keysPerImg, const int32_t *__restrict__ candCnt,
     uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
-    const int32_t *__restrict__ tab, int capMax, int pow2cap, int scratchInts, int dbgStop,
-    const int32_t *__restrict__ fallback) {
+    const int32_t *__restrict__ tab, int capMax, int pow2cap, int scratchInts, int dbgStop, int l, int b) {
     extern __shared__ __align__(16) uint8_t smem[];
-    // level-major block order: the large levels start first and the small ones fill the gaps
-    const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
-    if (fallback && !fallback[b * nlevels + l]) return;  // done by k_octree_pyr
+    const int tid = threadIdx.x;
     const LevelGeom g = geom[l];
     // ---- carve LDS
     uint8_t *sp = smem;
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
     S.split = sp; sp += capMax;
     __shared__ int rootCnt[ORBX_MAX_ROOTS], rootMap[ORBX_MAX_ROOTS];
 
-    uint32_t *keys = cand + (size_t)b * keysPerImg + g.keyOff;
+    const uint32_t *keys = cand + (size_t)b * keysPerImg + g.keyOff;
     uint16_t *nof = nodeOf + (size_t)b * keysPerImg + g.keyOff;
 
     // ---- A/B. keys were gathered in vToDistributeKeys order by k_cell_scan + k_gather
@@ -723,4 +727,14 @@ __global__ __launch_bounds__(OCT_T) void k_octree(
     const int Lout = min(L, g.nodeCap);
     for (int k = tid; k < Lout; k += OCT_T) okp[k] = keys[0xFFFFFFu - (best[k] & 0xFFFFFFu)];
     if (tid == 0) lvlCnt[b * nlevels + l] = Lout;
+}
+
+__global__ __launch_bounds__(OCT_T) void k_octree(
+    const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand,
+    uint16_t *__restrict__ nodeOf, size_t keysPerImg, const int32_t *__restrict__ candCnt,
+    uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
+    const int32_t *__restrict__ tab, int capMax, int pow2cap, int scratchInts, int dbgStop) {
+    // level-major block order: the large levels start first and the small ones fill the gaps
+    octree_exact_level(geom, nlevels, cand, nodeOf, keysPerImg, candCnt, lvlKp, lvlKpCap, lvlCnt, tab, capMax, pow2cap, scratchInts,
+                       dbgStop, blockIdx.y, blockIdx.x);
 }

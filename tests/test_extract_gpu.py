@@ -15,13 +15,20 @@ def _cands(a):
 
 
 @pytest.mark.parametrize("w,h,nf", SIZES)
-def test_staged_parity(pkg, oracle, synth, w, h, nf):
+@pytest.mark.parametrize("fast_kernel", ["auto", "strips"])
+def test_staged_parity(pkg, oracle, synth, w, h, nf, fast_kernel):
+    """fast_kernel: a single image takes k_fast_cells by default (the batch-size rule of orbx_extract.hip); "strips" forces
+    k_fast_strips, the kernel a large batch runs on (developer knob 6 = 3)."""
     img = synth.frame(w, h, k=3)
     ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
     ok, od = None, None
     orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
     ok, od = orc.extract(img)
-    gk, gd = ex(img)
+    pkg.lib().orbx_debug_set(6, 3 if fast_kernel == "strips" else 0)
+    try:
+        gk, gd = ex(img)
+    finally:
+        pkg.lib().orbx_debug_set(6, 0)
     for l in range(8):
         np.testing.assert_array_equal(ex.pyramid_level(l, padded=True), orc.pyramid_level(l, padded=True),
                                       err_msg="pyramid level %d" % l)
@@ -53,9 +60,25 @@ def test_batch_matches_single(pkg, oracle, synth):
 
 
 def _compare(pkg, oracle, img, nf, sf=1.2, nl=8, ini=20, mn=7):
+    """One image through the HIP path, TWICE - with the FAST kernel a single image takes by default (k_fast_cells, one wave per
+    cell) and with the one a large batch takes (k_fast_strips, forced by developer knob 6 = 3) - against the oracle."""
     ex = pkg.ORBextractor(nf, sf, nl, ini, mn)
     orc = oracle.Extractor(nf, sf, nl, ini, mn)
     ok, od = orc.extract(img)
+    knob = pkg.lib().orbx_debug_set
+    if _KNOB6[0] == 0:
+        knob(6, 3)
+        try:
+            _check_against(ex, orc, ok, od, img, nl)
+        finally:
+            knob(6, 0)
+    return _check_against(ex, orc, ok, od, img, nl)
+
+
+_KNOB6 = [0]   # tests that set knob 6 themselves (test_fast_cell_kernel_instances) say so here
+
+
+def _check_against(ex, orc, ok, od, img, nl):
     gk, gd = ex(img)
     for l in range(nl):
         np.testing.assert_array_equal(ex.debug_level_points(l, 0), _cands(orc.level_candidates(l)),
@@ -307,10 +330,12 @@ def test_fast_cell_kernel_instances(pkg, oracle, synth):
     (reached naturally by 60-px-tall single-cell levels, stride 60)."""
     for knob in (1, 2):
         pkg.lib().orbx_debug_set(6, knob)
+        _KNOB6[0] = knob
         try:
             _compare(pkg, oracle, synth.frame(752, 480, 85), 1000)
             _compare(pkg, oracle, synth.frame(1241, 376, 86), 1000)
         finally:
+            _KNOB6[0] = 0
             pkg.lib().orbx_debug_set(6, 0)
     _compare(pkg, oracle, synth.frame(1241, 376, 86), 1000)
     _compare(pkg, oracle, synth.frame(333, 211, 87), 300, sf=1.3, nl=5)
