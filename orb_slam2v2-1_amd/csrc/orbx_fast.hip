@@ -489,33 +489,42 @@ __global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ ge
     xcd_block_map(bx, b);
     const int gc0 = bx * GATHER_CELLS_PER_BLOCK, gc = gc0 + grp;
     const uint32_t *cc = cellCnt + (size_t)b * totalCells;
-    const int l0 = level_of_cell(cb, nlevels, gc0), base0 = cb.v[l0];
+    const bool live = gc < totalCells;
+    const int gcl = live ? gc : totalCells - 1;
+    // everything that does not depend on the cell's place in the key array is requested first - its own list included - so that
+    // the dependent loads of this kernel (counts -> place -> stores) overlap instead of queueing up: it is latency-bound
+    const int l = level_of_cell(cb, nlevels, gcl);
+    const int cn = live ? (int)cc[gcl] : 0;
+    const uint32_t rw = live ? cellRaw[(size_t)b * totalCells + gcl] : 0u;
+    const LevelGeom *gp = geom + l;
+    const int capc = gp->capc, cellBase = gp->cellBase, ncells = gp->ncells;
+    const unsigned long long slotOff = gp->slotOff, keyOff = gp->keyOff;
+    const int nraw = (int)(rw & 0x7FFFFFFFu);
+    const uint32_t thr = (rw >> 31) ? (uint32_t)iniTh : (uint32_t)minTh;
+    const uint32_t *src = slots + (size_t)b * slotsPerImg + slotOff + (size_t)(gcl - cellBase) * capc;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = src[min(sub + 16 * k, max(nraw - 1, 0))];
     // kept keys of the cells [base0, gc0) of the block's first level
+    const int l0 = level_of_cell(cb, nlevels, gc0), base0 = cb.v[l0];
     int part = 0;
     for (int i = base0 + tid; i < gc0; i += 256) part += (int)cc[i];
     part = wave_total_i32(part);
     if ((tid & 63) == 0) wsum[tid >> 6] = part;
-    const bool live = gc < totalCells;
-    const int l = live ? level_of_cell(cb, nlevels, gc) : -1;
-    const int cn = live ? (int)cc[gc] : 0;
-    if (sub == 0) { ccnt[grp] = cn; clvl[grp] = l; }
+    if (sub == 0) { ccnt[grp] = cn; clvl[grp] = live ? l : -1; }
     __syncthreads();
     if (!live) return;
     int off = l == l0 ? wsum[0] + wsum[1] + wsum[2] + wsum[3] : 0;
     for (int k = 0; k < grp; k++) off += clvl[k] == l ? ccnt[k] : 0;
-    const LevelGeom g = geom[l];
-    if (sub == 0 && gc == g.cellBase + g.ncells - 1) candCnt[b * nlevels + l] = off + cn;
-    const uint32_t rw = cellRaw[(size_t)b * totalCells + gc];
-    const int nraw = (int)(rw & 0x7FFFFFFFu);
-    const uint32_t thr = (rw >> 31) ? (uint32_t)iniTh : (uint32_t)minTh;
-    const uint32_t *src = slots + (size_t)b * slotsPerImg + g.slotOff + (size_t)(gc - g.cellBase) * g.capc;
-    uint32_t *dst = cand + (size_t)b * keysPerImg + g.keyOff + off;
+    if (sub == 0 && gc == cellBase + ncells - 1) candCnt[b * nlevels + l] = off + cn;
+    uint32_t *dst = cand + (size_t)b * keysPerImg + keyOff + off;
     const int gshift = (tid & 48);   // my group's 16 lanes inside the wave's ballot
     int kept = 0;
-    for (int j0 = 0; j0 < nraw; j0 += 64) {   // four loads in flight per lane before the stores
-        uint32_t v[4];
+    for (int j0 = 0; j0 < nraw; j0 += 64) {   // four loads in flight per lane before the stores (the first four: above)
+        if (j0 > 0) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = src[min(j0 + sub + 16 * k, nraw - 1)];
+            for (int k = 0; k < 4; k++) v[k] = src[min(j0 + sub + 16 * k, nraw - 1)];
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const bool keep = j0 + sub + 16 * k < nraw && (v[k] >> 24) >= thr;

@@ -132,7 +132,7 @@ __device__ __forceinline__ uint32_t pyr_count(const uint32_t *pyr, int nIni, int
     return pyr[off + c];
 }
 
-__device__ __noinline__ void octree_exact_level(const LevelGeom *geom, int nlevels, const uint32_t *cand, uint16_t *nodeOf, size_t keysPerImg,
+__device__ __forceinline__ void octree_exact_level(const LevelGeom *geom, int nlevels, const uint32_t *cand, uint16_t *nodeOf, size_t keysPerImg,
                                                 const int32_t *candCnt, uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab,
                                                 int capMax, int pow2cap, int scratchInts, int dbgStop, int l, int b);
 __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
 
 // K3 (exact form): one sweep over the keys per pass.  Called by k_octree_pyr for the levels whose tree outgrows the count
 // pyramid (a block that finds out simply carries on here: no second launch), and launched on its own with developer knob 4.
-__device__ __noinline__ void octree_exact_level(
+__device__ __forceinline__ void octree_exact_level(
     const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand,
     uint16_t *__restrict__ nodeOf, size_t keysPerImg, const int32_t *__restrict__ candCnt,
     uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
