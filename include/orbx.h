@@ -208,6 +208,20 @@ int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
                                     const int32_t *ext_obs, float th, int mono, int check_orientation,
                                     int device, int *nmatches);
 
+/* Device-resident form for a tracking front-end (Tracking::TrackWithMotionModel, src/Tracking.cc:1010-1041): the current
+ * frame's keypoints, descriptors and mvuRight are the DEVICE outputs of orbx_extract_batch_device / orbm_stereo_batch_device
+ * (first n entries of the frame's rows) and d_last_desc the previous frame's descriptor rows, still in HBM; only the
+ * per-keypoint map-point records (`last`, 28 B each), the poses and the holders cross the bus.  The kernels run on
+ * `stream`, i.e. behind the kernels that produce the arrays; the call returns when the results are on the host.
+ * Same results as orbm_search_by_projection_frame. */
+int orbm_search_by_projection_frame_device(const orbx_keypoint_t *d_kun, const uint8_t *d_desc, const float *d_uright,
+                                           int n, const orbm_grid_geom_t *g, const float *scale_factors,
+                                           int nlevels, const orbm_camera_t *cam, const float *Tcw_cur16,
+                                           const float *Tcw_last16, const orbm_lastpoint_t *last,
+                                           const uint8_t *d_last_desc, int nlast, int32_t *cur_mp,
+                                           const int32_t *ext_obs, float th, int mono, int check_orientation,
+                                           int device, int *nmatches, void *stream);
+
 /* ---- the step before SearchByProjection(F, MPs) — Frame::isInFrustum
  * (src/Frame.cc:284-340) for all local map points at once (Tracking::SearchLocalPoints,
  * src/Tracking.cc:1290-1340).  A point's tracking variables come back as orbm_mappoint_t. */
@@ -238,6 +252,15 @@ int orbm_search_local_points(const orbx_keypoint_t *kun, const uint8_t *desc, co
                              const orbm_camera_t *cam, float viewing_cos_limit, const float *thresholds,
                              int32_t *frame_mp, const int32_t *ext_obs, float th, float nnratio, int device,
                              int *nmatches, orbm_mappoint_t *proj_out);
+
+/* orbm_search_local_points with the frame's keypoints / descriptors / mvuRight already in HBM (see
+ * orbm_search_by_projection_frame_device); the map points' records and descriptors come from the host map. */
+int orbm_search_local_points_device(const orbx_keypoint_t *d_kun, const uint8_t *d_desc, const float *d_uright, int n,
+                                    const orbm_grid_geom_t *g, const float *scale_factors, int nlevels,
+                                    const orbm_worldpoint_t *pts, const uint8_t *mp_desc, int m, const float *Tcw16,
+                                    const orbm_camera_t *cam, float viewing_cos_limit, const float *thresholds,
+                                    int32_t *frame_mp, const int32_t *ext_obs, float th, float nnratio, int device,
+                                    int *nmatches, orbm_mappoint_t *proj_out, void *stream);
 
 /* Generic projected-window matcher: the common core of the reference's SearchByProjection
  * family once the caller has projected its map points.  For every valid

@@ -42,6 +42,7 @@ EXPORTS = [
     "orbm_search_local_points", "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_transform",
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
     "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch", "orbx_debug_sincosf",
+    "orbm_search_by_projection_frame_device", "orbm_search_local_points_device",
 ]
 
 
@@ -141,6 +142,7 @@ def lib():
                                                f32, f32, i32, C.POINTER(i32)]
     L.orbm_search_by_projection_frame.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp, i32, C.POINTER(Camera),
                                                   vp, vp, vp, vp, i32, vp, vp, f32, i32, i32, i32, C.POINTER(i32)]
+    L.orbm_search_by_projection_frame_device.argtypes = L.orbm_search_by_projection_frame.argtypes + [vp]
     L.orbm_match_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, vp, i32, i32, i32, C.POINTER(i32)]
     L.orbm_distinctive_descriptors.argtypes = [vp, vp, i32, vp, vp, i32]
     L.orbm_predict_scale_thresholds.argtypes = [f32, i32, vp]
@@ -156,6 +158,7 @@ def lib():
     L.orbm_is_in_frustum.argtypes = [vp, i32, vp, C.POINTER(Camera), C.POINTER(GridGeom), f32, vp, i32, vp, i32]
     L.orbm_search_local_points.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), vp, i32, vp, vp, i32, vp, C.POINTER(Camera), f32,
                                            vp, vp, vp, f32, f32, i32, C.POINTER(i32), vp]
+    L.orbm_search_local_points_device.argtypes = L.orbm_search_local_points.argtypes + [vp]
     L.orbm_best_in_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, i32, vp, vp, i32]
     L.orbx_debug_sincosf.argtypes = [vp, i32, vp, vp, i32]
     L.orbx_last_error.restype = C.c_char_p
@@ -402,6 +405,38 @@ class ORBmatcher:
                                                      len(last), _p(cm), _p(eo), float(th), int(bMono),
                                                      int(self.mbCheckOrientation), self.device, C.byref(n)))
         return n.value, cm
+
+
+def search_by_projection_frame_device(d_kun, d_desc, d_uright, n, geom, scale_factors, cam, Tcw_cur, Tcw_last, last, d_last_desc,
+                                      cur_mp, ext_obs=None, th=7.0, bMono=False, check_orientation=True, device=0, stream=0):
+    """orbm_search_by_projection_frame_device: d_* are raw device pointers (the extractor's / stereo matcher's outputs in HBM)
+    -> (nmatches, cur_mp')"""
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    last = np.ascontiguousarray(last, LASTPT_DTYPE)
+    Tc = np.ascontiguousarray(Tcw_cur, np.float32); Tl = np.ascontiguousarray(Tcw_last, np.float32)
+    cm = np.ascontiguousarray(cur_mp, np.int32).copy()
+    eo = None if ext_obs is None else np.ascontiguousarray(ext_obs, np.int32)
+    nm = C.c_int(0)
+    _check(lib().orbm_search_by_projection_frame_device(d_kun, d_desc, d_uright, int(n), C.byref(geom), _p(sf), len(sf), C.byref(cam),
+                                                        _p(Tc), _p(Tl), _p(last), d_last_desc, len(last), _p(cm), _p(eo), float(th),
+                                                        int(bMono), int(check_orientation), int(device), C.byref(nm), stream))
+    return nm.value, cm
+
+
+def search_local_points_device(d_kun, d_desc, d_uright, n, geom, sf, pts, mp_desc, Tcw, cam, viewing_cos_limit, thresholds, frame_mp,
+                               ext_obs, th, nnratio, device=0, stream=0):
+    """orbm_search_local_points_device -> (nmatches, frame_mp', projections)"""
+    sf = np.ascontiguousarray(sf, np.float32)
+    pts = np.ascontiguousarray(pts, WORLDPOINT_DTYPE); md = np.ascontiguousarray(mp_desc, np.uint8)
+    T = np.ascontiguousarray(Tcw, np.float32); thr = np.ascontiguousarray(thresholds, np.float32)
+    fm = np.ascontiguousarray(frame_mp, np.int32).copy()
+    eo = None if ext_obs is None else np.ascontiguousarray(ext_obs, np.int32)
+    proj = np.zeros(len(pts), MP_DTYPE)
+    nm = C.c_int(0)
+    _check(lib().orbm_search_local_points_device(d_kun, d_desc, d_uright, int(n), C.byref(geom), _p(sf), len(sf), _p(pts), _p(md),
+                                                 len(pts), _p(T), C.byref(cam), float(viewing_cos_limit), _p(thr), _p(fm), _p(eo),
+                                                 float(th), float(nnratio), int(device), C.byref(nm), _p(proj), stream))
+    return nm.value, fm, proj
 
 
 def match_windows(kun, desc, uright, geom, queries, query_desc, holder, ext_blocks=None, max_dist=100,

@@ -116,12 +116,14 @@ int orbx_internal_level(const orbx_extractor *h, int level, int *w, int *hgt, in
 int fast_search_for_initialization(const orbx_keypoint_t *k1, const uint8_t *d1, int n1, const orbx_keypoint_t *k2,
                                    const uint8_t *d2, int n2, const orbm_grid_geom_t *g2, float *prev, int32_t *m12,
                                    int window, float nnratio, int check_ori, int device, int *nmatches);
+// frame arrays that are already device-resident (the *_device matcher entry points): the kernels then run on `stream`
+struct DevFrame { hipStream_t stream; };
 struct FrustumArgs { const orbm_worldpoint_t *pts; const float *Tcw16; const orbm_camera_t *cam; float viewCosLimit; const float *thr; };
 int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
                                  const orbm_grid_geom_t *g, const float *sf, int nlevels, const orbm_mappoint_t *mps,
                                  const uint8_t *mp_desc, int m, int32_t *frame_mp, const int32_t *ext_obs, float th,
                                  float nnratio, int device, int *nmatches, const FrustumArgs *world = nullptr,
-                                 orbm_mappoint_t *proj_out = nullptr);
+                                 orbm_mappoint_t *proj_out = nullptr, const DevFrame *dev = nullptr);
 int fast_is_in_frustum(const orbm_worldpoint_t *pts, int m, const float *Tcw16, const orbm_camera_t *cam,
                        const orbm_grid_geom_t *g, float viewCosLimit, const float *thr, int nlevels, orbm_mappoint_t *out,
                        int device);
@@ -129,7 +131,7 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
                                     const orbm_grid_geom_t *g, const float *sf, int nlevels, const orbm_camera_t *cam,
                                     const float *Tc16, const float *Tl16, const orbm_lastpoint_t *last,
                                     const uint8_t *last_desc, int nlast, int32_t *cur_mp, const int32_t *ext_obs,
-                                    float th, int mono, int check_ori, int device, int *nmatches);
+                                    float th, int mono, int check_ori, int device, int *nmatches, const DevFrame *dev = nullptr);
 int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
                        const orbm_grid_geom_t *g, const orbm_grid_geom_t *ga, const orbm_window_query_t *q,
                        const uint8_t *qdesc, int m,

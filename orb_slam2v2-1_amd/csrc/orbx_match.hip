@@ -751,7 +751,8 @@ __global__ __launch_bounds__(SQ_T) void k_search_proj_mp(
 static int exact_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
                                          const orbm_grid_geom_t *g, const float *scale_factors, int nlevels,
                                          const orbm_mappoint_t *mps, const uint8_t *mp_desc, int m, int32_t *frame_mp,
-                                         const int32_t *ext_obs, float th, float nnratio, int device, int *nmatches);
+                                         const int32_t *ext_obs, float th, float nnratio, int device, int *nmatches,
+                                         const DevFrame *dev = nullptr);
 
 // MapPoint::PredictScale as a threshold table (see include/orbx.h): host code, uses the host's logf on purpose
 static int predict_scale_host(float ratio, float log_sf, int nlevels) {
@@ -789,12 +790,12 @@ extern "C" int orbm_is_in_frustum(const orbm_worldpoint_t *pts, int m, const flo
     return fast_is_in_frustum(pts, m, Tcw16, cam, g, viewing_cos_limit, thresholds, nlevels, out, device);
 }
 
-extern "C" int orbm_search_local_points(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
-                                        const orbm_grid_geom_t *g, const float *scale_factors, int nlevels,
-                                        const orbm_worldpoint_t *pts, const uint8_t *mp_desc, int m, const float *Tcw16,
-                                        const orbm_camera_t *cam, float viewing_cos_limit, const float *thresholds,
-                                        int32_t *frame_mp, const int32_t *ext_obs, float th, float nnratio, int device,
-                                        int *nmatches, orbm_mappoint_t *proj_out) {
+static int search_local_points_impl(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                                    const orbm_grid_geom_t *g, const float *scale_factors, int nlevels,
+                                    const orbm_worldpoint_t *pts, const uint8_t *mp_desc, int m, const float *Tcw16,
+                                    const orbm_camera_t *cam, float viewing_cos_limit, const float *thresholds,
+                                    int32_t *frame_mp, const int32_t *ext_obs, float th, float nnratio, int device,
+                                    int *nmatches, orbm_mappoint_t *proj_out, const DevFrame *dev) {
     if (n < 0 || m < 0 || !g || !scale_factors || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || !nmatches || !Tcw16 || !cam ||
         (nlevels > 1 && !thresholds) || (n > 0 && (!kun || !desc || !uright || !frame_mp)) || (m > 0 && (!pts || !mp_desc)) || n > 65535) {
         orbx_set_error("orbm_search_local_points: bad arguments");
@@ -809,14 +810,33 @@ extern "C" int orbm_search_local_points(const orbx_keypoint_t *kun, const uint8_
     int frc = ORBX_FAST_FALLBACK_RC;
     if (!g_debug[2])
         frc = fast_search_by_projection_mp(kun, desc, uright, n, g, scale_factors, nlevels, nullptr, mp_desc, m, frame_mp, ext_obs,
-                                           th, nnratio, device, nmatches, &w, proj_out);
+                                           th, nnratio, device, nmatches, &w, proj_out, dev);
     else {
         const int rc = fast_is_in_frustum(pts, m, Tcw16, cam, g, viewing_cos_limit, thresholds, nlevels, proj_out, device);
         if (rc) return rc;
     }
     if (frc <= 0) return frc;
     return exact_search_by_projection_mp(kun, desc, uright, n, g, scale_factors, nlevels, proj_out, mp_desc, m, frame_mp, ext_obs,
-                                         th, nnratio, device, nmatches);
+                                         th, nnratio, device, nmatches, dev);
+}
+extern "C" int orbm_search_local_points(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
+                                        const orbm_grid_geom_t *g, const float *scale_factors, int nlevels,
+                                        const orbm_worldpoint_t *pts, const uint8_t *mp_desc, int m, const float *Tcw16,
+                                        const orbm_camera_t *cam, float viewing_cos_limit, const float *thresholds,
+                                        int32_t *frame_mp, const int32_t *ext_obs, float th, float nnratio, int device,
+                                        int *nmatches, orbm_mappoint_t *proj_out) {
+    return search_local_points_impl(kun, desc, uright, n, g, scale_factors, nlevels, pts, mp_desc, m, Tcw16, cam, viewing_cos_limit,
+                                    thresholds, frame_mp, ext_obs, th, nnratio, device, nmatches, proj_out, nullptr);
+}
+extern "C" int orbm_search_local_points_device(const orbx_keypoint_t *d_kun, const uint8_t *d_desc, const float *d_uright, int n,
+                                               const orbm_grid_geom_t *g, const float *scale_factors, int nlevels,
+                                               const orbm_worldpoint_t *pts, const uint8_t *mp_desc, int m, const float *Tcw16,
+                                               const orbm_camera_t *cam, float viewing_cos_limit, const float *thresholds,
+                                               int32_t *frame_mp, const int32_t *ext_obs, float th, float nnratio, int device,
+                                               int *nmatches, orbm_mappoint_t *proj_out, void *stream) {
+    const DevFrame dev = {(hipStream_t)stream};
+    return search_local_points_impl(d_kun, d_desc, d_uright, n, g, scale_factors, nlevels, pts, mp_desc, m, Tcw16, cam, viewing_cos_limit,
+                                    thresholds, frame_mp, ext_obs, th, nnratio, device, nmatches, proj_out, &dev);
 }
 
 extern "C" int orbm_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright,
@@ -848,9 +868,10 @@ extern "C" int orbm_search_by_projection_mp(const orbx_keypoint_t *kun, const ui
 static int exact_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
                                          const orbm_grid_geom_t *g, const float *scale_factors, int nlevels,
                                          const orbm_mappoint_t *mps, const uint8_t *mp_desc, int m, int32_t *frame_mp,
-                                         const int32_t *ext_obs, float th, float nnratio, int device, int *nmatches) {
-    StagePlan pl;
-    const size_t o_k = pl.take(sizeof(orbx_keypoint_t) * n), o_d = pl.take((size_t)32 * n), o_u = pl.take(4 * (size_t)n),
+                                         const int32_t *ext_obs, float th, float nnratio, int device, int *nmatches,
+                                         const DevFrame *dev) {
+    StagePlan pl;   // dev: the frame's keypoints / descriptors / mvuRight are device arrays, used in place
+    const size_t o_k = pl.take(dev ? 0 : sizeof(orbx_keypoint_t) * n), o_d = pl.take(dev ? 0 : (size_t)32 * n), o_u = pl.take(dev ? 0 : 4 * (size_t)n),
                  o_sf = pl.take(4 * (size_t)nlevels), o_mp = pl.take(sizeof(orbm_mappoint_t) * m), o_md = pl.take((size_t)32 * m),
                  o_eo = pl.take(ext_obs ? 4 * (size_t)n : 0), o_fm = pl.take(4 * (size_t)n);
     pl.mark_inputs();
@@ -858,15 +879,16 @@ static int exact_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8
     int rc = stage_reserve(device, pl.off);
     if (rc) return rc;
     ORBX_HIP(hipSetDevice(device));
-    hipStream_t st = g_sp.st;
-    stage_put(o_k, kun, sizeof(orbx_keypoint_t) * n); stage_put(o_d, desc, (size_t)32 * n); stage_put(o_u, uright, 4 * (size_t)n);
+    hipStream_t st = dev ? dev->stream : g_sp.st;
+    if (!dev) { stage_put(o_k, kun, sizeof(orbx_keypoint_t) * n); stage_put(o_d, desc, (size_t)32 * n); stage_put(o_u, uright, 4 * (size_t)n); }
     stage_put(o_sf, scale_factors, 4 * (size_t)nlevels); stage_put(o_mp, mps, sizeof(orbm_mappoint_t) * m);
     stage_put(o_md, mp_desc, (size_t)32 * m); stage_put(o_fm, frame_mp, 4 * (size_t)n);
     if (ext_obs) stage_put(o_eo, ext_obs, 4 * (size_t)n);
     ORBX_HIP(hipMemcpyAsync(g_sp.d, g_sp.h, pl.in_end, hipMemcpyHostToDevice, st));
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_search_proj_mp, dim3(1), dim3(SQ_T), 0, st, stage_dev<orbx_keypoint_t>(o_k), stage_dev<uint8_t>(o_d),
-                       stage_dev<float>(o_u), n, *g, stage_dev<float>(o_sf), stage_dev<orbm_mappoint_t>(o_mp), stage_dev<uint8_t>(o_md), m,
+    hipLaunchKernelGGL(k_search_proj_mp, dim3(1), dim3(SQ_T), 0, st, dev ? kun : stage_dev<orbx_keypoint_t>(o_k),
+                       dev ? desc : stage_dev<uint8_t>(o_d), dev ? uright : stage_dev<float>(o_u), n, *g, stage_dev<float>(o_sf),
+                       stage_dev<orbm_mappoint_t>(o_mp), stage_dev<uint8_t>(o_md), m,
                        stage_dev<int32_t>(o_fm), ext_obs ? stage_dev<int32_t>(o_eo) : (int32_t *)nullptr, stage_dev<uint16_t>(o_code), th,
                        nnratio, stage_dev<int32_t>(o_nm));
     ORBX_HIP(hipGetLastError());
@@ -990,13 +1012,13 @@ __global__ __launch_bounds__(SQ_T) void k_search_proj_frame(
     if (tid == 0) *nmatches_out = nm;
 }
 
-extern "C" int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright,
-                                               int n, const orbm_grid_geom_t *g, const float *scale_factors,
-                                               int nlevels, const orbm_camera_t *cam, const float *Tcw_cur16,
-                                               const float *Tcw_last16, const orbm_lastpoint_t *last,
-                                               const uint8_t *last_desc, int nlast, int32_t *cur_mp,
-                                               const int32_t *ext_obs, float th, int mono, int check_orientation,
-                                               int device, int *nmatches) {
+static int search_by_projection_frame_impl(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright,
+                                           int n, const orbm_grid_geom_t *g, const float *scale_factors,
+                                           int nlevels, const orbm_camera_t *cam, const float *Tcw_cur16,
+                                           const float *Tcw_last16, const orbm_lastpoint_t *last,
+                                           const uint8_t *last_desc, int nlast, int32_t *cur_mp,
+                                           const int32_t *ext_obs, float th, int mono, int check_orientation,
+                                           int device, int *nmatches, const DevFrame *dev) {
     if (n < 0 || nlast < 0 || !g || !scale_factors || nlevels < 1 || !cam || !Tcw_cur16 || !Tcw_last16 || !nmatches ||
         (n > 0 && (!kun || !desc || !uright || !cur_mp)) || (nlast > 0 && (!last || !last_desc)) || n > 65535) {
         orbx_set_error("orbm_search_by_projection_frame: bad arguments");
@@ -1012,30 +1034,34 @@ extern "C" int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const
     if (!g_debug[2]) {
         const int frc = fast_search_by_projection_frame(kun, desc, uright, n, g, scale_factors, nlevels, cam, Tcw_cur16,
                                                         Tcw_last16, last, last_desc, nlast, cur_mp, ext_obs, th, mono,
-                                                        check_orientation, device, nmatches);
+                                                        check_orientation, device, nmatches, dev);
         if (frc <= 0) return frc;
     }
-    StagePlan pl;
-    const size_t o_k = pl.take(sizeof(orbx_keypoint_t) * n), o_d = pl.take((size_t)32 * n), o_u = pl.take(4 * (size_t)n),
+    StagePlan pl;   // dev: kun / desc / uright / last_desc are device arrays, used in place
+    const size_t o_k = pl.take(dev ? 0 : sizeof(orbx_keypoint_t) * n), o_d = pl.take(dev ? 0 : (size_t)32 * n), o_u = pl.take(dev ? 0 : 4 * (size_t)n),
                  o_sf = pl.take(4 * (size_t)nlevels), o_T = pl.take(4 * 32), o_l = pl.take(sizeof(orbm_lastpoint_t) * nlast),
-                 o_ld = pl.take((size_t)32 * nlast), o_eo = pl.take(ext_obs ? 4 * (size_t)n : 0), o_cm = pl.take(4 * (size_t)n);
+                 o_ld = pl.take(dev ? 0 : (size_t)32 * nlast), o_eo = pl.take(ext_obs ? 4 * (size_t)n : 0), o_cm = pl.take(4 * (size_t)n);
     pl.mark_inputs();
     const size_t o_nm = pl.take(4), o_code = pl.take(2 * (size_t)n), o_hi = pl.take(4 * (size_t)nlast), o_hb = pl.take(4 * (size_t)nlast);
     int rc = stage_reserve(device, pl.off);
     if (rc) return rc;
     ORBX_HIP(hipSetDevice(device));
-    hipStream_t st = g_sp.st;
-    stage_put(o_k, kun, sizeof(orbx_keypoint_t) * n); stage_put(o_d, desc, (size_t)32 * n); stage_put(o_u, uright, 4 * (size_t)n);
+    hipStream_t st = dev ? dev->stream : g_sp.st;
+    if (!dev) {
+        stage_put(o_k, kun, sizeof(orbx_keypoint_t) * n); stage_put(o_d, desc, (size_t)32 * n); stage_put(o_u, uright, 4 * (size_t)n);
+        stage_put(o_ld, last_desc, (size_t)32 * nlast);
+    }
     stage_put(o_sf, scale_factors, 4 * (size_t)nlevels);
     stage_put(o_T, Tcw_cur16, 64); stage_put(o_T + 64, Tcw_last16, 64);
-    stage_put(o_l, last, sizeof(orbm_lastpoint_t) * nlast); stage_put(o_ld, last_desc, (size_t)32 * nlast);
+    stage_put(o_l, last, sizeof(orbm_lastpoint_t) * nlast);
     stage_put(o_cm, cur_mp, 4 * (size_t)n);
     if (ext_obs) stage_put(o_eo, ext_obs, 4 * (size_t)n);
     ORBX_HIP(hipMemcpyAsync(g_sp.d, g_sp.h, pl.in_end, hipMemcpyHostToDevice, st));
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_search_proj_frame, dim3(1), dim3(SQ_T), 0, st, stage_dev<orbx_keypoint_t>(o_k), stage_dev<uint8_t>(o_d),
-                       stage_dev<float>(o_u), n, *g, stage_dev<float>(o_sf), *cam, stage_dev<float>(o_T), stage_dev<float>(o_T) + 16,
-                       stage_dev<orbm_lastpoint_t>(o_l), stage_dev<uint8_t>(o_ld), nlast, stage_dev<int32_t>(o_cm),
+    hipLaunchKernelGGL(k_search_proj_frame, dim3(1), dim3(SQ_T), 0, st, dev ? kun : stage_dev<orbx_keypoint_t>(o_k),
+                       dev ? desc : stage_dev<uint8_t>(o_d), dev ? uright : stage_dev<float>(o_u), n, *g, stage_dev<float>(o_sf), *cam,
+                       stage_dev<float>(o_T), stage_dev<float>(o_T) + 16, stage_dev<orbm_lastpoint_t>(o_l),
+                       dev ? last_desc : stage_dev<uint8_t>(o_ld), nlast, stage_dev<int32_t>(o_cm),
                        ext_obs ? stage_dev<int32_t>(o_eo) : (int32_t *)nullptr, stage_dev<uint16_t>(o_code), stage_dev<int32_t>(o_hi),
                        stage_dev<int32_t>(o_hb), th, mono, check_orientation, stage_dev<int32_t>(o_nm));
     ORBX_HIP(hipGetLastError());
@@ -1044,6 +1070,28 @@ extern "C" int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const
     memcpy(cur_mp, g_sp.h + o_cm, 4 * (size_t)n);
     *nmatches = *(const int32_t *)(g_sp.h + o_nm);
     return ORBX_OK;
+}
+
+extern "C" int orbm_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright,
+                                               int n, const orbm_grid_geom_t *g, const float *scale_factors,
+                                               int nlevels, const orbm_camera_t *cam, const float *Tcw_cur16,
+                                               const float *Tcw_last16, const orbm_lastpoint_t *last,
+                                               const uint8_t *last_desc, int nlast, int32_t *cur_mp,
+                                               const int32_t *ext_obs, float th, int mono, int check_orientation,
+                                               int device, int *nmatches) {
+    return search_by_projection_frame_impl(kun, desc, uright, n, g, scale_factors, nlevels, cam, Tcw_cur16, Tcw_last16, last, last_desc,
+                                           nlast, cur_mp, ext_obs, th, mono, check_orientation, device, nmatches, nullptr);
+}
+extern "C" int orbm_search_by_projection_frame_device(const orbx_keypoint_t *d_kun, const uint8_t *d_desc, const float *d_uright,
+                                                      int n, const orbm_grid_geom_t *g, const float *scale_factors,
+                                                      int nlevels, const orbm_camera_t *cam, const float *Tcw_cur16,
+                                                      const float *Tcw_last16, const orbm_lastpoint_t *last,
+                                                      const uint8_t *d_last_desc, int nlast, int32_t *cur_mp,
+                                                      const int32_t *ext_obs, float th, int mono, int check_orientation,
+                                                      int device, int *nmatches, void *stream) {
+    const DevFrame dev = {(hipStream_t)stream};
+    return search_by_projection_frame_impl(d_kun, d_desc, d_uright, n, g, scale_factors, nlevels, cam, Tcw_cur16, Tcw_last16, last,
+                                           d_last_desc, nlast, cur_mp, ext_obs, th, mono, check_orientation, device, nmatches, &dev);
 }
 
 // ---- generic projected-window matcher, exact one-workgroup form (fallback of fast_match_windows)

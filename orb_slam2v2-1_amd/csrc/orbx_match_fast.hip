@@ -779,21 +779,26 @@ int fast_is_in_frustum(const orbm_worldpoint_t *pts, int m, const float *Tcw16, 
 int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc, const float *uright, int n,
                                  const orbm_grid_geom_t *g, const float *sf, int nlevels, const orbm_mappoint_t *mps,
                                  const uint8_t *mp_desc, int m, int32_t *frame_mp, const int32_t *ext_obs, float th,
-                                 float nnratio, int device, int *nmatches, const FrustumArgs *world, orbm_mappoint_t *proj_out) {
+                                 float nnratio, int device, int *nmatches, const FrustumArgs *world, orbm_mappoint_t *proj_out,
+                                 const DevFrame *dev) {
     if (n > 30000 && !world) return ORBX_FAST_FALLBACK;
     const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)m * (28 + 32 + QK * 8 + 64 + sizeof(orbm_worldpoint_t)) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
-    hipStream_t st = g_ar.st;
-    orbx_keypoint_t *dk = arena_get<orbx_keypoint_t>(n);
-    uint8_t *dd = arena_get<uint8_t>((size_t)32 * n), *dmd = arena_get<uint8_t>((size_t)32 * m), *dsb = arena_get<uint8_t>(n);
-    float *du = arena_get<float>(n), *dsf = arena_get<float>(nlevels);
+    // dev: the frame's keypoints / descriptors / mvuRight are already in HBM (outputs of orbx_extract_batch_device and
+    // orbm_stereo_batch_device) and the kernels run on the caller's stream, behind the kernels that produce them
+    hipStream_t st = dev ? dev->stream : g_ar.st;
+    orbx_keypoint_t *dk = dev ? const_cast<orbx_keypoint_t *>(kun) : arena_get<orbx_keypoint_t>(n);
+    uint8_t *dd = dev ? const_cast<uint8_t *>(desc) : arena_get<uint8_t>((size_t)32 * n);
+    uint8_t *dmd = arena_get<uint8_t>((size_t)32 * m), *dsb = arena_get<uint8_t>(n);
+    float *du = dev ? const_cast<float *>(uright) : arena_get<float>(n), *dsf = arena_get<float>(nlevels);
     orbm_mappoint_t *dmp = arena_get<orbm_mappoint_t>(m);
     int32_t *dfm = arena_get<int32_t>(n), *deo = arena_get<int32_t>(n), *dnc = arena_get<int32_t>(m), *dout = arena_get<int32_t>(4);
     uint16_t *dcode = arena_get<uint16_t>(n);
     GQuery *dq = arena_get<GQuery>(m);
     u64 *dkeys = arena_get<u64>((size_t)m * QK);
-    UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(du, uright, n); UP(dsf, sf, nlevels);
+    if (!dev) { UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(du, uright, n); }
+    UP(dsf, sf, nlevels);
     UP(dmd, mp_desc, (size_t)32 * m); UP(dfm, frame_mp, n);
     if (ext_obs) UP(deo, ext_obs, n);
     if (world) {
@@ -834,15 +839,16 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
                                     const orbm_grid_geom_t *g, const float *sf, int nlevels, const orbm_camera_t *cam,
                                     const float *Tc16, const float *Tl16, const orbm_lastpoint_t *last,
                                     const uint8_t *last_desc, int nlast, int32_t *cur_mp, const int32_t *ext_obs,
-                                    float th, int mono, int check_ori, int device, int *nmatches) {
+                                    float th, int mono, int check_ori, int device, int *nmatches, const DevFrame *dev) {
     if (n > 30000) return ORBX_FAST_FALLBACK;
     const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)nlast * (28 + 32 + QK * 8 + 64) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
-    hipStream_t st = g_ar.st;
-    orbx_keypoint_t *dk = arena_get<orbx_keypoint_t>(n);
-    uint8_t *dd = arena_get<uint8_t>((size_t)32 * n), *dld = arena_get<uint8_t>((size_t)32 * nlast), *dsb = arena_get<uint8_t>(n);
-    float *du = arena_get<float>(n), *dsf = arena_get<float>(nlevels), *dT = arena_get<float>(32);
+    hipStream_t st = dev ? dev->stream : g_ar.st;   // dev: kun / desc / uright / last_desc are device arrays (see fast_search_by_projection_mp)
+    orbx_keypoint_t *dk = dev ? const_cast<orbx_keypoint_t *>(kun) : arena_get<orbx_keypoint_t>(n);
+    uint8_t *dd = dev ? const_cast<uint8_t *>(desc) : arena_get<uint8_t>((size_t)32 * n);
+    uint8_t *dld = dev ? const_cast<uint8_t *>(last_desc) : arena_get<uint8_t>((size_t)32 * nlast), *dsb = arena_get<uint8_t>(n);
+    float *du = dev ? const_cast<float *>(uright) : arena_get<float>(n), *dsf = arena_get<float>(nlevels), *dT = arena_get<float>(32);
     orbm_lastpoint_t *dl = arena_get<orbm_lastpoint_t>(nlast);
     int32_t *dcm = arena_get<int32_t>(n), *deo = arena_get<int32_t>(n), *dnc = arena_get<int32_t>(nlast), *dout = arena_get<int32_t>(4);
     int32_t *dhi = arena_get<int32_t>(nlast), *dhb = arena_get<int32_t>(nlast);
@@ -851,8 +857,9 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
     u64 *dkeys = arena_get<u64>((size_t)nlast * QK);
     float T2[32];
     memcpy(T2, Tc16, 64); memcpy(T2 + 16, Tl16, 64);
-    UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(du, uright, n); UP(dsf, sf, nlevels); UP(dl, last, nlast);
-    UP(dld, last_desc, (size_t)32 * nlast); UP(dcm, cur_mp, n); UP(dT, T2, 32);
+    if (!dev) { UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(du, uright, n); UP(dld, last_desc, (size_t)32 * nlast); }
+    UP(dsf, sf, nlevels); UP(dl, last, nlast);
+    UP(dcm, cur_mp, n); UP(dT, T2, 32);
     if (ext_obs) UP(deo, ext_obs, n);
     FLUSH_UP();
     const int mx = std::max(n, nlast);

@@ -90,3 +90,26 @@ def stereo_pair_blocky(w, h, k=0, block=24):
 def batch(w, h, n, k0=0):
     """n mono frames [n, h, w]."""
     return np.stack([frame(w, h, k0 + i) for i in range(n)])
+
+
+def stereo_sequence(w, h, nframes, k=0, step=0.04, block=24):
+    """Rectified stereo SEQUENCE of a camera that translates along +X through a scene of fronto-parallel bands (depth
+    constant over blocks of `block` rows, as in stereo_pair_blocky).  A band of disparity d px moves step*d px per
+    frame, so with baseline b the camera advances step*b per frame: frame t shows the band shifted by round(t*step*d).
+    Returns (frames, disparity_per_row) with frames = [(left_t, right_t)]; independent sensor noise per image."""
+    rng = np.random.default_rng(1000 + k)
+    nb = (h + block - 1) // block
+    dblk = rng.integers(2, 61, size=nb)
+    pad = 64 + int(np.ceil(nframes * step * 60)) + 8
+    sc = _scene(rng, w, h, pad)
+    drow = np.array([int(dblk[y // block]) for y in range(h)])
+    frames = []
+    for t in range(nframes):
+        left = np.empty((h, w), np.float32)
+        right = np.empty((h, w), np.float32)
+        for y in range(h):
+            o = int(round(t * step * drow[y]))
+            left[y] = sc[y, o:o + w]
+            right[y] = sc[y, o + drow[y]:o + drow[y] + w]
+        frames.append((_finish(rng, left), _finish(rng, right)))
+    return frames, drow
