@@ -183,7 +183,7 @@ def measure(fe, steps, warmup, ramp, world, dist, dev, torch):
     for i in range(warmup):
         fe.step(i)
     fe.drain()
-    # Timed region: only the dominant kernel (k_fast_cells) is bracketed by HIP events on its launch stream.  Every
+    # Timed region: only the dominant kernel (the FAST stage: k_fast_strips) is bracketed by HIP events on its launch stream.  Every
     # recorded event idles the GPU for ~4.5 us, so the full stage breakdown is taken in a separate untimed pass below.
     ex.set_profiling(2)
     if world > 1:
@@ -201,7 +201,7 @@ def measure(fe, steps, warmup, ramp, world, dist, dev, torch):
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    fast_ms = float(ex.stage_ms()[0][1])            # k_fast_cells, averaged over the K timed steps
+    fast_ms = float(ex.stage_ms()[0][1])            # FAST stage, averaged over the K timed steps
     last = fe.results((warmup + steps - 1) % fe.ring.nbuf)   # outputs of the LAST TIMED step (host copies), checked later
     nprof = max(1, min(steps, 10))                  # untimed pass: events at every stage boundary
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(nprof)]
@@ -256,8 +256,9 @@ def roofline_block(fe, m, workload, B, value, world, traffic_lookup=True):
     # dominant single kernel of the step (HIP events on the launch stream, averaged over the
     # timed region).  Algorithmic bytes per image: FAST+NMS reads every level once = P;
     # quad-tree reads its candidates; describe reads P + writes 60 N (SURVEY section 8(d) split).
+    fast_names = fe.ex.fast_kernels(nimg)     # k_fast_strips for a GPU-filling batch (+ k_fast_cells for levels with wide cells)
     kern = {
-        "k_fast_cells": (m["fast_ms"], P * nimg),
+        "+".join(fast_names): (m["fast_ms"], P * nimg),
         "k_octree": (float(stage_ms[2]), 8.0 * ncand_img * nimg),   # 4 B key + 2 B node index read, 2 B written
         "k_describe": (float(stage_ms[3]), (P + 60 * navg) * nimg),
     }
@@ -269,9 +270,9 @@ def roofline_block(fe, m, workload, B, value, world, traffic_lookup=True):
     if traffic_lookup and os.path.exists(pmc_path):
         try:
             pm = json.load(open(pmc_path))
-            inst = [k for k in pm.get("kernels", {}) if k.split("<")[0] == dom]   # template instances: k_fast_cells<44>
+            inst = [k for k in pm.get("kernels", {}) if k.split("<")[0] in dom.split("+")]   # template instances: k_fast_cells<44>
             if pm.get("workload") == workload and pm.get("batch") == B and inst:
-                traffic = max(pm["kernels"][k]["hbm_bytes_per_launch"] for k in inst)
+                traffic = sum(pm["kernels"][k]["hbm_bytes_per_launch"] for k in inst)
         except Exception:
             traffic = None
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0,
@@ -455,7 +456,7 @@ def main():
                                   "images_per_call": fe.nimg, "calls_averaged": m["ncalls"],
                                   "fast_timed_region": round(m["fast_ms"], 4),
                                   "note": "stage breakdown from an untimed pass of %d steps after the timed region; "
-                                          "roofline.kernel_ms is k_fast_cells over the %d timed steps" % (m["nprof"], args.steps)},
+                                          "roofline.kernel_ms is the FAST stage (%s) over the %d timed steps" % (m["nprof"], roof["kernel"], args.steps)},
         }
         if others:
             # the other north-star sizes, same definition of a step, short runs (not the headline; the driver times only `value`)

@@ -113,6 +113,10 @@ int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, int stage, in
  * around k_fast_cells ([1] is filled, the rest stays 0) - every recorded event idles the GPU for ~4.5 us,
  * so a throughput run brackets just the kernel whose duration it reports. */
 #define ORBX_NUM_STAGES 5
+/* Stage [1] is k_fast_strips (one wave per strip of four cells; levels whose cells are at most 32 px wide, batches that fill
+ * the GPU) and / or k_fast_cells (one wave per cell; the other levels, small batches): which of them a batch of B images of
+ * the planned size runs.  Same results either way. */
+int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, int *cells);
 int orbx_set_profiling(orbx_extractor_t *h, int enabled);
 int orbx_get_stage_ms(orbx_extractor_t *h, float *ms5, int *ncalls);
 

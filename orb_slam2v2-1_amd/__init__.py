@@ -42,7 +42,7 @@ EXPORTS = [
     "orbm_search_local_points", "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_transform",
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
     "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch", "orbx_debug_sincosf",
-    "orbm_search_by_projection_frame_device", "orbm_search_local_points_device",
+    "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels",
 ]
 
 
@@ -129,6 +129,7 @@ def lib():
     L.orbx_pyramid_device.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.orbx_debug_level_points.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
     L.orbx_set_profiling.argtypes = [vp, i32]
+    L.orbx_fast_kernels.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.orbx_record_bytes.argtypes = [i32]
     L.orbx_pack_records_device.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp]
     L.orbx_get_stage_ms.argtypes = [vp, vp, C.POINTER(i32)]
@@ -297,6 +298,12 @@ class ORBextractor:
         if n.value:
             _check(self._L.orbx_debug_level_points(self._h, b, level, stage, _p(out), n.value, C.byref(n)))
         return out[:n.value]
+
+    def fast_kernels(self, B):
+        """names of the FAST kernel(s) a batch of B images of the planned size runs"""
+        st, ce = C.c_int(0), C.c_int(0)
+        _check(self._L.orbx_fast_kernels(self._h, int(B), C.byref(st), C.byref(ce)))
+        return [n for n, f in (("k_fast_strips", st.value), ("k_fast_cells", ce.value)) if f]
 
     def set_profiling(self, mode=1):
         """0/False off, 1/True events at every stage boundary, 2 only around k_fast_cells (see orbx.h)."""

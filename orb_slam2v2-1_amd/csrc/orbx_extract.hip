@@ -739,6 +739,17 @@ extern "C" int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, in
     return n > cap ? ORBX_ERR_CAPACITY : ORBX_OK;
 }
 
+// Which FAST kernel(s) a batch of B images of the planned size runs (the rule of launch_pipeline): for benchmarks that name the
+// kernel they time.  *strips = 1 if k_fast_strips takes part, *cells = 1 if k_fast_cells does.
+extern "C" int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, int *cells) {
+    if (!h || h->pw == 0 || B < 1) { orbx_set_error("orbx_fast_kernels: no plan yet"); return ORBX_ERR_ARG; }
+    const bool st = h->totalStrips > 0 && (g_debug[6] == 0 ? (size_t)h->totalStrips * B >= 4096 : g_debug[6] == 3);
+    const unsigned lv = st ? h->stripLevels : 0u;
+    if (strips) *strips = st ? 1 : 0;
+    if (cells) *cells = lv != (1u << h->nlevels) - 1u ? 1 : 0;
+    return ORBX_OK;
+}
+
 extern "C" int orbx_set_profiling(orbx_extractor_t *h, int enabled) {
     if (!h) return ORBX_ERR_ARG;
     ORBX_HIP(hipSetDevice(h->device));

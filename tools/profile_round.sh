@@ -10,7 +10,7 @@ cd $GRAFT_REPO_ROOT
 python3 bench.py > $out/bench.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf $out/prof_bench
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $out/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-other-workloads --no-verify > $out/prof_bench.log 2>&1
 cp $(ls $out/prof_bench/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 PMC_NO_HEARTBEAT=1 bash $GRAFT_REPO_ROOT/tools/pmc_traffic.sh > /dev/null
 bash $GRAFT_REPO_ROOT/tools/pmc_run.sh a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
