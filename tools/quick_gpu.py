@@ -7,7 +7,10 @@ synth = importlib.import_module("orb_slam2v2-1_amd.synth")
 import torch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 w, h, nf = 1241, 376, 1000
-imgs = synth.batch(w, h, 8, 0)
+if "noise" in sys.argv:    # uniform noise: the worst case for any early-rejection scheme, the densest candidate lists
+    imgs = np.random.default_rng(8).integers(0, 256, (8, h, w), dtype=np.uint8)
+else:
+    imgs = synth.batch(w, h, 8, 0)
 imgs = np.concatenate([imgs] * ((B + 7) // 8))[:B]
 import os as _os
 if _os.environ.get("PYR_T"): pkg.lib().orbx_debug_set(3, int(_os.environ["PYR_T"]))
