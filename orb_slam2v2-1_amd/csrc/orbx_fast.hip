@@ -417,8 +417,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
     // NMS state: S1 = scores (+1) of row y-1, H1 / H2 = 3-wide horizontal maxima of rows y-1 / y-2, LR1 = max(left, right) of row y-1
     uint32_t S1 = 0, H1 = 0, H2 = 0, LR1 = 0;
     uint32_t nRaw = 0, nHi = 0;   // survivors >= min(iniTh, minTh) so far in my cell (same in its 16 lanes) / MY survivors >= max(iniTh, minTh)
-    for (int yv = 0; yv <= chS; yv++) {
-        const int y = __builtin_amdgcn_readfirstlane(yv);   // everything derived from the row number stays on the scalar unit
+    // one evaluated row: scores of row y, suppression verdict for row y-1 (sign flags of its two pixels, its scores), ring update
+    auto rowstep = [&](int y, uint32_t &kpOut, uint32_t &sOut) {
         uint32_t S = 0;
         if (y < chS) {   // wave-uniform
             const uint32_t *q = q0 + __builtin_amdgcn_readfirstlane((y & 7) * STRIP_ES);   // window rows y .. y+6 = ring slots (y & 7) .. + 6
@@ -442,24 +442,37 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
         // strict 3x3 maximum of row y-1 (rows y-2 and y through their horizontal maxima) and score >= tlo: ONE sign test per
         // pixel (exact on these values; a negative f16 is a negative int16)
         const half2v nb = pk_max3(__builtin_bit_cast(half2v, H2), __builtin_bit_cast(half2v, H0), __builtin_bit_cast(half2v, LR1));
-        const short2v kp = __builtin_bit_cast(short2v, __builtin_bit_cast(half2v, S1) - nb);
-        // the two pixels of a pair are neighbours: at most ONE of them is a strict maximum, so a lane emits at most one key per row
-        const bool k0 = kp.x > 0, k1 = kp.y > 0;
-        const unsigned long long m = __ballot(k0 || k1);
-        if (m) {   // wave-uniform
-            const uint32_t a = (uint32_t)(m >> cs) & 0xFFFFu;                    // my cell's 16 lanes of the ballot (one 64-bit shift)
-            const uint32_t sc = k1 ? S1 >> 16 : S1 & 0xFFFFu;                    // score + 1 of my survivor
-            const uint32_t pos = cellOff + nRaw + __popc(a & ltc);               // row-major order: the survivors of my cell's lower lanes first
-            // (a cell cannot hold more than capc = ceil(w/2) * ceil(h/2) strict 3x3 maxima: no two of them are neighbours)
-            if (k0 || k1) lvlSlots[pos] = (sc << 24) + (k1 ? x0 + 1u : x0) + ((ybase + (uint32_t)(y - 1)) << 12) - (1u << 24);
-            nHi += (k0 || k1) && sc > (uint32_t)thi ? 1u : 0u;
-            nRaw += __popc(a);
-        }
+        kpOut = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, S1) - nb);
+        sOut = S1;
         S1 = S; H2 = H1; H1 = H0; LR1 = LR0;
         // stream: window row y+7 (loaded during this iteration) replaces row y-1 in the ring; row y+8 goes in flight
         if (y + 7 < thS) write_row(y + 7, pre);   // wave-uniform
         pre = load_row(y + 8);
         wave_sync();
+    };
+    // Two rows per loop iteration, ONE emission for both: the two pixels of a pair and the pair of the next row are all
+    // neighbours of each other, so among the four at most one is a strict 3x3 maximum - a lane emits at most one key per two rows.
+    for (int yv = 0; yv <= chS; yv += 2) {
+        const int y = __builtin_amdgcn_readfirstlane(yv);   // everything derived from the row number stays on the scalar unit
+        uint32_t kpA, sA, kpB, sB;
+        rowstep(y, kpA, sA);          // verdict for row y-1
+        rowstep(y + 1, kpB, sB);      // verdict for row y   (y + 1 > chS: an all-zero row, nothing survives)
+        const short2v fa = __builtin_bit_cast(short2v, kpA), fb = __builtin_bit_cast(short2v, kpB);
+        const bool inA = fa.x > 0 || fa.y > 0, inB = fb.x > 0 || fb.y > 0;
+        const unsigned long long mA = __ballot(inA), mB = __ballot(inB);
+        if (mA | mB) {   // wave-uniform
+            const uint32_t aA = (uint32_t)(mA >> cs) & 0xFFFFu, aB = (uint32_t)(mB >> cs) & 0xFFFFu;   // my cell's 16 lanes of the ballots
+            const bool second = inB ? fb.y > 0 : fa.y > 0;                       // my survivor is the pair's second pixel
+            const uint32_t sv = inB ? sB : sA;
+            const uint32_t sc = second ? sv >> 16 : sv & 0xFFFFu;                // its score + 1
+            // row-major order: row y-1 before row y, inside a row the survivors of my cell's lower lanes first
+            const uint32_t pos = cellOff + nRaw + (inB ? __popc(aA) + __popc(aB & ltc) : __popc(aA & ltc));
+            // (a cell cannot hold more than capc = ceil(w/2) * ceil(h/2) strict 3x3 maxima: no two of them are neighbours)
+            if (inA || inB)
+                lvlSlots[pos] = (sc << 24) + (second ? x0 + 1u : x0) + ((ybase + (uint32_t)(y - 1) + (inB ? 1u : 0u)) << 12) - (1u << 24);
+            nHi += (inA || inB) && sc > (uint32_t)thi ? 1u : 0u;
+            nRaw += __popc(aA) + __popc(aB);
+        }
     }
     // per-cell totals: the 16 lanes of a cell
 #pragma unroll
