@@ -117,6 +117,8 @@ extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int i
 static void free_plan(orbx_extractor *h) {
     hipFree(h->d_cellRaw); h->d_cellRaw = nullptr;
     hipFree(h->d_octFallback); h->d_octFallback = nullptr;
+    hipFree(h->d_octPart); hipFree(h->d_octLeaf); hipFree(h->d_octBest); hipFree(h->d_octState);
+    h->d_octPart = nullptr; h->d_octLeaf = nullptr; h->d_octBest = nullptr; h->d_octState = nullptr;
     hipFree(h->d_geom); hipFree(h->d_tab); hipFree(h->d_pyr); hipFree(h->d_cellCnt); hipFree(h->d_slots);
     hipFree(h->d_cand); hipFree(h->d_lvlKp); hipFree(h->d_nodeOf); hipFree(h->d_candCnt); hipFree(h->d_lvlCnt);
     h->d_geom = nullptr; h->d_tab = nullptr; h->d_pyr = nullptr; h->d_cellCnt = nullptr; h->d_slots = nullptr;
@@ -173,7 +175,8 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     B = std::max(B, keepB);
     std::vector<int32_t> tab;
     size_t poff = 0, slotOff = 0, keyOff = 0;
-    int cellBase = 0, lvlKpOff = 0, maxNodeCap = 0, maxCells = 0, maxPyrWords = 0;
+    int cellBase = 0, lvlKpOff = 0, maxNodeCap = 0, maxCells = 0, maxPyrWords = 0, maxDeepWords = 0;
+    unsigned bigMask = 0;
     int maxTw = 0, maxTh = 0;
     int kpBound = 0;
     for (int l = 0; l < h->nlevels; l++) {
@@ -231,6 +234,9 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
             g.pyrDepth = d;
             const int words = g.nIni * (((1 << (2 * d)) - 1) / 3) + ((g.nIni << (2 * d)) + 1) / 2 + 1;
             maxPyrWords = std::max(maxPyrWords, words);
+            maxDeepWords = std::max(maxDeepWords, ((g.nIni << (2 * d)) + 1) / 2 + 1);
+            // a level with this many FAST cells carries tens of thousands of keys: its quad-tree is shared by several workgroups
+            if (g.ncells >= 600) bigMask |= 1u << l;
         }
         kpBound += std::max(g.N + 2, 4 * g.nIni);
         maxNodeCap = std::max(maxNodeCap, g.nodeCap);
@@ -419,6 +425,15 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     ORBX_HIP(hipMalloc(&h->d_lvlKp, sizeof(uint32_t) * (size_t)h->lvlKpCap * Bz));
     ORBX_HIP(hipMalloc(&h->d_octFallback, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
     ORBX_HIP(hipMemset(h->d_octFallback, 0, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
+    h->octBigMask = bigMask; h->octDeepMax = maxDeepWords;
+    {
+        const size_t slots = Bz * h->nlevels;
+        ORBX_HIP(hipMalloc(&h->d_octPart, sizeof(uint32_t) * slots * OCT_BIG_K * (size_t)maxDeepWords));
+        ORBX_HIP(hipMalloc(&h->d_octLeaf, sizeof(uint32_t) * slots * (size_t)maxPyrWords));
+        ORBX_HIP(hipMalloc(&h->d_octBest, sizeof(uint32_t) * slots * (size_t)maxNodeCap));
+        ORBX_HIP(hipMalloc(&h->d_octState, sizeof(int32_t) * slots * 4));
+        ORBX_HIP(hipMemset(h->d_octState, 0, sizeof(int32_t) * slots * 4));
+    }
     ORBX_HIP(hipMemcpy(h->d_geom, h->geom, sizeof(LevelGeom) * ORBX_MAX_LEVELS, hipMemcpyHostToDevice));
     if (!tab.empty()) ORBX_HIP(hipMemcpy(h->d_tab, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice));
     h->pw = w; h->ph = hgt; h->pB = B;
@@ -525,14 +540,34 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
         hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
                            dim3(256), 0, st, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_cellRaw, h->d_slots,
                            h->slotsPerImg, h->d_cand, h->keysPerImg, h->d_candCnt, h->ini_th, h->min_th, cb);
-        const bool usePyr = g_debug[4] == 0;
+        // developer knob 4: 0 default, 1 = the exact form alone, 2 = EVERY level by the multi-workgroup form, 3 = none
+        const bool usePyr = g_debug[4] != 1;
         if (usePyr) {   // a level whose tree outgrows the count pyramid is redone by the same block with the exact form: one launch
             const size_t lds = std::max(h->octPyrLdsBytes, h->octLdsBytes);
-            ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_pyr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_octree_pyr, dim3(B, nl), dim3(OCT_T), lds, st, h->d_geom, nl, h->d_cand,
-                               h->keysPerImg, h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap,
-                               pow2, h->octPyrWords, h->d_octFallback, g_debug[7], h->d_nodeOf, scratch, g_debug[1]);
-        } else {        // developer knob 4: the exact form alone
+            const unsigned bigMask = g_debug[4] == 2 ? (1u << nl) - 1u : g_debug[4] == 3 ? 0u : h->octBigMask;
+            OctBig big = {};
+            big.part = h->d_octPart; big.leaf = h->d_octLeaf; big.best = h->d_octBest; big.state = h->d_octState;
+            big.K = OCT_BIG_K; big.deepMax = h->octDeepMax; big.pyrMax = h->octPyrWords;
+            for (int l = 0; l < nl; l++) if ((bigMask >> l) & 1u) big.levelOf[big.nBig++] = l;
+            if (big.nBig > 0) {   // large levels: K workgroups histogram, the last one runs the passes ...
+                ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_octree_big<1>, dim3(OCT_BIG_K, big.nBig, B), dim3(OCT_T), lds, st, h->d_geom, nl, h->d_cand, h->keysPerImg,
+                                   h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
+                                   h->d_octFallback, h->d_nodeOf, scratch, big);
+            }
+            if (bigMask != (1u << nl) - 1u) {
+                ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_pyr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_octree_pyr, dim3(B, nl), dim3(OCT_T), lds, st, h->d_geom, nl, h->d_cand,
+                                   h->keysPerImg, h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap,
+                                   pow2, h->octPyrWords, h->d_octFallback, g_debug[7], h->d_nodeOf, scratch, g_debug[1], bigMask);
+            }
+            if (big.nBig > 0) {   // ... and K workgroups elect the best key per node, the last one writes the level's keypoints
+                ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_octree_big<2>, dim3(OCT_BIG_K, big.nBig, B), dim3(OCT_T), lds, st, h->d_geom, nl, h->d_cand, h->keysPerImg,
+                                   h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
+                                   h->d_octFallback, h->d_nodeOf, scratch, big);
+            }
+        } else {        // developer knob 4 = 1: the exact form alone
             ORBX_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octLdsBytes));
             hipLaunchKernelGGL(k_octree, dim3(B, nl), dim3(OCT_T), h->octLdsBytes, st, h->d_geom, nl, h->d_cand, h->d_nodeOf,
                                h->keysPerImg, h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2,

@@ -77,9 +77,21 @@ __global__ void k_fast_cells(const uint8_t *pyr, size_t pyrImgBytes, const Level
 __global__ void k_gather(const LevelGeom *geom, int nlevels, int totalCells, const uint32_t *cellCnt, const uint32_t *cellRaw,
                          const uint32_t *slots, size_t slotsPerImg, uint32_t *cand, size_t keysPerImg, int32_t *candCnt, int iniTh,
                          int minTh, CellBases cb);                                                               // orbx_fast.hip
+struct OctBig {   // multi-workgroup quad-tree of large levels (orbx_octree.hip)
+    uint32_t *part, *leaf, *best;
+    int32_t *state;
+    int K, nBig, deepMax, pyrMax;
+    int levelOf[ORBX_MAX_LEVELS];
+};
+#define OCT_BIG_K 8   // workgroups sharing one large level
 __global__ void k_octree_pyr(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
                              uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
-                             int pyrWords, int32_t *fallback, int dbgStop, uint16_t *nodeOf, int scratchInts, int dbgStopExact);  // orbx_octree.hip
+                             int pyrWords, int32_t *fallback, int dbgStop, uint16_t *nodeOf, int scratchInts, int dbgStopExact,
+                             unsigned bigMask);                                                                  // orbx_octree.hip
+template <int MODE>
+__global__ void k_octree_big(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
+                             uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
+                             int pyrWords, int32_t *fallback, uint16_t *nodeOf, int scratchInts, OctBig big);    // orbx_octree.hip
 __global__ void k_octree(const LevelGeom *geom, int nlevels, const uint32_t *cand, uint16_t *nodeOf, size_t keysPerImg,
                          const int32_t *candCnt, uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax,
                          int pow2cap, int scratchInts, int dbgStop);                                             // orbx_octree.hip

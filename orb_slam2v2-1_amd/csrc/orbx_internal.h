@@ -74,6 +74,9 @@ struct orbx_extractor {
     size_t octLdsBytes, octPyrLdsBytes;
     int octPyrWords;
     int32_t *d_octFallback;
+    // multi-workgroup quad-tree of large levels: which levels, scratch (sized for every level so that a developer knob can force it)
+    unsigned octBigMask; int octDeepMax;
+    uint32_t *d_octPart, *d_octLeaf, *d_octBest; int32_t *d_octState;
     int pyrTilesX, pyrTilesY, pyrXSpanOff, pyrYSpanOff, pyrBufBytes, pyrMaxDim, pyrMaxPar;
     size_t pyrLdsBytes;
     // device buffers

@@ -135,13 +135,23 @@ __device__ __forceinline__ uint32_t pyr_count(const uint32_t *pyr, int nIni, int
 __device__ __forceinline__ void octree_exact_level(const LevelGeom *geom, int nlevels, const uint32_t *cand, uint16_t *nodeOf, size_t keysPerImg,
                                                 const int32_t *candCnt, uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab,
                                                 int capMax, int pow2cap, int scratchInts, int dbgStop, int l, int b);
-__global__ __launch_bounds__(OCT_T) void k_octree_pyr(
+// MODE 0: the whole level in this workgroup (k_octree_pyr).  Large levels (a 1920x1080 level 0 carries ~70 k keys; its two key
+// sweeps are bound by the LDS atomics of ONE CU: 47 + 86 us of a 195-us block) are shared by K workgroups instead:
+// MODE 1 (k_octree_big<1>): slice s histograms its K-th of the keys in LDS and writes the partial histogram to global memory;
+//         the workgroup that finishes LAST (a counter, no spinning) sums the K partials, builds the count pyramid, runs the
+//         passes and leaves leaf map + list length in global memory;
+// MODE 2 (k_octree_big<2>, the next launch): slice s loads the leaf map, elects the best key per node over its K-th of the keys
+//         (LDS atomicMax, then one global atomicMax per node it touched); the last workgroup writes the level's keypoints.
+// (struct OctBig: orbx_extract_dev.h - part [B][nBig][K][deepMax] partial histograms, leaf [B][nBig][pyrMax] leaf map,
+// best [B][nBig][capMax] best key per node, state [B][nBig][4]: arrival counters A and B, list length (-1: done by the exact form))
+template <int MODE>
+__device__ __forceinline__ void octree_pyr_body(
     const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand, size_t keysPerImg,
     const int32_t *__restrict__ candCnt, uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
     const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback, int dbgStop,
-    uint16_t *__restrict__ nodeOf, int scratchInts, int dbgStopExact) {
+    uint16_t *__restrict__ nodeOf, int scratchInts, int dbgStopExact, int l, int b, int slice, int bigIdx, const OctBig &big) {
     extern __shared__ __align__(16) uint8_t smem[];
-    const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;  // level-major: large levels start first
+    const int tid = threadIdx.x;
     const LevelGeom g = geom[l];
     const int Dm = g.pyrDepth, nIni = g.nIni, N = g.N;
     uint8_t *sp = smem;
@@ -153,18 +163,26 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
     uint32_t *pyr = (uint32_t *)sp; sp += 4 * (size_t)pyrWords;
     uint16_t *xlist = (uint16_t *)sp; sp += 2 * capMax;
     uint8_t *split = sp; sp += capMax;
-    __shared__ int sh_L, sh_Lnew, sh_finish, sh_phase, sh_abort;
+    __shared__ int sh_L, sh_Lnew, sh_finish, sh_phase, sh_abort, sh_last;
 
     const uint32_t *keys = cand + (size_t)b * keysPerImg + g.keyOff;
     const int n = candCnt[b * nlevels + l];
     const int32_t *xPath = tab + g.xPathOff, *yPath = tab + g.yPathOff;
     const uint32_t offDeep = (uint32_t)nIni * (((1u << (2 * Dm)) - 1u) / 3u);
 
+    // this workgroup's share of the keys (MODE 0: all of them), in whole groups of four
+    const int iLo = MODE == 0 ? 0 : (int)(((long long)n * slice / big.K) & ~3ll);
+    const int iHi = MODE == 0 || slice == big.K - 1 ? n : (int)(((long long)n * (slice + 1) / big.K) & ~3ll);
+    const size_t bigSlot = MODE == 0 ? 0 : (size_t)b * big.nBig + bigIdx;
+    int32_t *bstate = MODE == 0 ? nullptr : big.state + 4 * bigSlot;
+    uint32_t *gleaf = MODE == 0 ? nullptr : big.leaf + bigSlot * big.pyrMax, *gbest = MODE == 0 ? nullptr : big.best + bigSlot * capMax;
+    int L = 0, cur = 0;
+  if (MODE != 2) {
     // ---- 1. histogram of the keys at depth Dm (two 16-bit counters per word)
     for (int i = tid; i < pyrWords; i += OCT_T) pyr[i] = 0;
     if (tid == 0) sh_abort = 0;
     __syncthreads();
-    for (int i0 = 4 * tid; i0 < n; i0 += 4 * OCT_T) {
+    for (int i0 = iLo + 4 * tid; i0 < iHi; i0 += 4 * OCT_T) {
         uint32_t key[4], c[4];
         load_keys4(keys, i0, n, key);
 #pragma unroll
@@ -173,7 +191,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
         // consecutive keys (row-major inside a FAST cell) mostly share the deep cell: count runs, one LDS atomic per run
         uint32_t inc[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) inc[u] = i0 + u < n ? 1u : 0u;
+        for (int u = 0; u < 4; u++) inc[u] = i0 + u < iHi ? 1u : 0u;
 #pragma unroll
         for (int u = 0; u < 3; u++)
             if (c[u] == c[u + 1]) { inc[u + 1] += inc[u]; inc[u] = 0; }
@@ -182,6 +200,25 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
             if (inc[u]) atomicAdd(&pyr[offDeep + (c[u] >> 1)], inc[u] << (16 * (c[u] & 1)));
     }
     __syncthreads();
+    if (MODE == 1) {   // partial histogram -> global; the last workgroup to arrive carries on with the sum of all K
+        const int deepWords = ((nIni << (2 * Dm)) + 1) >> 1;
+        uint32_t *gp = big.part + (bigSlot * big.K + slice) * big.deepMax;
+        for (int i = tid; i < deepWords; i += OCT_T) gp[i] = pyr[offDeep + i];
+        __threadfence();     // my partial is visible device-wide before I am counted
+        __syncthreads();
+        if (tid == 0) sh_last = __hip_atomic_fetch_add(&bstate[0], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == big.K - 1;
+        __syncthreads();
+        if (!sh_last) return;
+        __threadfence();
+        const volatile uint32_t *ga = big.part + bigSlot * big.K * big.deepMax;   // other workgroups' stores: read past the L1
+        for (int i = tid; i < deepWords; i += OCT_T) {
+            uint32_t sum = 0;
+            for (int k = 0; k < big.K; k++) sum += ga[(size_t)k * big.deepMax + i];   // two 16-bit counters per word, no carry between them
+            pyr[offDeep + i] = sum;
+        }
+        if (tid == 0) bstate[0] = 0;   // ready for the next call
+        __syncthreads();
+    }
     if (dbgStop == 1) return;
     // ---- 2. counts of the shallower depths
     for (int d = Dm - 1; d >= 0; d--) {
@@ -206,7 +243,8 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
         sh_L = L0;
     }
     __syncthreads();
-    int L = sh_L, cur = 0, phase = 1;
+    L = sh_L;
+    int phase = 1;
 
     // ---- 4. passes: list bookkeeping on node counts only, by wave 0
     while (true) {
@@ -360,7 +398,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
         }
         __syncthreads();
         if (sh_abort) {   // counts deeper than the pyramid are needed: this block redoes its level with the exact form (same LDS, carved anew)
-            if (tid == 0) fallback[b * nlevels + l] = 1;   // (kept as a record: tests look at it)
+            if (tid == 0) { fallback[b * nlevels + l] = 1; if (MODE == 1) bstate[2] = -1; }   // (a record: tests look at it; MODE 2 skips the level)
             __syncthreads();
             octree_exact_level(geom, nlevels, cand, nodeOf, keysPerImg, candCnt, lvlKp, lvlKpCap, lvlCnt, tab, capMax, pow2cap, scratchInts,
                                dbgStopExact, l, b);
@@ -390,8 +428,21 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
         }
         __syncthreads();
     }
+    if (MODE == 1) {   // hand the leaf map to the K workgroups of the next launch
+        for (int i = tid; i < pyrWords; i += OCT_T) gleaf[i] = pyr[i];
+        for (int i = tid; i < L; i += OCT_T) gbest[i] = 0;
+        if (tid == 0) bstate[2] = L;
+        return;
+    }
+  } else {   // MODE 2: the leaf map of the previous launch
+    L = bstate[2];
+    if (L < 0) return;   // the level was finished by the exact form
+    for (int i = tid; i < pyrWords; i += OCT_T) pyr[i] = gleaf[i];
+    for (int i = tid; i < L; i += OCT_T) hist[i] = 0;
+    __syncthreads();
+  }
     // ---- 6. every key walks down to its leaf; best key of the node, first maximum wins (:744-760)
-    for (int i0 = 4 * tid; i0 < n; i0 += 4 * OCT_T) {
+    for (int i0 = iLo + 4 * tid; i0 < iHi; i0 += 4 * OCT_T) {
         uint32_t key[4], cd[4], node[4];
         load_keys4(keys, i0, n, key);
 #pragma unroll
@@ -422,7 +473,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             val[u] = ((key[u] >> 24) << 24) | (0xFFFFFFu - (uint32_t)(i0 + u));
-            if (i0 + u >= n) node[u] = 0xFFFFFFFFu;
+            if (i0 + u >= iHi) node[u] = 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int u = 0; u < 3; u++)
@@ -433,12 +484,51 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
     }
     __syncthreads();
     if (dbgStop == 4) return;
+    if (MODE == 2) {   // merge my nodes into the level's, count myself; the last workgroup to arrive writes the output
+        for (int k = tid; k < L; k += OCT_T) { const uint32_t v = hist[k]; if (v) atomicMax(&gbest[k], v); }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) sh_last = __hip_atomic_fetch_add(&bstate[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == big.K - 1;
+        __syncthreads();
+        if (!sh_last) return;
+        __threadfence();
+        const volatile uint32_t *gb = gbest;
+        for (int k = tid; k < L; k += OCT_T) hist[k] = gb[k];
+        if (tid == 0) bstate[1] = 0;
+        __syncthreads();
+    }
     // ---- 7. output in list order
     uint32_t *okp = lvlKp + (size_t)b * lvlKpCap + g.lvlKpOff;
     const int Lout = min(L, g.nodeCap);
     for (int k = tid; k < Lout; k += OCT_T) okp[k] = keys[0xFFFFFFu - (hist[k] & 0xFFFFFFu)];
     if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; fallback[b * nlevels + l] = 0; }
 }
+
+__global__ __launch_bounds__(OCT_T) void k_octree_pyr(
+    const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand, size_t keysPerImg,
+    const int32_t *__restrict__ candCnt, uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
+    const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback, int dbgStop,
+    uint16_t *__restrict__ nodeOf, int scratchInts, int dbgStopExact, unsigned bigMask) {
+    const int l = blockIdx.y, b = blockIdx.x;  // level-major: large levels start first
+    if ((bigMask >> l) & 1u) return;             // shared by several workgroups: k_octree_big
+    OctBig none = {};
+    octree_pyr_body<0>(geom, nlevels, cand, keysPerImg, candCnt, lvlKp, lvlKpCap, lvlCnt, tab, capMax, pow2cap, pyrWords, fallback, dbgStop,
+                       nodeOf, scratchInts, dbgStopExact, l, b, 0, 0, none);
+}
+template <int MODE>
+__global__ __launch_bounds__(OCT_T) void k_octree_big(
+    const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand, size_t keysPerImg,
+    const int32_t *__restrict__ candCnt, uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
+    const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback,
+    uint16_t *__restrict__ nodeOf, int scratchInts, OctBig big) {
+    const int slice = blockIdx.x, bigIdx = blockIdx.y, b = blockIdx.z;
+    octree_pyr_body<MODE>(geom, nlevels, cand, keysPerImg, candCnt, lvlKp, lvlKpCap, lvlCnt, tab, capMax, pow2cap, pyrWords, fallback, 0,
+                          nodeOf, scratchInts, 0, big.levelOf[bigIdx], b, slice, bigIdx, big);
+}
+template __global__ void k_octree_big<1>(const LevelGeom *, int, const uint32_t *, size_t, const int32_t *, uint32_t *, int, int32_t *,
+                                         const int32_t *, int, int, int, int32_t *, uint16_t *, int, OctBig);
+template __global__ void k_octree_big<2>(const LevelGeom *, int, const uint32_t *, size_t, const int32_t *, uint32_t *, int, int32_t *,
+                                         const int32_t *, int, int, int, int32_t *, uint16_t *, int, OctBig);
 
 // K3 (exact form): one sweep over the keys per pass.  Called by k_octree_pyr for the levels whose tree outgrows the count
 // pyramid (a block that finds out simply carries on here: no second launch), and launched on its own with developer knob 4.

@@ -323,6 +323,38 @@ def test_quadtree_sweep_kernel_alone(pkg, oracle, synth):
         pkg.lib().orbx_debug_set(4, 0)
 
 
+def test_quadtree_multi_workgroup_form(pkg, oracle, synth):
+    """Levels with >= 600 FAST cells (the finest levels of 1920x1080) share their quad-tree between 8 workgroups: partial
+    histograms merged by the last workgroup to arrive, best-key election merged by global atomicMax (k_octree_big<1>, <2>).
+    Developer knob 4 = 2 forces that form on EVERY level, = 3 forbids it; results must not depend on the choice - including
+    levels that outgrow the count pyramid inside the multi-workgroup form (clustered keys), empty levels and a batch."""
+    rng = np.random.default_rng(95)
+    clustered = np.full((480, 640), 128, np.uint8)
+    clustered[200:280, 260:380] = rng.integers(0, 256, (80, 120), dtype=np.uint8)   # all keys in one corner of the tree
+    flat = np.full((480, 640), 77, np.uint8)                                          # no keys at all
+    for knob in (2, 3):
+        pkg.lib().orbx_debug_set(4, knob)
+        try:
+            _compare(pkg, oracle, synth.frame(1241, 376, 96), 1000)
+            _compare(pkg, oracle, synth.frame(640, 480, 97), 2000)
+            _compare(pkg, oracle, clustered, 1000)
+            _compare(pkg, oracle, flat, 500)
+            _compare(pkg, oracle, rng.integers(0, 256, (376, 620), dtype=np.uint8), 2000)
+            # a batch: the arrival counters are per (image, level) and must come back to zero for the next call
+            imgs = synth.batch(752, 480, 6, k0=98)
+            ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+            orc = oracle.Extractor(1000, 1.2, 8, 20, 7)
+            for rep in range(2):
+                res = ex.extract_batch(imgs)
+                for i in range(6):
+                    ok, od = orc.extract(imgs[i])
+                    assert res[i][0].tobytes() == ok.tobytes() or (len(res[i][0]) == len(ok) and (res[i][1] == od).all()
+                                                                     and (res[i][0]["x"] == ok["x"]).all() and (res[i][0]["y"] == ok["y"]).all())
+        finally:
+            pkg.lib().orbx_debug_set(4, 0)
+    _compare(pkg, oracle, synth.frame(1920, 1080, 99), 4000)     # default rule: levels 0..3 take the multi-workgroup form
+
+
 def test_fast_cell_kernel_instances(pkg, oracle, synth):
     """FAST runs as k_fast_strips (one wave per strip of four cells) on levels whose cells are at most 32 px wide and as
     k_fast_cells (one wave per cell) on the others.  Developer knob 6 forces k_fast_cells on every level: 1 = its instances
