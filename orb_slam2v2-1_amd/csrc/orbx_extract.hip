@@ -544,28 +544,33 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
         const bool usePyr = g_debug[4] != 1;
         if (usePyr) {   // a level whose tree outgrows the count pyramid is redone by the same block with the exact form: one launch
             const size_t lds = std::max(h->octPyrLdsBytes, h->octLdsBytes);
-            const unsigned bigMask = g_debug[4] == 2 ? (1u << nl) - 1u : g_debug[4] == 3 ? 0u : h->octBigMask;
+            // The multi-workgroup form shortens ONE image's critical path (a 1920x1080 level 0: 195 us alone in its workgroup); a
+            // batch already fills the GPU with one workgroup per (image, level), and the extra hand-offs then cost more than they save
+            // (batch 32 of 1920x1080: 274 us against 215), so it is taken for small batches only.  Same results either way.
+            const unsigned bigMask = g_debug[4] == 2 ? (1u << nl) - 1u : (g_debug[4] == 3 || B > 4) ? 0u : h->octBigMask;
             OctBig big = {};
             big.part = h->d_octPart; big.leaf = h->d_octLeaf; big.best = h->d_octBest; big.state = h->d_octState;
             big.K = OCT_BIG_K; big.deepMax = h->octDeepMax; big.pyrMax = h->octPyrWords;
             for (int l = 0; l < nl; l++) if ((bigMask >> l) & 1u) big.levelOf[big.nBig++] = l;
-            if (big.nBig > 0) {   // large levels: K workgroups histogram, the last one runs the passes ...
+            if (big.nBig > 0 && g_debug[7] == 0 && g_debug[1] == 0) {
+                // large levels: K workgroups histogram, the last one to arrive runs the passes; the same launch carries the other
+                // levels (one workgroup each, listed behind the large ones) ...
+                int nall = big.nBig;
+                for (int l = 0; l < nl; l++) if (!((bigMask >> l) & 1u)) big.levelOf[nall++] = l;
                 ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_octree_big<1>, dim3(OCT_BIG_K, big.nBig, B), dim3(OCT_T), lds, st, h->d_geom, nl, h->d_cand, h->keysPerImg,
+                hipLaunchKernelGGL(k_octree_big<1>, dim3(OCT_BIG_K, nl, B), dim3(OCT_T), lds, st, h->d_geom, nl, h->d_cand, h->keysPerImg,
                                    h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
                                    h->d_octFallback, h->d_nodeOf, scratch, big);
-            }
-            if (bigMask != (1u << nl) - 1u) {
-                ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_pyr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_octree_pyr, dim3(B, nl), dim3(OCT_T), lds, st, h->d_geom, nl, h->d_cand,
-                                   h->keysPerImg, h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap,
-                                   pow2, h->octPyrWords, h->d_octFallback, g_debug[7], h->d_nodeOf, scratch, g_debug[1], bigMask);
-            }
-            if (big.nBig > 0) {   // ... and K workgroups elect the best key per node, the last one writes the level's keypoints
+                // ... then K workgroups elect the best key per node, the last one writes the level's keypoints
                 ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(k_octree_big<2>, dim3(OCT_BIG_K, big.nBig, B), dim3(OCT_T), lds, st, h->d_geom, nl, h->d_cand, h->keysPerImg,
                                    h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
                                    h->d_octFallback, h->d_nodeOf, scratch, big);
+            } else {   // no large level (or a phase-stop knob is set): one workgroup per level, one launch
+                ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_pyr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_octree_pyr, dim3(B, nl), dim3(OCT_T), lds, st, h->d_geom, nl, h->d_cand,
+                                   h->keysPerImg, h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap,
+                                   pow2, h->octPyrWords, h->d_octFallback, g_debug[7], h->d_nodeOf, scratch, g_debug[1], 0u);
             }
         } else {        // developer knob 4 = 1: the exact form alone
             ORBX_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octLdsBytes));

@@ -204,13 +204,18 @@ __device__ __forceinline__ void octree_pyr_body(
         const int deepWords = ((nIni << (2 * Dm)) + 1) >> 1;
         uint32_t *gp = big.part + (bigSlot * big.K + slice) * big.deepMax;
         for (int i = tid; i < deepWords; i += OCT_T) gp[i] = pyr[offDeep + i];
-        __threadfence();     // my partial is visible device-wide before I am counted
+        // hand-off across workgroups (they may sit on different XCDs, each with its own L2): every wave's stores are done at the
+        // barrier; then ONE lane releases at agent scope (L2 write-back), counts the workgroup, and - if it is the last to arrive -
+        // an acquire fence invalidates this CU's L1 and the stale L2 lines, so that the whole workgroup may read the partials with
+        // plain loads.  (A fence in every thread makes every one of them flush / invalidate the caches: 5-15x slower at batch 32.)
         __syncthreads();
-        if (tid == 0) sh_last = __hip_atomic_fetch_add(&bstate[0], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == big.K - 1;
+        if (tid == 0) {
+            sh_last = __hip_atomic_fetch_add(&bstate[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == big.K - 1;
+            if (sh_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // only the last arrival pays the invalidation
+        }
         __syncthreads();
         if (!sh_last) return;
-        __threadfence();
-        const volatile uint32_t *ga = big.part + bigSlot * big.K * big.deepMax;   // other workgroups' stores: read past the L1
+        const uint32_t *ga = big.part + bigSlot * big.K * big.deepMax;
         for (int i = tid; i < deepWords; i += OCT_T) {
             uint32_t sum = 0;
             for (int k = 0; k < big.K; k++) sum += ga[(size_t)k * big.deepMax + i];   // two 16-bit counters per word, no carry between them
@@ -486,14 +491,12 @@ __device__ __forceinline__ void octree_pyr_body(
     if (dbgStop == 4) return;
     if (MODE == 2) {   // merge my nodes into the level's, count myself; the last workgroup to arrive writes the output
         for (int k = tid; k < L; k += OCT_T) { const uint32_t v = hist[k]; if (v) atomicMax(&gbest[k], v); }
-        __threadfence();
         __syncthreads();
-        if (tid == 0) sh_last = __hip_atomic_fetch_add(&bstate[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == big.K - 1;
+        if (tid == 0) sh_last = __hip_atomic_fetch_add(&bstate[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == big.K - 1;
         __syncthreads();
         if (!sh_last) return;
-        __threadfence();
-        const volatile uint32_t *gb = gbest;
-        for (int k = tid; k < L; k += OCT_T) hist[k] = gb[k];
+        // the atomics above executed at the memory side; read their result the same way (no cached copy can be stale)
+        for (int k = tid; k < L; k += OCT_T) hist[k] = __hip_atomic_load(&gbest[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) bstate[1] = 0;
         __syncthreads();
     }
@@ -521,7 +524,16 @@ __global__ __launch_bounds__(OCT_T) void k_octree_big(
     const int32_t *__restrict__ candCnt, uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
     const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback,
     uint16_t *__restrict__ nodeOf, int scratchInts, OctBig big) {
-    const int slice = blockIdx.x, bigIdx = blockIdx.y, b = blockIdx.z;
+    const int slice = blockIdx.x, b = blockIdx.z;
+    if (MODE == 1 && (int)blockIdx.y >= big.nBig) {
+        // the first launch also carries the levels that one workgroup handles alone (grid y = nBig .. nlevels-1, slice 0 only):
+        // they run beside the large levels' histograms and passes instead of in a launch of their own
+        if (slice != 0) return;
+        octree_pyr_body<0>(geom, nlevels, cand, keysPerImg, candCnt, lvlKp, lvlKpCap, lvlCnt, tab, capMax, pow2cap, pyrWords, fallback, 0,
+                           nodeOf, scratchInts, 0, big.levelOf[blockIdx.y], b, 0, 0, big);
+        return;
+    }
+    const int bigIdx = blockIdx.y;
     octree_pyr_body<MODE>(geom, nlevels, cand, keysPerImg, candCnt, lvlKp, lvlKpCap, lvlCnt, tab, capMax, pow2cap, pyrWords, fallback, 0,
                           nodeOf, scratchInts, 0, big.levelOf[bigIdx], b, slice, bigIdx, big);
 }
