@@ -334,6 +334,16 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  * Never set in production: keys 0, 1 and 7 leave outputs incomplete; 2, 4, 5, 6 select an alternative
  * kernel with identical results (tests use them to cover those kernels). */
 int orbx_debug_set(int key, int value);
+/* Test hooks for two rows of the scope table that have no output of their own.
+ * orbx_debug_blur_patches (a8, cv::GaussianBlur 7x7 sigma 2 - fused into the descriptor kernel, never stored): enable = 1, then
+ * orbx_extract of ONE image with cap <= the handle's keypoint bound, then out != NULL fetches the 37x37 blurred block around each
+ * of the first n keypoints (n * 1369 bytes, keypoint order); enable = 0 releases the buffer.
+ * orbm_debug_features_in_area (a12, Frame::GetFeaturesInArea src/Frame.cc:342-395): the indices the query returns, in the
+ * reference's order (column-major over grid cells, insertion order inside a cell) - the order every matcher's "first minimum
+ * wins" depends on. */
+int orbx_debug_blur_patches(orbx_extractor_t *h, int enable, uint8_t *out, int n);
+int orbm_debug_features_in_area(const orbx_keypoint_t *kun, int n, const orbm_grid_geom_t *g, float x, float y, float r,
+                                int min_level, int max_level, int32_t *out_idx, int *n_out, int device);
 /* Test hook: the device's restatement of libm cosf / sinf (the float overloads src/ORBextractor.cc:113 resolves to) on n
  * host angles in [0, 2 pi]; the descriptor kernel uses exactly this routine. */
 int orbx_debug_sincosf(const float *angles, int n, float *sin_out, float *cos_out, int device);

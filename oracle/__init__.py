@@ -225,6 +225,13 @@ class Extractor:
         full = _arr(ptr.value, ps.value * (h.value + 38), np.uint8).reshape(h.value + 38, ps.value)
         return full if padded else full[19:19 + h.value, 19:19 + w.value].copy()
 
+    def blurred_level(self, level):
+        """The level after GaussianBlur(7x7, sigma 2, REFLECT_101) (src/ORBextractor.cc:1085-1086), [h, w] uint8."""
+        ptr, w, h, ps = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+        if self.L.oracle_pyramid_level(self.h, level, C.byref(ptr), C.byref(w), C.byref(h), C.byref(ps)):
+            raise RuntimeError("no pyramid")
+        return _arr(self.L.oracle_blurred_level(self.h, level), w.value * h.value, np.uint8).reshape(h.value, w.value)
+
     def level_candidates(self, level):
         ptr = C.c_void_p()
         n = self.L.oracle_level_candidates(self.h, level, C.byref(ptr))

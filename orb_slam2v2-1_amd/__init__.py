@@ -42,7 +42,7 @@ EXPORTS = [
     "orbm_search_local_points", "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_transform",
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
     "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch", "orbx_debug_sincosf",
-    "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels",
+    "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels", "orbx_debug_blur_patches", "orbm_debug_features_in_area",
 ]
 
 
@@ -162,6 +162,8 @@ def lib():
     L.orbm_search_local_points_device.argtypes = L.orbm_search_local_points.argtypes + [vp]
     L.orbm_best_in_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, i32, vp, vp, i32]
     L.orbx_debug_sincosf.argtypes = [vp, i32, vp, vp, i32]
+    L.orbx_debug_blur_patches.argtypes = [vp, i32, vp, i32]
+    L.orbm_debug_features_in_area.argtypes = [vp, i32, C.POINTER(GridGeom), f32, f32, f32, i32, i32, vp, C.POINTER(i32), i32]
     L.orbx_last_error.restype = C.c_char_p
     L.orbx_version.restype = C.c_char_p
     for name in EXPORTS:
@@ -305,6 +307,18 @@ class ORBextractor:
         _check(self._L.orbx_fast_kernels(self._h, int(B), C.byref(st), C.byref(ce)))
         return [n for n, f in (("k_fast_strips", st.value), ("k_fast_cells", ce.value)) if f]
 
+    def debug_blur_patches(self, image):
+        """Test hook: extract one image and also return the 37x37 blurred block around every keypoint [N,37,37]."""
+        _check(self._L.orbx_debug_blur_patches(self._h, 1, None, 0))
+        try:
+            k, d = self(image)
+            out = np.zeros((max(len(k), 1), 37, 37), np.uint8)
+            if len(k):
+                _check(self._L.orbx_debug_blur_patches(self._h, 1, _p(out), len(k)))
+        finally:
+            self._L.orbx_debug_blur_patches(self._h, 0, None, 0)
+        return k, d, out[:len(k)]
+
     def set_profiling(self, mode=1):
         """0/False off, 1/True events at every stage boundary, 2 only around k_fast_cells (see orbx.h)."""
         _check(self._L.orbx_set_profiling(self._h, int(mode)))
@@ -315,6 +329,16 @@ class ORBextractor:
         n = C.c_int(0)
         _check(self._L.orbx_get_stage_ms(self._h, _p(ms), C.byref(n)))
         return ms, n.value
+
+
+def debug_features_in_area(kun, geom, x, y, r, min_level=-1, max_level=-1, device=0):
+    """Test hook: Frame::GetFeaturesInArea as the matchers see it -> indices in the reference's order."""
+    kun = np.ascontiguousarray(kun, KP_DTYPE)
+    out = np.zeros(max(len(kun), 1), np.int32)
+    n = C.c_int(0)
+    _check(lib().orbm_debug_features_in_area(_p(kun), len(kun), C.byref(geom), float(x), float(y), float(r), int(min_level),
+                                             int(max_level), _p(out), C.byref(n), int(device)))
+    return out[:n.value].copy()
 
 
 def debug_sincosf(angles, device=0):

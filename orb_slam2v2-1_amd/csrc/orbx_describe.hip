@@ -112,7 +112,7 @@ __constant__ const IcTab c_ic = make_ic_tab();
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
     const uint32_t *__restrict__ lvlKp, int lvlKpCap, const int32_t *__restrict__ lvlCnt,
-    orbx_keypoint_t *__restrict__ kps, uint8_t *__restrict__ desc, int32_t *__restrict__ counts, int cap) {
+    orbx_keypoint_t *__restrict__ kps, uint8_t *__restrict__ desc, int32_t *__restrict__ counts, int cap, uint8_t *__restrict__ dbgBlur) {
     __shared__ __align__(16) uint8_t smem[DESC_WAVES * DESC_LDS_PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int bx, b;
@@ -315,6 +315,10 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     }
     wave_sync();
 
+    if (dbgBlur) {   // test hook (wave-uniform, NULL in production): the 37x37 blurred block around the keypoint, rows of 37 bytes
+        uint8_t *o37 = dbgBlur + ((size_t)b * cap + o) * (TCOLS * TCOLS);
+        for (int i = lane; i < TCOLS * TCOLS; i += 64) o37[i] = Bl[(i / TCOLS) * BSTRIDE + i % TCOLS];
+    }
     // ---- steered BRIEF: 4 rounds x 64 pairs, one ballot = 8 descriptor bytes
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ang = angle * factorPI;

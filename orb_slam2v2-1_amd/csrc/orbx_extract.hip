@@ -134,7 +134,7 @@ extern "C" int orbx_destroy(orbx_extractor_t *h) {
     if (h->st_stream) hipStreamSynchronize(h->st_stream);
     orbx_internal_free_stereo_scratch(h);
     free_plan(h);
-    hipFree(h->d_in); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts);
+    hipFree(h->d_in); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_dbgBlur);
     if (h->h_kps) { hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); }
     for (int r = 0; r < ORBX_EV_RING; r++)
         for (int i = 0; i < ORBX_NUM_STAGES; i++) hipEventDestroy(h->ev[r][i]);
@@ -584,7 +584,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
         const int maxo = std::min(cap, h->max_kp);
         dim3 grid((maxo + DESC_WAVES - 1) / DESC_WAVES, B);
         hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, st, h->d_pyr, h->pyrImgBytes, h->d_geom, nl,
-                           h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, d_kps, d_desc, d_counts, cap);
+                           h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, d_kps, d_desc, d_counts, cap, h->d_dbgBlur);
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[4], st));
     if (profFast) { h->ev_pending[h->ev_head % ORBX_EV_RING] = (unsigned char)h->profiling; h->ev_head++; }
@@ -787,6 +787,26 @@ extern "C" int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, 
     const unsigned lv = st ? h->stripLevels : 0u;
     if (strips) *strips = st ? 1 : 0;
     if (cells) *cells = lv != (1u << h->nlevels) - 1u ? 1 : 0;
+    return ORBX_OK;
+}
+
+// Test hook for SURVEY section 8 row a8 (cv::GaussianBlur 7x7, sigma 2, fused into k_describe and never stored): the next
+// single-image orbx_extract calls also write, for keypoint i, the 37x37 blurred block centred on it (the only blurred
+// pixels the descriptor can read) to a device buffer, fetched here.  enable = 0 frees the buffer.
+extern "C" int orbx_debug_blur_patches(orbx_extractor_t *h, int enable, uint8_t *out, int n) {
+    if (!h) return ORBX_ERR_ARG;
+    ORBX_HIP(hipSetDevice(h->device));
+    if (h->last_stream) ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    if (out && n > 0) {
+        if (!h->d_dbgBlur || n > h->dbgBlurCap) { orbx_set_error("orbx_debug_blur_patches: not enabled or n too large"); return ORBX_ERR_ARG; }
+        ORBX_HIP(hipMemcpy(out, h->d_dbgBlur, (size_t)n * 37 * 37, hipMemcpyDeviceToHost));
+        return ORBX_OK;
+    }
+    hipFree(h->d_dbgBlur); h->d_dbgBlur = nullptr; h->dbgBlurCap = 0;
+    if (enable) {
+        h->dbgBlurCap = h->max_kp > 0 ? h->max_kp + 300 : h->nfeatures + 3 * h->nlevels + 300;
+        ORBX_HIP(hipMalloc(&h->d_dbgBlur, (size_t)h->dbgBlurCap * 37 * 37));
+    }
     return ORBX_OK;
 }
 

@@ -97,4 +97,4 @@ __global__ void k_octree(const LevelGeom *geom, int nlevels, const uint32_t *can
                          int pow2cap, int scratchInts, int dbgStop);                                             // orbx_octree.hip
 __global__ void k_describe(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, const uint32_t *lvlKp,
                            int lvlKpCap, const int32_t *lvlCnt, orbx_keypoint_t *kps, uint8_t *desc, int32_t *counts,
-                           int cap);                                                                             // orbx_describe.hip
+                           int cap, uint8_t *dbgBlur);                                                                             // orbx_describe.hip

@@ -90,6 +90,7 @@ struct orbx_extractor {
     uint8_t *d_in; size_t d_in_bytes;
     orbx_keypoint_t *d_kps; uint8_t *d_desc; int32_t *d_counts; int out_cap, out_B;
     orbx_keypoint_t *h_kps; uint8_t *h_desc; int32_t *h_counts;   // pinned mirrors of the three above
+    uint8_t *d_dbgBlur; int dbgBlurCap;   // test hook: blurred 37x37 blocks of a single-image call (orbx_debug_blur_patches)
     hipStream_t stream;      // own stream
     hipStream_t last_stream; // stream of the last batch call
     int lastB;

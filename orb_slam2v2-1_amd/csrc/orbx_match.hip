@@ -14,6 +14,7 @@
 #define ORBX_FAST_FALLBACK_RC 1   // what the fast_* entry points return when the exact kernels must run
 #include <math.h>
 #include <algorithm>
+#include <vector>
 
 extern "C" int orbm_hamming(const uint8_t *a, const uint8_t *b) {
     if (!a || !b) return ORBX_ERR_ARG;
@@ -572,6 +573,46 @@ __device__ Top2 block_top2(Top2 t, u64 *sh) {
         r = top2_merge(r, u);
     }
     return r;
+}
+
+// ---- test hook: Frame::GetFeaturesInArea (src/Frame.cc:342-395) as the matchers see it - the predicate in_area() and the
+// scan-order key (column-major over cells, index order inside a cell).  Every matcher takes "the first minimum in this
+// order"; here the order itself comes out: key (cellx, celly, j) of every keypoint the query returns, ~0 for the others,
+// sorted by the caller.
+__global__ __launch_bounds__(256) void k_debug_area(const orbx_keypoint_t *__restrict__ k, int n, orbm_grid_geom_t g, float x, float y, float r,
+                                                    int minLevel, int maxLevel, unsigned long long *__restrict__ keys) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const AreaQuery q = make_query(g, x, y, r, minLevel, maxLevel);
+    const unsigned code = cell_code(g, k[j]);
+    keys[j] = (!q.empty && in_area(q, code, k[j])) ? scan_key(0, code, j) : ~0ull;
+}
+extern "C" int orbm_debug_features_in_area(const orbx_keypoint_t *kun, int n, const orbm_grid_geom_t *g, float x, float y, float r,
+                                           int min_level, int max_level, int32_t *out_idx, int *n_out, int device) {
+    if (!kun || n < 1 || n > 65535 || !g || !out_idx || !n_out) { orbx_set_error("orbm_debug_features_in_area: bad arguments"); return ORBX_ERR_ARG; }
+    StagePlan pl;
+    const size_t o_k = pl.take(sizeof(orbx_keypoint_t) * n);
+    pl.mark_inputs();
+    const size_t o_keys = pl.take(8 * (size_t)n);
+    int rc = stage_reserve(device, pl.off);
+    if (rc) return rc;
+    ORBX_HIP(hipSetDevice(device));
+    hipStream_t st = g_sp.st;
+    stage_put(o_k, kun, sizeof(orbx_keypoint_t) * n);
+    ORBX_HIP(hipMemcpyAsync(g_sp.d, g_sp.h, pl.in_end, hipMemcpyHostToDevice, st));
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_debug_area, dim3((n + 255) / 256), dim3(256), 0, st, stage_dev<orbx_keypoint_t>(o_k), n, *g, x, y, r, min_level,
+                       max_level, stage_dev<unsigned long long>(o_keys));
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(g_sp.h + o_keys, g_sp.d + o_keys, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    const unsigned long long *keys = (const unsigned long long *)(g_sp.h + o_keys);
+    std::vector<unsigned long long> v;
+    for (int j = 0; j < n; j++) if (keys[j] != ~0ull) v.push_back(keys[j]);
+    std::sort(v.begin(), v.end());
+    for (size_t i = 0; i < v.size(); i++) out_idx[i] = (int32_t)(v[i] & 0xFFFF);
+    *n_out = (int)v.size();
+    return ORBX_OK;
 }
 
 // ---- SearchForInitialization: one workgroup, F1 keypoints in order (the steal / gate on

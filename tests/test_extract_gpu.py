@@ -439,3 +439,58 @@ def test_device_sincosf_equals_oracle_and_host_libm(pkg, oracle):
         oracle.set_sincos_mode(0)
         np.testing.assert_array_equal(gs.view(np.uint32), os_.view(np.uint32), err_msg="sin, oracle mode %d" % mode)
         np.testing.assert_array_equal(gc.view(np.uint32), oc.view(np.uint32), err_msg="cos, oracle mode %d" % mode)
+
+
+def test_blurred_patches_direct(pkg, oracle, synth):
+    """SURVEY row a8 checked directly: the 7x7 sigma-2 blur is fused into the descriptor kernel and never stored, so a test hook
+    dumps the 37x37 blurred block around every keypoint; it must equal the oracle's blurred LEVEL (cv::GaussianBlur of the
+    whole level, <= 3.3 fixed point, REFLECT_101) at the same pixels - including keypoints whose block hangs over the level's
+    edge (mirrored there) and a saturated image, where the taps' sum of 257 reaches the clamp."""
+    rng = np.random.default_rng(31)
+    sat = np.zeros((480, 640), np.uint8)
+    for _ in range(400):
+        x, y = rng.integers(0, 636), rng.integers(0, 476)
+        sat[y:y + rng.integers(2, 40), x:x + rng.integers(2, 40)] = 255 if rng.random() < 0.5 else 0
+    for img, nf in ((synth.frame(752, 480, 70), 1000), (sat, 800)):
+        ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+        orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+        ok, od = orc.extract(img)
+        k, d, patches = ex.debug_blur_patches(img)
+        np.testing.assert_array_equal(d, od)
+        isf = orc.inv_scale_factors
+        nedge = 0
+        for i in range(len(k)):
+            l = int(k["octave"][i])
+            bl = orc.blurred_level(l)
+            h, w = bl.shape
+            cx = int(round(float(k["x"][i]) * float(isf[l]))) if l else int(k["x"][i])
+            cy = int(round(float(k["y"][i]) * float(isf[l]))) if l else int(k["y"][i])
+            ys, xs = np.arange(cy - 18, cy + 19), np.arange(cx - 18, cx + 19)
+            inside = (ys[:, None] >= 0) & (ys[:, None] < h) & (xs[None, :] >= 0) & (xs[None, :] < w)
+            nedge += int(not inside.all())
+            want = bl[np.clip(ys, 0, h - 1)[:, None], np.clip(xs, 0, w - 1)[None, :]]
+            # pixels of the block outside the level are never read by a descriptor tap: compare what lies inside
+            assert (patches[i][inside] == want[inside]).all(), "keypoint %d level %d" % (i, l)
+        assert len(k) > 500
+
+
+def test_get_features_in_area_order_direct(pkg, oracle, synth):
+    """SURVEY row a12 checked directly: Frame::GetFeaturesInArea (src/Frame.cc:342-395) is never materialised on the device (a
+    predicate + a scan-order key inside the matchers); the hook returns what a query would return, in order, against the
+    oracle's 64x48 grid lists - level filters (incl. the bCheckLevels quirk minLevel > 0 || maxLevel >= 0), windows hanging over
+    the image, empty windows."""
+    w, h = 752, 480
+    orc = oracle.Extractor(1500, 1.2, 8, 20, 7)
+    k, _ = orc.extract(synth.frame(w, h, 71))
+    go, gg = oracle.grid_geom(w, h), pkg.grid_geom(w, h)
+    rng = np.random.default_rng(32)
+    nonempty = 0
+    for q in range(300):
+        x, y = rng.uniform(-20, w + 20), rng.uniform(-20, h + 20)
+        r = float(rng.choice([3.0, 7.5, 15.0, 40.0, 100.0]))
+        mn, mx = [(-1, -1), (0, -1), (0, 0), (2, 4), (1, -1), (0, 7), (3, 2)][q % 7]
+        want = oracle.grid_query(k, go, x, y, r, mn, mx)
+        got = pkg.debug_features_in_area(k, gg, x, y, r, mn, mx)
+        np.testing.assert_array_equal(got, want, err_msg="query %d (%.1f, %.1f, r %.1f, levels %d..%d)" % (q, x, y, r, mn, mx))
+        nonempty += len(want) > 1
+    assert nonempty > 100
