@@ -324,7 +324,7 @@ def test_quadtree_sweep_kernel_alone(pkg, oracle, synth):
 
 
 def test_quadtree_multi_workgroup_form(pkg, oracle, synth):
-    """Levels with >= 600 FAST cells (the finest levels of 1920x1080) share their quad-tree between 8 workgroups: partial
+    """In a small batch, levels with >= 100 FAST cells share their quad-tree between 8 workgroups: partial
     histograms merged by the last workgroup to arrive, best-key election merged by global atomicMax (k_octree_big<1>, <2>).
     Developer knob 4 = 2 forces that form on EVERY level, = 3 forbids it; results must not depend on the choice - including
     levels that outgrow the count pyramid inside the multi-workgroup form (clustered keys), empty levels and a batch."""
@@ -352,7 +352,7 @@ def test_quadtree_multi_workgroup_form(pkg, oracle, synth):
                                                                      and (res[i][0]["x"] == ok["x"]).all() and (res[i][0]["y"] == ok["y"]).all())
         finally:
             pkg.lib().orbx_debug_set(4, 0)
-    _compare(pkg, oracle, synth.frame(1920, 1080, 99), 4000)     # default rule: levels 0..3 take the multi-workgroup form
+    _compare(pkg, oracle, synth.frame(1920, 1080, 99), 4000)     # default rule: a single image, the larger levels take the multi-workgroup form
 
 
 def test_fast_cell_kernel_instances(pkg, oracle, synth):
