@@ -235,9 +235,10 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
             const int words = g.nIni * (((1 << (2 * d)) - 1) / 3) + ((g.nIni << (2 * d)) + 1) / 2 + 1;
             maxPyrWords = std::max(maxPyrWords, words);
             maxDeepWords = std::max(maxDeepWords, ((g.nIni << (2 * d)) + 1) / 2 + 1);
-            // a level with this many FAST cells carries thousands of keys: in a small batch its quad-tree is shared by several
-            // workgroups (single image, orbx_extract host to host: 1241x376 184 -> 168 us, 1920x1080 418 -> 327 us with every level shared)
-            if (g.ncells >= 100) bigMask |= 1u << l;
+            // a level with this many FAST cells carries tens of thousands of keys: in a small batch its quad-tree is shared by several
+            // workgroups (single image, orbx_extract host to host: 1920x1080 / 4000 features 418 -> 348 us).  Smaller levels gain
+            // nothing reliable: with every level >= 100 cells shared, 1241x376 / 1000 features went 184 -> 176 us, / 2000 features 225 -> 233 us
+            if (g.ncells >= 600) bigMask |= 1u << l;
         }
         kpBound += std::max(g.N + 2, 4 * g.nIni);
         maxNodeCap = std::max(maxNodeCap, g.nodeCap);

@@ -324,7 +324,7 @@ def test_quadtree_sweep_kernel_alone(pkg, oracle, synth):
 
 
 def test_quadtree_multi_workgroup_form(pkg, oracle, synth):
-    """In a small batch, levels with >= 100 FAST cells share their quad-tree between 8 workgroups: partial
+    """In a small batch, levels with >= 600 FAST cells (the finest levels of 1920x1080) share their quad-tree between 8 workgroups: partial
     histograms merged by the last workgroup to arrive, best-key election merged by global atomicMax (k_octree_big<1>, <2>).
     Developer knob 4 = 2 forces that form on EVERY level, = 3 forbids it; results must not depend on the choice - including
     levels that outgrow the count pyramid inside the multi-workgroup form (clustered keys), empty levels and a batch."""
