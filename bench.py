@@ -185,7 +185,7 @@ def measure(fe, steps, warmup, ramp, world, dist, dev, torch):
     fe.drain()
     # Timed region: only the dominant kernel (the FAST stage: k_fast_strips) is bracketed by HIP events on its launch stream.  Every
     # recorded event idles the GPU for ~4.5 us, so the full stage breakdown is taken in a separate untimed pass below.
-    ex.set_profiling(2)
+    ex.set_profiling(3)     # the FAST stage of every 4th timed step (two events idle the GPU for ~9 us)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

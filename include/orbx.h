@@ -111,7 +111,8 @@ int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, int stage, in
  * orbx_get_stage_ms returns the AVERAGE per call since orbx_set_profiling(h,mode) and the number
  * of calls averaged (ncalls may be NULL).  mode 0: off; 1: all stage boundaries; 2: only the two events
  * around k_fast_cells ([1] is filled, the rest stays 0) - every recorded event idles the GPU for ~4.5 us,
- * so a throughput run brackets just the kernel whose duration it reports. */
+ * so a throughput run brackets just the kernel whose duration it reports; 3: as 2, on every 4th call only (the average is over the
+ * bracketed calls). */
 #define ORBX_NUM_STAGES 5
 /* Stage [1] is k_fast_strips (one wave per strip of four cells; levels whose cells are at most 32 px wide, batches that fill
  * the GPU) and / or k_fast_cells (one wave per cell; the other levels, small batches): which of them a batch of B images of

@@ -476,7 +476,8 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
     for (int l = 0; l <= ORBX_MAX_LEVELS; l++) cb.v[l] = l < nl ? h->geom[l].cellBase : h->totalCells;
     // profiling 1: events at every stage boundary; 2: only around k_fast_cells (an event costs ~4.5 us of idle GPU, so
     // a throughput measurement brackets just the kernel it reports)
-    const bool prof = h->profiling == 1, profFast = h->profiling != 0;
+    // mode 3 = mode 2 on every 4th call only: the two events cost ~9 us of idle GPU per call they bracket
+    const bool prof = h->profiling == 1, profFast = h->profiling != 0 && (h->profiling != 3 || (h->prof_calls++ & 3) == 0);
     (void)hipGetLastError();  // drop stale errors of other HIP users in this process
     hipEvent_t *ev = nullptr;
     if (profFast) {
@@ -589,7 +590,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
                            h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, d_kps, d_desc, d_counts, cap, h->d_dbgBlur);
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[4], st));
-    if (profFast) { h->ev_pending[h->ev_head % ORBX_EV_RING] = (unsigned char)h->profiling; h->ev_head++; }
+    if (profFast) { h->ev_pending[h->ev_head % ORBX_EV_RING] = (unsigned char)(h->profiling == 3 ? 2 : h->profiling); h->ev_head++; }
     ORBX_HIP(hipGetLastError());
     h->last_stream = st;
     h->lastB = B;
@@ -817,8 +818,9 @@ extern "C" int orbx_set_profiling(orbx_extractor_t *h, int enabled) {
     ORBX_HIP(hipSetDevice(h->device));
     for (int r = 0; r < ORBX_EV_RING; r++)
         if (h->ev_pending[r]) { ORBX_HIP(hipEventSynchronize(h->ev[r][h->ev_pending[r] == 2 ? 2 : 4])); h->ev_pending[r] = 0; }
-    if (enabled < 0 || enabled > 2) { orbx_set_error("orbx_set_profiling: mode %d", enabled); return ORBX_ERR_ARG; }
+    if (enabled < 0 || enabled > 3) { orbx_set_error("orbx_set_profiling: mode %d", enabled); return ORBX_ERR_ARG; }
     h->profiling = enabled;
+    h->prof_calls = 0;
     h->ev_head = 0;
     h->acc_n = 0;
     for (int i = 0; i < ORBX_NUM_STAGES; i++) h->acc_ms[i] = 0;

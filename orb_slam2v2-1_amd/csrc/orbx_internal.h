@@ -99,7 +99,7 @@ struct orbx_extractor {
     int32_t *st_sad; uint2 *st_rc; int32_t *st_binStart; uint4 *st_items; size_t st_n; int st_nB;
     hipStream_t st_stream;   // stream of the last stereo call on this handle
     // per-stage HIP-event timing: a ring of event sets so that timing never forces a sync
-    int profiling;
+    int profiling; unsigned prof_calls;
     hipEvent_t ev[ORBX_EV_RING][ORBX_NUM_STAGES];
     unsigned char ev_pending[ORBX_EV_RING];
     int ev_head;
