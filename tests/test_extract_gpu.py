@@ -253,7 +253,8 @@ def test_device_batch_on_a_torch_side_stream(pkg, oracle, synth):
 
 
 def test_stage_profiling_modes(pkg, synth):
-    """orbx_set_profiling: mode 1 brackets every stage, mode 2 only k_fast_cells; results do not depend on the mode."""
+    """orbx_set_profiling: mode 1 brackets every stage, mode 2 only the FAST stage, mode 3 the FAST stage of every 4th call;
+    results do not depend on the mode."""
     imgs = synth.batch(640, 480, 4, k0=90)
     ex = pkg.ORBextractor(500, 1.2, 8, 20, 7)
     base = ex.extract_batch(imgs)
@@ -268,13 +269,18 @@ def test_stage_profiling_modes(pkg, synth):
     ms2, n2 = ex.stage_ms()
     assert n2 == 40 and ms2[1] > 0 and ms2[0] == 0 and ms2[2] == 0 and ms2[3] == 0 and ms2[4] == 0
     assert 0.3 * ms[1] < ms2[1] < 3 * ms[1]
+    ex.set_profiling(3)
+    for _ in range(10):          # calls 0, 4, 8 are bracketed
+        r3 = ex.extract_batch(imgs)
+    ms3, n3 = ex.stage_ms()
+    assert n3 == 3 and 0.3 * ms[1] < ms3[1] < 3 * ms[1] and ms3[0] == 0
     ex.set_profiling(0)
-    for r in (r1, r2):
+    for r in (r1, r2, r3):
         for (k, d), (k0, d0) in zip(r, base):
             np.testing.assert_array_equal(d, d0)
             np.testing.assert_array_equal(k.view(np.uint8), k0.view(np.uint8))
     with pytest.raises(pkg.OrbxError):
-        ex.set_profiling(3)
+        ex.set_profiling(4)
 
 
 def _pyr(oracle, img, nf, level):
