@@ -87,6 +87,17 @@ int orbx_extract_batch_device(orbx_extractor_t *h, const uint8_t *d_imgs, int B,
                               int stride, size_t image_stride_bytes, orbx_keypoint_t *d_kps,
                               uint8_t *d_desc, int32_t *d_counts, int cap, void *stream);
 
+/* Software pipelining across batches (optional).  Starts ComputePyramid (src/ORBextractor.cc:1107-1132) of the NEXT batch on a
+ * stream owned by the handle, into a second pyramid buffer, ordered behind the FAST stage of the orbx_extract_batch_device call
+ * issued last on this handle: the memory-bound pyramid then runs beside that call's latency-bound gather / quad-tree, its
+ * descriptor kernel and the stereo matcher instead of in front of the next call's FAST.  The next orbx_extract_batch_device call
+ * with the SAME (d_imgs, B, w, hgt, stride, image_stride_bytes) takes that pyramid and skips its own; any other call ignores it.
+ * Contract: the images must be complete in HBM when this is called (it does not wait for the caller's stream) and must stay
+ * unchanged until that next call has been issued; calls on one handle come from one stream.  Results are identical with or
+ * without it. */
+int orbx_extract_batch_device_prefetch(orbx_extractor_t *h, const uint8_t *d_imgs, int B, int w, int hgt, int stride,
+                                       size_t image_stride_bytes);
+
 /* mvImagePyramid[level] of image `b` of the last call (include/ORBextractor.h:85): copies
  * the inner level (padded=0) or the whole bordered buffer (padded=1, 19 px border,
  * BORDER_REFLECT_101) into dst (dst_stride bytes per row) and reports its size. dst may
@@ -116,8 +127,10 @@ int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, int stage, in
 #define ORBX_NUM_STAGES 5
 /* Stage [1] is k_fast_strips (one wave per strip of four cells; levels whose cells are at most 32 px wide, batches that fill
  * the GPU) and / or k_fast_cells (one wave per cell; the other levels, small batches): which of them a batch of B images of
- * the planned size runs.  Same results either way. */
-int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, int *cells);
+ * the planned size runs.  Same results either way.  A batch of 32 images or more is cut into two chunks whose kernels overlap on
+ * two streams (the call keeps its stream semantics); the events of stage [1] bracket the first chunk's launch, which covers
+ * *images_per_launch images. */
+int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, int *cells, int *images_per_launch);
 int orbx_set_profiling(orbx_extractor_t *h, int enabled);
 int orbx_get_stage_ms(orbx_extractor_t *h, float *ms5, int *ncalls);
 
@@ -331,7 +344,8 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  * multi-workgroup form k_octree_big (default: levels with >= 600 FAST cells when the batch is at most 4 images), 3 = no level by it;
  * key 5: pyramid by the one-launch fused kernel; key 6: 1 = every level's FAST by k_fast_cells (one wave per cell) instead of
  * k_fast_strips, 2 = ... with run-time tile strides, 3 = k_fast_strips even for a small batch (default: by batch size);
- * key 7: stop k_octree_pyr after phase n).
+ * key 7: stop k_octree_pyr after phase n; key 8: n >= 2 cuts a batch into n chunks (at most 4) whose kernels
+ * overlap on the handle's side streams (measured: no gain, default one chunk); key 9: ignore pyramids built ahead).
  * Never set in production: keys 0, 1 and 7 leave outputs incomplete; 2, 4, 5, 6 select an alternative
  * kernel with identical results (tests use them to cover those kernels). */
 int orbx_debug_set(int key, int value);

@@ -42,7 +42,7 @@ EXPORTS = [
     "orbm_search_local_points", "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_transform",
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
     "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch", "orbx_debug_sincosf",
-    "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels", "orbx_debug_blur_patches", "orbm_debug_features_in_area",
+    "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels", "orbx_extract_batch_device_prefetch", "orbx_debug_blur_patches", "orbm_debug_features_in_area",
 ]
 
 
@@ -125,11 +125,12 @@ def lib():
     L.orbx_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
     L.orbx_extract_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
     L.orbx_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, sz, vp, vp, vp, i32, vp]
+    L.orbx_extract_batch_device_prefetch.argtypes = [vp, vp, i32, i32, i32, i32, sz]
     L.orbx_pyramid_host.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.orbx_pyramid_device.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.orbx_debug_level_points.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
     L.orbx_set_profiling.argtypes = [vp, i32]
-    L.orbx_fast_kernels.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.orbx_fast_kernels.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.orbx_record_bytes.argtypes = [i32]
     L.orbx_pack_records_device.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp]
     L.orbx_get_stage_ms.argtypes = [vp, vp, C.POINTER(i32)]
@@ -275,6 +276,10 @@ class ORBextractor:
                                                  d_counts, cap, stream))
         self._shape = (h, w)
 
+    def prefetch_batch_device(self, d_imgs, B, w, h, stride, image_stride):
+        """Start the pyramid of the NEXT batch now (orbx_extract_batch_device_prefetch): the images must be complete in HBM."""
+        _check(self._L.orbx_extract_batch_device_prefetch(self._h, d_imgs, B, w, h, stride, image_stride))
+
     # -- mvImagePyramid (include/ORBextractor.h:85)
     def pyramid_level(self, level, b=0, padded=False):
         w, h = C.c_int(), C.c_int()
@@ -303,8 +308,9 @@ class ORBextractor:
 
     def fast_kernels(self, B):
         """names of the FAST kernel(s) a batch of B images of the planned size runs"""
-        st, ce = C.c_int(0), C.c_int(0)
-        _check(self._L.orbx_fast_kernels(self._h, int(B), C.byref(st), C.byref(ce)))
+        st, ce, ipl = C.c_int(0), C.c_int(0), C.c_int(0)
+        _check(self._L.orbx_fast_kernels(self._h, int(B), C.byref(st), C.byref(ce), C.byref(ipl)))
+        self.fast_images_per_launch = ipl.value
         return [n for n, f in (("k_fast_strips", st.value), ("k_fast_cells", ce.value)) if f]
 
     def debug_blur_patches(self, image):

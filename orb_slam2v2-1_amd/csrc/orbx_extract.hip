@@ -40,8 +40,8 @@ extern "C" int orbx_thread_release_scratch(void) {
     return ORBX_OK;
 }
 
-int g_debug[8] = {0};
-extern "C" int orbx_debug_set(int key, int value) { if (key < 0 || key >= 8) return ORBX_ERR_ARG; g_debug[key] = value; return ORBX_OK; }
+int g_debug[16] = {0};
+extern "C" int orbx_debug_set(int key, int value) { if (key < 0 || key >= 16) return ORBX_ERR_ARG; g_debug[key] = value; return ORBX_OK; }
 
 // ------------------------------------------------------------------------------------
 // host side
@@ -106,6 +106,13 @@ extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int i
     }
     h->max_kp = 0;
     ORBX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i < ORBX_SIDE_STREAMS; i++) {
+        ORBX_HIP(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+        ORBX_HIP(hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming));
+    }
+    for (int i = 0; i < ORBX_MAX_CHUNKS; i++) ORBX_HIP(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming));
+    ORBX_HIP(hipEventCreateWithFlags(&h->evFastDone, hipEventDisableTiming));
+    ORBX_HIP(hipEventCreateWithFlags(&h->evPrefetch, hipEventDisableTiming));
     for (int r = 0; r < ORBX_EV_RING; r++)
         // timing-only events: no system-scope fence (cache write-back + invalidate) when they complete — with the default
         // flags every stage boundary of a profiled batch cost ~5 us of idle GPU, which the step time then contained
@@ -117,6 +124,7 @@ extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int i
 static void free_plan(orbx_extractor *h) {
     hipFree(h->d_cellRaw); h->d_cellRaw = nullptr;
     hipFree(h->d_octFallback); h->d_octFallback = nullptr;
+    hipFree(h->d_pyrAlt); h->d_pyrAlt = nullptr; h->pyrAltBytes = 0; h->pfValid = 0;
     hipFree(h->d_octPart); hipFree(h->d_octLeaf); hipFree(h->d_octBest); hipFree(h->d_octState);
     h->d_octPart = nullptr; h->d_octLeaf = nullptr; h->d_octBest = nullptr; h->d_octState = nullptr;
     hipFree(h->d_geom); hipFree(h->d_tab); hipFree(h->d_pyr); hipFree(h->d_cellCnt); hipFree(h->d_slots);
@@ -130,7 +138,7 @@ extern "C" int orbx_destroy(orbx_extractor_t *h) {
     if (!h) return ORBX_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    if (h->last_stream) hipStreamSynchronize(h->last_stream);
+    if (h->last_valid) hipStreamSynchronize(h->last_stream);
     if (h->st_stream) hipStreamSynchronize(h->st_stream);
     orbx_internal_free_stereo_scratch(h);
     free_plan(h);
@@ -138,6 +146,9 @@ extern "C" int orbx_destroy(orbx_extractor_t *h) {
     if (h->h_kps) { hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); }
     for (int r = 0; r < ORBX_EV_RING; r++)
         for (int i = 0; i < ORBX_NUM_STAGES; i++) hipEventDestroy(h->ev[r][i]);
+    for (int i = 0; i < ORBX_SIDE_STREAMS; i++) { hipStreamSynchronize(h->side[i]); hipStreamDestroy(h->side[i]); hipEventDestroy(h->evJoin[i]); }
+    for (int i = 0; i < ORBX_MAX_CHUNKS; i++) hipEventDestroy(h->evPyr[i]);
+    hipEventDestroy(h->evFastDone); hipEventDestroy(h->evPrefetch);
     hipStreamDestroy(h->stream);
     delete h;
     return ORBX_OK;
@@ -169,7 +180,8 @@ extern "C" int orbx_max_keypoints(const orbx_extractor_t *h) {
 static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     if (h->pw == w && h->ph == hgt && h->pB >= B) return ORBX_OK;
     ORBX_HIP(hipSetDevice(h->device));
-    if (h->last_stream) ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    for (int i = 0; i < ORBX_SIDE_STREAMS; i++) ORBX_HIP(hipStreamSynchronize(h->side[i]));
     const int keepB = (h->pw == w && h->ph == hgt) ? h->pB : 0;
     free_plan(h);
     B = std::max(B, keepB);
@@ -468,40 +480,56 @@ static int harvest_events(orbx_extractor *h, int slot) {
     return ORBX_OK;
 }
 
-static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int w, int hgt, int stride,
-                           size_t img_stride, orbx_keypoint_t *d_kps, uint8_t *d_desc, int32_t *d_counts,
-                           int cap, hipStream_t st) {
+// K1: ComputePyramid of B images into pyr
+static void launch_pyramid(orbx_extractor *h, const uint8_t *d_imgs, uint8_t *pyr, int B, int stride, size_t img_stride, hipStream_t st) {
+    const int nl = h->nlevels;
+    if (g_debug[5] == 0 && h->scale_factor <= 3.0) {   // one launch per level (a lane's two source byte pairs fit 8 bytes)
+        const LevelGeom &g0 = h->geom[0];
+        hipLaunchKernelGGL(k_pyr_pad<true>, dim3(((g0.pstride >> 4) * g0.prows + 255) / 256, 1, B), dim3(256), 0, st, d_imgs, stride,
+                           img_stride, pyr, h->pyrImgBytes, h->d_geom, 0);
+        for (int l = 1; l < nl; l++) {
+            const int nxc = (h->geom[l].w + 1 + 127) / 128, nbands = (h->geom[l].h + PYR_RW - 1) / PYR_RW;
+            hipLaunchKernelGGL(k_pyr_level, dim3((nxc * nbands + 3) / 4, B), dim3(256), 0, st, pyr, h->pyrImgBytes,
+                               h->d_geom, l, h->d_tab, nxc, nbands);
+        }
+    } else {   // fused form (orbx_debug_set(5, 1)): writes every frame itself
+        hipLaunchKernelGGL(k_pyramid_fused, dim3(h->pyrTilesX * h->pyrTilesY, B), dim3(256), h->pyrLdsBytes, st, d_imgs,
+                           stride, img_stride, pyr, h->pyrImgBytes, h->d_geom, nl, h->d_tab, h->pyrXSpanOff,
+                           h->pyrYSpanOff, h->pyrTilesX, h->pyrTilesY, h->pyrBufBytes, h->pyrMaxPar);
+    }
+}
+
+// The per-image buffers of a handle as seen by ONE chunk of a batch: every base pointer already points at the chunk's first image.
+struct ChunkView {
+    const uint8_t *imgs; uint8_t *pyr; uint32_t *cellCnt, *cellRaw, *slots, *cand, *lvlKp; uint16_t *nodeOf;
+    int32_t *candCnt, *lvlCnt, *octFallback; orbx_keypoint_t *kps; uint8_t *desc; int32_t *counts;
+};
+static ChunkView chunk_view(const orbx_extractor *h, const uint8_t *d_imgs, size_t img_stride, orbx_keypoint_t *d_kps, uint8_t *d_desc,
+                            int32_t *d_counts, int cap, int b0) {
+    ChunkView v;
+    const size_t z = (size_t)b0;
+    v.imgs = d_imgs + z * img_stride; v.pyr = h->d_pyr + z * h->pyrImgBytes;
+    v.cellCnt = h->d_cellCnt + z * h->totalCells; v.cellRaw = h->d_cellRaw + z * h->totalCells;
+    v.slots = h->d_slots + z * h->slotsPerImg; v.cand = h->d_cand + z * h->keysPerImg; v.nodeOf = h->d_nodeOf + z * h->keysPerImg;
+    v.lvlKp = h->d_lvlKp + z * h->lvlKpCap;
+    v.candCnt = h->d_candCnt + z * h->nlevels; v.lvlCnt = h->d_lvlCnt + z * h->nlevels; v.octFallback = h->d_octFallback + z * h->nlevels;
+    v.kps = d_kps + z * cap; v.desc = d_desc + z * cap * 32; v.counts = d_counts + b0;
+    return v;
+}
+
+// One chunk (B images from v) through the whole pipeline on stream st.  ev / prof / profFast: this chunk carries the stage events;
+// evPyrDone (may be NULL) is recorded behind the chunk's pyramid.
+static void launch_pyramid(orbx_extractor *h, const uint8_t *d_imgs, uint8_t *pyr, int B, int stride, size_t img_stride, hipStream_t st);
+static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride, size_t img_stride, int cap, hipStream_t st,
+                        hipEvent_t *ev, bool prof, bool profFast, hipEvent_t evPyrDone, bool skipPyr) {
     const int nl = h->nlevels;
     CellBases cb;
     for (int l = 0; l <= ORBX_MAX_LEVELS; l++) cb.v[l] = l < nl ? h->geom[l].cellBase : h->totalCells;
-    // profiling 1: events at every stage boundary; 2: only around k_fast_cells (an event costs ~4.5 us of idle GPU, so
-    // a throughput measurement brackets just the kernel it reports)
-    // mode 3 = mode 2 on every 4th call only: the two events cost ~9 us of idle GPU per call they bracket
-    const bool prof = h->profiling == 1, profFast = h->profiling != 0 && (h->profiling != 3 || (h->prof_calls++ & 3) == 0);
-    (void)hipGetLastError();  // drop stale errors of other HIP users in this process
-    hipEvent_t *ev = nullptr;
-    if (profFast) {
-        const int slot = h->ev_head % ORBX_EV_RING;
-        if (h->ev_pending[slot]) { int rc = harvest_events(h, slot); if (rc) return rc; }
-        ev = h->ev[slot];
-        if (prof) ORBX_HIP(hipEventRecord(ev[0], st));
-    }
-    if (g_debug[5] == 0 && h->scale_factor <= 3.0) {   // K1, one launch per level (a lane's two source byte pairs fit 8 bytes)
-        const LevelGeom &g0 = h->geom[0];
-        hipLaunchKernelGGL(k_pyr_pad<true>, dim3(((g0.pstride >> 4) * g0.prows + 255) / 256, 1, B), dim3(256), 0, st, d_imgs, stride,
-                           img_stride, h->d_pyr, h->pyrImgBytes, h->d_geom, 0);
-        for (int l = 1; l < nl; l++) {
-            const int nxc = (h->geom[l].w + 1 + 127) / 128, nbands = (h->geom[l].h + PYR_RW - 1) / PYR_RW;
-            hipLaunchKernelGGL(k_pyr_level, dim3((nxc * nbands + 3) / 4, B), dim3(256), 0, st, h->d_pyr, h->pyrImgBytes,
-                               h->d_geom, l, h->d_tab, nxc, nbands);
-        }
-        h->framesStale = nl > 1 ? B : 0;   // frames of levels >= 1: written on demand (ensure_frames)
-    } else {   // K1, fused form (orbx_debug_set(5, 1)): writes every frame itself
-        h->framesStale = 0;
-        hipLaunchKernelGGL(k_pyramid_fused, dim3(h->pyrTilesX * h->pyrTilesY, B), dim3(256), h->pyrLdsBytes, st, d_imgs,
-                           stride, img_stride, h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->d_tab, h->pyrXSpanOff,
-                           h->pyrYSpanOff, h->pyrTilesX, h->pyrTilesY, h->pyrBufBytes, h->pyrMaxPar);
-    }
+    const uint8_t *d_imgs = v.imgs;
+    orbx_keypoint_t *d_kps = v.kps; uint8_t *d_desc = v.desc; int32_t *d_counts = v.counts;
+    if (prof) ORBX_HIP(hipEventRecord(ev[0], st));
+    if (!skipPyr) launch_pyramid(h, d_imgs, v.pyr, B, stride, img_stride, st);   // K1 (skipped when the pyramid was built ahead)
+    if (evPyrDone) ORBX_HIP(hipEventRecord(evPyrDone, st));
     if (profFast) ORBX_HIP(hipEventRecord(ev[1], st));
     {   // K2
         // developer knob 6: 1 = every level by k_fast_cells (compile-time tile strides), 2 = ... with run-time strides
@@ -513,14 +541,14 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
             StripBases sb;
             for (int l = 0; l <= ORBX_MAX_LEVELS; l++) sb.v[l] = h->stripBase[l];
             hipLaunchKernelGGL(k_fast_strips, dim3((h->totalStrips + FAST_WAVES - 1) / FAST_WAVES, B), dim3(64 * FAST_WAVES), 0, st,
-                               h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->totalStrips, h->totalCells, h->d_cellCnt, h->d_cellRaw,
-                               h->d_slots, h->slotsPerImg, h->ini_th, h->min_th, sb);
+                               v.pyr, h->pyrImgBytes, h->d_geom, nl, h->totalStrips, h->totalCells, v.cellCnt, v.cellRaw,
+                               v.slots, h->slotsPerImg, h->ini_th, h->min_th, sb);
         }
         if (stripLevels != (1u << nl) - 1u) {   // levels with wider cells (the coarsest ones of small images)
             dim3 grid((h->totalCells + FAST_WAVES - 1) / FAST_WAVES, B);
 #define ORBX_LAUNCH_FAST(EST)                                                                                         \
     hipLaunchKernelGGL(k_fast_cells<EST>, grid, dim3(64 * FAST_WAVES), (size_t)h->fastLdsPerWave * FAST_WAVES, st,  \
-                       h->d_pyr, h->pyrImgBytes, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_cellRaw, h->d_slots, \
+                       v.pyr, h->pyrImgBytes, h->d_geom, nl, h->totalCells, v.cellCnt, v.cellRaw, v.slots, \
                        h->slotsPerImg, h->ini_th, h->min_th, h->fastTileStride, h->fastScoreStride, h->fastTileRows, \
                        h->fastLdsPerWave, g_debug[0], cb, stripLevels)
             const int es = (h->fastScoreStride == h->fastTileStride - 8 && g_debug[6] != 2) ? h->fastTileStride : 0;
@@ -534,6 +562,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
         }
     }
     if (profFast) ORBX_HIP(hipEventRecord(ev[2], st));
+    if (h->pfUsed && evPyrDone == nullptr) ORBX_HIP(hipEventRecord(h->evFastDone, st));   // a pyramid built ahead starts behind this FAST stage
     {   // K3
         int pow2 = 1;
         while (pow2 < h->maxNodeCap) pow2 <<= 1;
@@ -541,8 +570,8 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
         for (int l = 0; l < nl; l++) maxCells = std::max(maxCells, h->geom[l].ncells);
         const int scratch = std::max(4 * h->maxNodeCap, maxCells + 1);
         hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
-                           dim3(256), 0, st, h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_cellRaw, h->d_slots,
-                           h->slotsPerImg, h->d_cand, h->keysPerImg, h->d_candCnt, h->ini_th, h->min_th, cb);
+                           dim3(256), 0, st, h->d_geom, nl, h->totalCells, v.cellCnt, v.cellRaw, v.slots,
+                           h->slotsPerImg, v.cand, h->keysPerImg, v.candCnt, h->ini_th, h->min_th, cb);
         // developer knob 4: 0 default, 1 = the exact form alone, 2 = EVERY level by the multi-workgroup form, 3 = none
         const bool usePyr = g_debug[4] != 1;
         if (usePyr) {   // a level whose tree outgrows the count pyramid is redone by the same block with the exact form: one launch
@@ -561,24 +590,24 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
                 int nall = big.nBig;
                 for (int l = 0; l < nl; l++) if (!((bigMask >> l) & 1u)) big.levelOf[nall++] = l;
                 ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_octree_big<1>, dim3(OCT_BIG_K, nl, B), dim3(OCT_T), lds, st, h->d_geom, nl, h->d_cand, h->keysPerImg,
-                                   h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
-                                   h->d_octFallback, h->d_nodeOf, scratch, big);
+                hipLaunchKernelGGL(k_octree_big<1>, dim3(OCT_BIG_K, nl, B), dim3(OCT_T), lds, st, h->d_geom, nl, v.cand, h->keysPerImg,
+                                   v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
+                                   v.octFallback, v.nodeOf, scratch, big);
                 // ... then K workgroups elect the best key per node, the last one writes the level's keypoints
                 ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_octree_big<2>, dim3(OCT_BIG_K, big.nBig, B), dim3(OCT_T), lds, st, h->d_geom, nl, h->d_cand, h->keysPerImg,
-                                   h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
-                                   h->d_octFallback, h->d_nodeOf, scratch, big);
+                hipLaunchKernelGGL(k_octree_big<2>, dim3(OCT_BIG_K, big.nBig, B), dim3(OCT_T), lds, st, h->d_geom, nl, v.cand, h->keysPerImg,
+                                   v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
+                                   v.octFallback, v.nodeOf, scratch, big);
             } else {   // no large level (or a phase-stop knob is set): one workgroup per level, one launch
                 ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_pyr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_octree_pyr, dim3(B, nl), dim3(OCT_T), lds, st, h->d_geom, nl, h->d_cand,
-                                   h->keysPerImg, h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap,
-                                   pow2, h->octPyrWords, h->d_octFallback, g_debug[7], h->d_nodeOf, scratch, g_debug[1], 0u);
+                hipLaunchKernelGGL(k_octree_pyr, dim3(B, nl), dim3(OCT_T), lds, st, h->d_geom, nl, v.cand,
+                                   h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
+                                   pow2, h->octPyrWords, v.octFallback, g_debug[7], v.nodeOf, scratch, g_debug[1], 0u);
             }
         } else {        // developer knob 4 = 1: the exact form alone
             ORBX_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octLdsBytes));
-            hipLaunchKernelGGL(k_octree, dim3(B, nl), dim3(OCT_T), h->octLdsBytes, st, h->d_geom, nl, h->d_cand, h->d_nodeOf,
-                               h->keysPerImg, h->d_candCnt, h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, h->d_tab, h->maxNodeCap, pow2,
+            hipLaunchKernelGGL(k_octree, dim3(B, nl), dim3(OCT_T), h->octLdsBytes, st, h->d_geom, nl, v.cand, v.nodeOf,
+                               h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2,
                                scratch, g_debug[1]);
         }
     }
@@ -586,13 +615,55 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
     {   // K4
         const int maxo = std::min(cap, h->max_kp);
         dim3 grid((maxo + DESC_WAVES - 1) / DESC_WAVES, B);
-        hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, st, h->d_pyr, h->pyrImgBytes, h->d_geom, nl,
-                           h->d_lvlKp, h->lvlKpCap, h->d_lvlCnt, d_kps, d_desc, d_counts, cap, h->d_dbgBlur);
+        hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
+                           v.lvlKp, h->lvlKpCap, v.lvlCnt, d_kps, d_desc, d_counts, cap, h->d_dbgBlur);
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[4], st));
+    return ORBX_OK;
+}
+
+// A batch runs as up to ORBX_MAX_CHUNKS chunks of images.  Chunk 0 goes to the caller's stream, the others to the handle's side
+// streams, and chunk c's pyramid waits for chunk c-1's: the memory-bound pyramid and the latency-bound gather / quad-tree of one
+// chunk then overlap the issue-bound FAST and descriptor kernels of another (the kernels are the same, per-image results do not
+// depend on the chunking), and the caller's stream waits for the side streams at the end, so the call keeps its stream semantics.
+static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int w, int hgt, int stride,
+                           size_t img_stride, orbx_keypoint_t *d_kps, uint8_t *d_desc, int32_t *d_counts,
+                           int cap, hipStream_t st, bool skipPyr = false) {
+    // profiling 1: events at every stage boundary; 2: only around the FAST stage (an event costs ~4.5 us of idle GPU, so
+    // a throughput measurement brackets just the kernel it reports); mode 3 = mode 2 on every 4th call only
+    const bool prof = h->profiling == 1, profFast = h->profiling != 0 && (h->profiling != 3 || (h->prof_calls++ & 3) == 0);
+    (void)hipGetLastError();  // drop stale errors of other HIP users in this process
+    hipEvent_t *ev = nullptr;
+    if (profFast) {
+        const int slot = h->ev_head % ORBX_EV_RING;
+        if (h->ev_pending[slot]) { int rc = harvest_events(h, slot); if (rc) return rc; }
+        ev = h->ev[slot];
+    }
+    // developer knob 8: n >= 2 = n chunks (default: one - measured on 64 stereo frames, two chunks: 773 us against 742, the
+    // latency-bound gather / quad-tree do not shrink with the chunk and the pyramid slows the FAST it overlaps by as much as it gains).
+    int nch = g_debug[8] <= 1 ? 1 : std::min(g_debug[8], ORBX_MAX_CHUNKS);
+    nch = std::min(nch, B);
+    if (prof || skipPyr || g_debug[0] || g_debug[1] || g_debug[7]) nch = 1;
+    h->lastChunks = nch;
+    h->framesStale = (g_debug[5] == 0 && h->scale_factor <= 3.0 && h->nlevels > 1) ? B : 0;   // frames of levels >= 1: written on demand (ensure_frames)
+    int b0 = 0;
+    for (int c = 0; c < nch; c++) {
+        const int Bc = (B - b0) / (nch - c);
+        const ChunkView v = chunk_view(h, d_imgs, img_stride, d_kps, d_desc, d_counts, cap, b0);
+        hipStream_t sc = c == 0 ? st : h->side[(c - 1) % ORBX_SIDE_STREAMS];
+        if (c > 0) ORBX_HIP(hipStreamWaitEvent(sc, h->evPyr[c - 1], 0));
+        int rc = launch_chunk(h, v, Bc, stride, img_stride, cap, sc, ev, prof && c == 0, profFast && c == 0, c + 1 < nch ? h->evPyr[c] : nullptr, skipPyr);
+        if (rc) return rc;
+        b0 += Bc;
+    }
+    for (int s = 0; s < std::min(nch - 1, ORBX_SIDE_STREAMS); s++) {   // the caller's stream carries on when every side stream is done
+        ORBX_HIP(hipEventRecord(h->evJoin[s], h->side[s]));
+        ORBX_HIP(hipStreamWaitEvent(st, h->evJoin[s], 0));
+    }
     if (profFast) { h->ev_pending[h->ev_head % ORBX_EV_RING] = (unsigned char)(h->profiling == 3 ? 2 : h->profiling); h->ev_head++; }
     ORBX_HIP(hipGetLastError());
     h->last_stream = st;
+    h->last_valid = 1;
     h->lastB = B;
     (void)w; (void)hgt;
     return ORBX_OK;
@@ -609,7 +680,43 @@ extern "C" int orbx_extract_batch_device(orbx_extractor_t *h, const uint8_t *d_i
     int rc = ensure_plan(h, w, hgt, B);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream, as in every HIP API
-    return launch_pipeline(h, d_imgs, B, w, hgt, stride, image_stride_bytes, d_kps, d_desc, d_counts, cap, st);
+    // the pyramid of exactly this batch was built ahead (orbx_extract_batch_device_prefetch): take that buffer, skip K1
+    const bool ahead = h->pfValid && h->d_pyrAlt && h->pfImgs == d_imgs && h->pfB == B && h->pfW == w && h->pfH == hgt && h->pfStride == stride &&
+                       h->pfImgStride == image_stride_bytes && g_debug[9] == 0;
+    h->pfValid = 0;
+    if (ahead) {
+        std::swap(h->d_pyr, h->d_pyrAlt);
+        ORBX_HIP(hipStreamWaitEvent(st, h->evPrefetch, 0));
+    }
+    return launch_pipeline(h, d_imgs, B, w, hgt, stride, image_stride_bytes, d_kps, d_desc, d_counts, cap, st, ahead);
+}
+
+// Software pipelining across batches: start ComputePyramid of the NEXT batch now, into the handle's second pyramid buffer, on a
+// stream of the handle's own.  It is ordered behind the FAST stage of the extraction call issued last, i.e. it runs beside that
+// call's gather / quad-tree (latency-bound), descriptors and the stereo matcher instead of in front of the next call's FAST.
+extern "C" int orbx_extract_batch_device_prefetch(orbx_extractor_t *h, const uint8_t *d_imgs, int B, int w, int hgt, int stride,
+                                                  size_t image_stride_bytes) {
+    if (!h || !d_imgs || B < 1 || w < 1 || hgt < 1 || stride < w) { orbx_set_error("orbx_extract_batch_device_prefetch: bad arguments"); return ORBX_ERR_ARG; }
+    ORBX_HIP(hipSetDevice(h->device));
+    int rc = ensure_plan(h, w, hgt, B);
+    if (rc) return rc;
+    const size_t need = h->pyrImgBytes * (size_t)h->pB;
+    if (h->pyrAltBytes < need) {
+        ORBX_HIP(hipStreamSynchronize(h->side[0]));
+        hipFree(h->d_pyrAlt); h->d_pyrAlt = nullptr; h->pyrAltBytes = 0;
+        ORBX_HIP(hipMalloc(&h->d_pyrAlt, need));
+        h->pyrAltBytes = need;
+    }
+    hipStream_t sd = h->side[0];
+    (void)hipGetLastError();
+    if (h->pfUsed && h->last_valid) ORBX_HIP(hipStreamWaitEvent(sd, h->evFastDone, 0));   // (the first time there is no such event yet: the
+    else if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));             //  second buffer is new, wait for the handle to be idle)
+    h->pfUsed = 1;
+    launch_pyramid(h, d_imgs, h->d_pyrAlt, B, stride, image_stride_bytes, sd);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipEventRecord(h->evPrefetch, sd));
+    h->pfValid = 1; h->pfImgs = d_imgs; h->pfB = B; h->pfW = w; h->pfH = hgt; h->pfStride = stride; h->pfImgStride = image_stride_bytes;
+    return ORBX_OK;
 }
 
 static int ensure_staging(orbx_extractor *h, size_t in_bytes, int B, int cap) {
@@ -743,7 +850,7 @@ extern "C" int orbx_pyramid_host(orbx_extractor_t *h, int b, int level, int padd
     if (dst_stride < ow) { orbx_set_error("dst_stride < width"); return ORBX_ERR_ARG; }
     ORBX_HIP(hipSetDevice(h->device));
     if (padded && level > 0) { const int rc = ensure_frames(h); if (rc) return rc; }
-    if (h->last_stream) ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));
     const uint8_t *src = h->d_pyr + (size_t)b * h->pyrImgBytes + g.poff +
                          (padded ? 0 : (size_t)ORBX_EDGE * g.pstride + ORBX_EDGE);
     // linear device-to-host copy of the row span, rows unpacked on the host (2-D copies of odd widths are very slow)
@@ -762,7 +869,7 @@ extern "C" int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, in
         return ORBX_ERR_ARG;
     }
     ORBX_HIP(hipSetDevice(h->device));
-    if (h->last_stream) ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));
     const LevelGeom &g = h->geom[level];
     int32_t n = 0;
     const int32_t *cntp = (stage == 0 ? h->d_candCnt : h->d_lvlCnt) + b * h->nlevels + level;
@@ -784,8 +891,13 @@ extern "C" int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, in
 
 // Which FAST kernel(s) a batch of B images of the planned size runs (the rule of launch_pipeline): for benchmarks that name the
 // kernel they time.  *strips = 1 if k_fast_strips takes part, *cells = 1 if k_fast_cells does.
-extern "C" int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, int *cells) {
+extern "C" int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, int *cells, int *images_per_launch) {
     if (!h || h->pw == 0 || B < 1) { orbx_set_error("orbx_fast_kernels: no plan yet"); return ORBX_ERR_ARG; }
+    int nch = g_debug[8] <= 1 ? 1 : std::min(g_debug[8], ORBX_MAX_CHUNKS);
+    nch = std::min(nch, B);
+    if (h->profiling == 1) nch = 1;
+    B = B / nch;                                   // the first chunk is the one whose FAST stage carries the events
+    if (images_per_launch) *images_per_launch = B;
     const bool st = h->totalStrips > 0 && (g_debug[6] == 0 ? (size_t)h->totalStrips * B >= 4096 : g_debug[6] == 3);
     const unsigned lv = st ? h->stripLevels : 0u;
     if (strips) *strips = st ? 1 : 0;
@@ -799,7 +911,7 @@ extern "C" int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, 
 extern "C" int orbx_debug_blur_patches(orbx_extractor_t *h, int enable, uint8_t *out, int n) {
     if (!h) return ORBX_ERR_ARG;
     ORBX_HIP(hipSetDevice(h->device));
-    if (h->last_stream) ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));
     if (out && n > 0) {
         if (!h->d_dbgBlur || n > h->dbgBlurCap) { orbx_set_error("orbx_debug_blur_patches: not enabled or n too large"); return ORBX_ERR_ARG; }
         ORBX_HIP(hipMemcpy(out, h->d_dbgBlur, (size_t)n * 37 * 37, hipMemcpyDeviceToHost));

@@ -14,6 +14,8 @@
 #define ORBX_DESC_R 18      // max |rotated tap| : pattern radius^2 = 338 -> cvRound <= 18
 #define ORBX_MAX_ROOTS 64
 #define ORBX_EV_RING 32
+#define ORBX_MAX_CHUNKS 4      // chunks a batch may be cut into (launch_pipeline)
+#define ORBX_SIDE_STREAMS 2    // handle-owned streams for the chunks behind the first
 
 void orbx_set_error(const char *fmt, ...);
 
@@ -92,7 +94,12 @@ struct orbx_extractor {
     orbx_keypoint_t *h_kps; uint8_t *h_desc; int32_t *h_counts;   // pinned mirrors of the three above
     uint8_t *d_dbgBlur; int dbgBlurCap;   // test hook: blurred 37x37 blocks of a single-image call (orbx_debug_blur_patches)
     hipStream_t stream;      // own stream
-    hipStream_t last_stream; // stream of the last batch call
+    hipStream_t side[ORBX_SIDE_STREAMS]; hipEvent_t evPyr[ORBX_MAX_CHUNKS], evJoin[ORBX_SIDE_STREAMS]; int lastChunks;   // chunk overlap (launch_pipeline)
+    // pyramid of the NEXT batch, built ahead on side[0] into a second buffer (orbx_extract_batch_device_prefetch)
+    uint8_t *d_pyrAlt; size_t pyrAltBytes; int pfValid, pfUsed, pfB, pfW, pfH, pfStride; const uint8_t *pfImgs; size_t pfImgStride;
+    hipEvent_t evFastDone, evPrefetch;
+    hipStream_t last_stream; // stream of the last batch call (NULL is a stream too: the HIP default stream)
+    int last_valid;          // ... once there has been one
     int lastB;
     int framesStale;         // > 0: the frames of levels >= 1 of that many images have not been written (see ensure_frames)
     // scratch of Frame::ComputeStereoMatches when this handle is the LEFT extractor (orbx_match.hip: stereo_scratch_reserve)
@@ -146,7 +153,7 @@ int fast_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const 
                          int32_t *best_dist, int device);
 int fast_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, int npoints, int32_t *best_row,
                                  int32_t *best_median, int device);
-extern int g_debug[8];  // developer knobs (orbx_debug_set); [2] != 0 forces the exact one-workgroup matcher kernels
+extern int g_debug[16];  // developer knobs (orbx_debug_set); [2] != 0 forces the exact one-workgroup matcher kernels
 
 // XCD-aware block -> (image, block-in-image) map for grids of (blocks per image, images).  Workgroups are dealt round-robin
 // to the 8 XCDs in linear-id order and every XCD has its own L2, so with the identity map neighbouring blocks - which

@@ -402,7 +402,7 @@ static int fill_stereo_levels(orbx_extractor *hl, orbx_extractor *hr, StereoLeve
 static int stereo_scratch_reserve(orbx_extractor *hl, int B, int cap) {
     const size_t need = (size_t)B * cap;
     if (hl->st_n >= need && hl->st_nB >= B) return ORBX_OK;
-    if (hl->last_stream) ORBX_HIP(hipStreamSynchronize(hl->last_stream));
+    if (hl->last_valid) ORBX_HIP(hipStreamSynchronize(hl->last_stream));
     if (hl->st_stream) ORBX_HIP(hipStreamSynchronize(hl->st_stream));
     hipFree(hl->st_sad); hipFree(hl->st_rc); hipFree(hl->st_binStart); hipFree(hl->st_items);
     hl->st_sad = nullptr; hl->st_rc = nullptr; hl->st_binStart = nullptr; hl->st_items = nullptr; hl->st_n = 0; hl->st_nB = 0;

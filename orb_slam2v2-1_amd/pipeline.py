@@ -19,7 +19,7 @@ KITTI_FX, KITTI_BF = 718.856, 386.1448  # KITTI-00 calibration (fx, baseline*fx)
 
 class FrontEnd:
     def __init__(self, w, h, nfeatures, stereo, B, device_index=0, nbuf=3, streams=1, world=1, gather=False,
-                 gather_via_host=False, mbf=KITTI_BF, fx=KITTI_FX, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+                 gather_via_host=False, mbf=KITTI_BF, fx=KITTI_FX, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, prefetch=True):
         if not torch.cuda.is_available():
             raise RuntimeError("orb_slam2v2-1_amd.pipeline.FrontEnd needs a GPU: the HIP path has no CPU fallback")
         self.w, self.h, self.nf, self.stereo, self.B = w, h, nfeatures, stereo, B
@@ -28,6 +28,7 @@ class FrontEnd:
         self.dev = torch.device("cuda", device_index)
         self.mbf = float(mbf)
         self.mb = float(np.float32(mbf) / np.float32(fx))
+        self.prefetch = prefetch       # build the next step's pyramid beside this step's latency-bound kernels (same handle)
         self.S = max(1, streams)
         self.exs = [ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th, device=device_index) for _ in range(self.S)]
         self.ex = self.exs[0]
@@ -58,6 +59,9 @@ class FrontEnd:
         B, cap, w, h = self.B, self.cap, self.w, self.h
         exi.extract_batch_device(self.d_imgs.data_ptr(), self.nimg, w, h, w, w * h, r.kps[j].data_ptr(), r.desc[j].data_ptr(),
                                  r.cnt[j].data_ptr(), cap, st)
+        if self.prefetch:
+            # the next step of this handle reads the same resident images: its pyramid starts behind this step's FAST stage
+            exi.prefetch_batch_device(self.d_imgs.data_ptr(), self.nimg, w, h, w, w * h)
         if self.stereo:
             if ev_before_match is not None:
                 ev_before_match.record(stream)

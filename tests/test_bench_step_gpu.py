@@ -65,6 +65,91 @@ def test_bench_step_three_handles_three_streams_one_thread():
     _run_stereo(1241, 376, 1000, 16, seed0=200, streams=3, steps=20)
 
 
+@pytest.mark.parametrize("chunks", [2, 3, 4])
+def test_batch_chunking_does_not_change_results(chunks):
+    """Developer knob 8 cuts a batch into chunks whose kernels overlap on the handle's side streams (measured slower than one
+    chunk, so off by default): per-image results must not depend on it, uneven chunk sizes included (26 images in 3 or 4
+    chunks), and the stereo matcher behind it must see finished arrays."""
+    pkg = importlib.import_module(PKG)
+    pkg.lib().orbx_debug_set(8, chunks)
+    try:
+        _run_stereo(752, 480, 700, 13, seed0=400, steps=3)
+    finally:
+        pkg.lib().orbx_debug_set(8, 0)
+
+
+def test_pyramid_built_ahead_is_used_only_for_the_same_batch():
+    """orbx_extract_batch_device_prefetch: the step above always builds the next step's pyramid ahead (FrontEnd.prefetch).
+    Here the edges: a pyramid built ahead for batch X must be ignored by a call on batch Y, used by a call on X (same
+    bytes out as without it, mvImagePyramid included), and a second prefetch replaces the first."""
+    import torch
+    pkg = importlib.import_module(PKG)
+    ref = _ref()
+    w, h, nf, B = 640, 480, 600, 3
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    sets = []
+    for s in (0, 1, 2):
+        exp = ref.run_pool(ref.mono_frame, [(w, h, nf, 900 + 10 * s + i) for i in range(B)])
+        sets.append((exp, torch.from_numpy(np.stack([e["img"] for e in exp])).cuda()))
+    ex(sets[0][0][0]["img"])
+    cap = ex.max_keypoints()
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(which):
+        d = sets[which][1]
+        ex.extract_batch_device(d.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)
+        torch.cuda.synchronize()
+        k = kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+        for b in range(B):
+            n = int(cnt[b])
+            got = np.frombuffer(k[b, :n].tobytes(), pkg.KP_DTYPE)
+            m = ref.image_mismatch(got, desc[b, :n].cpu().numpy(), sets[which][0][b]["k"], sets[which][0][b]["d"])
+            assert m is None, (which, b, m)
+        return [ex.pyramid_level(l, 1).copy() for l in (0, 3, 7)]
+
+    def pre(which):
+        ex.prefetch_batch_device(sets[which][1].data_ptr(), B, w, h, w, w * h)
+
+    plain = [run(0), run(1)]
+    pre(0)
+    for a, b_ in zip(run(0), plain[0]):          # used
+        assert np.array_equal(a, b_)
+    pre(0)
+    for a, b_ in zip(run(1), plain[1]):          # built for batch 0, call on batch 1: ignored
+        assert np.array_equal(a, b_)
+    pre(0)
+    pre(1)                                       # replaced
+    for a, b_ in zip(run(1), plain[1]):
+        assert np.array_equal(a, b_)
+    for a, b_ in zip(run(0), plain[0]):          # nothing pending any more
+        assert np.array_equal(a, b_)
+    # Ordering by events alone: park the stream behind ~50 ms of other work so that all six calls below are issued before the
+    # first one runs; three image sets against two pyramid buffers, so a pyramid written too early (before the FAST stage of
+    # the call in front has finished with the buffer's previous contents) shows as another set's key points.
+    outs = [(torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"), torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
+             torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(6)]
+    x = torch.randn((8192, 8192), device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(6):
+        x = (x @ x) * 1e-4
+    for i in range(6):
+        w3 = i % 3
+        pre(w3)
+        d = sets[w3][1]
+        ex.extract_batch_device(d.data_ptr(), B, w, h, w, w * h, outs[i][0].data_ptr(), outs[i][1].data_ptr(), outs[i][2].data_ptr(), cap, st)
+    torch.cuda.synchronize()
+    for i in range(6):
+        k = outs[i][0].cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+        for b in range(B):
+            n = int(outs[i][2][b])
+            got = np.frombuffer(k[b, :n].tobytes(), pkg.KP_DTYPE)
+            m = ref.image_mismatch(got, outs[i][1][b, :n].cpu().numpy(), sets[i % 3][0][b]["k"], sets[i % 3][0][b]["d"])
+            assert m is None, (i, b, m)
+
+
 def test_bench_step_mono_full_hd_batch32():
     """Config 4's per-GPU share: 32 frames of 1920x1080, 4000 features, one batched call."""
     pl, ref = _pipeline(), _ref()
