@@ -206,12 +206,16 @@ def measure(fe, steps, warmup, ramp, world, dist, dev, torch):
     nprof = max(1, min(steps, 10))                  # untimed pass: events at every stage boundary
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(nprof)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(nprof)]
+    pf, fe.prefetch = fe.prefetch, False            # stage events need the stages one after the other: no pyramid built ahead here
+    fe.step(warmup + steps)                         # (this call still takes the pyramid the last timed step started)
+    fe.drain()
     ex.set_profiling(1)
     for i in range(nprof):
         fe.step(warmup + steps + i, ev0[i], ev1[i])
     fe.drain()
     stage_ms, ncalls = ex.stage_ms()
     ex.set_profiling(0)
+    fe.prefetch = pf
     match_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)])) if fe.stereo else 0.0
     return {"dt": dt, "fast_ms": fast_ms, "stage_ms": stage_ms, "ncalls": ncalls, "match_ms": match_ms, "last": last,
             "nprof": nprof}
@@ -258,7 +262,6 @@ def roofline_block(fe, m, workload, B, value, world, traffic_lookup=True):
     # quad-tree reads its candidates; describe reads P + writes 60 N (SURVEY section 8(d) split).
     fast_names = fe.ex.fast_kernels(nimg)     # k_fast_strips for a GPU-filling batch (+ k_fast_cells for levels with wide cells)
     kern = {
-        # the batch runs as chunks on two streams; the events bracket the FIRST chunk's FAST launch: its images, its duration
         "+".join(fast_names): (m["fast_ms"], P * fe.ex.fast_images_per_launch),
         "k_octree": (float(stage_ms[2]), 8.0 * ncand_img * nimg),   # 4 B key + 2 B node index read, 2 B written
         "k_describe": (float(stage_ms[3]), (P + 60 * navg) * nimg),
@@ -307,6 +310,12 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="S > 1: consecutive steps alternate over S extractor handles on S streams (independent steps overlap; "
                          "the default 1 keeps every kernel alone on the GPU so that its measured duration is its own)")
+    ap.add_argument("--gen-workers", type=int, default=0,
+                    help="processes that generate the synthetic frames (0 = by core count).  1 = no forked workers: use it under "
+                         "rocprofv3, whose tool library in a forked worker can hang when the pool is torn down")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not build the next step's pyramid ahead (orbx_extract_batch_device_prefetch): every step then runs its "
+                         "kernels strictly one after the other")
     ap.add_argument("--overlap-pass", action="store_true",
                     help="after the measurement, an extra pass of K steps alternating over 3 handles on 3 streams; its throughput "
                          "is reported beside the headline value (\"overlapped\").  Off by default so that the kernel launches of "
@@ -336,7 +345,7 @@ def main():
     else:
         B, seed0 = args.batch, 1000 * rank
     # host-side work that forks worker processes happens BEFORE this process touches the GPU
-    workers = max(1, min((os.cpu_count() or 1) // max(world, 1), 16))
+    workers = args.gen_workers if args.gen_workers > 0 else max(1, min((os.cpu_count() or 1) // max(world, 1), 16))
     left, right = make_frames(w, h, B, seed0, stereo, workers)
     seeds = [seed0 + i for i in range(B)]
     others = []
@@ -387,7 +396,7 @@ def main():
 
     S = max(1, args.streams)
     fe = pipeline.FrontEnd(w, h, nf, stereo, B, device_index=dev_index, nbuf=3, streams=S, world=world, gather=gather,
-                           gather_via_host=(args.backend != "nccl"))
+                           gather_via_host=(args.backend != "nccl"), prefetch=not args.no_prefetch)
     fe.upload(left, right)
     m = measure(fe, args.steps, args.warmup, args.ramp_steps, world, dist, dev, torch)
     dt, stage_ms = m["dt"], m["stage_ms"]
@@ -448,6 +457,7 @@ def main():
                        "ini_th_fast": 20, "min_th_fast": 7, "frames_per_step_per_gpu": B, "clock_ramp_steps": args.ramp_steps,
                        "total_frames_per_step": frames_per_step,
                        "match": "Frame::ComputeStereoMatches" if stereo else "none",
+                       "pipelining": "pyramid of the next step built ahead (orbx_extract_batch_device_prefetch)" if fe.prefetch else "none",
                        "parallelism": "frames sharded over %d GPU(s)%s" % (world, ", results all-gathered (%s)" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal") if gather else ""),
                        "world_size_observed": world_seen, "ranks": ranks,
                        "avg_keypoints_per_image": round(navg, 1)},
@@ -457,8 +467,9 @@ def main():
                                   "extract_total": round(float(stage_ms[4]), 4), "stereo_match": round(m["match_ms"], 4),
                                   "images_per_call": fe.nimg, "calls_averaged": m["ncalls"],
                                   "fast_timed_region": round(m["fast_ms"], 4),
-                                  "note": "stage breakdown from an untimed pass of %d steps after the timed region, taken with the batch as ONE chunk "
-                                          "(stage events need the stages one after the other; the timed steps run it as two overlapping chunks); "
+                                  "note": "stage breakdown from an untimed pass of %d steps after the timed region, every stage alone on the GPU "
+                                          "(in the timed steps the pyramid of step i+1 runs on a side stream behind the FAST stage of step i, beside "
+                                          "the quad-tree / descriptor kernels, which makes those longer and the step shorter than the sum here); "
                                           "roofline.kernel_ms is the FAST stage (%s) over the %d timed steps" % (m["nprof"], roof["kernel"], args.steps)},
         }
         if others:

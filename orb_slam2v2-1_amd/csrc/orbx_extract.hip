@@ -562,7 +562,8 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
         }
     }
     if (profFast) ORBX_HIP(hipEventRecord(ev[2], st));
-    if (h->pfUsed && evPyrDone == nullptr) ORBX_HIP(hipEventRecord(h->evFastDone, st));   // a pyramid built ahead starts behind this FAST stage
+    const bool gate = h->pfUsed && evPyrDone == nullptr;   // a pyramid built ahead starts behind this FAST stage (knob 10: 1 behind the quad-tree, 2 behind the descriptors)
+    if (gate && g_debug[10] == 0) ORBX_HIP(hipEventRecord(h->evFastDone, st));
     {   // K3
         int pow2 = 1;
         while (pow2 < h->maxNodeCap) pow2 <<= 1;
@@ -612,6 +613,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
         }
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[3], st));
+    if (gate && g_debug[10] == 1) ORBX_HIP(hipEventRecord(h->evFastDone, st));
     {   // K4
         const int maxo = std::min(cap, h->max_kp);
         dim3 grid((maxo + DESC_WAVES - 1) / DESC_WAVES, B);
@@ -619,6 +621,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
                            v.lvlKp, h->lvlKpCap, v.lvlCnt, d_kps, d_desc, d_counts, cap, h->d_dbgBlur);
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[4], st));
+    if (gate && g_debug[10] == 2) ORBX_HIP(hipEventRecord(h->evFastDone, st));
     return ORBX_OK;
 }
 

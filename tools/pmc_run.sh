@@ -5,4 +5,4 @@ set -e
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
-rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -- python3 $GRAFT_REPO_ROOT/tools/quick_gpu.py 128 > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1
+timeout -k 10 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -- python3 $GRAFT_REPO_ROOT/tools/quick_gpu.py 128 > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1

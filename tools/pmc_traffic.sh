@@ -11,7 +11,7 @@ if [ -z "$PMC_NO_HEARTBEAT" ]; then   # PMC passes are slow and silent; gpurun k
 fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf $out/pmc_fetch $out/pmc_write
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --ramp-steps 0 --no-cpu-baseline --no-other-workloads --no-verify > $out/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --ramp-steps 0 --no-cpu-baseline --no-other-workloads --no-verify > $out/pmc_write.log 2>&1
+timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --ramp-steps 0 --no-cpu-baseline --no-other-workloads --no-verify --gen-workers 1 > $out/pmc_fetch.log 2>&1
+timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --ramp-steps 0 --no-cpu-baseline --no-other-workloads --no-verify --gen-workers 1 > $out/pmc_write.log 2>&1
 python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write > $out/pmc_traffic.json
 cat $out/pmc_traffic.json
