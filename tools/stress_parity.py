@@ -1,5 +1,7 @@
-"""Randomised parity stress: python tools/stress_parity.py [N] — GPU extractor vs CPU oracle on
-random sizes / budgets / thresholds / image statistics (not part of the pytest suite)."""
+"""Randomised parity stress: python tools/stress_parity.py [N] [seed] — GPU extractor vs CPU oracle on
+random sizes / budgets / thresholds / image statistics (not part of the pytest suite).  Every configuration runs three times:
+the default kernel choice of a single image (k_fast_cells, one-workgroup quad-tree), the strip FAST kernel forced (developer
+knob 6 = 3), and strips + the multi-workgroup quad-tree on every level (knob 4 = 2)."""
 import sys, os, importlib, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,7 +10,7 @@ synth = importlib.import_module("orb_slam2v2-1_amd.synth")
 import oracle
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 bad = 0
 t0 = time.time()
 for it in range(N):
@@ -54,11 +56,20 @@ for it in range(N):
     except RuntimeError:
         continue
     ex = pkg.ORBextractor(nf, sf, nl, ini, mn)
-    gk, gd = ex(img)
-    same = len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and gd.tobytes() == od.tobytes()
-    if not same:
-        bad += 1
-        print("MISMATCH", it, w, h, nf, sf, nl, ini, mn, kind, len(gk), len(ok))
+    for variant, knobs in (("default", ()), ("strips", ((6, 3),)), ("strips+multi-wg quad-tree", ((6, 3), (4, 2)))):
+        for k, v in knobs:
+            pkg.lib().orbx_debug_set(k, v)
+        try:
+            gk, gd = ex(img)
+        finally:
+            for k, v in knobs:
+                pkg.lib().orbx_debug_set(k, 0)
+        same = len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and gd.tobytes() == od.tobytes()
+        if not same:
+            bad += 1
+            print("MISMATCH", variant, it, w, h, nf, sf, nl, ini, mn, kind, len(gk), len(ok), flush=True)
     ex.close()
+    if it % 100 == 99:
+        print("  ... %d configs, %d mismatches, %.0f s" % (it + 1, bad, time.time() - t0), flush=True)
 print("stress: %d configs, %d mismatches, %.1f s" % (N, bad, time.time() - t0))
 sys.exit(1 if bad else 0)

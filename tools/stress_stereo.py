@@ -8,7 +8,7 @@ synth = importlib.import_module("orb_slam2v2-1_amd.synth")
 import oracle
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-rng = np.random.default_rng(777)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 777)
 bad = 0
 t0 = time.time()
 for it in range(N):
