@@ -314,8 +314,9 @@ def main():
                     help="processes that generate the synthetic frames (0 = by core count).  1 = no forked workers: use it under "
                          "rocprofv3, whose tool library in a forked worker can hang when the pool is torn down")
     ap.add_argument("--no-prefetch", action="store_true",
-                    help="do not build the next step's pyramid ahead (orbx_extract_batch_device_prefetch): every step then runs its "
-                         "kernels strictly one after the other")
+                    help="no software pipelining across steps (pyramid of the next step / stereo matcher of the previous one on a side "
+                         "stream): every step then runs its kernels strictly one after the other")
+    ap.add_argument("--no-lag-stereo", action="store_true", help="keep the pyramid built ahead but match each step's frames inside the step")
     ap.add_argument("--overlap-pass", action="store_true",
                     help="after the measurement, an extra pass of K steps alternating over 3 handles on 3 streams; its throughput "
                          "is reported beside the headline value (\"overlapped\").  Off by default so that the kernel launches of "
@@ -396,7 +397,7 @@ def main():
 
     S = max(1, args.streams)
     fe = pipeline.FrontEnd(w, h, nf, stereo, B, device_index=dev_index, nbuf=3, streams=S, world=world, gather=gather,
-                           gather_via_host=(args.backend != "nccl"), prefetch=not args.no_prefetch)
+                           gather_via_host=(args.backend != "nccl"), prefetch=not args.no_prefetch, lag_stereo=not args.no_lag_stereo)
     fe.upload(left, right)
     m = measure(fe, args.steps, args.warmup, args.ramp_steps, world, dist, dev, torch)
     dt, stage_ms = m["dt"], m["stage_ms"]
@@ -457,7 +458,8 @@ def main():
                        "ini_th_fast": 20, "min_th_fast": 7, "frames_per_step_per_gpu": B, "clock_ramp_steps": args.ramp_steps,
                        "total_frames_per_step": frames_per_step,
                        "match": "Frame::ComputeStereoMatches" if stereo else "none",
-                       "pipelining": "pyramid of the next step built ahead (orbx_extract_batch_device_prefetch)" if fe.prefetch else "none",
+                       "pipelining": ("behind the FAST stage of step i, on a side stream: stereo matcher of step i-1, then pyramid of step i+1" if fe.lag
+                                      else "pyramid of the next step built ahead (orbx_extract_batch_device_prefetch)") if fe.prefetch else "none",
                        "parallelism": "frames sharded over %d GPU(s)%s" % (world, ", results all-gathered (%s)" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal") if gather else ""),
                        "world_size_observed": world_seen, "ranks": ranks,
                        "avg_keypoints_per_image": round(navg, 1)},
@@ -468,8 +470,9 @@ def main():
                                   "images_per_call": fe.nimg, "calls_averaged": m["ncalls"],
                                   "fast_timed_region": round(m["fast_ms"], 4),
                                   "note": "stage breakdown from an untimed pass of %d steps after the timed region, every stage alone on the GPU "
-                                          "(in the timed steps the pyramid of step i+1 runs on a side stream behind the FAST stage of step i, beside "
-                                          "the quad-tree / descriptor kernels, which makes those longer and the step shorter than the sum here); "
+                                          "(in the timed steps the stereo matcher of step i-1 and the pyramid of step i+1 run on a side stream behind the FAST "
+                                          "stage of step i, beside its gather / quad-tree / descriptor kernels, which makes those longer and the step shorter "
+                                          "than the sum here); "
                                           "roofline.kernel_ms is the FAST stage (%s) over the %d timed steps" % (m["nprof"], roof["kernel"], args.steps)},
         }
         if others:

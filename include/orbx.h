@@ -88,15 +88,28 @@ int orbx_extract_batch_device(orbx_extractor_t *h, const uint8_t *d_imgs, int B,
                               uint8_t *d_desc, int32_t *d_counts, int cap, void *stream);
 
 /* Software pipelining across batches (optional).  Starts ComputePyramid (src/ORBextractor.cc:1107-1132) of the NEXT batch on a
- * stream owned by the handle, into a second pyramid buffer, ordered behind the FAST stage of the orbx_extract_batch_device call
- * issued last on this handle: the memory-bound pyramid then runs beside that call's latency-bound gather / quad-tree, its
- * descriptor kernel and the stereo matcher instead of in front of the next call's FAST.  The next orbx_extract_batch_device call
- * with the SAME (d_imgs, B, w, hgt, stride, image_stride_bytes) takes that pyramid and skips its own; any other call ignores it.
- * Contract: the images must be complete in HBM when this is called (it does not wait for the caller's stream) and must stay
- * unchanged until that next call has been issued; calls on one handle come from one stream.  Results are identical with or
- * without it. */
+ * side stream - `side_stream`, or a stream owned by the handle when that is NULL - into a second pyramid buffer, ordered behind
+ * the FAST stage of the orbx_extract_batch_device call issued last on this handle: the memory-bound pyramid then runs beside that
+ * call's latency-bound gather / quad-tree and its descriptor kernel instead of in front of the next call's FAST.  The next
+ * orbx_extract_batch_device call with the SAME (d_imgs, B, w, hgt, stride, image_stride_bytes) takes that pyramid and skips its
+ * own; any other call ignores it.
+ * Contract: the images must be complete in HBM when this is called (it does not wait for the caller's main stream) and must stay
+ * unchanged until that next call has been issued; extraction calls on one handle come from one stream.  Results are identical with
+ * or without it. */
 int orbx_extract_batch_device_prefetch(orbx_extractor_t *h, const uint8_t *d_imgs, int B, int w, int hgt, int stride,
-                                       size_t image_stride_bytes);
+                                       size_t image_stride_bytes, void *side_stream);
+
+/* Orders `stream` behind the FAST stage of the extraction call issued last on h (the point the pyramid built ahead waits for).
+ * With orbm_stereo_batch_device_prev this lets a throughput pipeline run the stereo matcher of batch i-1 beside the gather /
+ * quad-tree / descriptor kernels of batch i:
+ *     orbx_extract_batch_device(h, batch i, main);  orbx_stream_wait_fast_stage(h, side);
+ *     orbm_stereo_batch_device_prev(h, h, ... arrays of batch i-1 ..., side);
+ *     orbx_extract_batch_device_prefetch(h, batch i+1, ..., side);      (same side stream: the matcher still reads the buffer) */
+int orbx_stream_wait_fast_stage(orbx_extractor_t *h, void *stream);
+
+/* The handle's own side stream (hipStream_t), for the pattern above.  HIP deals streams to a handful of hardware queues
+ * round-robin, so a stream the caller creates may share its queue with the main stream and overlap nothing. */
+void *orbx_side_stream(orbx_extractor_t *h);
 
 /* mvImagePyramid[level] of image `b` of the last call (include/ORBextractor.h:85): copies
  * the inner level (padded=0) or the whole bordered buffer (padded=1, 19 px border,
@@ -163,6 +176,17 @@ int orbx_pack_records_device(const orbx_keypoint_t *d_kps, const uint8_t *d_desc
  * hr may be the SAME handle when one extractor processed left and right images in one batch
  * (e.g. slots [0,B) left, [B,2B) right). */
 int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *hr, int B,
+                             int left_slot0, int right_slot0,
+                             const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
+                             const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
+                             int cap, float mbf, float mb, float *d_uright, float *d_depth,
+                             int32_t *d_nmatch, void *stream);
+
+/* orbm_stereo_batch_device on the pyramids of the extraction call BEFORE the last one on hl / hr.  Valid only while that
+ * pyramid still exists: the last extraction call took a pyramid built ahead (the two buffers swapped) and the next
+ * orbx_extract_batch_device_prefetch has not been issued yet - otherwise ORBX_ERR_ARG.  Issue it on the stream that builds the
+ * next pyramid afterwards (stream order protects the buffer). */
+int orbm_stereo_batch_device_prev(orbx_extractor_t *hl, orbx_extractor_t *hr, int B,
                              int left_slot0, int right_slot0,
                              const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
                              const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,

@@ -42,7 +42,7 @@ EXPORTS = [
     "orbm_search_local_points", "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_transform",
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
     "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch", "orbx_debug_sincosf",
-    "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels", "orbx_extract_batch_device_prefetch", "orbx_debug_blur_patches", "orbm_debug_features_in_area",
+    "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels", "orbx_extract_batch_device_prefetch", "orbx_stream_wait_fast_stage", "orbx_side_stream", "orbm_stereo_batch_device_prev", "orbx_debug_blur_patches", "orbm_debug_features_in_area",
 ]
 
 
@@ -125,7 +125,10 @@ def lib():
     L.orbx_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
     L.orbx_extract_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
     L.orbx_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, i32, sz, vp, vp, vp, i32, vp]
-    L.orbx_extract_batch_device_prefetch.argtypes = [vp, vp, i32, i32, i32, i32, sz]
+    L.orbx_extract_batch_device_prefetch.argtypes = [vp, vp, i32, i32, i32, i32, sz, vp]
+    L.orbx_stream_wait_fast_stage.argtypes = [vp, vp]
+    L.orbx_side_stream.argtypes = [vp]
+    L.orbx_side_stream.restype = vp
     L.orbx_pyramid_host.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.orbx_pyramid_device.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.orbx_debug_level_points.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
@@ -137,6 +140,7 @@ def lib():
     L.orbm_hamming.argtypes = [vp, vp]
     L.orbm_hamming_matrix_device.argtypes = [vp, i32, vp, i32, vp, vp]
     L.orbm_stereo_batch_device.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp]
+    L.orbm_stereo_batch_device_prev.argtypes = L.orbm_stereo_batch_device.argtypes
     L.orbm_stereo.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, f32, f32, vp, vp, C.POINTER(i32)]
     L.orbm_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, C.POINTER(GridGeom), vp, vp, i32, f32,
                                                  i32, i32, C.POINTER(i32)]
@@ -276,9 +280,17 @@ class ORBextractor:
                                                  d_counts, cap, stream))
         self._shape = (h, w)
 
-    def prefetch_batch_device(self, d_imgs, B, w, h, stride, image_stride):
+    def prefetch_batch_device(self, d_imgs, B, w, h, stride, image_stride, side_stream=0):
         """Start the pyramid of the NEXT batch now (orbx_extract_batch_device_prefetch): the images must be complete in HBM."""
-        _check(self._L.orbx_extract_batch_device_prefetch(self._h, d_imgs, B, w, h, stride, image_stride))
+        _check(self._L.orbx_extract_batch_device_prefetch(self._h, d_imgs, B, w, h, stride, image_stride, side_stream))
+
+    def side_stream(self):
+        """hipStream_t of the handle's own side stream (orbx_side_stream)."""
+        return self._L.orbx_side_stream(self._h)
+
+    def stream_wait_fast_stage(self, stream):
+        """Order `stream` behind the FAST stage of the last extraction call (orbx_stream_wait_fast_stage)."""
+        _check(self._L.orbx_stream_wait_fast_stage(self._h, stream))
 
     # -- mvImagePyramid (include/ORBextractor.h:85)
     def pyramid_level(self, level, b=0, padded=False):
@@ -361,11 +373,12 @@ def pack_records_device(d_kps, d_desc, d_uright, d_depth, d_counts, B, cap, d_re
 
 
 def stereo_batch_device(ex_left, ex_right, B, left_slot0, right_slot0, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap,
-                        mbf, mb, d_uright, d_depth, d_nmatch, stream=0):
-    """Device-resident Frame::ComputeStereoMatches for B frames (raw device pointers)."""
-    _check(lib().orbm_stereo_batch_device(ex_left._h, ex_right._h, B, left_slot0, right_slot0, d_kl, d_dl, d_nl,
-                                          d_kr, d_dr, d_nr, cap, float(mbf), float(mb), d_uright, d_depth,
-                                          d_nmatch, stream))
+                        mbf, mb, d_uright, d_depth, d_nmatch, stream=0, prev=False):
+    """Device-resident Frame::ComputeStereoMatches for B frames (raw device pointers).  prev: on the pyramids of the
+    extraction call before the last one (orbm_stereo_batch_device_prev)."""
+    fn = lib().orbm_stereo_batch_device_prev if prev else lib().orbm_stereo_batch_device
+    _check(fn(ex_left._h, ex_right._h, B, left_slot0, right_slot0, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, float(mbf), float(mb),
+              d_uright, d_depth, d_nmatch, stream))
 
 
 def compute_stereo_matches(ex_left, ex_right, kl, dl, kr, dr, mbf, mb):

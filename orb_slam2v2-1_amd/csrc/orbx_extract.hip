@@ -124,7 +124,7 @@ extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int i
 static void free_plan(orbx_extractor *h) {
     hipFree(h->d_cellRaw); h->d_cellRaw = nullptr;
     hipFree(h->d_octFallback); h->d_octFallback = nullptr;
-    hipFree(h->d_pyrAlt); h->d_pyrAlt = nullptr; h->pyrAltBytes = 0; h->pfValid = 0;
+    hipFree(h->d_pyrAlt); h->d_pyrAlt = nullptr; h->pyrAltBytes = 0; h->pfValid = 0; h->prevPyrValid = 0;
     hipFree(h->d_octPart); hipFree(h->d_octLeaf); hipFree(h->d_octBest); hipFree(h->d_octState);
     h->d_octPart = nullptr; h->d_octLeaf = nullptr; h->d_octBest = nullptr; h->d_octState = nullptr;
     hipFree(h->d_geom); hipFree(h->d_tab); hipFree(h->d_pyr); hipFree(h->d_cellCnt); hipFree(h->d_slots);
@@ -687,6 +687,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor_t *h, const uint8_t *d_i
     const bool ahead = h->pfValid && h->d_pyrAlt && h->pfImgs == d_imgs && h->pfB == B && h->pfW == w && h->pfH == hgt && h->pfStride == stride &&
                        h->pfImgStride == image_stride_bytes && g_debug[9] == 0;
     h->pfValid = 0;
+    h->prevPyrValid = ahead ? 1 : 0;   // the buffers swap: the other one keeps the previous call's pyramid until the next one is built into it
     if (ahead) {
         std::swap(h->d_pyr, h->d_pyrAlt);
         ORBX_HIP(hipStreamWaitEvent(st, h->evPrefetch, 0));
@@ -698,7 +699,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor_t *h, const uint8_t *d_i
 // stream of the handle's own.  It is ordered behind the FAST stage of the extraction call issued last, i.e. it runs beside that
 // call's gather / quad-tree (latency-bound), descriptors and the stereo matcher instead of in front of the next call's FAST.
 extern "C" int orbx_extract_batch_device_prefetch(orbx_extractor_t *h, const uint8_t *d_imgs, int B, int w, int hgt, int stride,
-                                                  size_t image_stride_bytes) {
+                                                  size_t image_stride_bytes, void *side_stream) {
     if (!h || !d_imgs || B < 1 || w < 1 || hgt < 1 || stride < w) { orbx_set_error("orbx_extract_batch_device_prefetch: bad arguments"); return ORBX_ERR_ARG; }
     ORBX_HIP(hipSetDevice(h->device));
     int rc = ensure_plan(h, w, hgt, B);
@@ -710,7 +711,8 @@ extern "C" int orbx_extract_batch_device_prefetch(orbx_extractor_t *h, const uin
         ORBX_HIP(hipMalloc(&h->d_pyrAlt, need));
         h->pyrAltBytes = need;
     }
-    hipStream_t sd = h->side[0];
+    hipStream_t sd = side_stream ? (hipStream_t)side_stream : h->side[0];   // the caller's side stream (work it queued there comes first) or the handle's own
+    h->prevPyrValid = 0;
     (void)hipGetLastError();
     if (h->pfUsed && h->last_valid) ORBX_HIP(hipStreamWaitEvent(sd, h->evFastDone, 0));   // (the first time there is no such event yet: the
     else if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));             //  second buffer is new, wait for the handle to be idle)
@@ -721,6 +723,21 @@ extern "C" int orbx_extract_batch_device_prefetch(orbx_extractor_t *h, const uin
     h->pfValid = 1; h->pfImgs = d_imgs; h->pfB = B; h->pfW = w; h->pfH = hgt; h->pfStride = stride; h->pfImgStride = image_stride_bytes;
     return ORBX_OK;
 }
+
+// Orders `stream` behind the FAST stage of the extraction call issued last on h (the event the pyramid built ahead waits for):
+// what a caller queues on `stream` afterwards runs beside that call's gather / quad-tree / descriptor kernels, not beside its FAST.
+extern "C" int orbx_stream_wait_fast_stage(orbx_extractor_t *h, void *stream) {
+    if (!h) { orbx_set_error("orbx_stream_wait_fast_stage: bad arguments"); return ORBX_ERR_ARG; }
+    ORBX_HIP(hipSetDevice(h->device));
+    if (h->pfUsed && h->last_valid) ORBX_HIP(hipStreamWaitEvent((hipStream_t)stream, h->evFastDone, 0));
+    else if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));   // no event yet (nothing was built ahead so far): wait on the host
+    return ORBX_OK;
+}
+
+// The handle's own side stream (the one pyramids are built ahead on when the caller names none).  A process has few hardware
+// queues and the runtime deals streams to them round-robin: a stream the caller creates may share its queue with the caller's main
+// stream and then overlaps nothing; this one was created next to the handle and is known to sit on a queue of its own.
+extern "C" void *orbx_side_stream(orbx_extractor_t *h) { return h ? (void *)h->side[0] : nullptr; }
 
 static int ensure_staging(orbx_extractor *h, size_t in_bytes, int B, int cap) {
     if (h->d_in_bytes < in_bytes) {

@@ -97,6 +97,7 @@ struct orbx_extractor {
     hipStream_t side[ORBX_SIDE_STREAMS]; hipEvent_t evPyr[ORBX_MAX_CHUNKS], evJoin[ORBX_SIDE_STREAMS]; int lastChunks;   // chunk overlap (launch_pipeline)
     // pyramid of the NEXT batch, built ahead on side[0] into a second buffer (orbx_extract_batch_device_prefetch)
     uint8_t *d_pyrAlt; size_t pyrAltBytes; int pfValid, pfUsed, pfB, pfW, pfH, pfStride; const uint8_t *pfImgs; size_t pfImgStride;
+    int prevPyrValid;   // d_pyrAlt still holds the pyramid of the call before the last one (orbm_stereo_batch_device_prev)
     hipEvent_t evFastDone, evPrefetch;
     hipStream_t last_stream; // stream of the last batch call (NULL is a stream too: the HIP default stream)
     int last_valid;          // ... once there has been one

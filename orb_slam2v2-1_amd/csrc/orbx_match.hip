@@ -419,17 +419,23 @@ void orbx_internal_free_stereo_scratch(orbx_extractor *h) {
 }
 
 #define SM_LDS_CAP 12288   // k_stereo_median keeps a frame's SAD values in LDS up to this many keypoints (48 KB), beyond: global memory
-extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, int left_slot0,
-                                        int right_slot0, const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
-                                        const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
-                                        int cap, float mbf, float mb, float *d_uright, float *d_depth,
-                                        int32_t *d_nmatch, void *stream) {
+static int stereo_batch_impl(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, int left_slot0,
+                             int right_slot0, const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
+                             const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
+                             int cap, float mbf, float mb, float *d_uright, float *d_depth,
+                             int32_t *d_nmatch, void *stream, bool prev) {
     if (!hl || !hr || !d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_uright || !d_depth || B < 1 ||
         cap < 1 || left_slot0 < 0 || right_slot0 < 0 || left_slot0 + B > hl->pB || right_slot0 + B > hr->pB) {
         orbx_set_error("orbm_stereo_batch_device: bad arguments");
         return ORBX_ERR_ARG;
     }
     if (cap > 65535) { orbx_set_error("orbm_stereo: %d keypoints per image (limit 65535)", cap); return ORBX_ERR_UNSUPPORTED; }
+    if (prev && !(hl->prevPyrValid && hr->prevPyrValid)) {
+        orbx_set_error("orbm_stereo_batch_device_prev: the pyramid of the call before the last one is gone (the last extraction call did "
+                       "not take a pyramid built ahead, or the next one has been started already)");
+        return ORBX_ERR_ARG;
+    }
+    const uint8_t *pyrL = prev ? hl->d_pyrAlt : hl->d_pyr, *pyrR = prev ? hr->d_pyrAlt : hr->d_pyr;
     StereoLevels lv;
     int rc = fill_stereo_levels(hl, hr, &lv);
     if (rc) return rc;
@@ -445,8 +451,8 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
     dim3 grid((cap + ST_WAVES - 1) / ST_WAVES, B);
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_stereo_bins, dim3(B), dim3(256), 0, st, lv, d_kr, hl->st_rc, d_nr, cap, bhShift, nbins, hl->st_binStart, hl->st_items);
-    hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), 0, st, lv, hl->d_pyr + (size_t)left_slot0 * hl->pyrImgBytes, hl->pyrImgBytes,
-                       hr->d_pyr + (size_t)right_slot0 * hr->pyrImgBytes, hr->pyrImgBytes, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
+    hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), 0, st, lv, pyrL + (size_t)left_slot0 * hl->pyrImgBytes, hl->pyrImgBytes,
+                       pyrR + (size_t)right_slot0 * hr->pyrImgBytes, hr->pyrImgBytes, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
                        hl->st_sad, hl->st_rc, hl->st_binStart, hl->st_items, bhShift, nbins);
     const int useLds = cap <= SM_LDS_CAP;
     hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(SM_T), useLds ? sizeof(int32_t) * cap : 0, st, d_nl, cap, d_uright,
@@ -454,6 +460,26 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
     ORBX_HIP(hipGetLastError());
     hl->st_stream = st;
     return ORBX_OK;
+}
+
+extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, int left_slot0,
+                                        int right_slot0, const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
+                                        const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
+                                        int cap, float mbf, float mb, float *d_uright, float *d_depth,
+                                        int32_t *d_nmatch, void *stream) {
+    return stereo_batch_impl(hl, hr, B, left_slot0, right_slot0, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
+                             d_nmatch, stream, false);
+}
+
+// The same on the pyramids of the extraction call BEFORE the last one (software pipelining: the matcher of batch i-1 issued
+// after the extraction of batch i, see include/orbx.h).
+extern "C" int orbm_stereo_batch_device_prev(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, int left_slot0,
+                                             int right_slot0, const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
+                                             const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
+                                             int cap, float mbf, float mb, float *d_uright, float *d_depth,
+                                             int32_t *d_nmatch, void *stream) {
+    return stereo_batch_impl(hl, hr, B, left_slot0, right_slot0, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
+                             d_nmatch, stream, true);
 }
 
 // thread-local device scratch with a pinned host mirror of the same layout and a non-blocking stream of its own: the

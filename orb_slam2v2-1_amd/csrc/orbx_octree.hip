@@ -514,6 +514,9 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
     uint16_t *__restrict__ nodeOf, int scratchInts, int dbgStopExact, unsigned bigMask) {
     const int l = blockIdx.y, b = blockIdx.x;  // level-major: large levels start first
     if ((bigMask >> l) & 1u) return;             // shared by several workgroups: k_octree_big
+    // A level is ONE workgroup walking a serial chain: when other kernels share its CU (the pyramid built ahead, the stereo
+    // matcher of the previous batch), its waves take the issue slots first - the chain is the critical path, the others are not.
+    __builtin_amdgcn_s_setprio(3);
     OctBig none = {};
     octree_pyr_body<0>(geom, nlevels, cand, keysPerImg, candCnt, lvlKp, lvlKpCap, lvlCnt, tab, capMax, pow2cap, pyrWords, fallback, dbgStop,
                        nodeOf, scratchInts, dbgStopExact, l, b, 0, 0, none);

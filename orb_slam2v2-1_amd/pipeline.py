@@ -4,6 +4,11 @@
     left images in slots [0,B), right images in [B,2B) of the same handle)  ->  Frame::ComputeStereoMatches for the B
     pairs (orbm_stereo_batch_device with hl == hr)  ->  with N > 1 ranks: one packed record per frame, one all-gather.
 
+Software pipelining across steps (one handle, results identical, each step still does one of everything): after the FAST stage
+of step i the GPU has three independent things to do - gather / quad-tree / descriptors of step i (main stream), the stereo
+matcher of step i-1 and the pyramid of step i+1 (both on a side stream, in that order).  The latency-bound kernels of one fill
+the idle issue slots of the others; FAST itself always runs alone.  `prefetch` / `lag_stereo` switch the two halves off.
+
 Reference call sites: src/Frame.cc:78-81 (two extractors), :84 ComputeStereoMatches, src/ORBextractor.cc:1043-1105.
 Host-side plumbing only (torch = device memory, streams, torch.distributed); every computation is a kernel of the HIP
 library, and there is no CPU fallback: constructing a FrontEnd without a GPU raises.
@@ -19,7 +24,7 @@ KITTI_FX, KITTI_BF = 718.856, 386.1448  # KITTI-00 calibration (fx, baseline*fx)
 
 class FrontEnd:
     def __init__(self, w, h, nfeatures, stereo, B, device_index=0, nbuf=3, streams=1, world=1, gather=False,
-                 gather_via_host=False, mbf=KITTI_BF, fx=KITTI_FX, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, prefetch=True):
+                 gather_via_host=False, mbf=KITTI_BF, fx=KITTI_FX, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, prefetch=True, lag_stereo=True):
         if not torch.cuda.is_available():
             raise RuntimeError("orb_slam2v2-1_amd.pipeline.FrontEnd needs a GPU: the HIP path has no CPU fallback")
         self.w, self.h, self.nf, self.stereo, self.B = w, h, nfeatures, stereo, B
@@ -32,6 +37,12 @@ class FrontEnd:
         self.S = max(1, streams)
         self.exs = [ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th, device=device_index) for _ in range(self.S)]
         self.ex = self.exs[0]
+        # the matcher of step i-1 is issued after the extraction of step i, on the side stream, behind that extraction's FAST stage
+        self.lag = bool(lag_stereo and prefetch and stereo and self.S == 1)
+        # the handle's own side stream: a new torch stream may land on the main stream's hardware queue and overlap nothing
+        self.side = torch.cuda.ExternalStream(self.ex.side_stream(), device=self.dev) if self.lag else None
+        self._pend = None              # (buffer set, step) whose matcher has not been issued yet
+        self._ev_side = {}             # buffer set -> event behind its matcher on the side stream
         self.streams = [torch.cuda.current_stream(self.dev)] + [torch.cuda.Stream(self.dev) for _ in range(self.S - 1)]
         self.d_imgs = None
         self.cap = None
@@ -46,10 +57,41 @@ class FrontEnd:
             e(imgs[0])                  # plan for this image size; max_keypoints() is now exact
         self.cap = self.ex.max_keypoints()
         self.d_imgs = torch.from_numpy(np.ascontiguousarray(imgs)).to(self.dev)
+        self.d_sets = [self.d_imgs]
         nbuf, world, gather, via_host = self._ring_args
         self.ring = ResultRing(nbuf, self.B, self.nimg, self.cap, self.dev, world=world, gather=gather,
                                blocking_via_host=via_host)
         return self
+
+    def upload_more(self, left, right=None):
+        """One more resident batch of the same shape: step i then works on batch i % (number of batches)."""
+        imgs = np.concatenate([left, right]) if self.stereo else left
+        assert imgs.shape == (self.nimg, self.h, self.w) and imgs.dtype == np.uint8
+        self.d_sets.append(torch.from_numpy(np.ascontiguousarray(imgs)).to(self.dev))
+        return self
+
+    def _imgs(self, i):
+        return self.d_sets[i % len(self.d_sets)].data_ptr()
+
+    def _match(self, exi, j, st, prev=False):
+        r, B, cap = self.ring, self.B, self.cap
+        stereo_batch_device(exi, exi, B, 0, B, r.kps[j].data_ptr(), r.desc[j].data_ptr(), r.cnt[j].data_ptr(),
+                            r.kps[j][B:].data_ptr(), r.desc[j][B:].data_ptr(), r.cnt[j][B:].data_ptr(),
+                            cap, self.mbf, self.mb, r.ur[j].data_ptr(), r.dp[j].data_ptr(), r.nm[j].data_ptr(), st, prev=prev)
+
+    def _flush(self):
+        """Issue the matcher still owed (the last step's): its pyramid is the handle's current one."""
+        if self._pend is None:
+            return
+        j, step = self._pend
+        self._pend = None
+        main = self.streams[0]
+        self.side.wait_stream(main)
+        self._match(self.ex, j, self.side.cuda_stream)
+        if self.ring.gather:
+            with torch.cuda.stream(self.side):
+                self.ring.publish(j, step)
+        main.wait_stream(self.side)
 
     def step(self, i, ev_before_match=None, ev_after_match=None):
         r = self.ring
@@ -57,17 +99,35 @@ class FrontEnd:
         exi, stream = self.exs[i % self.S], self.streams[i % self.S]
         st = stream.cuda_stream
         B, cap, w, h = self.B, self.cap, self.w, self.h
-        exi.extract_batch_device(self.d_imgs.data_ptr(), self.nimg, w, h, w, w * h, r.kps[j].data_ptr(), r.desc[j].data_ptr(),
+        lag = self.lag and self.prefetch and ev_before_match is None
+        if not lag:
+            self._flush() if self.lag else None
+        elif j in self._ev_side:
+            stream.wait_event(self._ev_side.pop(j))     # the matcher that last wrote buffer set j (nbuf steps ago) is long done
+        exi.extract_batch_device(self._imgs(i), self.nimg, w, h, w, w * h, r.kps[j].data_ptr(), r.desc[j].data_ptr(),
                                  r.cnt[j].data_ptr(), cap, st)
+        if lag:
+            sd = self.side.cuda_stream
+            if self._pend is not None:
+                pj, pstep = self._pend
+                exi.stream_wait_fast_stage(sd)
+                self._match(exi, pj, sd, prev=True)       # step i-1: its pyramid is the buffer the call above swapped out
+                if r.gather:
+                    with torch.cuda.stream(self.side):
+                        r.publish(pj, pstep)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                self._ev_side[pj] = ev
+            exi.prefetch_batch_device(self._imgs(i + self.S), self.nimg, w, h, w, w * h, sd)   # behind the matcher: it reads that buffer
+            self._pend = (j, i)
+            return j
         if self.prefetch:
             # the next step of this handle reads the same resident images: its pyramid starts behind this step's FAST stage
-            exi.prefetch_batch_device(self.d_imgs.data_ptr(), self.nimg, w, h, w, w * h)
+            exi.prefetch_batch_device(self._imgs(i + self.S), self.nimg, w, h, w, w * h)
         if self.stereo:
             if ev_before_match is not None:
                 ev_before_match.record(stream)
-            stereo_batch_device(exi, exi, B, 0, B, r.kps[j].data_ptr(), r.desc[j].data_ptr(), r.cnt[j].data_ptr(),
-                                r.kps[j][B:].data_ptr(), r.desc[j][B:].data_ptr(), r.cnt[j][B:].data_ptr(),
-                                cap, self.mbf, self.mb, r.ur[j].data_ptr(), r.dp[j].data_ptr(), r.nm[j].data_ptr(), st)
+            self._match(exi, j, st)
             if ev_after_match is not None:
                 ev_after_match.record(stream)
         if r.gather:
@@ -76,6 +136,8 @@ class FrontEnd:
         return j
 
     def drain(self):
+        if self.lag:
+            self._flush()
         self.ring.drain()
         torch.cuda.synchronize(self.dev)
 

@@ -65,6 +65,39 @@ def test_bench_step_three_handles_three_streams_one_thread():
     _run_stereo(1241, 376, 1000, 16, seed0=200, streams=3, steps=20)
 
 
+@pytest.mark.parametrize("mode", ["pipelined", "pyramid_ahead_only", "plain"])
+def test_bench_step_rotating_batches(mode):
+    """The software-pipelined step (pyramid of step i+1 and stereo matcher of step i-1 on the side stream beside the tail of step
+    i) over THREE different resident batches and the handle's TWO pyramid buffers, seven steps without a host synchronisation:
+    a matcher or a FAST stage that read the wrong buffer, or read it too early / too late, would see another batch's pixels.
+    Every result still resident at the end (steps 4, 5, 6 = batches 1, 2, 0) must equal the oracle of ITS batch."""
+    pl, ref = _pipeline(), _ref()
+    w, h, nf, B, nsets, steps = 752, 480, 600, 6, 3, 7
+    fe = pl.FrontEnd(w, h, nf, True, B, prefetch=(mode != "plain"), lag_stereo=(mode == "pipelined"))
+    assert fe.lag == (mode == "pipelined")
+    exps = [ref.run_pool(ref.stereo_frame, [(w, h, nf, 700 + 50 * s + i, fe.mbf, fe.mb) for i in range(B)]) for s in range(nsets)]
+    fe.upload(np.stack([e["left"] for e in exps[0]]), np.stack([e["right"] for e in exps[0]]))
+    for s in range(1, nsets):
+        fe.upload_more(np.stack([e["left"] for e in exps[s]]), np.stack([e["right"] for e in exps[s]]))
+    for i in range(steps):
+        fe.step(i)
+    fe.drain()
+    bad = []
+    for i in range(steps - fe.ring.nbuf, steps):
+        exp = exps[i % nsets]
+        imgs, frames = fe.results(i % fe.ring.nbuf)
+        for b in range(B):
+            e = exp[b]
+            for side, k, d, gi in (("left", e["kl"], e["dl"], b), ("right", e["kr"], e["dr"], B + b)):
+                m = ref.image_mismatch(imgs[gi][0], imgs[gi][1], k, d)
+                if m:
+                    bad.append("step %d frame %d %s: %s" % (i, b, side, m))
+            m = ref.stereo_mismatch(frames[b], e)
+            if m:
+                bad.append("step %d frame %d stereo: %s" % (i, b, m))
+    assert not bad, "\n".join(bad[:20])
+
+
 @pytest.mark.parametrize("chunks", [2, 3, 4])
 def test_batch_chunking_does_not_change_results(chunks):
     """Developer knob 8 cuts a batch into chunks whose kernels overlap on the handle's side streams (measured slower than one
