@@ -38,7 +38,8 @@ class FrontEnd:
         self.exs = [ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th, device=device_index) for _ in range(self.S)]
         self.ex = self.exs[0]
         # the matcher of step i-1 is issued after the extraction of step i, on the side stream, behind that extraction's FAST stage
-        self.lag = bool(lag_stereo and prefetch and stereo and self.S == 1)
+        # (not with the all-gather of results: that collective stays on the caller's stream, ordered behind the step's own matcher)
+        self.lag = bool(lag_stereo and prefetch and stereo and self.S == 1 and not gather)
         # the handle's own side stream: a new torch stream may land on the main stream's hardware queue and overlap nothing
         self.side = torch.cuda.ExternalStream(self.ex.side_stream(), device=self.dev) if self.lag else None
         self._pend = None              # (buffer set, step) whose matcher has not been issued yet
@@ -88,9 +89,6 @@ class FrontEnd:
         main = self.streams[0]
         self.side.wait_stream(main)
         self._match(self.ex, j, self.side.cuda_stream)
-        if self.ring.gather:
-            with torch.cuda.stream(self.side):
-                self.ring.publish(j, step)
         main.wait_stream(self.side)
 
     def step(self, i, ev_before_match=None, ev_after_match=None):
@@ -112,9 +110,6 @@ class FrontEnd:
                 pj, pstep = self._pend
                 exi.stream_wait_fast_stage(sd)
                 self._match(exi, pj, sd, prev=True)       # step i-1: its pyramid is the buffer the call above swapped out
-                if r.gather:
-                    with torch.cuda.stream(self.side):
-                        r.publish(pj, pstep)
                 ev = torch.cuda.Event()
                 ev.record(self.side)
                 self._ev_side[pj] = ev
