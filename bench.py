@@ -470,10 +470,11 @@ def main():
                                   "images_per_call": fe.nimg, "calls_averaged": m["ncalls"],
                                   "fast_timed_region": round(m["fast_ms"], 4),
                                   "note": "stage breakdown from an untimed pass of %d steps after the timed region, every stage alone on the GPU "
-                                          "(in the timed steps the stereo matcher of step i-1 and the pyramid of step i+1 run on a side stream behind the FAST "
-                                          "stage of step i, beside its gather / quad-tree / descriptor kernels, which makes those longer and the step shorter "
-                                          "than the sum here); "
-                                          "roofline.kernel_ms is the FAST stage (%s) over the %d timed steps" % (m["nprof"], roof["kernel"], args.steps)},
+                                          "(in the timed steps %s on a side stream behind the FAST stage of step i, beside its gather / quad-tree / descriptor "
+                                          "kernels, which makes those longer and the step shorter than the sum here); "
+                                          "roofline.kernel_ms is the FAST stage (%s) over the %d timed steps" % (
+                                              m["nprof"], "the stereo matcher of step i-1 and the pyramid of step i+1 run" if fe.lag else
+                                              "the pyramid of step i+1 runs" if fe.prefetch else "nothing runs", roof["kernel"], args.steps)},
         }
         if others:
             # the other north-star sizes, same definition of a step, short runs (not the headline; the driver times only `value`)
