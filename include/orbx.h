@@ -366,7 +366,7 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  * key 1: stop k_octree early; key 2: force the exact one-workgroup matcher kernels;
  * key 3: pyramid tile size; key 4: 1 = quad-tree by k_octree alone, without the count pyramid, 2 = every level by the
  * multi-workgroup form k_octree_big (default: levels with >= 600 FAST cells when the batch is at most 4 images), 3 = no level by it;
- * key 5: pyramid by the one-launch fused kernel; key 6: 1 = every level's FAST by k_fast_cells (one wave per cell) instead of
+ * key 5: 1 = pyramid by the one-launch fused kernel, 3 = levels 3.. by it (default: one launch per level); key 6: 1 = every level's FAST by k_fast_cells (one wave per cell) instead of
  * k_fast_strips, 2 = ... with run-time tile strides, 3 = k_fast_strips even for a small batch (default: by batch size);
  * key 7: stop k_octree_pyr after phase n; key 8: n >= 2 cuts a batch into n chunks (at most 4) whose kernels
  * overlap on the handle's side streams (measured: no gain, default one chunk); key 9: ignore pyramids built ahead).

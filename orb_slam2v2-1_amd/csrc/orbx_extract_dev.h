@@ -60,7 +60,7 @@ __device__ __forceinline__ int level_of_cell(const CellBases &cb, int nlevels, i
 // ---- kernels (definitions: see the file named on the right)
 __global__ void k_pyramid_fused(const uint8_t *src, int sstride, size_t simg, uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom,
                                 int nlevels, const int32_t *tab, int xSpanOff, int ySpanOff, int tilesX, int tilesY, int bufBytes,
-                                int maxPar);                                                                     // orbx_pyramid.hip
+                                int maxPar, int l0);                                                             // orbx_pyramid.hip
 __global__ void k_pyr_level(uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int l, const int32_t *tab, int nxc,
                             int nbands);                                                                         // orbx_pyramid.hip
 template <bool FULL>

@@ -15,7 +15,7 @@
 __global__ __launch_bounds__(256) void k_pyramid_fused(
     const uint8_t *__restrict__ src, int sstride, size_t simg, uint8_t *__restrict__ pyr, size_t pyrImgBytes,
     const LevelGeom *__restrict__ geom, int nlevels, const int32_t *__restrict__ tab, int xSpanOff, int ySpanOff,
-    int tilesX, int tilesY, int bufBytes, int maxPar) {
+    int tilesX, int tilesY, int bufBytes, int maxPar, int l0) {
     extern __shared__ __align__(16) uint8_t smem[];
     // per-column {i0 | i1<<16, a0 | a1<<16} and per-row {r0 | r1<<16, b0 | b1<<16} of every level
     uint2 *xpar = (uint2 *)(smem + 2 * bufBytes), *ypar = xpar + maxPar;
@@ -27,9 +27,9 @@ __global__ __launch_bounds__(256) void k_pyramid_fused(
     __syncthreads();
     if (tid == 0) {
         int ax = 0, ay = 0;
-        for (int l = 0; l < nlevels; l++) {
+        for (int l = 0; l < nlevels; l++) {   // parameter space of the levels this launch builds (l > l0)
             xo[l] = ax; yo[l] = ay;
-            ax += sX[l].c1 - sX[l].c0; ay += sY[l].c1 - sY[l].c0;
+            if (l > l0) { ax += sX[l].c1 - sX[l].c0; ay += sY[l].c1 - sY[l].c0; }
         }
         xo[nlevels] = ax; yo[nlevels] = ay;
     }
@@ -40,9 +40,8 @@ __global__ __launch_bounds__(256) void k_pyramid_fused(
             const bool isx = i < nx;
             const int j = isx ? i : i - nx;
             const int *off = isx ? xo : yo;
-            int l = 1;
-            while (l + 1 <= nlevels && j >= off[l + 1]) l++;   // level of entry j (level 0 has no parameters)
-            if (j < off[1]) continue;
+            int l = l0 + 1;
+            while (l + 1 <= nlevels && j >= off[l + 1]) l++;   // level of entry j (the source level l0 has no parameters)
             const LevelGeom *g = geom + l;
             const PyrSpan cs = isx ? sX[l] : sY[l], ps = isx ? sX[l - 1] : sY[l - 1];
             const int k = cs.c0 + (j - off[l]);
@@ -59,24 +58,28 @@ __global__ __launch_bounds__(256) void k_pyramid_fused(
                 ypar[j] = q;
             }
         }
-        const PyrSpan X = sX[0], Y = sY[0];
+        const PyrSpan X = sX[l0], Y = sY[l0];
         const int cw = X.c1 - X.c0, ch = Y.c1 - Y.c0;
-        const uint8_t *s = src + (size_t)b * simg + (size_t)Y.c0 * sstride + X.c0;
+        // l0 == 0: the input image; l0 > 0 (levels 1..l0 were built by k_pyr_level): the inner rows of level l0 in the pyramid
+        const int ss = l0 == 0 ? sstride : geom[l0].pstride;
+        const uint8_t *s = (l0 == 0 ? src + (size_t)b * simg
+                                    : pyr + (size_t)b * pyrImgBytes + geom[l0].poff + (size_t)ORBX_EDGE * ss + ORBX_EDGE) + (size_t)Y.c0 * ss + X.c0;
         const unsigned M = ((1u << 20) + cw - 1) / cw;
+        uint8_t *first = smem + (l0 & 1) * bufBytes;
         for (int i = tid; i < cw * ch; i += 256) {
             const int y = (int)(((unsigned)i * M) >> 20), x = i - y * cw;
-            smem[i] = s[(size_t)y * sstride + x];
+            first[i] = s[(size_t)y * ss + x];
         }
     }
     __syncthreads();
     uint8_t *base = pyr + (size_t)b * pyrImgBytes;
-    for (int l = 0; l < nlevels; l++) {
+    for (int l = l0; l < nlevels; l++) {
         const PyrSpan X = sX[l], Y = sY[l];
         const int cw = X.c1 - X.c0, ch = Y.c1 - Y.c0;
         uint8_t *cur = smem + (l & 1) * bufBytes;  // ping-pong; plain offsets keep the LDS address space
         const LevelGeom *g = geom + l;
         const int lw = g->w, lh = g->h, pstride = g->pstride;
-        if (l > 0) {
+        if (l > l0) {
             const uint8_t *prev = smem + ((l & 1) ^ 1) * bufBytes;
             const int pw = sX[l - 1].c1 - sX[l - 1].c0;
             const uint2 *xp = xpar + xo[l], *yp = ypar + yo[l];
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(256) void k_pyramid_fused(
             }
             __syncthreads();
         }
+        if (l == l0 && l0 > 0) continue;   // the source level is in memory already
         // write the owned rectangle and its mirror images in the 19-px REFLECT_101 frame
         uint8_t *dst = base + g->poff;
         const int ow = X.o1 - X.o0, oh = Y.o1 - Y.o0;

@@ -306,6 +306,27 @@ def test_fused_pyramid_kernel(pkg, oracle, synth):
         pkg.lib().orbx_debug_set(5, 0)
 
 
+@pytest.mark.parametrize("knob", [2, 3])
+def test_pyramid_forms_agree(pkg, oracle, synth, knob):
+    """Developer knob 5: 2 = one launch per level (the default), 3 = the hybrid (levels 1, 2 per launch, levels 3.. chained
+    through LDS in ONE launch; measured slower, kept as a tested alternative): every level byte for byte, frame included,
+    for an odd size, a 3-, 4- and a 10-level pyramid, and the key points behind them."""
+    pkg.lib().orbx_debug_set(5, knob)
+    try:
+        for (w, h, nl, sf, seed) in ((641, 479, 8, 1.2, 84), (1241, 376, 8, 1.2, 85), (500, 400, 4, 1.3, 86), (900, 700, 10, 1.2, 87), (320, 240, 3, 1.2, 88)):
+            img = synth.frame(w, h, seed)
+            ex = pkg.ORBextractor(500, sf, nl, 20, 7)
+            k, d = ex(img)
+            o = oracle.Extractor(500, sf, nl, 20, 7)
+            ok, od = o.extract(img)
+            assert k.tobytes() == ok.tobytes() and d.tobytes() == od.tobytes(), (w, h, nl)
+            for lvl in range(nl):
+                np.testing.assert_array_equal(ex.pyramid_level(lvl, padded=True), o.pyramid_level(lvl, padded=True), err_msg=str((w, h, nl, lvl)))
+            ex.close()
+    finally:
+        pkg.lib().orbx_debug_set(5, 0)
+
+
 def test_small_budget_many_roots(pkg, oracle, synth):
     """The coarsest level of a 1229x497 image at scale 1.5 has 4 quad-tree roots and a budget of 5: the first pass splits all
     roots (16 nodes) before N is looked at (src/ORBextractor.cc:606-672)."""
