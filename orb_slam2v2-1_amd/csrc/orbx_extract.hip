@@ -418,7 +418,9 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
                        4 * (size_t)scratch + 64;
         h->octLdsBytes = bytes;
         h->octPyrWords = maxPyrWords;
-        h->octPyrLdsBytes = sizeof(unsigned long long) * pow2 + (size_t)maxNodeCap * (8 + 8 + 16 + 4 + 2 + 1) + 4 * (size_t)maxPyrWords + 64;
+        int maxPath = 0;   // the level's path tables ride in LDS (k_octree_pyr / k_octree_big)
+        for (int l = 0; l < h->nlevels; l++) maxPath = std::max(maxPath, h->geom[l].regW + h->geom[l].regH);
+        h->octPyrLdsBytes = sizeof(unsigned long long) * pow2 + (size_t)maxNodeCap * (8 + 8 + 16 + 4 + 2 + 1) + 4 * (size_t)maxPyrWords + 4 * (size_t)maxPath + 64 + 8;
         if (h->octPyrLdsBytes > 150 * 1024) { orbx_set_error("quad-tree pyramid needs %zu B of LDS", h->octPyrLdsBytes); return ORBX_ERR_UNSUPPORTED; }
         if (bytes > 150 * 1024) {
             orbx_set_error("quad-tree needs %zu B of LDS (features per level %d): unsupported", bytes, maxNodeCap);

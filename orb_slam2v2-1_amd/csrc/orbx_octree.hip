@@ -167,7 +167,15 @@ __device__ __forceinline__ void octree_pyr_body(
 
     const uint32_t *keys = cand + (size_t)b * keysPerImg + g.keyOff;
     const int n = candCnt[b * nlevels + l];
-    const int32_t *xPath = tab + g.xPathOff, *yPath = tab + g.yPathOff;
+    // the level's path tables (regW + regH words, x then y) are staged into LDS: a sweep iteration then waits for ONE global
+    // latency (its keys, requested an iteration ahead) instead of two dependent ones (keys, then tables)
+    uint32_t *pathL = (uint32_t *)(smem + (((size_t)(sp - smem) + 3) & ~(size_t)3));
+    {
+        const int nPath = g.regW + g.regH;
+        const int32_t *tp = tab + g.xPathOff;
+        for (int i = tid; i < nPath; i += OCT_T) pathL[i] = (uint32_t)tp[i];
+    }
+    const uint32_t *xPath = pathL, *yPath = pathL + g.regW;
     const uint32_t offDeep = (uint32_t)nIni * (((1u << (2 * Dm)) - 1u) / 3u);
 
     // this workgroup's share of the keys (MODE 0: all of them), in whole groups of four
@@ -182,12 +190,16 @@ __device__ __forceinline__ void octree_pyr_body(
     for (int i = tid; i < pyrWords; i += OCT_T) pyr[i] = 0;
     if (tid == 0) sh_abort = 0;
     __syncthreads();
+    uint32_t nkey[4];
+    if (iLo + 4 * tid < iHi) load_keys4(keys, iLo + 4 * tid, n, nkey);
     for (int i0 = iLo + 4 * tid; i0 < iHi; i0 += 4 * OCT_T) {
         uint32_t key[4], c[4];
-        load_keys4(keys, i0, n, key);
 #pragma unroll
-        for (int u = 0; u < 4; u++)   // unconditional (a missing key is 0): all 8 lookups in flight at once
-            c[u] = (uint32_t)xPath[key[u] & 0xFFF] | (uint32_t)yPath[(key[u] >> 12) & 0xFFF];
+        for (int u = 0; u < 4; u++) key[u] = nkey[u];
+        load_keys4(keys, i0 + 4 * OCT_T < iHi ? i0 + 4 * OCT_T : i0, n, nkey);   // the next iteration's keys (unconditional: no load behind a branch)
+#pragma unroll
+        for (int u = 0; u < 4; u++)   // a missing key is 0
+            c[u] = xPath[key[u] & 0xFFF] | yPath[(key[u] >> 12) & 0xFFF];
         // consecutive keys (row-major inside a FAST cell) mostly share the deep cell: count runs, one LDS atomic per run
         uint32_t inc[4];
 #pragma unroll
@@ -447,12 +459,16 @@ __device__ __forceinline__ void octree_pyr_body(
     __syncthreads();
   }
     // ---- 6. every key walks down to its leaf; best key of the node, first maximum wins (:744-760)
+    uint32_t nkey2[4];
+    if (iLo + 4 * tid < iHi) load_keys4(keys, iLo + 4 * tid, n, nkey2);
     for (int i0 = iLo + 4 * tid; i0 < iHi; i0 += 4 * OCT_T) {
         uint32_t key[4], cd[4], node[4];
-        load_keys4(keys, i0, n, key);
+#pragma unroll
+        for (int u = 0; u < 4; u++) key[u] = nkey2[u];
+        load_keys4(keys, i0 + 4 * OCT_T < iHi ? i0 + 4 * OCT_T : i0, n, nkey2);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            cd[u] = (uint32_t)xPath[key[u] & 0xFFF] | (uint32_t)yPath[(key[u] >> 12) & 0xFFF];
+            cd[u] = xPath[key[u] & 0xFFF] | yPath[(key[u] >> 12) & 0xFFF];
             node[u] = 0xFFFFFFFFu;
         }
         // the leaves partition the region: exactly one cell on a key's path is in the map, so the depths

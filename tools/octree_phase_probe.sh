@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 for stop in 1 2 3 4 0; do
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/octp_$stop
-  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/octp_$stop -- python3 $GRAFT_REPO_ROOT/tools/octree_phase_probe.py $1 $2 $3 $stop > /dev/null 2>&1
+  timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/octp_$stop -- python3 $GRAFT_REPO_ROOT/tools/octree_phase_probe.py $1 $2 $3 $stop > /dev/null 2>&1
   python3 - <<PY
 import csv, glob
 for f in glob.glob("$GRAFT_REPO_ROOT/gpurun_out/octp_$stop/*/*kernel_stats.csv"):
