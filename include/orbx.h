@@ -369,7 +369,8 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  * key 5: 1 = pyramid by the one-launch fused kernel, 3 = levels 3.. by it (default: one launch per level); key 6: 1 = every level's FAST by k_fast_cells (one wave per cell) instead of
  * k_fast_strips, 2 = ... with run-time tile strides, 3 = k_fast_strips even for a small batch (default: by batch size);
  * key 7: stop k_octree_pyr after phase n; key 8: n >= 2 cuts a batch into n chunks (at most 4) whose kernels
- * overlap on the handle's side streams (measured: no gain, default one chunk); key 9: ignore pyramids built ahead).
+ * overlap on the handle's side streams (measured: no gain, default one chunk); key 9: ignore pyramids built ahead; key 11: quad-tree kernels in
+ * the 1024-thread build never (1) / always (2) instead of by image size).
  * Never set in production: keys 0, 1 and 7 leave outputs incomplete; 2, 4, 5, 6 select an alternative
  * kernel with identical results (tests use them to cover those kernels). */
 int orbx_debug_set(int key, int value);

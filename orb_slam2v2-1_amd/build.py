@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "liborbx_hip.so")
-SOURCES = ["orbx_extract.hip", "orbx_pyramid.hip", "orbx_fast.hip", "orbx_octree.hip", "orbx_describe.hip",
+SOURCES = ["orbx_extract.hip", "orbx_pyramid.hip", "orbx_fast.hip", "orbx_octree.hip", "orbx_octree_wide.hip", "orbx_describe.hip",
            "orbx_match.hip", "orbx_match_fast.hip", "orbx_bow.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-value", "-Wno-unused-result"]

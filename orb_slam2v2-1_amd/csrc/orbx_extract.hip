@@ -600,31 +600,41 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             big.part = h->d_octPart; big.leaf = h->d_octLeaf; big.best = h->d_octBest; big.state = h->d_octState;
             big.K = OCT_BIG_K; big.deepMax = h->octDeepMax; big.pyrMax = h->octPyrWords;
             for (int l = 0; l < nl; l++) if ((bigMask >> l) & 1u) big.levelOf[big.nBig++] = l;
+            // 1024-thread instances for images with a large level (>= 600 FAST cells; developer knob 11: 1 = never, 2 = always)
+            const bool wide = g_debug[11] == 0 ? h->octBigMask != 0 : g_debug[11] == 2;
+#define ORBX_OCT_LAUNCH(KERN, KERNW, GRID, LDS, ...)                                                                       \
+    do {                                                                                                                \
+        if (wide) {                                                                                                     \
+            ORBX_HIP(hipFuncSetAttribute((const void *)KERNW, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS))); \
+            hipLaunchKernelGGL(KERNW, GRID, dim3(OCT_T_WIDE), LDS, st, __VA_ARGS__);                                    \
+        } else {                                                                                                        \
+            ORBX_HIP(hipFuncSetAttribute((const void *)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)));  \
+            hipLaunchKernelGGL(KERN, GRID, dim3(OCT_T), LDS, st, __VA_ARGS__);                                          \
+        }                                                                                                               \
+    } while (0)
             if (big.nBig > 0 && g_debug[7] == 0 && g_debug[1] == 0) {
                 // large levels: K workgroups histogram, the last one to arrive runs the passes; the same launch carries the other
                 // levels (one workgroup each, listed behind the large ones) ...
                 int nall = big.nBig;
                 for (int l = 0; l < nl; l++) if (!((bigMask >> l) & 1u)) big.levelOf[nall++] = l;
-                ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_octree_big<1>, dim3(OCT_BIG_K, nl, B), dim3(OCT_T), lds, st, h->d_geom, nl, v.cand, h->keysPerImg,
-                                   v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
-                                   v.octFallback, v.nodeOf, scratch, big);
+                ORBX_OCT_LAUNCH(k_octree_big<1>, k_octree_big_wide<1>, dim3(OCT_BIG_K, nl, B), lds, h->d_geom, nl, v.cand, h->keysPerImg,
+                                v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
+                                v.octFallback, v.nodeOf, scratch, big);
                 // ... then K workgroups elect the best key per node, the last one writes the level's keypoints
-                ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_octree_big<2>, dim3(OCT_BIG_K, big.nBig, B), dim3(OCT_T), lds, st, h->d_geom, nl, v.cand, h->keysPerImg,
-                                   v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
-                                   v.octFallback, v.nodeOf, scratch, big);
+                ORBX_OCT_LAUNCH(k_octree_big<2>, k_octree_big_wide<2>, dim3(OCT_BIG_K, big.nBig, B), lds, h->d_geom, nl, v.cand, h->keysPerImg,
+                                v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
+                                v.octFallback, v.nodeOf, scratch, big);
             } else {   // no large level (or a phase-stop knob is set): one workgroup per level, one launch
-                ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_pyr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_octree_pyr, dim3(B, nl), dim3(OCT_T), lds, st, h->d_geom, nl, v.cand,
-                                   h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
-                                   pow2, h->octPyrWords, v.octFallback, g_debug[7], v.nodeOf, scratch, g_debug[1], 0u);
+                ORBX_OCT_LAUNCH(k_octree_pyr, k_octree_pyr_wide, dim3(B, nl), lds, h->d_geom, nl, v.cand,
+                                h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
+                                pow2, h->octPyrWords, v.octFallback, g_debug[7], v.nodeOf, scratch, g_debug[1], 0u);
             }
         } else {        // developer knob 4 = 1: the exact form alone
-            ORBX_HIP(hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->octLdsBytes));
-            hipLaunchKernelGGL(k_octree, dim3(B, nl), dim3(OCT_T), h->octLdsBytes, st, h->d_geom, nl, v.cand, v.nodeOf,
-                               h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2,
-                               scratch, g_debug[1]);
+            const bool wide = g_debug[11] == 0 ? h->octBigMask != 0 : g_debug[11] == 2;
+            ORBX_OCT_LAUNCH(k_octree, k_octree_wide, dim3(B, nl), h->octLdsBytes, h->d_geom, nl, v.cand, v.nodeOf,
+                            h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2,
+                            scratch, g_debug[1]);
+#undef ORBX_OCT_LAUNCH
         }
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[3], st));

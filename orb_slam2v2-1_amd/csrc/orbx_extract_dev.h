@@ -47,7 +47,10 @@ struct PyrSpan { short o0, o1, c0, c1; };  // owned [o0,o1) and computed [c0,c1)
 #define PYR_SR 12  // source rows fetched up front: covers PYR_RW rows at scale factors up to ~1.4
 #define FAST_WAVES 4
 #define GATHER_CELLS_PER_BLOCK 16
+#ifndef OCT_T
 #define OCT_T 512   // 1024-thread workgroups are resident one per CU only; 512 packs 2x better at batch 128 and costs 6 us on a single frame
+#endif
+#define OCT_T_WIDE 1024   // the same kernels built a second time (orbx_octree_wide.hip) for images whose level 0 has >= 600 FAST cells: twice the threads on the LDS-bound key sweeps of ONE level (1920x1080 level 0: 174 -> 150 us)
 #define DESC_WAVES 4
 struct CellBases { int v[ORBX_MAX_LEVELS + 1]; };
 __device__ __forceinline__ int level_of_cell(const CellBases &cb, int nlevels, int gc) {
@@ -95,6 +98,17 @@ __global__ void k_octree_big(const LevelGeom *geom, int nlevels, const uint32_t 
 __global__ void k_octree(const LevelGeom *geom, int nlevels, const uint32_t *cand, uint16_t *nodeOf, size_t keysPerImg,
                          const int32_t *candCnt, uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax,
                          int pow2cap, int scratchInts, int dbgStop);                                             // orbx_octree.hip
+__global__ void k_octree_pyr_wide(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
+                                  uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
+                                  int pyrWords, int32_t *fallback, int dbgStop, uint16_t *nodeOf, int scratchInts, int dbgStopExact,
+                                  unsigned bigMask);                                                             // orbx_octree_wide.hip
+template <int MODE>
+__global__ void k_octree_big_wide(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
+                                  uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
+                                  int pyrWords, int32_t *fallback, uint16_t *nodeOf, int scratchInts, OctBig big);
+__global__ void k_octree_wide(const LevelGeom *geom, int nlevels, const uint32_t *cand, uint16_t *nodeOf, size_t keysPerImg,
+                              const int32_t *candCnt, uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax,
+                              int pow2cap, int scratchInts, int dbgStop);
 __global__ void k_describe(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, const uint32_t *lvlKp,
                            int lvlKpCap, const int32_t *lvlCnt, orbx_keypoint_t *kps, uint8_t *desc, int32_t *counts,
                            int cap, uint8_t *dbgBlur);                                                                             // orbx_describe.hip

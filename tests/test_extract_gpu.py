@@ -382,6 +382,27 @@ def test_quadtree_multi_workgroup_form(pkg, oracle, synth):
     _compare(pkg, oracle, synth.frame(1920, 1080, 99), 4000)     # default rule: a single image, the larger levels take the multi-workgroup form
 
 
+@pytest.mark.parametrize("wide,form", [(2, 0), (2, 1), (2, 2), (1, 0), (1, 2)])
+def test_quadtree_workgroup_width(pkg, oracle, synth, wide, form):
+    """The quad-tree kernels exist in a 512- and a 1024-thread build (orbx_octree_wide.hip; images with a level of >= 600 FAST cells
+    take the wide one).  Developer knob 11 = 2 forces the wide build on small images, = 1 the narrow one on large images; crossed
+    with knob 4 (0 default, 1 the exact form alone, 2 every level multi-workgroup).  Same bytes, clustered and empty levels included."""
+    rng = np.random.default_rng(195)
+    clustered = np.full((480, 640), 128, np.uint8)
+    clustered[200:280, 260:380] = rng.integers(0, 256, (80, 120), dtype=np.uint8)
+    pkg.lib().orbx_debug_set(11, wide)
+    pkg.lib().orbx_debug_set(4, form)
+    try:
+        _compare(pkg, oracle, synth.frame(1241, 376, 196), 2000)
+        _compare(pkg, oracle, clustered, 1000)
+        _compare(pkg, oracle, np.full((480, 640), 77, np.uint8), 500)
+        _compare(pkg, oracle, synth.frame(1920, 1080, 197), 4000)
+        _compare(pkg, oracle, rng.integers(0, 256, (376, 620), dtype=np.uint8), 3000)
+    finally:
+        pkg.lib().orbx_debug_set(11, 0)
+        pkg.lib().orbx_debug_set(4, 0)
+
+
 def test_fast_cell_kernel_instances(pkg, oracle, synth):
     """FAST runs as k_fast_strips (one wave per strip of four cells) on levels whose cells are at most 32 px wide and as
     k_fast_cells (one wave per cell) on the others.  Developer knob 6 forces k_fast_cells on every level: 1 = its instances
