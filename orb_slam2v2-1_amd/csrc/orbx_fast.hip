@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
 //     cell's 16 lanes); the per-cell threshold fallback (:809-816) is decided at the end of the strip from per-lane counters
 //     (nA: survivors >= iniTh, nB: >= minTh) and applied by k_gather while it compacts: count = nA ? nA : nB.
 #define STRIP_ES 144      // dwords per tile row: 4 x 32 px + 6 px of window + alignment shift (<= 3) + the last pair's partner, 16-B rows
-#define STRIP_SLOTS 14    // ring of 8 rows + mirror of its rows 0..5
+#define STRIP_SLOTS 8     // ring of 8 window rows (the loop is unrolled by 8 rows, so every ring slot is a compile-time offset)
 __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
 __device__ __forceinline__ uint32_t dpp_row_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }
 
@@ -382,22 +382,20 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
         return d;
     };
     uint32_t *Ew = E + 4 * qi;
-    auto write_row = [&](int r, uint2 d) {
+    auto write_row = [&](int slot, uint2 d) {   // slot = row & 7, a compile-time constant at every call site
         uint4 e;  // bytes b0..b3 of d.x and b4 = first byte of d.y -> pairs (b0,b1) (b1,b2) (b2,b3) (b3,b4)
         e.x = __builtin_amdgcn_perm(d.y, d.x, 0x0c010c00u);
         e.y = __builtin_amdgcn_perm(d.y, d.x, 0x0c020c01u);
         e.z = __builtin_amdgcn_perm(d.y, d.x, 0x0c030c02u);
         e.w = __builtin_amdgcn_perm(d.y, d.x, 0x0c040c03u);
-        const int slot = __builtin_amdgcn_readfirstlane(r & 7);
         *(uint4 *)(Ew + slot * STRIP_ES) = e;
-        if (slot < 6) *(uint4 *)(Ew + (slot + 8) * STRIP_ES) = e;   // wave-uniform
     };
     {   // rows 0..6 (the first evaluated row's ring) + row 7 in flight: all eight loads issued before the first LDS write
         uint2 d[7];
 #pragma unroll
         for (int r = 0; r < 7; r++) d[r] = load_row(r);
 #pragma unroll
-        for (int r = 0; r < 7; r++) write_row(r, d[r]);
+        for (int r = 0; r < 7; r++) write_row(r, d[r]);   // rows 0..6 -> slots 0..6
     }
     uint2 pre = load_row(7);
     wave_sync();
@@ -418,16 +416,20 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
     uint32_t S1 = 0, H1 = 0, H2 = 0, LR1 = 0;
     uint32_t nRaw = 0, nHi = 0;   // survivors >= min(iniTh, minTh) so far in my cell (same in its 16 lanes) / MY survivors >= max(iniTh, minTh)
     // one evaluated row: scores of row y, suppression verdict for row y-1 (sign flags of its two pixels, its scores), ring update
-    auto rowstep = [&](int y, uint32_t &kpOut, uint32_t &sOut) {
+    // R = y & 7 is a compile-time constant at every call site (the loop below advances by 8 rows): window row y + k sits in ring
+    // slot (R + k) & 7, an immediate offset from ONE base register - no mirror of the ring's first rows, no per-row address
+    auto rowstep = [&](const int R, int y, uint32_t &kpOut, uint32_t &sOut) {
         uint32_t S = 0;
         if (y < chS) {   // wave-uniform
-            const uint32_t *q = q0 + __builtin_amdgcn_readfirstlane((y & 7) * STRIP_ES);   // window rows y .. y+6 = ring slots (y & 7) .. + 6
-            const uint32_t vv = q[3 * STRIP_ES];
+            const uint32_t *q = q0;
+#define SLOT(k) (((R + (k)) & 7) * STRIP_ES)
+            const uint32_t vv = q[SLOT(3)];
             uint32_t rr[16];
-            rr[0] = q[6 * STRIP_ES];       rr[1] = q[6 * STRIP_ES + 1];   rr[2] = q[5 * STRIP_ES + 2];   rr[3] = q[4 * STRIP_ES + 3];
-            rr[4] = q[3 * STRIP_ES + 3];   rr[5] = q[2 * STRIP_ES + 3];   rr[6] = q[1 * STRIP_ES + 2];   rr[7] = q[1];
-            rr[8] = q[0];                  rr[9] = q[-1];                 rr[10] = q[1 * STRIP_ES - 2];  rr[11] = q[2 * STRIP_ES - 3];
-            rr[12] = q[3 * STRIP_ES - 3];  rr[13] = q[4 * STRIP_ES - 3];  rr[14] = q[5 * STRIP_ES - 2];  rr[15] = q[6 * STRIP_ES - 1];
+            rr[0] = q[SLOT(6)];       rr[1] = q[SLOT(6) + 1];   rr[2] = q[SLOT(5) + 2];   rr[3] = q[SLOT(4) + 3];
+            rr[4] = q[SLOT(3) + 3];   rr[5] = q[SLOT(2) + 3];   rr[6] = q[SLOT(1) + 2];   rr[7] = q[SLOT(0) + 1];
+            rr[8] = q[SLOT(0)];       rr[9] = q[SLOT(0) - 1];   rr[10] = q[SLOT(1) - 2];  rr[11] = q[SLOT(2) - 3];
+            rr[12] = q[SLOT(3) - 3];  rr[13] = q[SLOT(4) - 3];  rr[14] = q[SLOT(5) - 2];  rr[15] = q[SLOT(6) - 1];
+#undef SLOT
             const half2v best = fast_ring_score(vv, rr);
             // score + 1, clamped at 0, pixels outside the cell's evaluated area = 0
             S = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(best, (half2v){(_Float16)0, (_Float16)0})) & vmask;
@@ -446,17 +448,17 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
         sOut = S1;
         S1 = S; H2 = H1; H1 = H0; LR1 = LR0;
         // stream: window row y+7 (loaded during this iteration) replaces row y-1 in the ring; row y+8 goes in flight
-        if (y + 7 < thS) write_row(y + 7, pre);   // wave-uniform
+        if (y + 7 < thS) write_row((R + 7) & 7, pre);   // wave-uniform
         pre = load_row(y + 8);
         wave_sync();
     };
-    // Two rows per loop iteration, ONE emission for both: the two pixels of a pair and the pair of the next row are all
-    // neighbours of each other, so among the four at most one is a strict 3x3 maximum - a lane emits at most one key per two rows.
-    for (int yv = 0; yv <= chS; yv += 2) {
-        const int y = __builtin_amdgcn_readfirstlane(yv);   // everything derived from the row number stays on the scalar unit
+    // Two rows per emission: the two pixels of a pair and the pair of the next row are all neighbours of each other, so among the
+    // four at most one is a strict 3x3 maximum - a lane emits at most one key per two rows.  Eight rows per loop iteration, so that
+    // a row's ring slots are compile-time constants.
+    auto rowpair = [&](const int R, int y) {     // rows y, y + 1 (R = y & 7): verdicts for rows y - 1 and y
         uint32_t kpA, sA, kpB, sB;
-        rowstep(y, kpA, sA);          // verdict for row y-1
-        rowstep(y + 1, kpB, sB);      // verdict for row y   (y + 1 > chS: an all-zero row, nothing survives)
+        rowstep(R, y, kpA, sA);          // verdict for row y-1
+        rowstep(R + 1, y + 1, kpB, sB);  // verdict for row y   (y + 1 > chS: an all-zero row, nothing survives)
         const short2v fa = __builtin_bit_cast(short2v, kpA), fb = __builtin_bit_cast(short2v, kpB);
         const bool inA = fa.x > 0 || fa.y > 0, inB = fb.x > 0 || fb.y > 0;
         const unsigned long long mA = __ballot(inA), mB = __ballot(inB);
@@ -473,6 +475,13 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
             nHi += (inA || inB) && sc > (uint32_t)thi ? 1u : 0u;
             nRaw += __popc(aA) + __popc(aB);
         }
+    };
+    for (int yv = 0; yv <= chS; yv += 8) {
+        const int y = __builtin_amdgcn_readfirstlane(yv);   // everything derived from the row number stays on the scalar unit
+        rowpair(0, y);
+        if (y + 2 <= chS) rowpair(2, y + 2);   // wave-uniform
+        if (y + 4 <= chS) rowpair(4, y + 4);
+        if (y + 6 <= chS) rowpair(6, y + 6);
     }
     // per-cell totals: the 16 lanes of a cell
 #pragma unroll
