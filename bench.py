@@ -369,6 +369,9 @@ def main():
     pkg = importlib.import_module("orb_slam2v2-1_amd")
     pipeline = importlib.import_module("orb_slam2v2-1_amd.pipeline")
     pkg.lib()  # fails loudly if the HIP library is missing
+    for kv in os.environ.get("ORBX_BENCH_KNOBS", "").split(","):   # developer knobs for A/B runs, e.g. ORBX_BENCH_KNOBS=12=1
+        if "=" in kv:
+            pkg.lib().orbx_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():

@@ -482,6 +482,8 @@ static int harvest_events(orbx_extractor *h, int slot) {
     return ORBX_OK;
 }
 
+__global__ void k_nop() {}
+
 // K1: ComputePyramid of B images into pyr.  Developer knob 5: 0 / 2 = one launch per level (the default), 1 = every level in the
 // fused launch, 3 = hybrid.
 static bool pyramid_fused_all(const orbx_extractor *h) { return g_debug[5] == 1 || h->scale_factor > 3.0; }
@@ -545,6 +547,10 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     if (prof) ORBX_HIP(hipEventRecord(ev[0], st));
     if (!skipPyr) launch_pyramid(h, d_imgs, v.pyr, B, stride, img_stride, st);   // K1 (skipped when the pyramid was built ahead)
     if (evPyrDone) ORBX_HIP(hipEventRecord(evPyrDone, st));
+    // With the pyramid built ahead nothing but a stream wait (for that pyramid) sits in front of the FAST launch, and a timing
+    // event recorded right behind a pending wait can be stamped before the wait is over: the bracket then reads wait + FAST
+    // (seen as 0.30 instead of 0.27 ms in one run out of four).  An empty kernel orders the stamp behind the wait.
+    if (profFast && skipPyr && g_debug[12] == 0) hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, st);
     if (profFast) ORBX_HIP(hipEventRecord(ev[1], st));
     {   // K2
         // developer knob 6: 1 = every level by k_fast_cells (compile-time tile strides), 2 = ... with run-time strides
@@ -977,6 +983,10 @@ extern "C" int orbx_set_profiling(orbx_extractor_t *h, int enabled) {
         if (h->ev_pending[r]) { ORBX_HIP(hipEventSynchronize(h->ev[r][h->ev_pending[r] == 2 ? 2 : 4])); h->ev_pending[r] = 0; }
     if (enabled < 0 || enabled > 3) { orbx_set_error("orbx_set_profiling: mode %d", enabled); return ORBX_ERR_ARG; }
     h->profiling = enabled;
+    if (enabled) {   // the ordering kernel in front of the FAST bracket: its first launch loads code, keep that out of the timed calls
+        hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, h->stream);
+        ORBX_HIP(hipStreamSynchronize(h->stream));
+    }
     h->prof_calls = 0;
     h->ev_head = 0;
     h->acc_n = 0;
