@@ -370,7 +370,8 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  * k_fast_strips, 2 = ... with run-time tile strides, 3 = k_fast_strips even for a small batch (default: by batch size);
  * key 7: stop k_octree_pyr after phase n; key 8: n >= 2 cuts a batch into n chunks (at most 4) whose kernels
  * overlap on the handle's side streams (measured: no gain, default one chunk); key 9: ignore pyramids built ahead; key 11: quad-tree kernels in
- * the 1024-thread build never (1) / always (2) instead of by image size).
+ * the 1024-thread build never (1) / always (2) instead of by image size; key 12: 1 = no ordering kernel in front of the FAST
+ * stage's start event).
  * Never set in production: keys 0, 1 and 7 leave outputs incomplete; 2, 4, 5, 6 select an alternative
  * kernel with identical results (tests use them to cover those kernels). */
 int orbx_debug_set(int key, int value);
