@@ -177,8 +177,14 @@ def measure(fe, steps, warmup, ramp, world, dist, dev, torch):
     """Ramp + warm-up + K timed steps of fe (barrier + synchronize on both sides, MAX over ranks) + an untimed
     stage-profile pass.  Returns dict(dt, fast_ms, stage_ms, ncalls, match_ms, last_results)."""
     ex = fe.ex
-    for i in range(ramp):               # clock ramp (untimed, not counted as warm-up steps)
+    # clock ramp (untimed, not counted as warm-up steps): at least `ramp` steps AND at least half a second of GPU load - a box that
+    # sat idle needs that long before the clocks hold (one fresh box in a dozen measured 9 % low behind a 0.13-s ramp)
+    t_ramp, i = time.perf_counter(), 0
+    while ramp > 0 and (i < ramp or time.perf_counter() - t_ramp < 0.5):
         fe.step(i)
+        i += 1
+        if i % 50 == 0:
+            fe.drain()                  # keeps the clock comparison about executed, not merely enqueued, steps
     fe.drain()
     for i in range(warmup):
         fe.step(i)
