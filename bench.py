@@ -61,12 +61,24 @@ def _gen_pair(args):
     return synth.frame(w, h, k), None
 
 
-def make_frames(w, h, n, k0, stereo, workers):
+def _pool_map(fn, jobs, workers):
+    """fn over jobs on a SPAWN pool whose workers exit by themselves (close + join, never terminate): a forked worker inherits
+    whatever the parent has loaded - under rocprofv3 the tool library with its signal handlers, and the pool's SIGTERM at teardown
+    then aborted the workers (gpurun_out/r02_bench3.err)."""
     import multiprocessing as mp
+    pool = mp.get_context("spawn").Pool(workers)
+    try:
+        out = pool.map(fn, jobs)
+    finally:
+        pool.close()
+        pool.join()
+    return out
+
+
+def make_frames(w, h, n, k0, stereo, workers):
     jobs = [(w, h, k0 + i, stereo) for i in range(n)]
     if workers > 1 and n > 2:
-        with mp.get_context("fork").Pool(min(workers, n)) as pool:
-            out = pool.map(_gen_pair, jobs)
+        out = _pool_map(_gen_pair, jobs, min(workers, n))
     else:
         out = [_gen_pair(j) for j in jobs]
     left = np.stack([o[0] for o in out])
@@ -102,7 +114,6 @@ def _cpu_frame(args):
 
 def cpu_baseline(w, h, nf, stereo, budget_s=20.0):
     """Times the oracle on the host cores over a bounded sample of the same workload."""
-    import multiprocessing as mp
     import oracle
     oracle.build()
     cores = max(1, min(os.cpu_count() or 1, 16))
@@ -110,8 +121,7 @@ def cpu_baseline(w, h, nf, stereo, budget_s=20.0):
     nframes = int(max(cores, min(8 * cores, budget_s * cores / max(t1, 1e-3))))
     jobs = [(w, h, nf, 100 + i, stereo) for i in range(nframes)]
     t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_frame, jobs)
+    res = _pool_map(_cpu_frame, jobs, cores)
     wall = time.perf_counter() - t0
     gen = sum(r[1] for r in res)
     work = sum(r[0] for r in res)
@@ -209,6 +219,10 @@ def measure(fe, steps, warmup, ramp, world, dist, dev, torch):
         dt = float(tt.item())
     fast_ms = float(ex.stage_ms()[0][1])            # FAST stage, averaged over the K timed steps
     last = fe.results((warmup + steps - 1) % fe.ring.nbuf)   # outputs of the LAST TIMED step (host copies), checked later
+    gath = None
+    if fe.ring.gather:                              # ... and what the all-gather of that step delivered (every rank's records)
+        jl = (warmup + steps - 1) % fe.ring.nbuf
+        gath = (jl, warmup + steps - 1, fe.ring.gathered_steps[jl], {k: v.clone() for k, v in fe.ring.gathered(jl).items()})
     nprof = max(1, min(steps, 10))                  # untimed pass: events at every stage boundary
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(nprof)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(nprof)]
@@ -224,12 +238,13 @@ def measure(fe, steps, warmup, ramp, world, dist, dev, torch):
     fe.prefetch = pf
     match_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)])) if fe.stereo else 0.0
     return {"dt": dt, "fast_ms": fast_ms, "stage_ms": stage_ms, "ncalls": ncalls, "match_ms": match_ms, "last": last,
-            "nprof": nprof}
+            "nprof": nprof, "gathered": gath}
 
 
 def verify_against_oracle(fe, last, seeds, frames):
-    """Checker leg (outside every timed region): frames `frames` of the last timed step against the CPU oracle,
-    byte for byte (keypoints, descriptors, counts; mvuRight / mvDepth / match count for stereo)."""
+    """Checker leg (outside every timed region): frames `frames` of the last timed step against the CPU oracle: keypoint
+    coordinates, sizes, responses, octaves, counts and descriptors bit for bit, angles within 1e-4 (north_star's float tolerance;
+    bit-identical in practice); mvuRight / mvDepth / match count for stereo bit for bit."""
     import oracle
     oracle.build()
     ref = importlib.import_module("oracle.reference_frames")
@@ -251,6 +266,46 @@ def verify_against_oracle(fe, last, seeds, frames):
             if m:
                 bad.append("frame %d: %s" % (b, m))
     return bad
+
+
+def verify_gathered(fe, gath, ranks, frames_of_rank):
+    """N > 1 checker leg (rank 0, outside every timed region): the ALL-GATHERED records of the last timed step - every
+    rank's frames as they arrived over the collective - against the CPU oracle of that rank's seeds.  frames_of_rank(B) picks the
+    frames of each rank's block that are checked.  Returns (list of mismatches, frames checked)."""
+    import oracle
+    oracle.build()
+    ref = importlib.import_module("oracle.reference_frames")
+    pkg = importlib.import_module("orb_slam2v2-1_amd")
+    bad = []
+    j, step, held, rec = gath          # captured by measure() right behind the timed region (later passes refill the buffer sets)
+    if held != step:
+        return ["buffer set %d holds the gathered records of step %s, expected step %d" % (j, held, step)], 0
+    g = {k: v.cpu().numpy() for k, v in rec.items()}
+    B, cap, nchk = fe.B, fe.cap, 0
+    jobs, where = [], []
+    for r in ranks:
+        for b in frames_of_rank(B):
+            seed = r["first_seed"] + b
+            jobs.append((fe.w, fe.h, fe.nf, seed, fe.mbf, fe.mb) if fe.stereo else (fe.w, fe.h, fe.nf, seed))
+            where.append((r["rank"], b))
+    exp = ref.run_pool(ref.stereo_frame if fe.stereo else ref.mono_frame, jobs)
+    for (rk, b), e in zip(where, exp):
+        row = rk * B + b
+        n = int(g["counts"][row])
+        if n < 0 or n > cap:
+            bad.append("rank %d frame %d: count %d" % (rk, b, n))
+            continue
+        k = np.frombuffer(g["kps"][row, :n].tobytes(), pkg.KP_DTYPE)
+        d = g["desc"][row, :n]
+        m = ref.image_mismatch(k, d, e["kl"] if fe.stereo else e["k"], e["dl"] if fe.stereo else e["d"])
+        if m:
+            bad.append("rank %d frame %d: %s" % (rk, b, m))
+        if fe.stereo:
+            ur, dp = g["uright"][row, :n], g["depth"][row, :n]
+            if ur.tobytes() != e["uright"].tobytes() or dp.tobytes() != e["depth"].tobytes():
+                bad.append("rank %d frame %d: gathered mvuRight / mvDepth differ" % (rk, b))
+        nchk += 1
+    return bad, nchk
 
 
 def roofline_block(fe, m, workload, B, value, world, traffic_lookup=True):
@@ -275,7 +330,7 @@ def roofline_block(fe, m, workload, B, value, world, traffic_lookup=True):
     dom = max(kern, key=lambda k: kern[k][0])
     dom_ms, dom_bytes = kern[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if traffic_lookup and os.path.exists(pmc_path):
         try:
@@ -283,10 +338,11 @@ def roofline_block(fe, m, workload, B, value, world, traffic_lookup=True):
             inst = [k for k in pm.get("kernels", {}) if k.split("<")[0] in dom.split("+")]   # template instances: k_fast_cells<44>
             if pm.get("workload") == workload and pm.get("batch") == B and inst:
                 traffic = sum(pm["kernels"][k]["hbm_bytes_per_launch"] for k in inst)
+                traffic_source = "profiles/pmc_traffic.json (separate rocprofv3 --pmc run of this command, NOT measured in this run)"
         except Exception:
             traffic = None
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0,
-            "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+            "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_source,
             "kernel_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
             "images_per_launch": fe.ex.fast_images_per_launch if dom.startswith("k_fast") else nimg,
             "pipeline_GBps": round(bytes_frame * value / world / 1e9, 2),
@@ -313,6 +369,9 @@ def main():
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short untimed-by-the-driver runs of the other north-star sizes (other_workloads block)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step")
+    ap.add_argument("--verify-all-gathered", action="store_true",
+                    help="N > 1: check EVERY frame of every rank in the all-gathered records of the last timed step against the oracle "
+                         "(default: the first and last frame of each rank's block)")
     ap.add_argument("--streams", type=int, default=1,
                     help="S > 1: consecutive steps alternate over S extractor handles on S streams (independent steps overlap; "
                          "the default 1 keeps every kernel alone on the GPU so that its measured duration is its own)")
@@ -453,15 +512,24 @@ def main():
             vf = sorted({0, B // 2, B - 1})
             bad = verify_against_oracle(fe, m["last"], seeds, vf)
             verified = not bad
-            vnote = ("frames %s of the last timed step == CPU oracle, byte for byte (keypoints, descriptors, counts%s)"
-                     % (vf, ", mvuRight, mvDepth, match counts" if stereo else "")) if verified else "; ".join(bad[:5])
+            vnote = ("frames %s of the last timed step == CPU oracle: keypoint x / y / size / response / octave, counts and descriptors "
+                     "bit for bit, angles within 1e-4%s" % (vf, ", mvuRight / mvDepth / match counts bit for bit" if stereo else "")
+                     ) if verified else "; ".join(bad[:5])
+        gathered_verified, gnote = None, None
+        if m["gathered"] is not None and not args.no_verify:
+            pick = (lambda nb: range(nb)) if args.verify_all_gathered else (lambda nb: sorted({0, nb - 1}))
+            gbad, nchk = verify_gathered(fe, m["gathered"], ranks, pick)
+            gathered_verified = not gbad
+            gnote = ("%d frames (%s of every rank's block) of the all-gathered records of the last timed step, as received on rank 0, "
+                     "== CPU oracle of the owning rank's seeds" % (nchk, "all" if args.verify_all_gathered else "first and last")
+                     ) if gathered_verified else "; ".join(gbad[:5])
         out = {
             "metric": "frames/s ORB extract+match @1241x376 8-lvl 1000-feat" if args.workload.startswith("kitti_stereo_1241x376_1000")
             else "frames/s ORB extract+match (%s)" % args.workload,
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "verified": verified, "verified_note": vnote,
+            "verified": verified, "verified_note": vnote, "gathered_verified": gathered_verified, "gathered_verified_note": gnote,
             "config": {"workload": args.workload, "frame": "stereo pair (2 images)" if stereo else "mono image",
                        "width": w, "height": h, "nlevels": 8, "scale_factor": 1.2, "nfeatures": nf,
                        "ini_th_fast": 20, "min_th_fast": 7, "frames_per_step_per_gpu": B, "clock_ramp_steps": args.ramp_steps,

@@ -140,9 +140,9 @@ int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, int stage, in
 #define ORBX_NUM_STAGES 5
 /* Stage [1] is k_fast_strips (one wave per strip of four cells; levels whose cells are at most 32 px wide, batches that fill
  * the GPU) and / or k_fast_cells (one wave per cell; the other levels, small batches): which of them a batch of B images of
- * the planned size runs.  Same results either way.  A batch of 32 images or more is cut into two chunks whose kernels overlap on
- * two streams (the call keeps its stream semantics); the events of stage [1] bracket the first chunk's launch, which covers
- * *images_per_launch images. */
+ * the planned size runs.  Same results either way.  A call is ONE chunk by default (developer knob 8 cuts a batch into up to
+ * four chunks whose kernels overlap on the handle's side streams; the call keeps its stream semantics); the events of stage
+ * [1] bracket the first chunk's launch, which covers *images_per_launch images (= B by default). */
 int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, int *cells, int *images_per_launch);
 int orbx_set_profiling(orbx_extractor_t *h, int enabled);
 int orbx_get_stage_ms(orbx_extractor_t *h, float *ms5, int *ncalls);

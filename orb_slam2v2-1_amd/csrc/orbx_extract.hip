@@ -520,6 +520,7 @@ static void launch_pyramid(orbx_extractor *h, const uint8_t *d_imgs, uint8_t *py
 struct ChunkView {
     const uint8_t *imgs; uint8_t *pyr; uint32_t *cellCnt, *cellRaw, *slots, *cand, *lvlKp; uint16_t *nodeOf;
     int32_t *candCnt, *lvlCnt, *octFallback; orbx_keypoint_t *kps; uint8_t *desc; int32_t *counts;
+    size_t octSlot0;   // first (image, level) slot of the chunk in the multi-workgroup quad-tree scratch (d_octPart / Leaf / Best / State)
 };
 static ChunkView chunk_view(const orbx_extractor *h, const uint8_t *d_imgs, size_t img_stride, orbx_keypoint_t *d_kps, uint8_t *d_desc,
                             int32_t *d_counts, int cap, int b0) {
@@ -531,6 +532,7 @@ static ChunkView chunk_view(const orbx_extractor *h, const uint8_t *d_imgs, size
     v.lvlKp = h->d_lvlKp + z * h->lvlKpCap;
     v.candCnt = h->d_candCnt + z * h->nlevels; v.lvlCnt = h->d_lvlCnt + z * h->nlevels; v.octFallback = h->d_octFallback + z * h->nlevels;
     v.kps = d_kps + z * cap; v.desc = d_desc + z * cap * 32; v.counts = d_counts + b0;
+    v.octSlot0 = z * h->nlevels;
     return v;
 }
 
@@ -603,7 +605,9 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             // (batch 32 of 1920x1080: 274 us against 215), so it is taken for small batches only.  Same results either way.
             const unsigned bigMask = g_debug[4] == 2 ? (1u << nl) - 1u : (g_debug[4] == 3 || B > 4) ? 0u : h->octBigMask;
             OctBig big = {};
-            big.part = h->d_octPart; big.leaf = h->d_octLeaf; big.best = h->d_octBest; big.state = h->d_octState;
+            // the kernels index this scratch by the chunk-local image: chunks that run side by side on two streams get disjoint slots
+            big.part = h->d_octPart + v.octSlot0 * OCT_BIG_K * (size_t)h->octDeepMax; big.leaf = h->d_octLeaf + v.octSlot0 * (size_t)h->octPyrWords;
+            big.best = h->d_octBest + v.octSlot0 * (size_t)h->maxNodeCap; big.state = h->d_octState + v.octSlot0 * 4;
             big.K = OCT_BIG_K; big.deepMax = h->octDeepMax; big.pyrMax = h->octPyrWords;
             for (int l = 0; l < nl; l++) if ((bigMask >> l) & 1u) big.levelOf[big.nBig++] = l;
             // 1024-thread instances for images with a large level (>= 600 FAST cells; developer knob 11: 1 = never, 2 = always)
@@ -656,6 +660,14 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     return ORBX_OK;
 }
 
+// Chunks a batch of B images is cut into (developer knob 8; default ONE).  The one rule for launch_pipeline and orbx_fast_kernels.
+static int chunk_count(int B, bool prof, bool skipPyr) {
+    int nch = g_debug[8] <= 1 ? 1 : std::min(g_debug[8], ORBX_MAX_CHUNKS);
+    nch = std::min(nch, B);
+    if (prof || skipPyr || g_debug[0] || g_debug[1] || g_debug[7]) nch = 1;
+    return nch;
+}
+
 // A batch runs as up to ORBX_MAX_CHUNKS chunks of images.  Chunk 0 goes to the caller's stream, the others to the handle's side
 // streams, and chunk c's pyramid waits for chunk c-1's: the memory-bound pyramid and the latency-bound gather / quad-tree of one
 // chunk then overlap the issue-bound FAST and descriptor kernels of another (the kernels are the same, per-image results do not
@@ -675,10 +687,9 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
     }
     // developer knob 8: n >= 2 = n chunks (default: one - measured on 64 stereo frames, two chunks: 773 us against 742, the
     // latency-bound gather / quad-tree do not shrink with the chunk and the pyramid slows the FAST it overlaps by as much as it gains).
-    int nch = g_debug[8] <= 1 ? 1 : std::min(g_debug[8], ORBX_MAX_CHUNKS);
-    nch = std::min(nch, B);
-    if (prof || skipPyr || g_debug[0] || g_debug[1] || g_debug[7]) nch = 1;
+    const int nch = chunk_count(B, prof, skipPyr);
     h->lastChunks = nch;
+    h->prevPyrValid = skipPyr ? 1 : 0;   // d_pyr is overwritten unless this call took a pyramid built ahead (then d_pyrAlt keeps the previous one)
     h->framesStale = (!pyramid_fused_all(h) && h->nlevels > 1) ? B : 0;   // frames of levels >= 1: written on demand (ensure_frames)
     int b0 = 0;
     for (int c = 0; c < nch; c++) {
@@ -944,9 +955,8 @@ extern "C" int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, in
 // kernel they time.  *strips = 1 if k_fast_strips takes part, *cells = 1 if k_fast_cells does.
 extern "C" int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, int *cells, int *images_per_launch) {
     if (!h || h->pw == 0 || B < 1) { orbx_set_error("orbx_fast_kernels: no plan yet"); return ORBX_ERR_ARG; }
-    int nch = g_debug[8] <= 1 ? 1 : std::min(g_debug[8], ORBX_MAX_CHUNKS);
-    nch = std::min(nch, B);
-    if (h->profiling == 1) nch = 1;
+    // the last call's own chunk count when it was a batch of this size (it knows whether its pyramid was built ahead), else the rule
+    const int nch = (h->last_valid && h->lastB == B) ? h->lastChunks : chunk_count(B, h->profiling == 1, false);
     B = B / nch;                                   // the first chunk is the one whose FAST stage carries the events
     if (images_per_launch) *images_per_launch = B;
     const bool st = h->totalStrips > 0 && (g_debug[6] == 0 ? (size_t)h->totalStrips * B >= 4096 : g_debug[6] == 3);

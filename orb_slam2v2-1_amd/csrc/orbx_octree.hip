@@ -508,7 +508,7 @@ __device__ __forceinline__ void octree_pyr_body(
     if (MODE == 2) {   // merge my nodes into the level's, count myself; the last workgroup to arrive writes the output
         for (int k = tid; k < L; k += OCT_T) { const uint32_t v = hist[k]; if (v) atomicMax(&gbest[k], v); }
         __syncthreads();
-        if (tid == 0) sh_last = __hip_atomic_fetch_add(&bstate[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == big.K - 1;
+        if (tid == 0) sh_last = __hip_atomic_fetch_add(&bstate[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == big.K - 1;   // one lane: the acquire orders the loads below behind the other workgroups' atomicMax
         __syncthreads();
         if (!sh_last) return;
         // the atomics above executed at the memory side; read their result the same way (no cached copy can be stale)

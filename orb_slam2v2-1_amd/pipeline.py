@@ -37,9 +37,9 @@ class FrontEnd:
         self.S = max(1, streams)
         self.exs = [ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th, device=device_index) for _ in range(self.S)]
         self.ex = self.exs[0]
-        # the matcher of step i-1 is issued after the extraction of step i, on the side stream, behind that extraction's FAST stage
-        # (not with the all-gather of results: that collective stays on the caller's stream, ordered behind the step's own matcher)
-        self.lag = bool(lag_stereo and prefetch and stereo and self.S == 1 and not gather)
+        # the matcher of step i-1 is issued after the extraction of step i, on the side stream, behind that extraction's FAST stage;
+        # with N > 1 ranks the pack kernel + all-gather of step i-1 follow it on that stream, so N = 1 and N > 1 run the same pipeline
+        self.lag = bool(lag_stereo and prefetch and stereo and self.S == 1)
         # the handle's own side stream: a new torch stream may land on the main stream's hardware queue and overlap nothing
         self.side = torch.cuda.ExternalStream(self.ex.side_stream(), device=self.dev) if self.lag else None
         self._pend = None              # (buffer set, step) whose matcher has not been issued yet
@@ -89,7 +89,15 @@ class FrontEnd:
         main = self.streams[0]
         self.side.wait_stream(main)
         self._match(self.ex, j, self.side.cuda_stream)
+        self._publish_side(j, step)
         main.wait_stream(self.side)
+
+    def _publish_side(self, j, step):
+        """N > 1: records of buffer set j packed and all-gathered right behind its matcher, in side-stream order (the collective
+        itself runs on the backend's own stream and overlaps whatever follows)."""
+        if self.ring.gather:
+            with torch.cuda.stream(self.side):
+                self.ring.publish(j, step)
 
     def step(self, i, ev_before_match=None, ev_after_match=None):
         r = self.ring
@@ -110,6 +118,7 @@ class FrontEnd:
                 pj, pstep = self._pend
                 exi.stream_wait_fast_stage(sd)
                 self._match(exi, pj, sd, prev=True)       # step i-1: its pyramid is the buffer the call above swapped out
+                self._publish_side(pj, pstep)
                 ev = torch.cuda.Event()
                 ev.record(self.side)
                 self._ev_side[pj] = ev
@@ -137,8 +146,17 @@ class FrontEnd:
         torch.cuda.synchronize(self.dev)
 
     def results(self, j):
-        """Host copies of buffer set j: list of per-image (keypoints, descriptors) + per-frame (uright, depth, nmatch)."""
+        """Host copies of buffer set j: list of per-image (keypoints, descriptors) + per-frame (uright, depth, nmatch).
+        In the pipelined mode the stereo outputs of step i are produced on the side stream one step later: a matcher still owed for
+        set j is issued here, and the copies wait for the side stream, so the caller never reads a set whose matcher is pending or
+        running (drain() first is cheaper when several sets are read)."""
         r = self.ring
+        if self.lag:
+            if self._pend is not None and self._pend[0] == j:
+                self._flush()
+            ev = self._ev_side.get(j)
+            if ev is not None:
+                self.streams[0].wait_event(ev)      # (kept: the next step that refills set j waits for it as well)
         cnt = r.cnt[j].cpu().numpy()
         kps = r.kps[j].cpu().numpy().view(np.uint8).reshape(self.nimg, self.cap, 28)
         desc = r.desc[j].cpu().numpy()

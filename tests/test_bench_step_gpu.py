@@ -3,7 +3,8 @@ orbx_extract_batch_device on 2B images, orbm_stereo_batch_device(h, h, B, 0, B, 
 frame of the batch byte for byte — keypoints, descriptors, counts, mvuRight, mvDepth, match counts.
 
 BASELINE configs covered here in their BATCHED form: 2 (KITTI 1241x376 stereo, 1000 and 2000 features), 3 (EuRoC 752x480
-stereo, 64-frame batch), 4's per-GPU share (32 frames of 1920x1080 / 4000 features).  Reference: src/Frame.cc:61-120,
+stereo, 64-frame batch), 4's per-GPU share (64 frames of 1920x1080 / 4000 features; the sharded two-rank form with the
+all-gather: tests/test_multirank_gpu.py).  Reference: src/Frame.cc:61-120,
 481-655; src/ORBextractor.cc:1043-1105."""
 import importlib
 
@@ -183,10 +184,11 @@ def test_pyramid_built_ahead_is_used_only_for_the_same_batch():
             assert m is None, (i, b, m)
 
 
-def test_bench_step_mono_full_hd_batch32():
-    """Config 4's per-GPU share: 32 frames of 1920x1080, 4000 features, one batched call."""
+def test_bench_step_mono_full_hd_batch64():
+    """BASELINE config 4's per-GPU share as written (512 frames over 8 GPUs): 64 frames of 1920x1080, 4000 features, ONE
+    batched call, every frame against the oracle."""
     pl, ref = _pipeline(), _ref()
-    w, h, nf, B = 1920, 1080, 4000, 32
+    w, h, nf, B = 1920, 1080, 4000, 64
     exp = ref.run_pool(ref.mono_frame, [(w, h, nf, 300 + i) for i in range(B)])
     fe = pl.FrontEnd(w, h, nf, False, B)
     fe.upload(np.stack([e["img"] for e in exp]))
