@@ -383,6 +383,13 @@ int orbx_debug_set(int key, int value);
  * reference's order (column-major over grid cells, insertion order inside a cell) - the order every matcher's "first minimum
  * wins" depends on. */
 int orbx_debug_blur_patches(orbx_extractor_t *h, int enable, uint8_t *out, int n);
+/* a8, the other form: levels whose keypoint budget makes per-keypoint blurring the more expensive way are blurred as a whole by
+ * k_blur_levels and the descriptor kernel only gathers (src/ORBextractor.cc:1083-1090 does exactly this for every level).
+ * *mask_out (may be NULL) = levels of the last call that took this form (bit l); dst != NULL fetches level `level` of image b
+ * (inner ROI, dst_stride bytes per row) - ORBX_ERR_ARG when that level is not in the mask.  Developer knob 13 (orbx_debug_set):
+ * 1 = no level, 2 = every level; knob 14 = the rule's threshold in percent (level-wide iff nfeatures_l * 37^2 * 100 >=
+ * thr * w_l * h_l).  Results never depend on the form. */
+int orbx_debug_blurred_level(orbx_extractor_t *h, int b, int level, uint8_t *dst, int dst_stride, unsigned *mask_out);
 int orbm_debug_features_in_area(const orbx_keypoint_t *kun, int n, const orbm_grid_geom_t *g, float x, float y, float r,
                                 int min_level, int max_level, int32_t *out_idx, int *n_out, int device);
 /* Test hook: the device's restatement of libm cosf / sinf (the float overloads src/ORBextractor.cc:113 resolves to) on n

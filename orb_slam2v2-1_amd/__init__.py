@@ -43,6 +43,7 @@ EXPORTS = [
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
     "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch", "orbx_debug_sincosf",
     "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels", "orbx_extract_batch_device_prefetch", "orbx_stream_wait_fast_stage", "orbx_side_stream", "orbm_stereo_batch_device_prev", "orbx_debug_blur_patches", "orbm_debug_features_in_area",
+    "orbx_debug_blurred_level",
 ]
 
 
@@ -168,6 +169,7 @@ def lib():
     L.orbm_best_in_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, i32, vp, vp, i32]
     L.orbx_debug_sincosf.argtypes = [vp, i32, vp, vp, i32]
     L.orbx_debug_blur_patches.argtypes = [vp, i32, vp, i32]
+    L.orbx_debug_blurred_level.argtypes = [vp, i32, i32, vp, i32, vp]
     L.orbm_debug_features_in_area.argtypes = [vp, i32, C.POINTER(GridGeom), f32, f32, f32, i32, i32, vp, C.POINTER(i32), i32]
     L.orbx_last_error.restype = C.c_char_p
     L.orbx_version.restype = C.c_char_p
@@ -324,6 +326,20 @@ class ORBextractor:
         _check(self._L.orbx_fast_kernels(self._h, int(B), C.byref(st), C.byref(ce), C.byref(ipl)))
         self.fast_images_per_launch = ipl.value
         return [n for n, f in (("k_fast_strips", st.value), ("k_fast_cells", ce.value)) if f]
+
+    def blurred_mask(self):
+        """Levels of the last call that were blurred as a whole by k_blur_levels (bit l)."""
+        m = C.c_uint()
+        _check(self._L.orbx_debug_blurred_level(self._h, 0, 0, None, 0, C.byref(m)))
+        return m.value
+
+    def blurred_level(self, level, b=0):
+        """Level `level` of image b after GaussianBlur(7x7, sigma 2) as k_blur_levels wrote it (levels in blurred_mask())."""
+        w, h = C.c_int(), C.c_int()
+        _check(self._L.orbx_pyramid_host(self._h, b, level, 0, None, 0, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        _check(self._L.orbx_debug_blurred_level(self._h, b, level, _p(out), w.value, None))
+        return out
 
     def debug_blur_patches(self, image):
         """Test hook: extract one image and also return the 37x37 blurred block around every keypoint [N,37,37]."""

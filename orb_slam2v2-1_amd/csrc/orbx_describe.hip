@@ -109,17 +109,133 @@ constexpr IcTab make_ic_tab() {
 }
 __constant__ const IcTab c_ic = make_ic_tab();
 
+
+// ------------------------------------------------------------------------------------
+// K1b: GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) of whole levels (src/ORBextractor.cc:1085-1086), for the levels whose
+// keypoints' 37x37 blocks would add up to more pixels than the level has (k_describe then only gathers).  Same fixed-point
+// arithmetic as the fused form: rows -> sum of taps [18 34 49 55 49 34 18] (<= 65535), columns -> (sum + 2^15) >> 16, saturated.
+// One wave = a tile of 64 dwords (256 columns) x BLUR_R rows of a level's padded buffer: a lane owns ONE dword column; its left
+// / right neighbours come from the adjacent lanes (DPP wave shifts; lanes 0 and 63 load theirs), the horizontal pass is 10
+// v_dot4_u32_u8 with the taps shifted to each output's byte offset, the vertical pass 4 v_dot2_u32_u16 per output on row pairs
+// built once per source row.  The frame of a level is never read: dwords that hold columns outside the level (and rows outside
+// it) are gathered byte by byte through reflect101, so the result is the reflected-border blur for every inner pixel whether or
+// not the level's 19-px frame has been written.  The blurred buffer has the geometry of the pyramid (same offsets and strides).
+__device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t dpp_wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+
+__global__ __launch_bounds__(256) void k_blur_levels(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, size_t pyrImgBytes,
+                                                     const LevelGeom *__restrict__ geom, int nlevels, int totalTiles, BlurPlan bp) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int bx, b;
+    xcd_block_map(bx, b);
+    const int t = bx * 4 + wave;
+    if (t >= totalTiles) return;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < ORBX_MAX_LEVELS; i++) l += (i < nlevels && t >= bp.tileBase[i]) ? 1 : 0;
+    const LevelGeom g = geom[l];
+    const int tt = t - bp.tileBase[l], ntx = bp.tilesX[l];
+    const int ty = tt / ntx, tx = tt - ty * ntx;
+    const int y0 = ty * BLUR_R, pstr4 = g.pstride >> 2;
+    const int D0 = 4 + tx * 64, DL = (g.w + ORBX_EDGE - 1) >> 2;   // first dword of the tile; dword of the level's last column
+    const int D = D0 + lane;
+    const uint8_t *src = pyr + (size_t)b * pyrImgBytes + g.poff;
+    // dword q of a padded row holds columns x = 4q - 19 .. 4q - 16 of the level; reflected where that is outside [0, w)
+    const bool tileEdge = tx == 0 || D0 + 64 >= DL;   // wave-uniform: some dword of the tile (or its right neighbour) needs reflection
+    const int Dx = lane == 0 ? D - 1 : D + 1;         // the neighbour dword lanes 0 / 63 fetch themselves
+    const int Dc = min(D, pstr4 - 1), Dxc = min(max(Dx, 0), pstr4 - 1);
+    int oc[4] = {0, 0, 0, 0}, ox[4] = {0, 0, 0, 0};
+    bool eC = false, eX = false;
+    if (tileEdge) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int xc = 4 * D + p - ORBX_EDGE, xx = 4 * Dx + p - ORBX_EDGE;
+            const int rc = reflect101c(xc, g.w), rx = reflect101c(xx, g.w);
+            eC |= rc != xc; eX |= rx != xx;
+            oc[p] = rc + ORBX_EDGE; ox[p] = rx + ORBX_EDGE;
+        }
+    }
+    const bool ends = lane == 0 || lane == 63;
+    uint32_t v[BLUR_SRC], ex[BLUR_SRC];
+#pragma unroll
+    for (int k = 0; k < BLUR_SRC; k++) {
+        const int ry = reflect101c(y0 - 3 + k, g.h);                              // wave-uniform
+        const uint8_t *rowp = src + (size_t)(ry + ORBX_EDGE) * g.pstride;
+        if (tileEdge && eC) v[k] = (uint32_t)rowp[oc[0]] | ((uint32_t)rowp[oc[1]] << 8) | ((uint32_t)rowp[oc[2]] << 16) | ((uint32_t)rowp[oc[3]] << 24);
+        else v[k] = ((const uint32_t *)rowp)[Dc];
+        ex[k] = 0;
+        if (ends) {
+            if (tileEdge && eX) ex[k] = (uint32_t)rowp[ox[0]] | ((uint32_t)rowp[ox[1]] << 8) | ((uint32_t)rowp[ox[2]] << 16) | ((uint32_t)rowp[ox[3]] << 24);
+            else ex[k] = ((const uint32_t *)rowp)[Dxc];
+        }
+    }
+    // ---- horizontal pass: output j of the dword = taps over bytes 1+j .. 7+j of (prev | cur | next)
+    constexpr uint32_t T0 = 18, T1 = 34, T2 = 49, T3 = 55;
+    constexpr uint32_t WP0 = (T0 << 8) | (T1 << 16) | (T2 << 24), WC0 = T3 | (T2 << 8) | (T1 << 16) | (T0 << 24);
+    constexpr uint32_t WP1 = (T0 << 16) | (T1 << 24), WC1 = T2 | (T3 << 8) | (T2 << 16) | (T1 << 24), WN1 = T0;
+    constexpr uint32_t WP2 = (T0 << 24), WC2 = T1 | (T2 << 8) | (T3 << 16) | (T2 << 24), WN2 = T1 | (T0 << 8);
+    constexpr uint32_t WC3 = T0 | (T1 << 8) | (T2 << 16) | (T3 << 24), WN3 = T2 | (T1 << 8) | (T0 << 16);
+    uint32_t h01[BLUR_SRC], h23[BLUR_SRC];
+#pragma unroll
+    for (int k = 0; k < BLUR_SRC; k++) {
+        const uint32_t c = v[k];
+        uint32_t pv = dpp_wave_shr1(c), nx = dpp_wave_shl1(c);
+        pv = lane == 0 ? ex[k] : pv;
+        nx = lane == 63 ? ex[k] : nx;
+        uint32_t o0 = __builtin_amdgcn_udot4(pv, WP0, 0u, false);
+        o0 = __builtin_amdgcn_udot4(c, WC0, o0, false);
+        uint32_t o1 = __builtin_amdgcn_udot4(pv, WP1, 0u, false);
+        o1 = __builtin_amdgcn_udot4(c, WC1, o1, false);
+        o1 = __builtin_amdgcn_udot4(nx, WN1, o1, false);
+        uint32_t o2 = __builtin_amdgcn_udot4(pv, WP2, 0u, false);
+        o2 = __builtin_amdgcn_udot4(c, WC2, o2, false);
+        o2 = __builtin_amdgcn_udot4(nx, WN2, o2, false);
+        uint32_t o3 = __builtin_amdgcn_udot4(c, WC3, 0u, false);
+        o3 = __builtin_amdgcn_udot4(nx, WN3, o3, false);
+        h01[k] = o0 | (o1 << 16);
+        h23[k] = o2 | (o3 << 16);
+    }
+    // ---- vertical pass: out[r] = (18,34).pair[r] + (49,55).pair[r+2] + (49,34).pair[r+4] + (0,18).pair[r+5] + 2^15, pair[k] = rows (k, k+1)
+    const uint32_t W01 = 18u | (34u << 16), W23 = 49u | (55u << 16), W45 = 49u | (34u << 16), W6 = 18u << 16;
+    uint32_t pr[BLUR_SRC - 1][4];
+#pragma unroll
+    for (int k = 0; k < BLUR_SRC - 1; k++) {
+        pr[k][0] = __builtin_amdgcn_perm(h01[k + 1], h01[k], 0x05040100u);
+        pr[k][1] = __builtin_amdgcn_perm(h01[k + 1], h01[k], 0x07060302u);
+        pr[k][2] = __builtin_amdgcn_perm(h23[k + 1], h23[k], 0x05040100u);
+        pr[k][3] = __builtin_amdgcn_perm(h23[k + 1], h23[k], 0x07060302u);
+    }
+    uint8_t *dst = blur + (size_t)b * pyrImgBytes + g.poff;
+    const bool col_ok = D <= DL;
+#pragma unroll
+    for (int r = 0; r < BLUR_R; r++) {
+        uint32_t a[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t s = udot2_u16_acc(pr[r][q], W01, 1u << 15);
+            s = udot2_u16_acc(pr[r + 2][q], W23, s);
+            s = udot2_u16_acc(pr[r + 4][q], W45, s);
+            s = udot2_u16_acc(pr[r + 5][q], W6, s);
+            a[q] = min(s, 0xFFFFFFu);   // the taps sum to 257: a saturated neighbourhood reaches 257 * 65535 + 2^15 > 2^24 (-> 255)
+        }
+        const uint32_t out = __builtin_amdgcn_perm(a[1], a[0], 0x0c0c0602u) | __builtin_amdgcn_perm(a[3], a[2], 0x06020c0cu);
+        const int y = y0 + r;
+        if (col_ok && y < g.h) ((uint32_t *)(dst + (size_t)(y + ORBX_EDGE) * g.pstride))[D] = out;
+    }
+}
+
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
     const uint32_t *__restrict__ lvlKp, int lvlKpCap, const int32_t *__restrict__ lvlCnt,
-    orbx_keypoint_t *__restrict__ kps, uint8_t *__restrict__ desc, int32_t *__restrict__ counts, int cap, uint8_t *__restrict__ dbgBlur) {
+    orbx_keypoint_t *__restrict__ kps, uint8_t *__restrict__ desc, int32_t *__restrict__ counts, int cap, uint8_t *__restrict__ dbgBlur,
+    const uint8_t *__restrict__ blur, unsigned blurMask, DescGroup grp) {
     __shared__ __align__(16) uint8_t smem[DESC_WAVES * DESC_LDS_PER_WAVE];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int bx, b;
     xcd_block_map(bx, b);   // all patches of an image are read through ONE L2
-    const int o = bx * DESC_WAVES + wave;
+    int o = bx * DESC_WAVES + wave;
     // locate (level, k) of output ordinal o: level-major concatenation (:1076-1104)
-    int l = 0, base = 0, total = 0;
+    int l = 0, base = 0, total = 0, obefore = 0;
     {   // lane i < nlevels holds the count of level i: ONE load, a 4-step prefix sum, a ballot (not nlevels dependent loads)
         const int c = lane < nlevels ? lvlCnt[b * nlevels + lane] : 0;
         int inc = c;
@@ -129,9 +245,25 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
             if (lane >= d) inc += t;
         }
         total = __builtin_amdgcn_readlane(inc, ORBX_MAX_LEVELS - 1);
-        if (bx == 0 && threadIdx.x == 0) counts[b] = min(total, cap);
-        const unsigned long long hit = __ballot(lane < nlevels && o < inc);
-        if (!hit || o >= cap) return;  // wave-uniform
+        if (grp.writeCounts && bx == 0 && threadIdx.x == 0) counts[b] = min(total, cap);
+        // keypoints in front of this launch's first level (0 for a launch that starts at level 0; the scratch arrays of the later
+        // levels are indexed from their own first keypoint)
+        const int before = grp.lvBegin > 0 ? __builtin_amdgcn_readlane(inc, max(grp.lvBegin - 1, 0)) : 0;
+        if (bx >= grp.copyBlock0) {
+            // move the records of the levels [lvEnd, nlevels) from the scratch arrays to their place behind this launch's levels
+            const int cA = __builtin_amdgcn_readlane(inc, grp.lvEnd - 1), cB = total - cA;
+            const int t = threadIdx.x, i = (bx - grp.copyBlock0) * DESC_COPY_PER_BLOCK + (t >> 4), part = t & 15;
+            if (i < cB && cA + i < cap && part < 15) {
+                const size_t si = (size_t)b * cap + i, di = (size_t)b * cap + cA + i;
+                if (part < 7) ((uint32_t *)(kps + di))[part] = ((const uint32_t *)(grp.kpsScratch + si))[part];
+                else ((uint32_t *)(desc + di * 32))[part - 7] = ((const uint32_t *)(grp.descScratch + si * 32))[part - 7];
+            }
+            return;
+        }
+        o += before;   // ordinal over all levels
+        obefore = before;
+        const unsigned long long hit = __ballot(lane >= grp.lvBegin && lane < grp.lvEnd && o < inc);
+        if (!hit || o - before >= cap) return;  // wave-uniform
         l = __builtin_ctzll(hit);
         base = __builtin_amdgcn_readlane(inc - c, l);
     }
@@ -165,7 +297,33 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     // level's edge (the frame of level 0 comes with the copy of the input).  Those keypoints mirror the coordinates
     // themselves, so the pipeline never writes the frames of levels >= 1 (orbx_pyramid_host writes them on demand).
     const bool edge = l > 0 && (cx < PR || cy < PR || cx + PR >= g.w || cy + PR >= g.h);   // wave-uniform
-    if (edge) {
+    // Level blurred as a whole by k_blur_levels (levels whose keypoints' 37x37 blocks add up to more pixels than the level has):
+    // stage the 31 rows of the IC_Angle disc from the level and the 37x37 block from the blurred level; no blur passes here.
+    const bool pre = (blurMask >> l) & 1u;                                                  // wave-uniform
+    int shB = 0;
+    if (pre) {
+        constexpr int NA = (31 * 12 + 63) / 64, NB = (TCOLS * 10 + 63) / 64;   // 6 + 6 loads per lane, all in flight before the first LDS write
+        uint32_t va[NA], vb[NB];
+        const uint8_t *sbase = (const uint8_t *)src + (size_t)(PR - 15) * g.pstride;   // row cy - 15 of the patch window
+#pragma unroll
+        for (int k = 0; k < NA; k++) {
+            const int i = min(lane + 64 * k, 31 * 12 - 1), r = i / 12, cc = i - r * 12;
+            va[k] = *(const uint32_t *)(sbase + (uint32_t)(r * pstr4 + cc) * 4u);
+        }
+        // blurred pixel (cx - 18 + c, cy - 18 + r): same padded geometry as the level
+        const size_t a2 = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((cy + ORBX_EDGE - ORBX_DESC_R) * g.pstride + (cx + ORBX_EDGE - ORBX_DESC_R));
+        shB = (int)(a2 & 3);
+        const uint8_t *bbase = blur + (size_t)b * pyrImgBytes + g.poff + (a2 - shB);
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int i = min(lane + 64 * k, TCOLS * 10 - 1), r = i / 10, cc = i - r * 10;
+            vb[k] = *(const uint32_t *)(bbase + (uint32_t)(r * pstr4 + cc) * 4u);
+        }
+#pragma unroll
+        for (int k = 0; k < NA; k++) ((uint32_t *)(P + (PR - 15) * PSTRIDE))[min(lane + 64 * k, 31 * 12 - 1)] = va[k];
+#pragma unroll
+        for (int k = 0; k < NB; k++) Tm[min(lane + 64 * k, TCOLS * 10 - 1)] = vb[k];   // rows of BSTRIDE = 40 bytes = 10 dwords
+    } else if (edge) {
         sh = 0;
         const uint8_t *inner = lvl + (size_t)ORBX_EDGE * g.pstride + ORBX_EDGE;
         for (int base0 = 0; base0 < PROWS * PSTRIDE; base0 += 64 * 8) {
@@ -240,6 +398,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     // 7-tap sum over bytes o .. o+6 of those 16 bytes, o = sh + j.  Instead of realigning the DATA (9 v_alignbyte per
     // group) the WEIGHTS are shifted: W[j] = taps << 8*o as a 128-bit constant, wave-uniform (scalar registers), and the
     // sum is a v_dot4_u32_u8 per dword the window can touch - 13 dot products per group, no alignment instructions.
+    const uint8_t *Bl0 = Bl;           // blurred pixel (cx - 18 + c, cy - 18 + r) = Bl0[r * BSTRIDE + c]
+    if (pre) Bl0 = (const uint8_t *)Tm + shB;
+    else {
     uint32_t Wt[4][4];
     {
         const unsigned __int128 K7 = (unsigned __int128)(18ull | (34ull << 8) | (49ull << 16) | (55ull << 24) | (49ull << 32) |
@@ -314,17 +475,18 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
         }
     }
     wave_sync();
+    }   // !pre
 
     if (dbgBlur) {   // test hook (wave-uniform, NULL in production): the 37x37 blurred block around the keypoint, rows of 37 bytes
         uint8_t *o37 = dbgBlur + ((size_t)b * cap + o) * (TCOLS * TCOLS);
-        for (int i = lane; i < TCOLS * TCOLS; i += 64) o37[i] = Bl[(i / TCOLS) * BSTRIDE + i % TCOLS];
+        for (int i = lane; i < TCOLS * TCOLS; i += 64) o37[i] = Bl0[(i / TCOLS) * BSTRIDE + i % TCOLS];
     }
     // ---- steered BRIEF: 4 rounds x 64 pairs, one ballot = 8 descriptor bytes
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ang = angle * factorPI;
     float ca, sa;
     sincosf_glibc(ang, sa, ca);
-    const uint8_t *Bc = Bl + ORBX_DESC_R * BSTRIDE + ORBX_DESC_R;
+    const uint8_t *Bc = Bl0 + ORBX_DESC_R * BSTRIDE + ORBX_DESC_R;
     unsigned long long bits[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -341,7 +503,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
         const int t1 = Bc[__float2int_rn(p1.x) * BSTRIDE + __float2int_rn(p1.y)];
         bits[r] = __ballot(t0 < t1);
     }
-    const size_t oi = (size_t)b * cap + o;
+    const size_t oi = (size_t)b * cap + (o - obefore);   // a launch that starts behind level 0 fills the scratch arrays from their start
     if (lane < 4) ((unsigned long long *)(desc + oi * 32))[lane] = bits[lane];
     if (lane == 0) {
         orbx_keypoint_t kp;

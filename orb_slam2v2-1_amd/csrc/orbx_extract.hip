@@ -112,6 +112,8 @@ extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int i
     }
     for (int i = 0; i < ORBX_MAX_CHUNKS; i++) ORBX_HIP(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming));
     ORBX_HIP(hipEventCreateWithFlags(&h->evFastDone, hipEventDisableTiming));
+    ORBX_HIP(hipEventCreateWithFlags(&h->evGather, hipEventDisableTiming));
+    ORBX_HIP(hipEventCreateWithFlags(&h->evOctA, hipEventDisableTiming));
     ORBX_HIP(hipEventCreateWithFlags(&h->evPrefetch, hipEventDisableTiming));
     for (int r = 0; r < ORBX_EV_RING; r++)
         // timing-only events: no system-scope fence (cache write-back + invalidate) when they complete — with the default
@@ -125,6 +127,7 @@ static void free_plan(orbx_extractor *h) {
     hipFree(h->d_cellRaw); h->d_cellRaw = nullptr;
     hipFree(h->d_octFallback); h->d_octFallback = nullptr;
     hipFree(h->d_pyrAlt); h->d_pyrAlt = nullptr; h->pyrAltBytes = 0; h->pfValid = 0; h->prevPyrValid = 0;
+    hipFree(h->d_blur); hipFree(h->d_blurAlt); h->d_blur = h->d_blurAlt = nullptr; h->blurBytes = h->blurAltBytes = 0; h->blurMaskLast = h->blurMaskAlt = 0;
     hipFree(h->d_octPart); hipFree(h->d_octLeaf); hipFree(h->d_octBest); hipFree(h->d_octState);
     h->d_octPart = nullptr; h->d_octLeaf = nullptr; h->d_octBest = nullptr; h->d_octState = nullptr;
     hipFree(h->d_geom); hipFree(h->d_tab); hipFree(h->d_pyr); hipFree(h->d_cellCnt); hipFree(h->d_slots);
@@ -148,7 +151,8 @@ extern "C" int orbx_destroy(orbx_extractor_t *h) {
         for (int i = 0; i < ORBX_NUM_STAGES; i++) hipEventDestroy(h->ev[r][i]);
     for (int i = 0; i < ORBX_SIDE_STREAMS; i++) { hipStreamSynchronize(h->side[i]); hipStreamDestroy(h->side[i]); hipEventDestroy(h->evJoin[i]); }
     for (int i = 0; i < ORBX_MAX_CHUNKS; i++) hipEventDestroy(h->evPyr[i]);
-    hipEventDestroy(h->evFastDone); hipEventDestroy(h->evPrefetch);
+    hipEventDestroy(h->evFastDone); hipEventDestroy(h->evPrefetch); hipEventDestroy(h->evGather); hipEventDestroy(h->evOctA);
+    hipFree(h->d_kpsB); hipFree(h->d_descB);
     hipStreamDestroy(h->stream);
     delete h;
     return ORBX_OK;
@@ -187,7 +191,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     B = std::max(B, keepB);
     std::vector<int32_t> tab;
     size_t poff = 0, slotOff = 0, keyOff = 0;
-    int cellBase = 0, lvlKpOff = 0, maxNodeCap = 0, maxCells = 0, maxPyrWords = 0, maxDeepWords = 0;
+    int cellBase = 0, lvlKpOff = 0, maxNodeCap = 0, maxCells = 0, maxPyrWords = 0, maxDeepWords = 0, maxBestWords = 0;
     unsigned bigMask = 0;
     int maxTw = 0, maxTh = 0;
     int kpBound = 0;
@@ -246,6 +250,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
             g.pyrDepth = d;
             const int words = g.nIni * (((1 << (2 * d)) - 1) / 3) + ((g.nIni << (2 * d)) + 1) / 2 + 1;
             maxPyrWords = std::max(maxPyrWords, words);
+            maxBestWords = std::max(maxBestWords, g.nIni * (((1 << (2 * (d + 1))) - 1) / 3));
             maxDeepWords = std::max(maxDeepWords, ((g.nIni << (2 * d)) + 1) / 2 + 1);
             // a level with this many FAST cells carries tens of thousands of keys: in a small batch its quad-tree is shared by several
             // workgroups (single image, orbx_extract host to host: 1920x1080 / 4000 features 418 -> 348 us).  Smaller levels gain
@@ -420,7 +425,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
         h->octPyrWords = maxPyrWords;
         int maxPath = 0;   // the level's path tables ride in LDS (k_octree_pyr / k_octree_big)
         for (int l = 0; l < h->nlevels; l++) maxPath = std::max(maxPath, h->geom[l].regW + h->geom[l].regH);
-        h->octPyrLdsBytes = sizeof(unsigned long long) * pow2 + (size_t)maxNodeCap * (8 + 8 + 16 + 4 + 2 + 1) + 4 * (size_t)maxPyrWords + 4 * (size_t)maxPath + 64 + 8;
+        h->octPyrLdsBytes = sizeof(unsigned long long) * pow2 + (size_t)maxNodeCap * (8 + 8 + 16 + 4 + 2 + 1) + 4 * (size_t)maxPyrWords + 2 * (size_t)maxPath + 4 * (size_t)maxBestWords + 64 + 8;
         if (h->octPyrLdsBytes > 150 * 1024) { orbx_set_error("quad-tree pyramid needs %zu B of LDS", h->octPyrLdsBytes); return ORBX_ERR_UNSUPPORTED; }
         if (bytes > 150 * 1024) {
             orbx_set_error("quad-tree needs %zu B of LDS (features per level %d): unsupported", bytes, maxNodeCap);
@@ -484,6 +489,60 @@ static int harvest_events(orbx_extractor *h, int slot) {
 
 __global__ void k_nop() {}
 
+// Which levels are blurred as a whole (k_blur_levels) instead of per keypoint inside k_describe, and their tiles.  A level of P_l
+// pixels with a budget of N_l keypoints costs N_l * 43 * 40 blurred pixels per keypoint block in the fused form; the level-wide
+// form costs P_l once plus a second staging load per keypoint.  Rule: N_l * 37^2 * 100 >= thr * P_l (developer knob 14 = thr in
+// percent; knob 13: 1 = never, 2 = every level).  Results are identical either way.
+// MEASURED (round 3, MI355X): the level-wide form LOSES at every size tried, so the default threshold is out of reach and the
+// form stays a tested alternative.  64 stereo frames 1241x376: 1000 features 0.650 ms per step with no level blurred as a whole,
+// 0.694 with the rule at 120 %, 0.901 with every level; 2000 features 0.858 / 1.047 / 1.047; 32 images 1920x1080 / 4000 features
+// 0.736 / 0.724 / 0.925.  Alone on the GPU at 2000 features: k_describe 0.325 -> 0.19 ms (its staging grows from 9 to 12 loads per
+// lane, which is what it is bound by once the blur passes are gone), k_blur_levels 0.26 ms (its row loop serialises on the
+// reflected-border branches; a branch-free version would still move 2.4 bytes per pixel: ~0.08 ms), so even the best case wins
+// ~0.05 of 0.89 ms at 2000 features and nothing at 1000.
+#define ORBX_BLUR_THR 100000000
+static unsigned blur_plan(const orbx_extractor *h, BlurPlan &bp, int &totalTiles) {
+    unsigned mask = 0;
+    totalTiles = 0;
+    const long thr = g_debug[14] > 0 ? g_debug[14] : ORBX_BLUR_THR;
+    for (int l = 0; l <= ORBX_MAX_LEVELS; l++) {
+        bp.tileBase[l] = totalTiles;
+        if (l >= h->nlevels) continue;
+        const LevelGeom &g = h->geom[l];
+        const bool on = g_debug[13] == 2 || (g_debug[13] == 0 && (long)g.N * 1369 * 100 >= thr * (long)g.w * g.h);
+        bp.tilesX[l] = 0;
+        if (!on) continue;
+        mask |= 1u << l;
+        const int ndw = ((g.w + ORBX_EDGE - 1) >> 2) - 4 + 1;
+        bp.tilesX[l] = (ndw + 63) / 64;
+        totalTiles += bp.tilesX[l] * ((g.h + BLUR_R - 1) / BLUR_R);
+    }
+    return mask;
+}
+static int ensure_blur(orbx_extractor *h, uint8_t **buf, size_t *bytes) {
+    const size_t need = h->pyrImgBytes * (size_t)h->pB;
+    if (*bytes >= need) return ORBX_OK;
+    if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    for (int i = 0; i < ORBX_SIDE_STREAMS; i++) ORBX_HIP(hipStreamSynchronize(h->side[i]));
+    hipFree(*buf); *buf = nullptr; *bytes = 0;
+    ORBX_HIP(hipMalloc(buf, need));
+    *bytes = need;
+    return ORBX_OK;
+}
+// the level-wide blur behind a pyramid (same stream); returns the mask of blurred levels through *maskOut
+static int launch_blur(orbx_extractor *h, const uint8_t *pyr, uint8_t **blurBuf, size_t *blurBytes, int b0, int B, hipStream_t st, unsigned *maskOut) {
+    BlurPlan bp;
+    int tiles = 0;
+    const unsigned mask = blur_plan(h, bp, tiles);
+    *maskOut = mask;
+    if (!mask) return ORBX_OK;
+    int rc = ensure_blur(h, blurBuf, blurBytes);
+    if (rc) return rc;
+    const size_t off = (size_t)b0 * h->pyrImgBytes;   // images [b0, b0 + B) of both buffers
+    hipLaunchKernelGGL(k_blur_levels, dim3((tiles + 3) / 4, B), dim3(256), 0, st, pyr + off, *blurBuf + off, h->pyrImgBytes, h->d_geom, h->nlevels, tiles, bp);
+    return ORBX_OK;
+}
+
 // K1: ComputePyramid of B images into pyr.  Developer knob 5: 0 / 2 = one launch per level (the default), 1 = every level in the
 // fused launch, 3 = hybrid.
 static bool pyramid_fused_all(const orbx_extractor *h) { return g_debug[5] == 1 || h->scale_factor > 3.0; }
@@ -520,6 +579,7 @@ static void launch_pyramid(orbx_extractor *h, const uint8_t *d_imgs, uint8_t *py
 struct ChunkView {
     const uint8_t *imgs; uint8_t *pyr; uint32_t *cellCnt, *cellRaw, *slots, *cand, *lvlKp; uint16_t *nodeOf;
     int32_t *candCnt, *lvlCnt, *octFallback; orbx_keypoint_t *kps; uint8_t *desc; int32_t *counts;
+    int b0;            // first image of the chunk
     size_t octSlot0;   // first (image, level) slot of the chunk in the multi-workgroup quad-tree scratch (d_octPart / Leaf / Best / State)
 };
 static ChunkView chunk_view(const orbx_extractor *h, const uint8_t *d_imgs, size_t img_stride, orbx_keypoint_t *d_kps, uint8_t *d_desc,
@@ -532,7 +592,7 @@ static ChunkView chunk_view(const orbx_extractor *h, const uint8_t *d_imgs, size
     v.lvlKp = h->d_lvlKp + z * h->lvlKpCap;
     v.candCnt = h->d_candCnt + z * h->nlevels; v.lvlCnt = h->d_lvlCnt + z * h->nlevels; v.octFallback = h->d_octFallback + z * h->nlevels;
     v.kps = d_kps + z * cap; v.desc = d_desc + z * cap * 32; v.counts = d_counts + b0;
-    v.octSlot0 = z * h->nlevels;
+    v.octSlot0 = z * h->nlevels; v.b0 = b0;
     return v;
 }
 
@@ -546,8 +606,15 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     for (int l = 0; l <= ORBX_MAX_LEVELS; l++) cb.v[l] = l < nl ? h->geom[l].cellBase : h->totalCells;
     const uint8_t *d_imgs = v.imgs;
     orbx_keypoint_t *d_kps = v.kps; uint8_t *d_desc = v.desc; int32_t *d_counts = v.counts;
+    int aSplit = 0;   // > 0: split call, the levels [0, aSplit) and [aSplit, nl) take different streams behind k_gather
     if (prof) ORBX_HIP(hipEventRecord(ev[0], st));
-    if (!skipPyr) launch_pyramid(h, d_imgs, v.pyr, B, stride, img_stride, st);   // K1 (skipped when the pyramid was built ahead)
+    if (!skipPyr) {   // K1 (skipped when the pyramid was built ahead: then its level-wide blur was, too)
+        launch_pyramid(h, d_imgs, v.pyr, B, stride, img_stride, st);
+        unsigned m = 0;
+        int rc = launch_blur(h, h->d_pyr, &h->d_blur, &h->blurBytes, v.b0, B, st, &m);
+        if (rc) return rc;
+        h->blurMaskLast = m;
+    }
     if (evPyrDone) ORBX_HIP(hipEventRecord(evPyrDone, st));
     // With the pyramid built ahead nothing but a stream wait (for that pyramid) sits in front of the FAST launch, and a timing
     // event recorded right behind a pending wait can be stamped before the wait is over: the bracket then reads wait + FAST
@@ -598,6 +665,22 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
                            h->slotsPerImg, v.cand, h->keysPerImg, v.candCnt, h->ini_th, h->min_th, cb);
         // developer knob 4: 0 default, 1 = the exact form alone, 2 = EVERY level by the multi-workgroup form, 3 = none
         const bool usePyr = g_debug[4] != 1;
+        // developer knob 15: a >= 2 = split call at level a (default 0: one launch sequence)
+        aSplit = (usePyr && !prof && h->lastChunks == 1 && B >= 8 && g_debug[7] == 0 && g_debug[1] == 0 && g_debug[15] >= 2 &&
+                  !(g_debug[4] == 2 || (g_debug[4] != 3 && B <= 4 && h->octBigMask)) && h->d_dbgBlur == nullptr)
+                     ? std::min(g_debug[15], nl - 1) : 0;   // (default: no split - measured slower)
+        if (nl < 3) aSplit = 0;
+        if (aSplit > 0) {   // scratch records of the levels [a, nl)
+            const size_t need = (size_t)h->pB * cap * 60;
+            if (h->splitBytes < need) {
+                ORBX_HIP(hipStreamSynchronize(st));
+                ORBX_HIP(hipStreamSynchronize(h->side[1]));
+                hipFree(h->d_kpsB); hipFree(h->d_descB); h->d_kpsB = nullptr; h->d_descB = nullptr; h->splitBytes = 0;
+                ORBX_HIP(hipMalloc(&h->d_kpsB, (size_t)h->pB * cap * sizeof(orbx_keypoint_t)));
+                ORBX_HIP(hipMalloc(&h->d_descB, (size_t)h->pB * cap * 32));
+                h->splitBytes = need;
+            }
+        }
         if (usePyr) {   // a level whose tree outgrows the count pyramid is redone by the same block with the exact form: one launch
             const size_t lds = std::max(h->octPyrLdsBytes, h->octLdsBytes);
             // The multi-workgroup form shortens ONE image's critical path (a 1920x1080 level 0: 195 us alone in its workgroup); a
@@ -612,16 +695,17 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             for (int l = 0; l < nl; l++) if ((bigMask >> l) & 1u) big.levelOf[big.nBig++] = l;
             // 1024-thread instances for images with a large level (>= 600 FAST cells; developer knob 11: 1 = never, 2 = always)
             const bool wide = g_debug[11] == 0 ? h->octBigMask != 0 : g_debug[11] == 2;
-#define ORBX_OCT_LAUNCH(KERN, KERNW, GRID, LDS, ...)                                                                       \
+#define ORBX_OCT_LAUNCH_ON(STREAM, KERN, KERNW, GRID, LDS, ...)                                                            \
     do {                                                                                                                \
         if (wide) {                                                                                                     \
             ORBX_HIP(hipFuncSetAttribute((const void *)KERNW, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS))); \
-            hipLaunchKernelGGL(KERNW, GRID, dim3(OCT_T_WIDE), LDS, st, __VA_ARGS__);                                    \
+            hipLaunchKernelGGL(KERNW, GRID, dim3(OCT_T_WIDE), LDS, STREAM, __VA_ARGS__);                                \
         } else {                                                                                                        \
             ORBX_HIP(hipFuncSetAttribute((const void *)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)));  \
-            hipLaunchKernelGGL(KERN, GRID, dim3(OCT_T), LDS, st, __VA_ARGS__);                                          \
+            hipLaunchKernelGGL(KERN, GRID, dim3(OCT_T), LDS, STREAM, __VA_ARGS__);                                      \
         }                                                                                                               \
     } while (0)
+#define ORBX_OCT_LAUNCH(KERN, KERNW, GRID, LDS, ...) ORBX_OCT_LAUNCH_ON(st, KERN, KERNW, GRID, LDS, __VA_ARGS__)
             if (big.nBig > 0 && g_debug[7] == 0 && g_debug[1] == 0) {
                 // large levels: K workgroups histogram, the last one to arrive runs the passes; the same launch carries the other
                 // levels (one workgroup each, listed behind the large ones) ...
@@ -634,10 +718,25 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
                 ORBX_OCT_LAUNCH(k_octree_big<2>, k_octree_big_wide<2>, dim3(OCT_BIG_K, big.nBig, B), lds, h->d_geom, nl, v.cand, h->keysPerImg,
                                 v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
                                 v.octFallback, v.nodeOf, scratch, big);
+            } else if (aSplit > 0) {
+                // Split call: the quad-tree of the large levels [0, a) - one workgroup per level walking a serial chain, the critical
+                // path of this stage - moves to a second stream, and the small levels [a, nl) go ahead on the caller's stream:
+                // their quad-tree, then their descriptors (a VALU-bound kernel that fills the GPU) into scratch arrays, beside that
+                // chain.  The descriptors of [0, a) follow when both are done and move the scratch records behind their own.
+                hipStream_t s2 = h->side[1];
+                ORBX_HIP(hipEventRecord(h->evGather, st));
+                ORBX_HIP(hipStreamWaitEvent(s2, h->evGather, 0));
+                ORBX_OCT_LAUNCH_ON(s2, k_octree_pyr, k_octree_pyr_wide, dim3(B, aSplit), lds, h->d_geom, nl, v.cand,
+                                   h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
+                                   pow2, h->octPyrWords, v.octFallback, 0, v.nodeOf, scratch, 0, 0u, 0);
+                ORBX_HIP(hipEventRecord(h->evOctA, s2));
+                ORBX_OCT_LAUNCH(k_octree_pyr, k_octree_pyr_wide, dim3(B, nl - aSplit), lds, h->d_geom, nl, v.cand,
+                                h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
+                                pow2, h->octPyrWords, v.octFallback, 0, v.nodeOf, scratch, 0, 0u, aSplit);
             } else {   // no large level (or a phase-stop knob is set): one workgroup per level, one launch
                 ORBX_OCT_LAUNCH(k_octree_pyr, k_octree_pyr_wide, dim3(B, nl), lds, h->d_geom, nl, v.cand,
                                 h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
-                                pow2, h->octPyrWords, v.octFallback, g_debug[7], v.nodeOf, scratch, g_debug[1], 0u);
+                                pow2, h->octPyrWords, v.octFallback, g_debug[7], v.nodeOf, scratch, g_debug[1], 0u, 0);
             }
         } else {        // developer knob 4 = 1: the exact form alone
             const bool wide = g_debug[11] == 0 ? h->octBigMask != 0 : g_debug[11] == 2;
@@ -645,15 +744,35 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
                             h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2,
                             scratch, g_debug[1]);
 #undef ORBX_OCT_LAUNCH
+#undef ORBX_OCT_LAUNCH_ON
         }
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[3], st));
     if (gate && g_debug[10] == 1) ORBX_HIP(hipEventRecord(h->evFastDone, st));
     {   // K4
-        const int maxo = std::min(cap, h->max_kp);
-        dim3 grid((maxo + DESC_WAVES - 1) / DESC_WAVES, B);
-        hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
-                           v.lvlKp, h->lvlKpCap, v.lvlCnt, d_kps, d_desc, d_counts, cap, h->d_dbgBlur);
+        const uint8_t *blurp = h->blurMaskLast ? h->d_blur + (size_t)v.b0 * h->pyrImgBytes : nullptr;
+        if (aSplit > 0) {
+            int boundA = 0, boundB = 0;
+            for (int l = 0; l < nl; l++) (l < aSplit ? boundA : boundB) += std::max(h->geom[l].N + 2, 4 * h->geom[l].nIni);
+            const int maxoA = std::min(cap, boundA), maxoB = std::min(cap, boundB);
+            orbx_keypoint_t *kB = h->d_kpsB + (size_t)v.b0 * cap;
+            uint8_t *dB = h->d_descB + (size_t)v.b0 * cap * 32;
+            const int nbB = (maxoB + DESC_WAVES - 1) / DESC_WAVES, nbA = (maxoA + DESC_WAVES - 1) / DESC_WAVES;
+            const DescGroup gB = {aSplit, nl, 0, nbB, nullptr, nullptr};
+            hipLaunchKernelGGL(k_describe, dim3(nbB, B), dim3(64 * DESC_WAVES), 0, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
+                               v.lvlKp, h->lvlKpCap, v.lvlCnt, kB, dB, d_counts, cap, (uint8_t *)nullptr, blurp, h->blurMaskLast, gB);
+            ORBX_HIP(hipStreamWaitEvent(st, h->evOctA, 0));
+            const DescGroup gA = {0, aSplit, 1, nbA, kB, dB};
+            hipLaunchKernelGGL(k_describe, dim3(nbA + (maxoB + DESC_COPY_PER_BLOCK - 1) / DESC_COPY_PER_BLOCK, B), dim3(64 * DESC_WAVES), 0, st,
+                               v.pyr, h->pyrImgBytes, h->d_geom, nl, v.lvlKp, h->lvlKpCap, v.lvlCnt, d_kps, d_desc, d_counts, cap,
+                               (uint8_t *)nullptr, blurp, h->blurMaskLast, gA);
+        } else {
+            const int maxo = std::min(cap, h->max_kp);
+            dim3 grid((maxo + DESC_WAVES - 1) / DESC_WAVES, B);
+            const DescGroup gAll = {0, nl, 1, (int)grid.x, nullptr, nullptr};
+            hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
+                               v.lvlKp, h->lvlKpCap, v.lvlCnt, d_kps, d_desc, d_counts, cap, h->d_dbgBlur, blurp, h->blurMaskLast, gAll);
+        }
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[4], st));
     if (gate && g_debug[10] == 2) ORBX_HIP(hipEventRecord(h->evFastDone, st));
@@ -732,6 +851,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor_t *h, const uint8_t *d_i
     h->prevPyrValid = ahead ? 1 : 0;   // the buffers swap: the other one keeps the previous call's pyramid until the next one is built into it
     if (ahead) {
         std::swap(h->d_pyr, h->d_pyrAlt);
+        std::swap(h->d_blur, h->d_blurAlt); std::swap(h->blurBytes, h->blurAltBytes); std::swap(h->blurMaskLast, h->blurMaskAlt);
         ORBX_HIP(hipStreamWaitEvent(st, h->evPrefetch, 0));
     }
     return launch_pipeline(h, d_imgs, B, w, hgt, stride, image_stride_bytes, d_kps, d_desc, d_counts, cap, st, ahead);
@@ -760,6 +880,8 @@ extern "C" int orbx_extract_batch_device_prefetch(orbx_extractor_t *h, const uin
     else if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));             //  second buffer is new, wait for the handle to be idle)
     h->pfUsed = 1;
     launch_pyramid(h, d_imgs, h->d_pyrAlt, B, stride, image_stride_bytes, sd);
+    rc = launch_blur(h, h->d_pyrAlt, &h->d_blurAlt, &h->blurAltBytes, 0, B, sd, &h->blurMaskAlt);
+    if (rc) return rc;
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipEventRecord(h->evPrefetch, sd));
     h->pfValid = 1; h->pfImgs = d_imgs; h->pfB = B; h->pfW = w; h->pfH = hgt; h->pfStride = stride; h->pfImgStride = image_stride_bytes;
@@ -983,6 +1105,28 @@ extern "C" int orbx_debug_blur_patches(orbx_extractor_t *h, int enable, uint8_t 
         h->dbgBlurCap = h->max_kp > 0 ? h->max_kp + 300 : h->nfeatures + 3 * h->nlevels + 300;
         ORBX_HIP(hipMalloc(&h->d_dbgBlur, (size_t)h->dbgBlurCap * 37 * 37));
     }
+    return ORBX_OK;
+}
+
+// Test hook: level `level` of image b as k_blur_levels left it in the last call (inner ROI), and the mask of levels that were
+// blurred as a whole (bit l).  A level outside the mask was blurred per keypoint inside k_describe: ORBX_ERR_ARG for it.
+extern "C" int orbx_debug_blurred_level(orbx_extractor_t *h, int b, int level, uint8_t *dst, int dst_stride, unsigned *mask_out) {
+    if (!h || h->pw == 0 || b < 0 || b >= h->pB) { orbx_set_error("orbx_debug_blurred_level: bad arguments"); return ORBX_ERR_ARG; }
+    if (mask_out) *mask_out = h->blurMaskLast;
+    if (!dst) return ORBX_OK;
+    if (level < 0 || level >= h->nlevels || !((h->blurMaskLast >> level) & 1u) || !h->d_blur) {
+        orbx_set_error("orbx_debug_blurred_level: level %d was not blurred as a whole (mask 0x%x)", level, h->blurMaskLast);
+        return ORBX_ERR_ARG;
+    }
+    const LevelGeom &g = h->geom[level];
+    if (dst_stride < g.w) { orbx_set_error("dst_stride < width"); return ORBX_ERR_ARG; }
+    ORBX_HIP(hipSetDevice(h->device));
+    if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    const uint8_t *src = h->d_blur + (size_t)b * h->pyrImgBytes + g.poff + (size_t)ORBX_EDGE * g.pstride + ORBX_EDGE;
+    const size_t span = (size_t)g.pstride * (g.h - 1) + g.w;
+    std::vector<uint8_t> tmp(span);
+    ORBX_HIP(hipMemcpy(tmp.data(), src, span, hipMemcpyDeviceToHost));
+    for (int r = 0; r < g.h; r++) memcpy(dst + (size_t)r * dst_stride, tmp.data() + (size_t)r * g.pstride, g.w);
     return ORBX_OK;
 }
 

@@ -52,6 +52,23 @@ struct PyrSpan { short o0, o1, c0, c1; };  // owned [o0,o1) and computed [c0,c1)
 #endif
 #define OCT_T_WIDE 1024   // the same kernels built a second time (orbx_octree_wide.hip) for images whose level 0 has >= 600 FAST cells: twice the threads on the LDS-bound key sweeps of ONE level (1920x1080 level 0: 174 -> 150 us)
 #define DESC_WAVES 4
+// One k_describe launch covers the levels [lvBegin, lvEnd).  The default is every level into the caller's arrays.  A call may be
+// split (launch_chunk): the levels [a, nlevels) are described first, into scratch arrays, beside the quad-tree of the large
+// levels [0, a) on another stream; the launch for [0, a) then writes the caller's arrays directly and its blocks
+// bx >= copyBlock0 move the scratch records of [a, nlevels) behind them (their place depends on the counts of [0, a)).
+struct DescGroup {
+    int lvBegin, lvEnd;
+    int writeCounts;                     // this launch writes counts[b] (the total over ALL levels)
+    int copyBlock0;                      // first copy block (grid.x when there is nothing to move)
+    const orbx_keypoint_t *kpsScratch;   // records of the levels [lvEnd, nlevels) to move
+    const uint8_t *descScratch;
+};
+#define DESC_COPY_PER_BLOCK 16
+#define BLUR_R 16                // output rows per wave of k_blur_levels
+#define BLUR_SRC (BLUR_R + 6)    // source rows a tile reads
+struct BlurPlan { int tileBase[ORBX_MAX_LEVELS + 1]; int tilesX[ORBX_MAX_LEVELS]; };   // tiles of the levels blurred as a whole (others own none)
+__global__ void k_blur_levels(const uint8_t *pyr, uint8_t *blur, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalTiles,
+                              BlurPlan bp);                                                                                        // orbx_describe.hip
 struct CellBases { int v[ORBX_MAX_LEVELS + 1]; };
 __device__ __forceinline__ int level_of_cell(const CellBases &cb, int nlevels, int gc) {
     int l = 0;
@@ -90,7 +107,7 @@ struct OctBig {   // multi-workgroup quad-tree of large levels (orbx_octree.hip)
 __global__ void k_octree_pyr(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
                              uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
                              int pyrWords, int32_t *fallback, int dbgStop, uint16_t *nodeOf, int scratchInts, int dbgStopExact,
-                             unsigned bigMask);                                                                  // orbx_octree.hip
+                             unsigned bigMask, int l0);                                                          // orbx_octree.hip
 template <int MODE>
 __global__ void k_octree_big(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
                              uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
@@ -101,7 +118,7 @@ __global__ void k_octree(const LevelGeom *geom, int nlevels, const uint32_t *can
 __global__ void k_octree_pyr_wide(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
                                   uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
                                   int pyrWords, int32_t *fallback, int dbgStop, uint16_t *nodeOf, int scratchInts, int dbgStopExact,
-                                  unsigned bigMask);                                                             // orbx_octree_wide.hip
+                                  unsigned bigMask, int l0);                                                     // orbx_octree_wide.hip
 template <int MODE>
 __global__ void k_octree_big_wide(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
                                   uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
@@ -111,4 +128,4 @@ __global__ void k_octree_wide(const LevelGeom *geom, int nlevels, const uint32_t
                               int pow2cap, int scratchInts, int dbgStop);
 __global__ void k_describe(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, const uint32_t *lvlKp,
                            int lvlKpCap, const int32_t *lvlCnt, orbx_keypoint_t *kps, uint8_t *desc, int32_t *counts,
-                           int cap, uint8_t *dbgBlur);                                                                             // orbx_describe.hip
+                           int cap, uint8_t *dbgBlur, const uint8_t *blur, unsigned blurMask, DescGroup grp);                                                                             // orbx_describe.hip

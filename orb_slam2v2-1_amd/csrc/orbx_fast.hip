@@ -529,8 +529,16 @@ __global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ ge
     for (int k = 0; k < 4; k++) v[k] = src[min(sub + 16 * k, max(nraw - 1, 0))];
     // kept keys of the cells [base0, gc0) of the block's first level
     const int l0 = level_of_cell(cb, nlevels, gc0), base0 = cb.v[l0];
+    // (four independent loads per round: a 1920x1080 level 0 has 2108 cells, and one load per round made the later blocks of such
+    //  a level wait for eight dependent memory latencies)
     int part = 0;
-    for (int i = base0 + tid; i < gc0; i += 256) part += (int)cc[i];
+    for (int i = base0 + tid; i < gc0; i += 1024) {
+        int q[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k] = (int)cc[min(i + 256 * k, gc0 - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; k++) part += i + 256 * k < gc0 ? q[k] : 0;
+    }
     part = wave_total_i32(part);
     if ((tid & 63) == 0) wsum[tid >> 6] = part;
     if (sub == 0) { ccnt[grp] = cn; clvl[grp] = live ? l : -1; }

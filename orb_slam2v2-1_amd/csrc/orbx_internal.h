@@ -97,6 +97,10 @@ struct orbx_extractor {
     hipStream_t side[ORBX_SIDE_STREAMS]; hipEvent_t evPyr[ORBX_MAX_CHUNKS], evJoin[ORBX_SIDE_STREAMS]; int lastChunks;   // chunk overlap (launch_pipeline)
     // pyramid of the NEXT batch, built ahead on side[0] into a second buffer (orbx_extract_batch_device_prefetch)
     uint8_t *d_pyrAlt; size_t pyrAltBytes; int pfValid, pfUsed, pfB, pfW, pfH, pfStride; const uint8_t *pfImgs; size_t pfImgStride;
+    // levels blurred as a whole (k_blur_levels) for k_describe's gather form: buffers with the pyramid's geometry, swapped with it
+    uint8_t *d_blur, *d_blurAlt; size_t blurBytes, blurAltBytes; unsigned blurMaskLast, blurMaskAlt;
+    // split call (launch_chunk): records of the small levels described ahead, and the events between the two streams
+    orbx_keypoint_t *d_kpsB; uint8_t *d_descB; size_t splitBytes; hipEvent_t evGather, evOctA;
     int prevPyrValid;   // d_pyrAlt still holds the pyramid of the call before the last one (orbm_stereo_batch_device_prev)
     hipEvent_t evFastDone, evPrefetch;
     hipStream_t last_stream; // stream of the last batch call (NULL is a stream too: the HIP default stream)

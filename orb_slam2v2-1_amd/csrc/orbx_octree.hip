@@ -169,14 +169,20 @@ __device__ __forceinline__ void octree_pyr_body(
     const int n = candCnt[b * nlevels + l];
     // the level's path tables (regW + regH words, x then y) are staged into LDS: a sweep iteration then waits for ONE global
     // latency (its keys, requested an iteration ahead) instead of two dependent ones (keys, then tables)
-    uint32_t *pathL = (uint32_t *)(smem + (((size_t)(sp - smem) + 3) & ~(size_t)3));
+    // (16-bit entries: a cell code at depth Dm is below nIni << 2 Dm <= 16384, ensure_plan caps Dm accordingly)
+    uint16_t *pathL = (uint16_t *)(smem + (((size_t)(sp - smem) + 3) & ~(size_t)3));
+    const int nPath = g.regW + g.regH;
     {
-        const int nPath = g.regW + g.regH;
         const int32_t *tp = tab + g.xPathOff;
-        for (int i = tid; i < nPath; i += OCT_T) pathL[i] = (uint32_t)tp[i];
+        for (int i = tid; i < nPath; i += OCT_T) pathL[i] = (uint16_t)tp[i];
     }
-    const uint32_t *xPath = pathL, *yPath = pathL + g.regW;
+    const uint16_t *xPath = pathL, *yPath = pathL + g.regW;
     const uint32_t offDeep = (uint32_t)nIni * (((1u << (2 * Dm)) - 1u) / 3u);
+    // MODE 0: best key (response << 24 | ~index: the first maximum wins, :744-760) of every cell of every depth, beside the counts:
+    // the histogram sweep elects it per deep cell, the shallower depths follow by maxima of four children, and a node of the final
+    // list - a cell (depth, code) - reads its keypoint straight from here.  No leaf map, no second sweep over the keys.
+    constexpr bool CB = MODE == 0;
+    uint32_t *bestP = (uint32_t *)(pathL + ((nPath + 1) & ~1));   // [nIni * (4^(Dm+1) - 1) / 3], depth d at nIni * (4^d - 1) / 3 like the counts
 
     // this workgroup's share of the keys (MODE 0: all of them), in whole groups of four
     const int iLo = MODE == 0 ? 0 : (int)(((long long)n * slice / big.K) & ~3ll);
@@ -188,6 +194,7 @@ __device__ __forceinline__ void octree_pyr_body(
   if (MODE != 2) {
     // ---- 1. histogram of the keys at depth Dm (two 16-bit counters per word)
     for (int i = tid; i < pyrWords; i += OCT_T) pyr[i] = 0;
+    if (CB) for (int i = tid; i < (nIni << (2 * Dm)); i += OCT_T) bestP[offDeep + i] = 0;
     if (tid == 0) sh_abort = 0;
     __syncthreads();
     uint32_t nkey[4];
@@ -199,17 +206,23 @@ __device__ __forceinline__ void octree_pyr_body(
         load_keys4(keys, i0 + 4 * OCT_T < iHi ? i0 + 4 * OCT_T : i0, n, nkey);   // the next iteration's keys (unconditional: no load behind a branch)
 #pragma unroll
         for (int u = 0; u < 4; u++)   // a missing key is 0
-            c[u] = xPath[key[u] & 0xFFF] | yPath[(key[u] >> 12) & 0xFFF];
+            c[u] = (uint32_t)xPath[key[u] & 0xFFF] | (uint32_t)yPath[(key[u] >> 12) & 0xFFF];
         // consecutive keys (row-major inside a FAST cell) mostly share the deep cell: count runs, one LDS atomic per run
-        uint32_t inc[4];
+        uint32_t inc[4], bv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) inc[u] = i0 + u < iHi ? 1u : 0u;
+        for (int u = 0; u < 4; u++) {
+            inc[u] = i0 + u < iHi ? 1u : 0u;
+            bv[u] = ((key[u] >> 24) << 24) | (0xFFFFFFu - (uint32_t)(i0 + u));
+        }
 #pragma unroll
         for (int u = 0; u < 3; u++)
-            if (c[u] == c[u + 1]) { inc[u + 1] += inc[u]; inc[u] = 0; }
+            if (c[u] == c[u + 1]) { inc[u + 1] += inc[u]; bv[u + 1] = inc[u] ? max(bv[u], bv[u + 1]) : bv[u + 1]; inc[u] = 0; }
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (inc[u]) atomicAdd(&pyr[offDeep + (c[u] >> 1)], inc[u] << (16 * (c[u] & 1)));
+            if (inc[u]) {
+                atomicAdd(&pyr[offDeep + (c[u] >> 1)], inc[u] << (16 * (c[u] & 1)));
+                if (CB) atomicMax(&bestP[offDeep + c[u]], bv[u]);
+            }
     }
     __syncthreads();
     if (MODE == 1) {   // partial histogram -> global; the last workgroup to arrive carries on with the sum of all K
@@ -246,6 +259,10 @@ __device__ __forceinline__ void octree_pyr_body(
 #pragma unroll
             for (int q = 0; q < 4; q++) s += pyr_count(pyr, nIni, Dm, d + 1, 4u * e + q);
             pyr[off + e] = s;
+            if (CB) {
+                const uint32_t *ch = bestP + (uint32_t)nIni * (((1u << (2 * (d + 1))) - 1u) / 3u) + 4u * e;
+                bestP[off + e] = max(max(ch[0], ch[1]), max(ch[2], ch[3]));
+            }
         }
         __syncthreads();
     }
@@ -429,6 +446,18 @@ __device__ __forceinline__ void octree_pyr_body(
     }
 
     if (dbgStop == 3) return;
+    if (CB) {   // ---- 5'. a node of the list is a cell of the pyramid: its best key is already there
+        const uint32_t *nid = nidA + cur * capMax;
+        uint32_t *okp = lvlKp + (size_t)b * lvlKpCap + g.lvlKpOff;
+        const int Lout = min(L, g.nodeCap);
+        for (int k = tid; k < Lout; k += OCT_T) {
+            const int d = (int)(nid[k] >> 28);
+            const uint32_t v = bestP[(uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u) + (nid[k] & 0x0FFFFFFFu)];
+            okp[k] = keys[0xFFFFFFu - (v & 0xFFFFFFu)];
+        }
+        if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; fallback[b * nlevels + l] = 0; }
+        return;
+    }
     // ---- 5. leaf map (depth, cell) -> list index, in place of the counts
     {
         const uint32_t *nid = nidA + cur * capMax;
@@ -468,7 +497,7 @@ __device__ __forceinline__ void octree_pyr_body(
         load_keys4(keys, i0 + 4 * OCT_T < iHi ? i0 + 4 * OCT_T : i0, n, nkey2);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            cd[u] = xPath[key[u] & 0xFFF] | yPath[(key[u] >> 12) & 0xFFF];
+            cd[u] = (uint32_t)xPath[key[u] & 0xFFF] | (uint32_t)yPath[(key[u] >> 12) & 0xFFF];
             node[u] = 0xFFFFFFFFu;
         }
         // the leaves partition the region: exactly one cell on a key's path is in the map, so the depths
@@ -527,8 +556,8 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
     const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand, size_t keysPerImg,
     const int32_t *__restrict__ candCnt, uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
     const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback, int dbgStop,
-    uint16_t *__restrict__ nodeOf, int scratchInts, int dbgStopExact, unsigned bigMask) {
-    const int l = blockIdx.y, b = blockIdx.x;  // level-major: large levels start first
+    uint16_t *__restrict__ nodeOf, int scratchInts, int dbgStopExact, unsigned bigMask, int l0) {
+    const int l = l0 + (int)blockIdx.y, b = blockIdx.x;  // level-major: large levels start first (l0: first level of a group launch)
     if ((bigMask >> l) & 1u) return;             // shared by several workgroups: k_octree_big
     // A level is ONE workgroup walking a serial chain: when other kernels share its CU (the pyramid built ahead, the stereo
     // matcher of the previous batch), its waves take the issue slots first - the chain is the critical path, the others are not.

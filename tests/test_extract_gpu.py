@@ -542,3 +542,121 @@ def test_get_features_in_area_order_direct(pkg, oracle, synth):
         np.testing.assert_array_equal(got, want, err_msg="query %d (%.1f, %.1f, r %.1f, levels %d..%d)" % (q, x, y, r, mn, mx))
         nonempty += len(want) > 1
     assert nonempty > 100
+
+
+def _saturated_image(rng, w, h):
+    img = np.zeros((h, w), np.uint8)
+    for _ in range(max(50, w * h // 800)):
+        x, y = rng.integers(0, w - 4), rng.integers(0, h - 4)
+        img[y:y + rng.integers(2, 40), x:x + rng.integers(2, 40)] = 255 if rng.random() < 0.5 else 0
+    return img
+
+
+@pytest.mark.parametrize("form", [1, 2], ids=["per_keypoint", "level_wide"])
+@pytest.mark.parametrize("w,h,nf,kind", [(1241, 376, 2000, "synth"), (640, 480, 1000, "sat"), (333, 257, 300, "synth"),
+                                         (1920, 1080, 4000, "synth"), (1000, 259, 700, "noise")])
+def test_blur_forms_agree_with_oracle(pkg, oracle, synth, form, w, h, nf, kind):
+    """Row a8 in both of its forms (developer knob 13): the 7x7 Gaussian per keypoint inside k_describe (1), or whole levels by
+    k_blur_levels with k_describe gathering from them (2).  Level-wide: every blurred level equals the oracle's
+    cv::GaussianBlur restatement at EVERY pixel - reflected borders (the levels' frames are not written), tiles that end inside a
+    dword, saturated neighbourhoods whose taps (sum 257) reach the clamp; final keypoints and descriptors equal the oracle
+    in both forms."""
+    rng = np.random.default_rng(w + nf)
+    img = synth.frame(w, h, k=41) if kind == "synth" else _saturated_image(rng, w, h) if kind == "sat" else \
+        rng.integers(0, 256, (h, w), dtype=np.uint8)
+    orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    ok, od = orc.extract(img)
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    pkg.lib().orbx_debug_set(13, form)
+    try:
+        gk, gd = ex(img)
+        mask = ex.blurred_mask()
+        assert mask == (0xFF if form == 2 else 0)
+        if form == 2:
+            for l in range(8):
+                np.testing.assert_array_equal(ex.blurred_level(l), orc.blurred_level(l), err_msg="blurred level %d" % l)
+        k2, d2, patches = ex.debug_blur_patches(img)     # the 37x37 blocks as k_describe saw them, whatever their source
+    finally:
+        pkg.lib().orbx_debug_set(13, 0)
+    assert len(gk) == len(ok) and len(ok) > 100
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        np.testing.assert_array_equal(gk[f], ok[f], err_msg=f)
+    np.testing.assert_allclose(gk["angle"], ok["angle"], atol=1e-4, rtol=0)
+    np.testing.assert_array_equal(gd, od)
+    np.testing.assert_array_equal(d2, od)
+    isf = orc.inv_scale_factors
+    for i in range(0, len(k2), 7):
+        l = int(k2["octave"][i])
+        bl = orc.blurred_level(l)
+        cx = int(round(float(k2["x"][i]) * float(isf[l]))) if l else int(k2["x"][i])
+        cy = int(round(float(k2["y"][i]) * float(isf[l]))) if l else int(k2["y"][i])
+        np.testing.assert_array_equal(patches[i], bl[cy - 18:cy + 19, cx - 18:cx + 19], err_msg="keypoint %d level %d" % (i, l))
+
+
+def test_blur_form_rule_and_batch(pkg, oracle, synth):
+    """The per-level rule (level-wide iff nfeatures_l * 37^2 * 100 >= thr * w_l * h_l, knob 14 = thr) and a batch in which the
+    two forms coexist: same results as the oracle for every image, masks as the rule says."""
+    w, h = 752, 480
+    imgs = synth.batch(w, h, 5, k0=60)
+    for nf, thr in ((1000, 0), (1000, 60), (2500, 120), (400, 250)):
+        orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+        ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+        pkg.lib().orbx_debug_set(14, thr)
+        try:
+            res = ex.extract_batch(imgs)
+            mask = ex.blurred_mask()
+        finally:
+            pkg.lib().orbx_debug_set(14, 0)
+        nfl = orc.features_per_level
+        orc.extract(imgs[0])
+        want = 0
+        for l in range(8):
+            lh, lw = orc.pyramid_level(l).shape
+            want |= (1 << l) if thr and int(nfl[l]) * 1369 * 100 >= thr * lw * lh else 0   # default: no level (measured slower)
+        assert mask == want, (nf, thr, bin(mask), bin(want))
+        for b in range(5):
+            ok, od = orc.extract(imgs[b])
+            gk, gd = res[b]
+            assert len(gk) == len(ok)
+            np.testing.assert_array_equal(gk[["x", "y", "response", "octave"]], ok[["x", "y", "response", "octave"]])
+            np.testing.assert_array_equal(gd, od)
+
+
+@pytest.mark.parametrize("split", [0, 2, 3, 5, 7])
+def test_split_call_level_groups(pkg, oracle, synth, split):
+    """A batch that fills the GPU runs as a split call (developer knob 15: 0 = never (the default: measured slower), a >= 2 = at level a): the
+    quad-tree of the levels [0, a) on a second stream beside the quad-tree + descriptors of the levels [a, 8), whose records
+    are described into scratch arrays and moved behind those of [0, a) by the second descriptor launch.  Keypoints, their order
+    and descriptors must not depend on it - nor on a caller's capacity that cuts the list inside either group."""
+    import torch
+    w, h, nf, B = 752, 480, 900, 9
+    imgs = synth.batch(w, h, B, k0=80)
+    imgs[4] = 0                                   # an image without keypoints inside the batch
+    orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    exp = [orc.extract(imgs[b]) for b in range(B)]
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    ex(imgs[0])
+    d_imgs = torch.from_numpy(imgs).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    pkg.lib().orbx_debug_set(15, split)
+    try:
+        for cap in (ex.max_keypoints(), 700, 150):
+            kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+            desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+            cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+            for rep in range(2):                  # twice: the second call reuses the scratch arrays and the events
+                ex.extract_batch_device(d_imgs.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)
+            torch.cuda.synchronize()
+            k = kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+            dd = desc.cpu().numpy()
+            for b in range(B):
+                ok, od = exp[b]
+                n = int(cnt[b])
+                assert n == min(len(ok), cap), (split, cap, b, n, len(ok))
+                got = np.frombuffer(k[b, :n].tobytes(), pkg.KP_DTYPE)
+                for f in ("x", "y", "size", "response", "octave", "class_id"):
+                    np.testing.assert_array_equal(got[f], ok[f][:n], err_msg="%s image %d cap %d" % (f, b, cap))
+                np.testing.assert_allclose(got["angle"], ok["angle"][:n], atol=1e-4, rtol=0)
+                np.testing.assert_array_equal(dd[b, :n], od[:n])
+    finally:
+        pkg.lib().orbx_debug_set(15, 0)
