@@ -34,10 +34,14 @@ WORKLOADS = {
     "mono_1241x376_1000feat": (1241, 376, 1000, False),
     "mono_640x480_1000feat": (640, 480, 1000, False),
     "mono_1920x1080_4000feat": (1920, 1080, 4000, False),
+    # corner-SPARSE scenes (synth.natural_pair: 2-5 % of the pixels are FAST corners at t = 7, the regime of real footage; the
+    # frames SURVEY section 8(d) prescribes are corner-saturated, 33-53 %)
+    "kitti_stereo_natural_1241x376_1000feat": (1241, 376, 1000, True),
 }
+NATURAL = {"kitti_stereo_natural_1241x376_1000feat"}
 # the other north-star sizes measured (briefly) after the headline: (workload, frames per step)
 OTHER_WORKLOADS = [("kitti_stereo_1241x376_2000feat", 64), ("euroc_stereo_752x480_1000feat", 64), ("mono_640x480_1000feat", 64),
-                   ("mono_1920x1080_4000feat", 32)]
+                   ("mono_1920x1080_4000feat", 32), ("kitti_stereo_natural_1241x376_1000feat", 64)]
 KITTI_FX, KITTI_BF = 718.856, 386.1448  # KITTI-00 calibration (fx, baseline*fx); same constants as pipeline.py
 
 
@@ -53,8 +57,10 @@ def level_pixels(w, h, nlevels=8, sf=1.2):
 
 
 def _gen_pair(args):
-    w, h, k, stereo = args
+    w, h, k, stereo, kind = args
     synth = importlib.import_module("orb_slam2v2-1_amd.synth")
+    if kind == "natural":
+        return synth.natural_pair(w, h, k) if stereo else (synth.natural(w, h, k), None)
     if stereo:
         l, r = synth.stereo_pair_blocky(w, h, k)
         return l, r
@@ -75,8 +81,8 @@ def _pool_map(fn, jobs, workers):
     return out
 
 
-def make_frames(w, h, n, k0, stereo, workers):
-    jobs = [(w, h, k0 + i, stereo) for i in range(n)]
+def make_frames(w, h, n, k0, stereo, workers, kind="dense"):
+    jobs = [(w, h, k0 + i, stereo, kind) for i in range(n)]
     if workers > 1 and n > 2:
         out = _pool_map(_gen_pair, jobs, min(workers, n))
     else:
@@ -241,7 +247,41 @@ def measure(fe, steps, warmup, ramp, world, dist, dev, torch):
             "nprof": nprof, "gathered": gath}
 
 
-def verify_against_oracle(fe, last, seeds, frames):
+def measure_end_to_end(fe, left, right, steps, warmup, torch):
+    """The same step fed from PINNED HOST memory and delivering to pinned host memory (FrontEnd.enable_host_streaming): uploads of
+    batch i + 2 and downloads of batch i - 1 on their own streams beside the kernels of batches i, i + 1.  Times K steps from the
+    first upload to the arrival of the last result on the host.  Returns (seconds, host copies of the last step's results)."""
+    fe.drain()
+    fe.enable_host_streaming()
+    pl = torch.from_numpy(np.ascontiguousarray(left)).pin_memory()
+    pr = torch.from_numpy(np.ascontiguousarray(right)).pin_memory() if right is not None else None
+
+    def run(K):
+        fe.submit(0, pl, pr)
+        if K > 1:
+            fe.submit(1, pl, pr)
+        for i in range(K):
+            fe.step(i)
+            if i >= 1:
+                fe.fetch(i - 1)
+            if i >= 3:
+                fe.wait(i - 3)      # the consumer takes each result as it lands: the host stays three steps ahead of the results
+            if i + 2 < K:           # (with everything enqueued unboundedly far ahead the same loop measured 1.36-2.0 ms per step)
+                fe.submit(i + 2, pl, pr)
+        fe.fetch(K - 1)
+        fe.wait(K - 1)
+    run(max(warmup, 3))
+    fe.drain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    dt = time.perf_counter() - t0
+    last = fe.host_results(steps - 1)
+    fe.drain()
+    return dt, last
+
+
+def verify_against_oracle(fe, last, seeds, frames, kind="dense"):
     """Checker leg (outside every timed region): frames `frames` of the last timed step against the CPU oracle: keypoint
     coordinates, sizes, responses, octaves, counts and descriptors bit for bit, angles within 1e-4 (north_star's float tolerance;
     bit-identical in practice); mvuRight / mvDepth / match count for stereo bit for bit."""
@@ -252,7 +292,7 @@ def verify_against_oracle(fe, last, seeds, frames):
     bad = []
     for b in frames:
         if fe.stereo:
-            e = ref.stereo_frame((fe.w, fe.h, fe.nf, seeds[b], fe.mbf, fe.mb))
+            e = ref.stereo_frame((fe.w, fe.h, fe.nf, seeds[b], fe.mbf, fe.mb, kind))
             for side, k, d, gi in (("left", e["kl"], e["dl"], b), ("right", e["kr"], e["dr"], fe.B + b)):
                 m = ref.image_mismatch(imgs[gi][0], imgs[gi][1], k, d)
                 if m:
@@ -261,14 +301,14 @@ def verify_against_oracle(fe, last, seeds, frames):
             if m:
                 bad.append("frame %d stereo: %s" % (b, m))
         else:
-            e = ref.mono_frame((fe.w, fe.h, fe.nf, seeds[b]))
+            e = ref.mono_frame((fe.w, fe.h, fe.nf, seeds[b], kind))
             m = ref.image_mismatch(imgs[b][0], imgs[b][1], e["k"], e["d"])
             if m:
                 bad.append("frame %d: %s" % (b, m))
     return bad
 
 
-def verify_gathered(fe, gath, ranks, frames_of_rank):
+def verify_gathered(fe, gath, ranks, frames_of_rank, kind="dense"):
     """N > 1 checker leg (rank 0, outside every timed region): the ALL-GATHERED records of the last timed step - every
     rank's frames as they arrived over the collective - against the CPU oracle of that rank's seeds.  frames_of_rank(B) picks the
     frames of each rank's block that are checked.  Returns (list of mismatches, frames checked)."""
@@ -286,7 +326,7 @@ def verify_gathered(fe, gath, ranks, frames_of_rank):
     for r in ranks:
         for b in frames_of_rank(B):
             seed = r["first_seed"] + b
-            jobs.append((fe.w, fe.h, fe.nf, seed, fe.mbf, fe.mb) if fe.stereo else (fe.w, fe.h, fe.nf, seed))
+            jobs.append((fe.w, fe.h, fe.nf, seed, fe.mbf, fe.mb, kind) if fe.stereo else (fe.w, fe.h, fe.nf, seed, kind))
             where.append((r["rank"], b))
     exp = ref.run_pool(ref.stereo_frame if fe.stereo else ref.mono_frame, jobs)
     for (rk, b), e in zip(where, exp):
@@ -369,6 +409,7 @@ def main():
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short untimed-by-the-driver runs of the other north-star sizes (other_workloads block)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-memory-to-host-memory pass (end_to_end block)")
     ap.add_argument("--verify-all-gathered", action="store_true",
                     help="N > 1: check EVERY frame of every rank in the all-gathered records of the last timed step against the oracle "
                          "(default: the first and last frame of each rank's block)")
@@ -412,7 +453,8 @@ def main():
         B, seed0 = args.batch, 1000 * rank
     # host-side work that forks worker processes happens BEFORE this process touches the GPU
     workers = args.gen_workers if args.gen_workers > 0 else max(1, min((os.cpu_count() or 1) // max(world, 1), 16))
-    left, right = make_frames(w, h, B, seed0, stereo, workers)
+    kind = "natural" if args.workload in NATURAL else "dense"
+    left, right = make_frames(w, h, B, seed0, stereo, workers, kind)
     seeds = [seed0 + i for i in range(B)]
     others = []
     if world == 1 and not args.no_other_workloads and not strong and args.streams == 1:
@@ -420,11 +462,12 @@ def main():
             if name == args.workload:
                 continue
             ow, oh, onf, ost = WORKLOADS[name]
-            if (ow, oh, ost) == (w, h, stereo) and ob <= B:
+            okind = "natural" if name in NATURAL else "dense"
+            if (ow, oh, ost, okind) == (w, h, stereo, kind) and ob <= B:
                 ol, orr = left[:ob], (right[:ob] if stereo else None)      # same images, other feature budget
                 oseeds = seeds[:ob]
             else:
-                ol, orr = make_frames(ow, oh, ob, 5000, ost, workers)
+                ol, orr = make_frames(ow, oh, ob, 5000, ost, workers, okind)
                 oseeds = [5000 + i for i in range(ob)]
             others.append((name, ob, ol, orr, oseeds))
     cpu = None
@@ -510,7 +553,7 @@ def main():
         verified, vnote = None, "skipped (--no-verify)"
         if not args.no_verify:
             vf = sorted({0, B // 2, B - 1})
-            bad = verify_against_oracle(fe, m["last"], seeds, vf)
+            bad = verify_against_oracle(fe, m["last"], seeds, vf, kind)
             verified = not bad
             vnote = ("frames %s of the last timed step == CPU oracle: keypoint x / y / size / response / octave, counts and descriptors "
                      "bit for bit, angles within 1e-4%s" % (vf, ", mvuRight / mvDepth / match counts bit for bit" if stereo else "")
@@ -518,7 +561,7 @@ def main():
         gathered_verified, gnote = None, None
         if m["gathered"] is not None and not args.no_verify:
             pick = (lambda nb: range(nb)) if args.verify_all_gathered else (lambda nb: sorted({0, nb - 1}))
-            gbad, nchk = verify_gathered(fe, m["gathered"], ranks, pick)
+            gbad, nchk = verify_gathered(fe, m["gathered"], ranks, pick, kind)
             gathered_verified = not gbad
             gnote = ("%d frames (%s of every rank's block) of the all-gathered records of the last timed step, as received on rank 0, "
                      "== CPU oracle of the owning rank's seeds" % (nchk, "all" if args.verify_all_gathered else "first and last")
@@ -553,6 +596,24 @@ def main():
                                               m["nprof"], "the stereo matcher of step i-1 and the pyramid of step i+1 run" if fe.lag else
                                               "the pyramid of step i+1 runs" if fe.prefetch else "nothing runs", roof["kernel"], args.steps)},
         }
+        if world == 1 and S == 1 and not args.no_end_to_end:
+            # beside the headline (never `value`): the step fed from host memory, PCIe both ways inside the clock
+            fe2 = pipeline.FrontEnd(w, h, nf, stereo, B, device_index=dev_index, nbuf=3)
+            fe2.upload(left, right)
+            dte, laste = measure_end_to_end(fe2, left, right, args.steps, 10, torch)
+            bade = [] if args.no_verify else verify_against_oracle(fe2, laste, seeds, sorted({0, B - 1}), kind)
+            up = fe2.nimg * w * h
+            down = sum(t.numel() * t.element_size() for t in fe2._hs.out[0].values())
+            out["end_to_end"] = {
+                "value": round(B * args.steps / dte, 2), "unit": "frames/s", "ms_per_step": round(dte / args.steps * 1e3, 4), "steps": args.steps,
+                "h2d_bytes_per_step": up, "d2h_bytes_per_step": down, "h2d_GBps": round(up * args.steps / dte / 1e9, 2),
+                "d2h_GBps": round(down * args.steps / dte / 1e9, 2), "verified": None if args.no_verify else not bade,
+                "note": "frames start in PINNED host memory and results (keypoints, descriptors, counts, mvuRight, mvDepth at full "
+                        "capacity) end in pinned host memory; one hipMemcpyAsync per camera and batch on an upload stream, three image "
+                        "buffers in HBM, downloads on a third stream, all overlapped with the kernels of the neighbouring batches; the host "
+                        "waits for the results of step i - 3 before it submits batch i + 2; clock from the first upload to the last "
+                        "result's arrival.  NOT the headline value (which starts with frames in HBM)"}
+            del fe2
         if others:
             # the other north-star sizes, same definition of a step, short runs (not the headline; the driver times only `value`)
             del fe
@@ -565,13 +626,24 @@ def main():
                 om = measure(ofe, osteps, 5, 60, 1, dist, dev, torch)
                 oval = ob * osteps / om["dt"]
                 oroof, onavg = roofline_block(ofe, om, name, ob, oval, 1, traffic_lookup=False)
-                obad = [] if args.no_verify else verify_against_oracle(ofe, om["last"], oseeds, [0, ob - 1])
+                okind = "natural" if name in NATURAL else "dense"
+                obad = [] if args.no_verify else verify_against_oracle(ofe, om["last"], oseeds, [0, ob - 1], okind)
                 ow_out[name] = {"value": round(oval, 2), "unit": "frames/s" if ost else "images/s", "frames_per_step": ob,
                                 "steps": osteps, "ms_per_step": round(om["dt"] / osteps * 1e3, 4),
                                 "dominant_kernel": oroof["kernel"], "dominant_kernel_ms": oroof["kernel_ms"],
                                 "roofline_frac": oroof["frac"], "pipeline_frac": oroof["pipeline_frac"],
                                 "avg_keypoints_per_image": round(onavg, 1),
+                                "stage_ms_alone": {k: round(float(v), 4) for k, v in zip(("pyramid", "fast", "quadtree", "describe"), om["stage_ms"][:4])},
                                 "verified": None if args.no_verify else not obad}
+                if okind == "natural":
+                    # the corner-sparse workload with and without k_fast_strips' exact row pre-test (developer knob 16 = 1: off)
+                    pkg.lib().orbx_debug_set(16, 1)
+                    om2 = measure(ofe, osteps, 5, 20, 1, dist, dev, torch)
+                    pkg.lib().orbx_debug_set(16, 0)
+                    ow_out[name].update({
+                        "corner_fraction_note": "2-5 % of the pixels are FAST corners at t = 7 (dense workloads: 33-53 %)",
+                        "fast_ms_with_row_pretest": round(om["fast_ms"], 4), "fast_ms_without": round(om2["fast_ms"], 4),
+                        "value_without_row_pretest": round(ob * osteps / om2["dt"], 2)})
                 del ofe
             out["other_workloads"] = ow_out
         if cpu is not None:

@@ -110,6 +110,11 @@ int orbx_stream_wait_fast_stage(orbx_extractor_t *h, void *stream);
 /* The handle's own side stream (hipStream_t), for the pattern above.  HIP deals streams to a handful of hardware queues
  * round-robin, so a stream the caller creates may share its queue with the main stream and overlap nothing. */
 void *orbx_side_stream(orbx_extractor_t *h);
+/* The same, made sure not to share a hardware queue with main_stream (two streams on one queue run strictly in order and overlap
+ * nothing): probed once with a 2-ms one-wave spin on main_stream and an empty kernel on the candidate, replaced by a fresh stream
+ * if it queued behind the spin.  Call it once per handle with the stream the extraction calls will be issued on (every handle
+ * after the first of a process is likely to need the replacement).  Returns the side stream to use. */
+void *orbx_side_stream_for(orbx_extractor_t *h, void *main_stream);
 
 /* mvImagePyramid[level] of image `b` of the last call (include/ORBextractor.h:85): copies
  * the inner level (padded=0) or the whole bordered buffer (padded=1, 19 px border,

@@ -43,7 +43,7 @@ EXPORTS = [
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
     "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch", "orbx_debug_sincosf",
     "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels", "orbx_extract_batch_device_prefetch", "orbx_stream_wait_fast_stage", "orbx_side_stream", "orbm_stereo_batch_device_prev", "orbx_debug_blur_patches", "orbm_debug_features_in_area",
-    "orbx_debug_blurred_level",
+    "orbx_debug_blurred_level", "orbx_side_stream_for",
 ]
 
 
@@ -130,6 +130,8 @@ def lib():
     L.orbx_stream_wait_fast_stage.argtypes = [vp, vp]
     L.orbx_side_stream.argtypes = [vp]
     L.orbx_side_stream.restype = vp
+    L.orbx_side_stream_for.argtypes = [vp, vp]
+    L.orbx_side_stream_for.restype = vp
     L.orbx_pyramid_host.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.orbx_pyramid_device.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.orbx_debug_level_points.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
@@ -289,6 +291,10 @@ class ORBextractor:
     def side_stream(self):
         """hipStream_t of the handle's own side stream (orbx_side_stream)."""
         return self._L.orbx_side_stream(self._h)
+
+    def side_stream_for(self, main_stream):
+        """The side stream, probed (and replaced if need be) so that it does not share a hardware queue with main_stream."""
+        return self._L.orbx_side_stream_for(self._h, main_stream)
 
     def stream_wait_fast_stage(self, stream):
         """Order `stream` behind the FAST stage of the last extraction call (orbx_stream_wait_fast_stage)."""

@@ -40,8 +40,8 @@ extern "C" int orbx_thread_release_scratch(void) {
     return ORBX_OK;
 }
 
-int g_debug[16] = {0};
-extern "C" int orbx_debug_set(int key, int value) { if (key < 0 || key >= 16) return ORBX_ERR_ARG; g_debug[key] = value; return ORBX_OK; }
+int g_debug[32] = {0};
+extern "C" int orbx_debug_set(int key, int value) { if (key < 0 || key >= 32) return ORBX_ERR_ARG; g_debug[key] = value; return ORBX_OK; }
 
 // ------------------------------------------------------------------------------------
 // host side
@@ -132,6 +132,7 @@ static void free_plan(orbx_extractor *h) {
     h->d_octPart = nullptr; h->d_octLeaf = nullptr; h->d_octBest = nullptr; h->d_octState = nullptr;
     hipFree(h->d_geom); hipFree(h->d_tab); hipFree(h->d_pyr); hipFree(h->d_cellCnt); hipFree(h->d_slots);
     hipFree(h->d_cand); hipFree(h->d_lvlKp); hipFree(h->d_nodeOf); hipFree(h->d_candCnt); hipFree(h->d_lvlCnt);
+    hipFree(h->d_sparse); h->d_sparse = nullptr;
     h->d_geom = nullptr; h->d_tab = nullptr; h->d_pyr = nullptr; h->d_cellCnt = nullptr; h->d_slots = nullptr;
     h->d_cand = nullptr; h->d_lvlKp = nullptr; h->d_nodeOf = nullptr; h->d_candCnt = nullptr; h->d_lvlCnt = nullptr;
     h->pw = h->ph = h->pB = 0;
@@ -443,6 +444,8 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     ORBX_HIP(hipMalloc(&h->d_nodeOf, sizeof(uint16_t) * h->keysPerImg * Bz));
     ORBX_HIP(hipMalloc(&h->d_candCnt, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
     ORBX_HIP(hipMalloc(&h->d_lvlCnt, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
+    ORBX_HIP(hipMalloc(&h->d_sparse, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
+    ORBX_HIP(hipMemset(h->d_sparse, 0, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));   // first call: every level scored row by row
     ORBX_HIP(hipMalloc(&h->d_lvlKp, sizeof(uint32_t) * (size_t)h->lvlKpCap * Bz));
     ORBX_HIP(hipMalloc(&h->d_octFallback, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
     ORBX_HIP(hipMemset(h->d_octFallback, 0, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
@@ -501,6 +504,9 @@ __global__ void k_nop() {}
 // reflected-border branches; a branch-free version would still move 2.4 bytes per pixel: ~0.08 ms), so even the best case wins
 // ~0.05 of 0.89 ms at 2000 features and nothing at 1000.
 #define ORBX_BLUR_THR 100000000
+// a level whose last call kept fewer FAST candidates per 30-px cell than this is "corner-sparse" (the benchmark's dense frames: ~60;
+// smooth natural scenes: 2-4)
+#define ORBX_SPARSE_PER_CELL 16
 static unsigned blur_plan(const orbx_extractor *h, BlurPlan &bp, int &totalTiles) {
     unsigned mask = 0;
     totalTiles = 0;
@@ -578,7 +584,7 @@ static void launch_pyramid(orbx_extractor *h, const uint8_t *d_imgs, uint8_t *py
 // The per-image buffers of a handle as seen by ONE chunk of a batch: every base pointer already points at the chunk's first image.
 struct ChunkView {
     const uint8_t *imgs; uint8_t *pyr; uint32_t *cellCnt, *cellRaw, *slots, *cand, *lvlKp; uint16_t *nodeOf;
-    int32_t *candCnt, *lvlCnt, *octFallback; orbx_keypoint_t *kps; uint8_t *desc; int32_t *counts;
+    int32_t *candCnt, *lvlCnt, *octFallback, *sparse; orbx_keypoint_t *kps; uint8_t *desc; int32_t *counts;
     int b0;            // first image of the chunk
     size_t octSlot0;   // first (image, level) slot of the chunk in the multi-workgroup quad-tree scratch (d_octPart / Leaf / Best / State)
 };
@@ -590,6 +596,7 @@ static ChunkView chunk_view(const orbx_extractor *h, const uint8_t *d_imgs, size
     v.cellCnt = h->d_cellCnt + z * h->totalCells; v.cellRaw = h->d_cellRaw + z * h->totalCells;
     v.slots = h->d_slots + z * h->slotsPerImg; v.cand = h->d_cand + z * h->keysPerImg; v.nodeOf = h->d_nodeOf + z * h->keysPerImg;
     v.lvlKp = h->d_lvlKp + z * h->lvlKpCap;
+    v.sparse = h->d_sparse + z * h->nlevels;
     v.candCnt = h->d_candCnt + z * h->nlevels; v.lvlCnt = h->d_lvlCnt + z * h->nlevels; v.octFallback = h->d_octFallback + z * h->nlevels;
     v.kps = d_kps + z * cap; v.desc = d_desc + z * cap * 32; v.counts = d_counts + b0;
     v.octSlot0 = z * h->nlevels; v.b0 = b0;
@@ -632,7 +639,8 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             for (int l = 0; l <= ORBX_MAX_LEVELS; l++) sb.v[l] = h->stripBase[l];
             hipLaunchKernelGGL(k_fast_strips, dim3((h->totalStrips + FAST_WAVES - 1) / FAST_WAVES, B), dim3(64 * FAST_WAVES), 0, st,
                                v.pyr, h->pyrImgBytes, h->d_geom, nl, h->totalStrips, h->totalCells, v.cellCnt, v.cellRaw,
-                               v.slots, h->slotsPerImg, h->ini_th, h->min_th, sb);
+                               v.slots, h->slotsPerImg, h->ini_th, h->min_th, sb,
+                               g_debug[16] == 1 ? (const int32_t *)nullptr : v.sparse);   // developer knob 16: 1 = never pre-test, 2 = always
         }
         if (stripLevels != (1u << nl) - 1u) {   // levels with wider cells (the coarsest ones of small images)
             dim3 grid((h->totalCells + FAST_WAVES - 1) / FAST_WAVES, B);
@@ -662,7 +670,8 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
         const int scratch = std::max(4 * h->maxNodeCap, maxCells + 1);
         hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
                            dim3(256), 0, st, h->d_geom, nl, h->totalCells, v.cellCnt, v.cellRaw, v.slots,
-                           h->slotsPerImg, v.cand, h->keysPerImg, v.candCnt, h->ini_th, h->min_th, cb);
+                           h->slotsPerImg, v.cand, h->keysPerImg, v.candCnt, h->ini_th, h->min_th, cb, v.sparse,
+                           g_debug[16] == 2 ? 1 << 20 : ORBX_SPARSE_PER_CELL);
         // developer knob 4: 0 default, 1 = the exact form alone, 2 = EVERY level by the multi-workgroup form, 3 = none
         const bool usePyr = g_debug[4] != 1;
         // developer knob 15: a >= 2 = split call at level a (default 0: one launch sequence)
@@ -902,6 +911,62 @@ extern "C" int orbx_stream_wait_fast_stage(orbx_extractor_t *h, void *stream) {
 // queues and the runtime deals streams to them round-robin: a stream the caller creates may share its queue with the caller's main
 // stream and then overlaps nothing; this one was created next to the handle and is known to sit on a queue of its own.
 extern "C" void *orbx_side_stream(orbx_extractor_t *h) { return h ? (void *)h->side[0] : nullptr; }
+
+// ~2 ms of nothing on one wave: the "busy" side of the queue probe below (constant 100 MHz counter)
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+// true iff a command on `cand` starts while `busy` is still occupied, i.e. the two streams do not share a hardware queue
+static bool streams_independent(hipStream_t busy, hipStream_t cand, hipEvent_t eb, hipEvent_t ec) {
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, busy, 200000ll);
+    if (hipEventRecord(eb, busy) != hipSuccess) return false;
+    hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, cand);
+    if (hipEventRecord(ec, cand) != hipSuccess) return false;
+    if (hipEventSynchronize(ec) != hipSuccess) return false;
+    const bool indep = hipEventQuery(eb) == hipErrorNotReady;   // the spin is still running: the candidate did not wait behind it
+    (void)hipEventSynchronize(eb);
+    (void)hipGetLastError();
+    return indep;
+}
+// The side stream of the handle, made sure NOT to share a hardware queue with `main_stream` (the stream the caller issues its
+// extraction calls on).  The runtime deals streams to a handful of hardware queues round-robin and has no API that tells which;
+// two streams on one queue run strictly in order, and the software pipeline (matcher of the previous batch, pyramid of the next on
+// the side stream beside the caller's kernels) then overlaps nothing - seen on every handle after the first of a process (the second
+// FrontEnd of bench.py: 1.53 instead of 1.13 ms per end-to-end step).  So the side stream is probed: a 2-ms one-wave spin goes to
+// main_stream, an empty kernel to the candidate; the candidate is kept if its kernel ran while the spin was still going.  One-off,
+// a few ms; the caller's stream is occupied for that long.  Returns the (possibly replaced) side stream.
+extern "C" void *orbx_side_stream_for(orbx_extractor_t *h, void *main_stream) {
+    if (!h) return nullptr;
+    if (hipSetDevice(h->device) != hipSuccess) return (void *)h->side[0];
+    hipStream_t ms = (hipStream_t)main_stream;
+    hipEvent_t eb = nullptr, ec = nullptr;
+    if (hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ec, hipEventDisableTiming) != hipSuccess) {
+        if (eb) hipEventDestroy(eb);
+        return (void *)h->side[0];
+    }
+    (void)hipStreamSynchronize(ms);
+    (void)hipStreamSynchronize(h->side[0]);
+    if (!streams_independent(ms, h->side[0], eb, ec)) {
+        std::vector<hipStream_t> tried;
+        hipStream_t found = nullptr;
+        for (int i = 0; i < 12 && !found; i++) {
+            hipStream_t c = nullptr;
+            if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
+            if (streams_independent(ms, c, eb, ec) && streams_independent(c, h->side[1], eb, ec)) found = c;
+            else tried.push_back(c);
+        }
+        for (hipStream_t c : tried) hipStreamDestroy(c);
+        if (found) {
+            hipStreamDestroy(h->side[0]);
+            h->side[0] = found;
+            h->pfValid = 0; h->prevPyrValid = 0;
+        }
+    }
+    hipEventDestroy(eb); hipEventDestroy(ec);
+    (void)hipGetLastError();
+    return (void *)h->side[0];
+}
 
 static int ensure_staging(orbx_extractor *h, size_t in_bytes, int B, int cap) {
     if (h->d_in_bytes < in_bytes) {

@@ -334,7 +334,7 @@ __device__ __forceinline__ uint32_t dpp_row_shl1(uint32_t v) { return (uint32_t)
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels, int totalStrips,
     int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ cellRaw, uint32_t *__restrict__ slots, size_t slotsPerImg,
-    int iniTh, int minTh, StripBases sb) {
+    int iniTh, int minTh, StripBases sb, const int32_t *__restrict__ sparseFlag) {
     __shared__ __align__(16) uint32_t smem[FAST_WAVES * STRIP_SLOTS * STRIP_ES];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int bx, b;
@@ -345,6 +345,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
 #pragma unroll
     for (int i = 1; i < ORBX_MAX_LEVELS; i++) l += (i < nlevels && strip >= sb.v[i]) ? 1 : 0;
     const LevelGeom g = geom[l];
+    // Corner-sparse level (the previous call found few candidates in this image slot's level, k_gather leaves the verdict): every
+    // row is first put through a cheap bound on the score and scored only if some pixel of the wave's 128 can reach the threshold.
+    const bool pretest = sparseFlag != nullptr && __builtin_amdgcn_readfirstlane(sparseFlag[b * nlevels + l]) != 0;   // wave-uniform
     const int s = strip - sb.v[l];
     const int ng = (g.nCols + 3) >> 2;
     const int ci = s / ng, cj0 = 4 * (s - ci * ng);
@@ -425,14 +428,32 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
 #define SLOT(k) (((R + (k)) & 7) * STRIP_ES)
             const uint32_t vv = q[SLOT(3)];
             uint32_t rr[16];
-            rr[0] = q[SLOT(6)];       rr[1] = q[SLOT(6) + 1];   rr[2] = q[SLOT(5) + 2];   rr[3] = q[SLOT(4) + 3];
-            rr[4] = q[SLOT(3) + 3];   rr[5] = q[SLOT(2) + 3];   rr[6] = q[SLOT(1) + 2];   rr[7] = q[SLOT(0) + 1];
-            rr[8] = q[SLOT(0)];       rr[9] = q[SLOT(0) - 1];   rr[10] = q[SLOT(1) - 2];  rr[11] = q[SLOT(2) - 3];
-            rr[12] = q[SLOT(3) - 3];  rr[13] = q[SLOT(4) - 3];  rr[14] = q[SLOT(5) - 2];  rr[15] = q[SLOT(6) - 1];
+            rr[0] = q[SLOT(6)];  rr[4] = q[SLOT(3) + 3];  rr[8] = q[SLOT(0)];  rr[12] = q[SLOT(3) - 3];
+            bool go = true;
+            if (pretest) {   // wave-uniform
+                // Every nine-arc of the ring holds r[0] or r[8] and r[4] or r[12].  So bright = (max over arcs of the arc's minimum) - v
+                // <= min(max(r0, r8), max(r4, r12)) - v and dark = v - (min over arcs of the arc's maximum) <= v - max(min(r0, r8),
+                // min(r4, r12)): an upper bound U of score + 1 from five pixels (the necessary condition cv::FAST itself tests first).
+                // A pixel with U <= min(iniTh, minTh) has a score below both thresholds: it is never emitted and never beats a
+                // neighbour that is, so its score may be taken as 0; when that holds for all 128 pixels of the row the 76-operation
+                // score is skipped.  Same keypoints by construction.
+                const half2v v = __builtin_bit_cast(half2v, vv), a0 = __builtin_bit_cast(half2v, rr[0]), a4 = __builtin_bit_cast(half2v, rr[4]),
+                             a8 = __builtin_bit_cast(half2v, rr[8]), a12 = __builtin_bit_cast(half2v, rr[12]);
+                const half2v ub = __builtin_elementwise_minimum(__builtin_elementwise_maximum(a0, a8), __builtin_elementwise_maximum(a4, a12)) - v;
+                const half2v ud = v - __builtin_elementwise_maximum(__builtin_elementwise_minimum(a0, a8), __builtin_elementwise_minimum(a4, a12));
+                const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_maximum(ub, ud), tl2) - tl2) & vmask;
+                go = __ballot(u != 0) != 0;   // U - tlo > 0 for some pixel of the evaluated area (exact on these values: max(U, tlo) - tlo >= 0)
+            }
+            if (go) {
+                rr[1] = q[SLOT(6) + 1];   rr[2] = q[SLOT(5) + 2];   rr[3] = q[SLOT(4) + 3];
+                rr[5] = q[SLOT(2) + 3];   rr[6] = q[SLOT(1) + 2];   rr[7] = q[SLOT(0) + 1];
+                rr[9] = q[SLOT(0) - 1];   rr[10] = q[SLOT(1) - 2];  rr[11] = q[SLOT(2) - 3];
+                rr[13] = q[SLOT(4) - 3];  rr[14] = q[SLOT(5) - 2];  rr[15] = q[SLOT(6) - 1];
+                const half2v best = fast_ring_score(vv, rr);
+                // score + 1, clamped at 0, pixels outside the cell's evaluated area = 0
+                S = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(best, (half2v){(_Float16)0, (_Float16)0})) & vmask;
+            }
 #undef SLOT
-            const half2v best = fast_ring_score(vv, rr);
-            // score + 1, clamped at 0, pixels outside the cell's evaluated area = 0
-            S = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(best, (half2v){(_Float16)0, (_Float16)0})) & vmask;
         }
         // row y: (left neighbour's second pixel, my first) and (my second, right neighbour's first); zero beyond the cell
         const uint32_t Lp = __builtin_amdgcn_perm(S, dpp_row_shr1(S), 0x05040302u);   // bytes: shr.hi | S.lo << 16
@@ -504,7 +525,7 @@ __global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ ge
                                                 const uint32_t *__restrict__ cellCnt, const uint32_t *__restrict__ cellRaw,
                                                 const uint32_t *__restrict__ slots, size_t slotsPerImg,
                                                 uint32_t *__restrict__ cand, size_t keysPerImg, int32_t *__restrict__ candCnt,
-                                                int iniTh, int minTh, CellBases cb) {
+                                                int iniTh, int minTh, CellBases cb, int32_t *__restrict__ sparseFlag, int sparsePerCell) {
     __shared__ int wsum[4], ccnt[GATHER_CELLS_PER_BLOCK], clvl[GATHER_CELLS_PER_BLOCK];
     const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
     int bx, b;
@@ -546,7 +567,12 @@ __global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ ge
     if (!live) return;
     int off = l == l0 ? wsum[0] + wsum[1] + wsum[2] + wsum[3] : 0;
     for (int k = 0; k < grp; k++) off += clvl[k] == l ? ccnt[k] : 0;
-    if (sub == 0 && gc == cellBase + ncells - 1) candCnt[b * nlevels + l] = off + cn;
+    if (sub == 0 && gc == cellBase + ncells - 1) {
+        candCnt[b * nlevels + l] = off + cn;
+        // verdict for the NEXT call's FAST stage on this image slot: a level with few candidates per cell is put through the
+        // row pre-test of k_fast_strips (speed only, never results)
+        if (sparseFlag) sparseFlag[b * nlevels + l] = (off + cn) < sparsePerCell * ncells ? 1 : 0;
+    }
     uint32_t *dst = cand + (size_t)b * keysPerImg + keyOff + off;
     const int gshift = (tid & 48);   // my group's 16 lanes inside the wave's ballot
     int kept = 0;

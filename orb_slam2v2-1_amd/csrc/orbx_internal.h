@@ -88,6 +88,7 @@ struct orbx_extractor {
     uint32_t *d_cellCnt, *d_cellRaw, *d_slots, *d_cand, *d_lvlKp;
     uint16_t *d_nodeOf;
     int32_t *d_candCnt, *d_lvlCnt;
+    int32_t *d_sparse;   // [B][nlevels] verdict of the last call: level with few FAST candidates (k_gather writes, k_fast_strips of the next call reads)
     // staging for the host API
     uint8_t *d_in; size_t d_in_bytes;
     orbx_keypoint_t *d_kps; uint8_t *d_desc; int32_t *d_counts; int out_cap, out_B;
@@ -158,7 +159,7 @@ int fast_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const 
                          int32_t *best_dist, int device);
 int fast_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, int npoints, int32_t *best_row,
                                  int32_t *best_median, int device);
-extern int g_debug[16];  // developer knobs (orbx_debug_set); [2] != 0 forces the exact one-workgroup matcher kernels
+extern int g_debug[32];  // developer knobs (orbx_debug_set); [2] != 0 forces the exact one-workgroup matcher kernels
 
 // XCD-aware block -> (image, block-in-image) map for grids of (blocks per image, images).  Workgroups are dealt round-robin
 // to the 8 XCDs in linear-id order and every XCD has its own L2, so with the identity map neighbouring blocks - which

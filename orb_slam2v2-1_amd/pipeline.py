@@ -22,6 +22,42 @@ from .batching import ResultRing
 KITTI_FX, KITTI_BF = 718.856, 386.1448  # KITTI-00 calibration (fx, baseline*fx)
 
 
+def independent_stream(dev, busy, ncand=8):
+    """A new torch stream whose commands do not queue behind those of the streams in `busy`.  HIP deals streams to a handful of
+    hardware queues round-robin, and a copy submitted on a stream that shares its queue with the compute stream starts only
+    when the kernels queued in front of it are done (seen in the kernel / copy trace of the end-to-end mode: every upload
+    started right behind the FAST kernel of the main stream).  There is no API that tells the queue of a stream, so candidates
+    are probed: a few ms of work goes to the busy stream, a tiny copy to the candidate - if the copy lands while the work is still
+    running, the two do not share a queue."""
+    a = torch.randn((4096, 4096), device=dev)
+    small_h = torch.zeros(64, dtype=torch.uint8).pin_memory()
+    small_d = torch.zeros(64, dtype=torch.uint8, device=dev)
+    cands = [torch.cuda.Stream(dev) for _ in range(ncand)]
+    for c in cands:
+        ok = True
+        for b in busy:
+            torch.cuda.synchronize(dev)
+            with torch.cuda.stream(b):
+                y = a @ a
+                for _ in range(3):
+                    y = y @ a
+                evb = torch.cuda.Event()
+                evb.record(b)
+            with torch.cuda.stream(c):
+                small_d.copy_(small_h, non_blocking=True)
+                evc = torch.cuda.Event()
+                evc.record(c)
+            evc.synchronize()
+            if evb.query():          # the work was over before the copy landed: it queued behind it (or nothing can be told)
+                ok = False
+                break
+        if ok:
+            torch.cuda.synchronize(dev)
+            return c
+    torch.cuda.synchronize(dev)
+    return cands[0]
+
+
 class FrontEnd:
     def __init__(self, w, h, nfeatures, stereo, B, device_index=0, nbuf=3, streams=1, world=1, gather=False,
                  gather_via_host=False, mbf=KITTI_BF, fx=KITTI_FX, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, prefetch=True, lag_stereo=True):
@@ -40,8 +76,10 @@ class FrontEnd:
         # the matcher of step i-1 is issued after the extraction of step i, on the side stream, behind that extraction's FAST stage;
         # with N > 1 ranks the pack kernel + all-gather of step i-1 follow it on that stream, so N = 1 and N > 1 run the same pipeline
         self.lag = bool(lag_stereo and prefetch and stereo and self.S == 1)
-        # the handle's own side stream: a new torch stream may land on the main stream's hardware queue and overlap nothing
-        self.side = torch.cuda.ExternalStream(self.ex.side_stream(), device=self.dev) if self.lag else None
+        # the handle's own side stream, probed against the main stream: two streams that share a hardware queue overlap nothing
+        main0 = torch.cuda.current_stream(self.dev)
+        self._side_raw = self.ex.side_stream_for(main0.cuda_stream) if (prefetch and self.S == 1) else self.ex.side_stream()
+        self.side = torch.cuda.ExternalStream(self._side_raw, device=self.dev) if self.lag else None
         self._pend = None              # (buffer set, step) whose matcher has not been issued yet
         self._ev_side = {}             # buffer set -> event behind its matcher on the side stream
         self.streams = [torch.cuda.current_stream(self.dev)] + [torch.cuda.Stream(self.dev) for _ in range(self.S - 1)]
@@ -49,6 +87,7 @@ class FrontEnd:
         self.cap = None
         self.ring = None
         self._ring_args = (max(nbuf, self.S), world, gather, gather_via_host)
+        self._hs = None                # host-streaming state (enable_host_streaming)
 
     def upload(self, left, right=None):
         """left / right: uint8 [B, h, w] host arrays -> HBM (slots [0,B) left, [B,2B) right); plans every handle."""
@@ -99,12 +138,99 @@ class FrontEnd:
             with torch.cuda.stream(self.side):
                 self.ring.publish(j, step)
 
+    # ---- end to end from host memory (src/ros_stereo.cc:133, src/Frame.cc:78-81: the reference receives its images on the host)
+    def enable_host_streaming(self, nimgbuf=3):
+        """Frames arrive in PINNED host memory and results leave to pinned host memory, both by asynchronous copies on their own
+        streams, overlapped with the kernels of other batches:
+            submit(i, left, right)   batch i: one hipMemcpyAsync host -> HBM on the upload stream into image buffer i % nimgbuf
+            step(i)                  the usual step; its kernels (and the pyramid built ahead for it) wait for that upload only
+            fetch(i)                 results of step i -> pinned host arrays on the download stream (call it after step(i + 1) has
+                                     been issued when the pipelined matcher is on: that is when step i's matcher is in the queue)
+            wait(i)                  host blocks until fetch(i) has landed; returns the pinned arrays
+        Three image buffers: the upload of batch i + 2 must not wait for the pyramid of batch i (two buffers would chain the copy
+        engine - the bottleneck, 60 MB per 64 stereo frames - to the compute queue).  Call after upload() (plans, result ring)."""
+        assert self.ring is not None and self.S == 1
+        hs = type("HostStream", (), {})()
+        hs.n = nimgbuf
+        hs.d = [torch.empty((self.nimg, self.h, self.w), dtype=torch.uint8, device=self.dev) for _ in range(nimgbuf)]
+        hs.side = torch.cuda.ExternalStream(self._side_raw, device=self.dev)
+        hs.up = independent_stream(self.dev, [self.streams[0], hs.side])            # copies must not queue behind kernels
+        hs.down = independent_stream(self.dev, [self.streams[0], hs.side, hs.up])
+        hs.ev_up = [None] * nimgbuf          # upload of the batch in buffer k complete
+        hs.ev_free = [None] * nimgbuf        # pyramid of the batch in buffer k built: the buffer may be overwritten
+        r, nb = self.ring, self.ring.nbuf
+        pin = lambda t: torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        hs.out = [{k: pin(getattr(r, k)[j]) for k in ("kps", "desc", "cnt", "ur", "dp", "nm")} for j in range(nb)]
+        hs.ev_out = [None] * nb
+        hs.ev_main = [None] * nb             # step's own kernels on the caller's stream done (buffer set j)
+        self.d_sets = hs.d
+        self._hs = hs
+        return self
+
+    def submit(self, i, left, right=None):
+        """left / right: pinned uint8 tensors [B, h, w] (torch.Tensor.pin_memory()) holding batch i."""
+        hs, B = self._hs, self.B
+        k = i % hs.n
+        if hs.ev_free[k] is not None:
+            hs.up.wait_event(hs.ev_free[k])
+        with torch.cuda.stream(hs.up):
+            hs.d[k][:B].copy_(left, non_blocking=True)
+            if self.stereo:
+                hs.d[k][B:].copy_(right, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(hs.up)
+        ev._batch = i
+        hs.ev_up[k] = ev
+
+    def fetch(self, i):
+        hs, r = self._hs, self.ring
+        j = i % r.nbuf
+        if self.lag:
+            if self._pend is not None and self._pend[0] == j:
+                self._flush()
+            ev = self._ev_side.get(j)
+            if ev is not None:
+                hs.down.wait_event(ev)
+        hs.down.wait_event(hs.ev_main[j])
+        with torch.cuda.stream(hs.down):
+            for k in ("cnt", "kps", "desc", "ur", "dp", "nm"):
+                if k in ("ur", "dp", "nm") and not self.stereo:
+                    continue
+                hs.out[j][k].copy_(getattr(r, k)[j], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(hs.down)
+        hs.ev_out[j] = ev
+
+    def wait(self, i):
+        hs = self._hs
+        j = i % self.ring.nbuf
+        hs.ev_out[j].synchronize()
+        return hs.out[j]
+
+    def host_results(self, i):
+        """wait(i) in the shape of results(): per-image (keypoints, descriptors) + per-frame (uright, depth, nmatch)."""
+        o = self.wait(i)
+        cnt = o["cnt"].numpy()
+        kps = o["kps"].numpy().view(np.uint8).reshape(self.nimg, self.cap, 28)
+        desc = o["desc"].numpy()
+        imgs = [(np.frombuffer(kps[b, :int(cnt[b])].tobytes(), KP_DTYPE).copy(), desc[b, :int(cnt[b])].copy()) for b in range(self.nimg)]
+        frames = []
+        if self.stereo:
+            ur, dp, nm = o["ur"].numpy(), o["dp"].numpy(), o["nm"].numpy()
+            frames = [(ur[b, :int(cnt[b])].copy(), dp[b, :int(cnt[b])].copy(), int(nm[b])) for b in range(self.B)]
+        return imgs, frames
+
     def step(self, i, ev_before_match=None, ev_after_match=None):
         r = self.ring
         j = r.acquire(i)
         exi, stream = self.exs[i % self.S], self.streams[i % self.S]
         st = stream.cuda_stream
         B, cap, w, h = self.B, self.cap, self.w, self.h
+        hs = self._hs
+        if hs is not None:
+            stream.wait_event(hs.ev_up[i % hs.n])            # this batch is in HBM (long since, when its pyramid was built ahead)
+            if hs.ev_out[j] is not None:
+                stream.wait_event(hs.ev_out[j])              # the results this buffer set held have left for the host
         lag = self.lag and self.prefetch and ev_before_match is None
         if not lag:
             self._flush() if self.lag else None
@@ -112,6 +238,16 @@ class FrontEnd:
             stream.wait_event(self._ev_side.pop(j))     # the matcher that last wrote buffer set j (nbuf steps ago) is long done
         exi.extract_batch_device(self._imgs(i), self.nimg, w, h, w, w * h, r.kps[j].data_ptr(), r.desc[j].data_ptr(),
                                  r.cnt[j].data_ptr(), cap, st)
+        if hs is not None:
+            k = i % hs.n
+            if getattr(hs.ev_free[k], "_batch", None) != i:     # pyramid not built ahead: the buffer is free behind this extraction
+                fr = torch.cuda.Event()
+                fr.record(stream)
+                fr._batch = i
+                hs.ev_free[k] = fr
+            if lag:                                              # keypoints / descriptors / counts of step i (its matcher: _ev_side)
+                hs.ev_main[j] = torch.cuda.Event()
+                hs.ev_main[j].record(stream)
         if lag:
             sd = self.side.cuda_stream
             if self._pend is not None:
@@ -122,12 +258,12 @@ class FrontEnd:
                 ev = torch.cuda.Event()
                 ev.record(self.side)
                 self._ev_side[pj] = ev
-            exi.prefetch_batch_device(self._imgs(i + self.S), self.nimg, w, h, w, w * h, sd)   # behind the matcher: it reads that buffer
+            self._prefetch_next(exi, i, self.side)          # behind the matcher: it reads that buffer
             self._pend = (j, i)
             return j
         if self.prefetch:
             # the next step of this handle reads the same resident images: its pyramid starts behind this step's FAST stage
-            exi.prefetch_batch_device(self._imgs(i + self.S), self.nimg, w, h, w, w * h)
+            self._prefetch_next(exi, i, hs.side if hs is not None else None)
         if self.stereo:
             if ev_before_match is not None:
                 ev_before_match.record(stream)
@@ -137,7 +273,29 @@ class FrontEnd:
         if r.gather:
             with torch.cuda.stream(stream):     # pack + collective are ordered behind this step's kernels
                 r.publish(j, i)
+        if hs is not None:
+            hs.ev_main[j] = torch.cuda.Event()
+            hs.ev_main[j].record(stream)
         return j
+
+    def _prefetch_next(self, exi, i, side):
+        """Pyramid of step i + S built ahead on `side` (None: the handle's own side stream).  Host streaming: only once that batch
+        has been submitted (its upload is then waited for on the side stream) - and the buffer is marked free behind the pyramid."""
+        hs = self._hs
+        sd = side.cuda_stream if side is not None else None
+        if hs is None:
+            exi.prefetch_batch_device(self._imgs(i + self.S), self.nimg, self.w, self.h, self.w, self.w * self.h, sd)
+            return
+        k = (i + 1) % hs.n
+        ev = hs.ev_up[k]
+        if ev is None or getattr(ev, "_batch", None) != i + 1:
+            return                       # batch i + 1 has not been submitted yet: its own step builds the pyramid
+        side.wait_event(ev)
+        exi.prefetch_batch_device(self._imgs(i + 1), self.nimg, self.w, self.h, self.w, self.w * self.h, sd)
+        fr = torch.cuda.Event()
+        fr.record(side)
+        fr._batch = i + 1
+        hs.ev_free[k] = fr
 
     def drain(self):
         if self.lag:

@@ -99,6 +99,51 @@ def test_bench_step_rotating_batches(mode):
     assert not bad, "\n".join(bad[:20])
 
 
+@pytest.mark.parametrize("mode", ["pipelined", "pyramid_ahead_only", "plain"])
+def test_host_streaming_rotating_batches(mode):
+    """End to end from host memory (FrontEnd.enable_host_streaming): THREE different batches in pinned host memory arrive by
+    asynchronous copies on an upload stream into three image buffers while other batches compute, results leave on a download
+    stream; eight steps without a host synchronisation until the last results are waited for.  Every result still in the pinned
+    host arrays at the end (steps 5, 6, 7) must equal the oracle of ITS batch: an upload that overtook the pyramid still reading
+    its buffer, a pyramid built ahead of its upload, or a download that left before the (lagged) matcher would show."""
+    import torch
+    pl, ref = _pipeline(), _ref()
+    w, h, nf, B, nsets, steps = 752, 480, 600, 6, 3, 8
+    fe = pl.FrontEnd(w, h, nf, True, B, prefetch=(mode != "plain"), lag_stereo=(mode == "pipelined"))
+    exps = [ref.run_pool(ref.stereo_frame, [(w, h, nf, 1700 + 50 * s + i, fe.mbf, fe.mb) for i in range(B)]) for s in range(nsets)]
+    fe.upload(np.stack([e["left"] for e in exps[0]]), np.stack([e["right"] for e in exps[0]]))
+    fe.enable_host_streaming()
+    src = [(torch.from_numpy(np.stack([e["left"] for e in ex])).pin_memory(), torch.from_numpy(np.stack([e["right"] for e in ex])).pin_memory())
+           for ex in exps]
+    x = torch.randn((4096, 4096), device="cuda")
+    for _ in range(4):                     # park the compute stream: everything below is queued before the first kernel runs
+        x = (x @ x) * 1e-4
+    fe.submit(0, *src[0])
+    fe.submit(1, *src[1])
+    for i in range(steps):
+        fe.step(i)
+        if i >= 1:
+            fe.fetch(i - 1)
+        if i + 2 < steps:
+            fe.submit(i + 2, *src[(i + 2) % nsets])
+    fe.fetch(steps - 1)
+    bad = []
+    for i in range(steps - fe.ring.nbuf, steps):
+        exp = exps[i % nsets]
+        imgs, frames = fe.host_results(i)
+        for b in range(B):
+            e = exp[b]
+            for side, k, d, gi in (("left", e["kl"], e["dl"], b), ("right", e["kr"], e["dr"], B + b)):
+                m = ref.image_mismatch(imgs[gi][0], imgs[gi][1], k, d)
+                if m:
+                    bad.append("step %d frame %d %s: %s" % (i, b, side, m))
+            m = ref.stereo_mismatch(frames[b], e)
+            if m:
+                bad.append("step %d frame %d stereo: %s" % (i, b, m))
+    fe.drain()
+    assert not bad, "\n".join(bad[:20])
+
+
 @pytest.mark.parametrize("chunks", [2, 3, 4])
 def test_batch_chunking_does_not_change_results(chunks):
     """Developer knob 8 cuts a batch into chunks whose kernels overlap on the handle's side streams (measured slower than one

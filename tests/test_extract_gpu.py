@@ -660,3 +660,38 @@ def test_split_call_level_groups(pkg, oracle, synth, split):
                 np.testing.assert_array_equal(dd[b, :n], od[:n])
     finally:
         pkg.lib().orbx_debug_set(15, 0)
+
+
+@pytest.mark.parametrize("kind", ["natural", "dense", "flat_with_one_blob"])
+@pytest.mark.parametrize("mode", [2, 0, 1], ids=["pretest_forced", "pretest_by_density", "pretest_off"])
+def test_fast_row_pretest_is_exact(pkg, oracle, synth, kind, mode):
+    """k_fast_strips' early-out for corner-sparse levels: a five-pixel upper bound of the score decides per row of 128 pixels
+    whether the score is computed at all (developer knob 16: 2 = every level pre-tested, 1 = never, 0 = by the candidate density
+    the previous call found).  FAST candidates per level (order included), keypoints and descriptors must equal the oracle's on
+    corner-sparse scenes, on the dense benchmark frames (where nearly every row passes the pre-test) and on an image whose rows are
+    mostly skipped; the second call on a handle is the one that sees the first call's verdicts."""
+    w, h, nf = 1241, 376, 1000
+    if kind == "natural":
+        img = synth.natural(w, h, 7)
+    elif kind == "dense":
+        img = synth.frame(w, h, 7)
+    else:
+        img = np.full((h, w), 90, np.uint8)
+        img[150:230, 500:640] = synth.frame(140, 80, 3)
+    orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    ok, od = orc.extract(img)
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    pkg.lib().orbx_debug_set(6, 3)       # the strip kernel for a single image
+    pkg.lib().orbx_debug_set(16, mode)
+    try:
+        for rep in range(3):
+            gk, gd = ex(img)
+            for l in range(8):
+                np.testing.assert_array_equal(ex.debug_level_points(l, 0), _cands(orc.level_candidates(l)),
+                                              err_msg="FAST candidates level %d call %d" % (l, rep))
+            assert len(gk) == len(ok)
+            np.testing.assert_array_equal(gk[["x", "y", "response", "octave"]], ok[["x", "y", "response", "octave"]])
+            np.testing.assert_array_equal(gd, od)
+    finally:
+        pkg.lib().orbx_debug_set(6, 0)
+        pkg.lib().orbx_debug_set(16, 0)
