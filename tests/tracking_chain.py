@@ -277,23 +277,38 @@ class GpuDeviceBackend(GpuHostBackend):
                               "nm": torch.zeros(1, dtype=torch.int32, device="cuda")})
         self.d_imgs = torch.zeros((2, h, w), dtype=torch.uint8, device="cuda")
         self.h_imgs = torch.zeros((2, h, w), dtype=torch.uint8).pin_memory()
+        # the frame's results come down as ONE packed record (orbx_pack_records_device: keypoints | descriptors | mvuRight | mvDepth |
+        # count) in one copy into pinned memory and one synchronisation (five separate torch copies cost 0.12 ms of a 0.37-ms frame)
+        batching = importlib.import_module(PKG + ".batching")
+        self.rb = batching.record_bytes(self.cap)
+        self.d_rec = torch.zeros((1, self.rb), dtype=torch.uint8, device="cuda")
+        self.h_rec = torch.zeros((1, self.rb), dtype=torch.uint8).pin_memory()
         self.i = 0
 
     def frame(self, left, right, mbf, mb):
+        """left / right: numpy arrays, or PINNED torch tensors (then uploaded without the staging memcpy)."""
         torch, pkg, s = self.torch, self.pkg, self.sets[self.i & 1]
         self.i += 1
-        self.h_imgs[0].copy_(torch.from_numpy(left)); self.h_imgs[1].copy_(torch.from_numpy(right))
-        self.d_imgs.copy_(self.h_imgs, non_blocking=True)
+        if isinstance(left, torch.Tensor):
+            self.d_imgs[0].copy_(left, non_blocking=True); self.d_imgs[1].copy_(right, non_blocking=True)
+        else:
+            self.h_imgs[0].copy_(torch.from_numpy(left)); self.h_imgs[1].copy_(torch.from_numpy(right))
+            self.d_imgs.copy_(self.h_imgs, non_blocking=True)
         w, h, cap = self.w, self.h, self.cap
         self.ex.extract_batch_device(self.d_imgs.data_ptr(), 2, w, h, w, w * h, s["kps"].data_ptr(), s["desc"].data_ptr(),
                                      s["cnt"].data_ptr(), cap, self.stream)
         pkg.stereo_batch_device(self.ex, self.ex, 1, 0, 1, s["kps"].data_ptr(), s["desc"].data_ptr(), s["cnt"].data_ptr(),
                                 s["kps"][1:].data_ptr(), s["desc"][1:].data_ptr(), s["cnt"][1:].data_ptr(), cap, mbf, mb,
                                 s["ur"].data_ptr(), s["dp"].data_ptr(), s["nm"].data_ptr(), self.stream)
-        n = int(s["cnt"][0])
-        k = np.frombuffer(s["kps"][0, :n].cpu().numpy().tobytes(), pkg.KP_DTYPE).copy()
-        return {"k": k, "d": s["desc"][0, :n].cpu().numpy(), "uright": s["ur"][0, :n].cpu().numpy(), "depth": s["dp"][0, :n].cpu().numpy(),
-                "set": s, "n": n}
+        pkg.pack_records_device(s["kps"].data_ptr(), s["desc"].data_ptr(), s["ur"].data_ptr(), s["dp"].data_ptr(), s["cnt"].data_ptr(),
+                                1, cap, self.d_rec.data_ptr(), self.stream)
+        self.h_rec.copy_(self.d_rec, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        r = self.h_rec.numpy()[0]
+        n = int(r[68 * cap:68 * cap + 4].view(np.int32)[0])
+        k = np.frombuffer(r[:28 * n].tobytes(), pkg.KP_DTYPE)
+        return {"k": k, "d": r[28 * cap:28 * cap + 32 * n].reshape(n, 32).copy(), "uright": r[60 * cap:60 * cap + 4 * n].view(np.float32).copy(),
+                "depth": r[64 * cap:64 * cap + 4 * n].view(np.float32).copy(), "set": s, "n": n}
 
     def search_frame(self, f, flast, Tc, Tl, lp, cur_mp, th):
         s, sl = f["set"], flast["set"]

@@ -14,15 +14,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import tracking_chain as tc   # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""          # "device": the device-resident chain alone (profiler runs)
 w, h, nf, step = 1241, 376, 2000, 0.04
 synth = importlib.import_module(tc.PKG + ".synth")
 frames, _ = synth.stereo_sequence(w, h, T, k=11, step=step)
 Ts = tc.poses(T, step)
 res = {}
-for B in (tc.GpuHostBackend, tc.GpuDeviceBackend):
+for B in ((tc.GpuDeviceBackend,) if ONLY == "device" else (tc.GpuHostBackend, tc.GpuDeviceBackend)):
     c = tc.Chain(B(w, h, nf), w, h, nf)
+    src = frames
+    if B is tc.GpuDeviceBackend:      # the device-resident chain takes its frames from pinned host memory (a capture buffer)
+        import torch
+        src = [(torch.from_numpy(l).pin_memory(), torch.from_numpy(r).pin_memory()) for l, r in frames]
     for t in range(T):
-        c.step(frames[t][0], frames[t][1], Ts[t])
+        c.step(src[t][0], src[t][1], Ts[t])
     log = c.log[5:]
     ms = lambda key: 1e3 * float(np.median([s[key] for s in log]))
     res[c.be.name] = c.log
@@ -31,4 +36,5 @@ for B in (tc.GpuHostBackend, tc.GpuDeviceBackend):
           % (c.be.name, w, h, nf, len(log), ms("t_frame"), ms("t_proj"), ms("t_local"), ms("t_frame") + ms("t_proj") + ms("t_local"),
              1e3 / (ms("t_frame") + ms("t_proj") + ms("t_local")), int(np.median([s["proj_n"] for s in log])),
              int(np.median([s["local_n"] for s in log]))))
-print("chains identical:", tc.first_difference(res["gpu-host"], res["gpu-device"]) is None)
+if not ONLY:
+    print("chains identical:", tc.first_difference(res["gpu-host"], res["gpu-device"]) is None)
