@@ -196,6 +196,30 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     unsigned bigMask = 0;
     int maxTw = 0, maxTh = 0;
     int kpBound = 0;
+    // Depth cap of the quad-tree count / best-key pyramids: the largest that fits the LDS budget of k_octree_pyr (a level that
+    // needs more depth than its pyramid has is redone by the exact form inside the same workgroup, so the cap costs speed only)
+    int pyrCellCap = 16384;
+    for (;; pyrCellCap >>= 2) {
+        int mNodeCap = 0, mPyr = 0, mBest = 0, mPath = 0;
+        for (int l = 0; l < h->nlevels; l++) {
+            const int lw = cv_round((float)w * h->isf[l]), lh = cv_round((float)hgt * h->isf[l]);
+            const int rW = lw - 2 * ORBX_MINB, rH = lh - 2 * ORBX_MINB;
+            if (rW < 30 || rH < 30) break;   // reported below
+            const int nIni = std::min(std::max((int)roundf((float)rW / rH), 1), ORBX_MAX_ROOTS), N = h->nfeat[l];
+            int d = 1;
+            while ((nIni << (2 * d)) < 4 * std::max(N, 1) && d < 7) d++;
+            while ((nIni << (2 * d)) > pyrCellCap && d > 1) d--;
+            mNodeCap = std::max(mNodeCap, std::max(N + 3, 4 * nIni) + 4 * nIni + 1);
+            mPyr = std::max(mPyr, nIni * (((1 << (2 * d)) - 1) / 3) + ((nIni << (2 * d)) + 1) / 2 + 1);
+            mBest = std::max(mBest, nIni * (((1 << (2 * (d + 1))) - 1) / 3));
+            mPath = std::max(mPath, rW + rH);
+        }
+        int p2 = 1;
+        while (p2 < mNodeCap) p2 <<= 1;
+        const size_t need = sizeof(unsigned long long) * p2 + (size_t)mNodeCap * (8 + 8 + 16 + 4 + 2 + 1) + 4 * (size_t)mPyr + 2 * (size_t)mPath +
+                            4 * (size_t)mBest + 64 + 8;
+        if (need <= 150 * 1024 || pyrCellCap <= 64) break;
+    }
     for (int l = 0; l < h->nlevels; l++) {
         LevelGeom &g = h->geom[l];
         memset(&g, 0, sizeof(g));
@@ -247,7 +271,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
         {   // depth of the count pyramid: enough cells for the passes of a dense level, bounded by LDS
             int d = 1;
             while ((g.nIni << (2 * d)) < 4 * std::max(g.N, 1) && d < 7) d++;
-            while ((g.nIni << (2 * d)) > 16384 && d > 1) d--;
+            while ((g.nIni << (2 * d)) > pyrCellCap && d > 1) d--;   // (cell codes must fit 16 bits: <= 16384; less when LDS is short)
             g.pyrDepth = d;
             const int words = g.nIni * (((1 << (2 * d)) - 1) / 3) + ((g.nIni << (2 * d)) + 1) / 2 + 1;
             maxPyrWords = std::max(maxPyrWords, words);

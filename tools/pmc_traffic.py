@@ -31,7 +31,9 @@ def per_kernel(d, counter):
 
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
-res = {"workload": "kitti_stereo_1241x376_1000feat", "batch": 64, "images_per_launch": 128,
+import os
+res = {"workload": os.environ.get("PMC_WORKLOAD", "kitti_stereo_1241x376_1000feat"), "batch": int(os.environ.get("PMC_BATCH", "64")),
+       "images_per_launch": int(os.environ.get("PMC_IMAGES", "128")),
        "note": "rocprofv3 --pmc, separate passes; FETCH_SIZE doubled per the gfx950 correction", "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     f, nf = fetch.get(k, (0.0, 0))

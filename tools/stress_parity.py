@@ -1,7 +1,8 @@
 """Randomised parity stress: python tools/stress_parity.py [N] [seed] — GPU extractor vs CPU oracle on
 random sizes / budgets / thresholds / image statistics (not part of the pytest suite).  Every configuration runs three times:
 the default kernel choice of a single image (k_fast_cells, one-workgroup quad-tree), the strip FAST kernel forced (developer
-knob 6 = 3), and strips + the multi-workgroup quad-tree on every level (knob 4 = 2)."""
+knob 6 = 3), strips + the multi-workgroup quad-tree on every level (knob 4 = 2), and strips with the row pre-test of corner-sparse
+levels forced on every level (knob 16 = 2)."""
 import sys, os, importlib, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -56,11 +57,14 @@ for it in range(N):
     except RuntimeError:
         continue
     ex = pkg.ORBextractor(nf, sf, nl, ini, mn)
-    for variant, knobs in (("default", ()), ("strips", ((6, 3),)), ("strips+multi-wg quad-tree", ((6, 3), (4, 2)))):
+    for variant, knobs in (("default", ()), ("strips", ((6, 3),)), ("strips+multi-wg quad-tree", ((6, 3), (4, 2))),
+                           ("strips+row pre-test", ((6, 3), (16, 2)))):
         for k, v in knobs:
             pkg.lib().orbx_debug_set(k, v)
         try:
             gk, gd = ex(img)
+            if variant.endswith("pre-test"):
+                gk, gd = ex(img)     # the second call runs under the verdicts the first one left (every level pre-tested)
         finally:
             for k, v in knobs:
                 pkg.lib().orbx_debug_set(k, 0)
