@@ -5,7 +5,7 @@ set -e
 out=$GRAFT_REPO_ROOT/gpurun_out
 cd $GRAFT_REPO_ROOT
 python3 bench.py > $out/r03_bench.json 2> $out/r03_bench.err
-PMC=1 SQ=1 PMC_WORKLOAD=kitti_stereo_1241x376_1000feat PMC_BATCH=64 PMC_IMAGES=128 bash tools/profile_workload.sh r03 --workload kitti_stereo_1241x376_1000feat
+PMC=1 SQ=1 PMC_WORKLOAD=kitti_stereo_1241x376_1000feat PMC_BATCH=64 PMC_IMAGES=128 bash tools/profile_workload.sh r03_headline --workload kitti_stereo_1241x376_1000feat
 PMC=1 SQ=1 PMC_WORKLOAD=kitti_stereo_1241x376_2000feat PMC_BATCH=64 PMC_IMAGES=128 bash tools/profile_workload.sh r03_kitti2000 --workload kitti_stereo_1241x376_2000feat
 PMC=1 SQ=1 PMC_WORKLOAD=mono_1920x1080_4000feat PMC_BATCH=64 PMC_IMAGES=64 bash tools/profile_workload.sh r03_fullhd --workload mono_1920x1080_4000feat --batch 64
 echo done
