@@ -224,6 +224,25 @@ def measure(fe, steps, warmup, ramp, world, dist, dev, torch):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     fast_ms = float(ex.stage_ms()[0][1])            # FAST stage, averaged over the K timed steps
+    # a short K (the driver's command: 20 steps = 13 ms) is one sample of a noisy quantity: the same loop once more over >= 100 steps,
+    # reported beside `value` as `long_run` (never as `value`: the contract times exactly K steps)
+    long_run = None
+    if steps < 100 and world == 1:
+        kk = 100
+        ex.set_profiling(0)
+        for i in range(kk // 5):
+            fe.step(i)
+        fe.drain()
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        for i in range(kk):
+            fe.step(i)
+        fe.drain()
+        torch.cuda.synchronize()
+        long_run = (kk, time.perf_counter() - tl)
+        for i in range(warmup + steps - fe.ring.nbuf, warmup + steps):   # the buffer sets hold the last timed steps' results again
+            fe.step(i)
+        fe.drain()
     last = fe.results((warmup + steps - 1) % fe.ring.nbuf)   # outputs of the LAST TIMED step (host copies), checked later
     gath = None
     if fe.ring.gather:                              # ... and what the all-gather of that step delivered (every rank's records)
@@ -244,7 +263,7 @@ def measure(fe, steps, warmup, ramp, world, dist, dev, torch):
     fe.prefetch = pf
     match_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)])) if fe.stereo else 0.0
     return {"dt": dt, "fast_ms": fast_ms, "stage_ms": stage_ms, "ncalls": ncalls, "match_ms": match_ms, "last": last,
-            "nprof": nprof, "gathered": gath}
+            "nprof": nprof, "gathered": gath, "long_run": long_run}
 
 
 def measure_end_to_end(fe, left, right, steps, warmup, torch):
@@ -584,6 +603,10 @@ def main():
                        "world_size_observed": world_seen, "ranks": ranks,
                        "avg_keypoints_per_image": round(navg, 1)},
             "roofline": roof,
+            "long_run": None if m.get("long_run") is None else {
+                "steps": m["long_run"][0], "value": round(B * m["long_run"][0] / m["long_run"][1], 2), "unit": "frames/s",
+                "ms_per_step": round(m["long_run"][1] / m["long_run"][0] * 1e3, 4),
+                "note": "the same loop over 100 steps right after the timed region (K < 100 is a short sample); informational, not `value`"},
             "stage_ms_per_call": {"pyramid": round(float(stage_ms[0]), 4), "fast": round(float(stage_ms[1]), 4),
                                   "quadtree": round(float(stage_ms[2]), 4), "describe": round(float(stage_ms[3]), 4),
                                   "extract_total": round(float(stage_ms[4]), 4), "stereo_match": round(m["match_ms"], 4),
