@@ -111,10 +111,12 @@ extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int i
         ORBX_HIP(hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming));
     }
     for (int i = 0; i < ORBX_MAX_CHUNKS; i++) ORBX_HIP(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming));
-    ORBX_HIP(hipEventCreateWithFlags(&h->evFastDone, hipEventDisableTiming));
+    // evFastDone orders the side stream's kernels behind FAST for SPEED only (they touch nothing FAST reads or writes): no memory fence
+    // is needed when it fires.  Developer knob 17 = 1 keeps the default (system-scope) fence.
+    ORBX_HIP(hipEventCreateWithFlags(&h->evFastDone, hipEventDisableTiming | (g_debug[17] == 1 ? 0u : hipEventDisableSystemFence)));
     ORBX_HIP(hipEventCreateWithFlags(&h->evGather, hipEventDisableTiming));
     ORBX_HIP(hipEventCreateWithFlags(&h->evOctA, hipEventDisableTiming));
-    ORBX_HIP(hipEventCreateWithFlags(&h->evPrefetch, hipEventDisableTiming));
+    ORBX_HIP(hipEventCreateWithFlags(&h->evPrefetch, hipEventDisableTiming | (g_debug[17] == 1 ? 0u : hipEventDisableSystemFence)));   // consumer: a kernel of the same device
     for (int r = 0; r < ORBX_EV_RING; r++)
         // timing-only events: no system-scope fence (cache write-back + invalidate) when they complete — with the default
         // flags every stage boundary of a profiled batch cost ~5 us of idle GPU, which the step time then contained
