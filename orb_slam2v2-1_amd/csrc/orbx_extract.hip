@@ -202,7 +202,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     // needs more depth than its pyramid has is redone by the exact form inside the same workgroup, so the cap costs speed only)
     int pyrCellCap = 16384;
     for (;; pyrCellCap >>= 2) {
-        int mNodeCap = 0, mPyr = 0, mBest = 0, mPath = 0;
+        int mNodeCap = 0, mPyr = 0, mBest = 0, mPath = 0, mCells = 0;
         for (int l = 0; l < h->nlevels; l++) {
             const int lw = cv_round((float)w * h->isf[l]), lh = cv_round((float)hgt * h->isf[l]);
             const int rW = lw - 2 * ORBX_MINB, rH = lh - 2 * ORBX_MINB;
@@ -215,11 +215,12 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
             mPyr = std::max(mPyr, nIni * (((1 << (2 * d)) - 1) / 3) + ((nIni << (2 * d)) + 1) / 2 + 1);
             mBest = std::max(mBest, nIni * (((1 << (2 * (d + 1))) - 1) / 3));
             mPath = std::max(mPath, rW + rH);
+            mCells = std::max(mCells, (int)((float)rW / 30) * (int)((float)rH / 30));
         }
         int p2 = 1;
         while (p2 < mNodeCap) p2 <<= 1;
         const size_t need = sizeof(unsigned long long) * p2 + (size_t)mNodeCap * (8 + 8 + 16 + 4 + 2 + 1) + 4 * (size_t)mPyr + 2 * (size_t)mPath +
-                            4 * (size_t)mBest + 64 + 8;
+                            4 * (size_t)mBest + 4 * (size_t)(mCells + 1) + 64 + 8;
         if (need <= 150 * 1024 || pyrCellCap <= 64) break;
     }
     for (int l = 0; l < h->nlevels; l++) {
@@ -452,7 +453,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
         h->octPyrWords = maxPyrWords;
         int maxPath = 0;   // the level's path tables ride in LDS (k_octree_pyr / k_octree_big)
         for (int l = 0; l < h->nlevels; l++) maxPath = std::max(maxPath, h->geom[l].regW + h->geom[l].regH);
-        h->octPyrLdsBytes = sizeof(unsigned long long) * pow2 + (size_t)maxNodeCap * (8 + 8 + 16 + 4 + 2 + 1) + 4 * (size_t)maxPyrWords + 2 * (size_t)maxPath + 4 * (size_t)maxBestWords + 64 + 8;
+        h->octPyrLdsBytes = sizeof(unsigned long long) * pow2 + (size_t)maxNodeCap * (8 + 8 + 16 + 4 + 2 + 1) + 4 * (size_t)maxPyrWords + 2 * (size_t)maxPath + 4 * (size_t)maxBestWords + 4 * (size_t)(maxCells + 1) + 64 + 8;
         if (h->octPyrLdsBytes > 150 * 1024) { orbx_set_error("quad-tree pyramid needs %zu B of LDS", h->octPyrLdsBytes); return ORBX_ERR_UNSUPPORTED; }
         if (bytes > 150 * 1024) {
             orbx_set_error("quad-tree needs %zu B of LDS (features per level %d): unsupported", bytes, maxNodeCap);
@@ -465,7 +466,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     ORBX_HIP(hipMalloc(&h->d_pyr, h->pyrImgBytes * Bz));
     ORBX_HIP(hipMalloc(&h->d_cellCnt, sizeof(uint32_t) * h->totalCells * Bz));
     ORBX_HIP(hipMalloc(&h->d_cellRaw, sizeof(uint32_t) * h->totalCells * Bz));
-    ORBX_HIP(hipMalloc(&h->d_slots, sizeof(uint32_t) * h->slotsPerImg * Bz));
+    ORBX_HIP(hipMalloc(&h->d_slots, sizeof(uint32_t) * (h->slotsPerImg * Bz + 64)));   // + 64: the 16-byte list reads of k_octree_pyr may run past the last cell's block
     ORBX_HIP(hipMalloc(&h->d_cand, sizeof(uint32_t) * h->keysPerImg * Bz));
     ORBX_HIP(hipMalloc(&h->d_nodeOf, sizeof(uint16_t) * h->keysPerImg * Bz));
     ORBX_HIP(hipMalloc(&h->d_candCnt, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
@@ -694,12 +695,24 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
         int maxCells = 0;
         for (int l = 0; l < nl; l++) maxCells = std::max(maxCells, h->geom[l].ncells);
         const int scratch = std::max(4 * h->maxNodeCap, maxCells + 1);
-        hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
-                           dim3(256), 0, st, h->d_geom, nl, h->totalCells, v.cellCnt, v.cellRaw, v.slots,
-                           h->slotsPerImg, v.cand, h->keysPerImg, v.candCnt, h->ini_th, h->min_th, cb, v.sparse,
-                           g_debug[16] == 2 ? 1 << 20 : ORBX_SPARSE_PER_CELL);
         // developer knob 4: 0 default, 1 = the exact form alone, 2 = EVERY level by the multi-workgroup form, 3 = none
         const bool usePyr = g_debug[4] != 1;
+        const int sparsePerCell = g_debug[16] == 2 ? 1 << 20 : ORBX_SPARSE_PER_CELL;
+        // Fused: k_octree_pyr reads the FAST stage's cell lists in place (no k_gather launch, no compacted key array: -35 us per
+        // 128 images 1241x376, -200 us per 64 images 1920x1080 in the pipelined step).  Not for the multi-workgroup form, the exact
+        // form alone and the phase-stop knobs, which sweep the compacted array (developer knob 18 = 1: never fused).
+        const bool multiWg = g_debug[4] == 2 || (g_debug[4] != 3 && B <= 4 && h->octBigMask != 0);
+        const bool fused = usePyr && !multiWg && g_debug[7] == 0 && g_debug[1] == 0 && g_debug[18] != 1;
+        OctSrc osrc = {};
+        if (fused) {
+            osrc.cellCnt = v.cellCnt; osrc.cellRaw = v.cellRaw; osrc.slots = v.slots; osrc.slotsPerImg = h->slotsPerImg;
+            osrc.totalCells = h->totalCells; osrc.iniTh = h->ini_th; osrc.minTh = h->min_th; osrc.candCntOut = v.candCnt;
+            osrc.sparseFlag = v.sparse; osrc.sparsePerCell = sparsePerCell; osrc.candOut = v.cand;
+            h->candStale = std::max(h->candStale, v.b0 + B);
+        } else
+            hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
+                               dim3(256), 0, st, h->d_geom, nl, h->totalCells, v.cellCnt, v.cellRaw, v.slots,
+                               h->slotsPerImg, v.cand, h->keysPerImg, v.candCnt, h->ini_th, h->min_th, cb, v.sparse, sparsePerCell);
         // developer knob 15: a >= 2 = split call at level a (default 0: one launch sequence)
         aSplit = (usePyr && !prof && h->lastChunks == 1 && B >= 8 && g_debug[7] == 0 && g_debug[1] == 0 && g_debug[15] >= 2 &&
                   !(g_debug[4] == 2 || (g_debug[4] != 3 && B <= 4 && h->octBigMask)) && h->d_dbgBlur == nullptr)
@@ -763,15 +776,15 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
                 ORBX_HIP(hipStreamWaitEvent(s2, h->evGather, 0));
                 ORBX_OCT_LAUNCH_ON(s2, k_octree_pyr, k_octree_pyr_wide, dim3(B, aSplit), lds, h->d_geom, nl, v.cand,
                                    h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
-                                   pow2, h->octPyrWords, v.octFallback, 0, v.nodeOf, scratch, 0, 0u, 0);
+                                   pow2, h->octPyrWords, v.octFallback, 0, v.nodeOf, scratch, 0, 0u, 0, osrc);
                 ORBX_HIP(hipEventRecord(h->evOctA, s2));
                 ORBX_OCT_LAUNCH(k_octree_pyr, k_octree_pyr_wide, dim3(B, nl - aSplit), lds, h->d_geom, nl, v.cand,
                                 h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
-                                pow2, h->octPyrWords, v.octFallback, 0, v.nodeOf, scratch, 0, 0u, aSplit);
+                                pow2, h->octPyrWords, v.octFallback, 0, v.nodeOf, scratch, 0, 0u, aSplit, osrc);
             } else {   // no large level (or a phase-stop knob is set): one workgroup per level, one launch
                 ORBX_OCT_LAUNCH(k_octree_pyr, k_octree_pyr_wide, dim3(B, nl), lds, h->d_geom, nl, v.cand,
                                 h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
-                                pow2, h->octPyrWords, v.octFallback, g_debug[7], v.nodeOf, scratch, g_debug[1], 0u, 0);
+                                pow2, h->octPyrWords, v.octFallback, g_debug[7], v.nodeOf, scratch, g_debug[1], 0u, 0, osrc);
             }
         } else {        // developer knob 4 = 1: the exact form alone
             const bool wide = g_debug[11] == 0 ? h->octBigMask != 0 : g_debug[11] == 2;
@@ -843,6 +856,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
     // latency-bound gather / quad-tree do not shrink with the chunk and the pyramid slows the FAST it overlaps by as much as it gains).
     const int nch = chunk_count(B, prof, skipPyr);
     h->lastChunks = nch;
+    h->candStale = 0;
     h->prevPyrValid = skipPyr ? 1 : 0;   // d_pyr is overwritten unless this call took a pyramid built ahead (then d_pyrAlt keeps the previous one)
     h->framesStale = (!pyramid_fused_all(h) && h->nlevels > 1) ? B : 0;   // frames of levels >= 1: written on demand (ensure_frames)
     int b0 = 0;
@@ -1137,6 +1151,21 @@ extern "C" int orbx_pyramid_host(orbx_extractor_t *h, int b, int level, int padd
     return ORBX_OK;
 }
 
+// the compacted key arrays of the last call, when k_octree_pyr read the cell lists in place: gathered now, for the test hooks
+static int ensure_cand(orbx_extractor *h) {
+    if (h->candStale <= 0) return ORBX_OK;
+    const int nl = h->nlevels, B = h->candStale;
+    CellBases cb;
+    for (int l = 0; l <= ORBX_MAX_LEVELS; l++) cb.v[l] = l < nl ? h->geom[l].cellBase : h->totalCells;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B), dim3(256), 0, h->last_stream,
+                       h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_cellRaw, h->d_slots, h->slotsPerImg, h->d_cand, h->keysPerImg,
+                       h->d_candCnt, h->ini_th, h->min_th, cb, (int32_t *)nullptr, 0);
+    ORBX_HIP(hipGetLastError());
+    h->candStale = 0;
+    return ORBX_OK;
+}
+
 extern "C" int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, int stage, int32_t *out, int cap,
                                        int *n_out) {
     if (!h || !n_out || level < 0 || level >= h->nlevels || h->pw == 0 || b < 0 || b >= h->pB || stage < 0 || stage > 1) {
@@ -1144,6 +1173,7 @@ extern "C" int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, in
         return ORBX_ERR_ARG;
     }
     ORBX_HIP(hipSetDevice(h->device));
+    if (stage == 0) { const int rc = ensure_cand(h); if (rc) return rc; }
     if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));
     const LevelGeom &g = h->geom[level];
     int32_t n = 0;

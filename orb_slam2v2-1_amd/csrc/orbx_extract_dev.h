@@ -104,10 +104,20 @@ struct OctBig {   // multi-workgroup quad-tree of large levels (orbx_octree.hip)
     int levelOf[ORBX_MAX_LEVELS];
 };
 #define OCT_BIG_K 8   // workgroups sharing one large level
+// Key source of k_octree_pyr when no k_gather ran (slots != NULL): the FAST stage's per-cell lists, read in place
+struct OctSrc {
+    const uint32_t *cellCnt, *cellRaw, *slots;
+    size_t slotsPerImg;
+    int totalCells, iniTh, minTh;
+    int32_t *candCntOut;     // kept keys per (image, level): what k_gather would have written
+    int32_t *sparseFlag;     // verdict for the next call's FAST stage (may be NULL)
+    int sparsePerCell;
+    uint32_t *candOut;       // compacted keys, written only by a level that falls back to the exact form
+};
 __global__ void k_octree_pyr(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
                              uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
                              int pyrWords, int32_t *fallback, int dbgStop, uint16_t *nodeOf, int scratchInts, int dbgStopExact,
-                             unsigned bigMask, int l0);                                                          // orbx_octree.hip
+                             unsigned bigMask, int l0, OctSrc src);                                              // orbx_octree.hip
 template <int MODE>
 __global__ void k_octree_big(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
                              uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
@@ -118,7 +128,7 @@ __global__ void k_octree(const LevelGeom *geom, int nlevels, const uint32_t *can
 __global__ void k_octree_pyr_wide(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
                                   uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
                                   int pyrWords, int32_t *fallback, int dbgStop, uint16_t *nodeOf, int scratchInts, int dbgStopExact,
-                                  unsigned bigMask, int l0);                                                     // orbx_octree_wide.hip
+                                  unsigned bigMask, int l0, OctSrc src);                                         // orbx_octree_wide.hip
 template <int MODE>
 __global__ void k_octree_big_wide(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
                                   uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,

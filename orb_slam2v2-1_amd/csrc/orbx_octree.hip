@@ -149,7 +149,7 @@ __device__ __forceinline__ void octree_pyr_body(
     const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand, size_t keysPerImg,
     const int32_t *__restrict__ candCnt, uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
     const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback, int dbgStop,
-    uint16_t *__restrict__ nodeOf, int scratchInts, int dbgStopExact, int l, int b, int slice, int bigIdx, const OctBig &big) {
+    uint16_t *__restrict__ nodeOf, int scratchInts, int dbgStopExact, int l, int b, int slice, int bigIdx, const OctBig &big, const OctSrc &src) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x;
     const LevelGeom g = geom[l];
@@ -165,8 +165,11 @@ __device__ __forceinline__ void octree_pyr_body(
     uint8_t *split = sp; sp += capMax;
     __shared__ int sh_L, sh_Lnew, sh_finish, sh_phase, sh_abort, sh_last;
 
+    // FUSED (MODE 0 with src.slots): the keys come straight from the FAST stage's per-cell lists - no k_gather launch, no compacted
+    // key array (k_gather materialises it on demand for the test hooks; a level that falls back to the exact form gathers itself)
+    const bool fused = MODE == 0 && src.slots != nullptr;   // uniform
     const uint32_t *keys = cand + (size_t)b * keysPerImg + g.keyOff;
-    const int n = candCnt[b * nlevels + l];
+    const int n = fused ? 0 : candCnt[b * nlevels + l];
     // the level's path tables (regW + regH words, x then y) are staged into LDS: a sweep iteration then waits for ONE global
     // latency (its keys, requested an iteration ahead) instead of two dependent ones (keys, then tables)
     // (16-bit entries: a cell code at depth Dm is below nIni << 2 Dm <= 16384, ensure_plan caps Dm accordingly)
@@ -183,6 +186,11 @@ __device__ __forceinline__ void octree_pyr_body(
     // list - a cell (depth, code) - reads its keypoint straight from here.  No leaf map, no second sweep over the keys.
     constexpr bool CB = MODE == 0;
     uint32_t *bestP = (uint32_t *)(pathL + ((nPath + 1) & ~1));   // [nIni * (4^(Dm+1) - 1) / 3], depth d at nIni * (4^d - 1) / 3 like the counts
+    int *cellOff = (int *)(bestP + (uint32_t)nIni * (((1u << (2 * (Dm + 1))) - 1u) / 3u));   // fused: [ncells + 1] first raw index of every FAST cell
+    __shared__ int sh_kept, wsumF[OCT_T / 64 + 1];
+    const uint32_t *fCnt = fused ? src.cellCnt + (size_t)b * src.totalCells + g.cellBase : nullptr;
+    const uint32_t *fRaw = fused ? src.cellRaw + (size_t)b * src.totalCells + g.cellBase : nullptr;
+    const uint32_t *fSlots = fused ? src.slots + (size_t)b * src.slotsPerImg + g.slotOff : nullptr;
 
     // this workgroup's share of the keys (MODE 0: all of them), in whole groups of four
     const int iLo = MODE == 0 ? 0 : (int)(((long long)n * slice / big.K) & ~3ll);
@@ -197,6 +205,66 @@ __device__ __forceinline__ void octree_pyr_body(
     if (CB) for (int i = tid; i < (nIni << (2 * Dm)); i += OCT_T) bestP[offDeep + i] = 0;
     if (tid == 0) sh_abort = 0;
     __syncthreads();
+    if (fused) {
+        // raw list lengths -> first raw index of every cell (the tie-break index of a key is its position in the concatenated RAW
+        // lists: same relative order as in vToDistributeKeys, which only drops entries); kept keys of the level for the records
+        if (tid == 0) sh_kept = 0;
+        __syncthreads();
+        int kept = 0;
+        for (int i = tid; i < g.ncells; i += OCT_T) { cellOff[i] = (int)(fRaw[i] & 0x7FFFFFFFu); kept += (int)fCnt[i]; }
+        kept = wave_total_i32(kept);
+        if ((tid & 63) == 0 && kept) atomicAdd(&sh_kept, kept);
+        __syncthreads();
+        const int rawTotal = array_scan_excl(cellOff, g.ncells, wsumF);
+        if (tid == 0) {
+            cellOff[g.ncells] = rawTotal;
+            src.candCntOut[b * nlevels + l] = sh_kept;
+            if (src.sparseFlag) src.sparseFlag[b * nlevels + l] = sh_kept < src.sparsePerCell * g.ncells ? 1 : 0;   // verdict for the next call's FAST
+        }
+        __syncthreads();
+        // one sweep over the cell lists: 16 lanes per cell, a lane owns four CONSECUTIVE entries (one 16-byte load; a cell's slot block
+        // is capc = 1 KB apart), so the run merging below works as on the compacted array; the next round's entries are in flight
+        constexpr int CPR = OCT_T / 16;
+        const int sub = tid & 15, cgrp = tid >> 4, capc = g.capc;
+        auto fetch = [&](int cell, uint4 &e, uint32_t &rw) {
+            const int cc = min(cell, g.ncells - 1);
+            rw = fRaw[cc];
+            e = *(const uint4 *)(fSlots + (size_t)cc * capc + 4 * sub);
+        };
+        uint4 en; uint32_t rwn;
+        fetch(cgrp, en, rwn);
+        for (int c0 = 0; c0 < g.ncells; c0 += CPR) {
+            const int cell = c0 + cgrp;
+            uint4 e = en; const uint32_t rw = rwn;
+            fetch(c0 + CPR + cgrp, en, rwn);
+            const int nraw = cell < g.ncells ? (int)(rw & 0x7FFFFFFFu) : 0;
+            const uint32_t thr = (rw >> 31) ? (uint32_t)src.iniTh : (uint32_t)src.minTh;
+            const int base = cellOff[min(cell, g.ncells)];
+            for (int j0 = 0; j0 < nraw; j0 += 64) {   // (wave-divergent trip count only for cells with more than 64 raw entries)
+                if (j0 > 0) e = *(const uint4 *)(fSlots + (size_t)cell * capc + j0 + 4 * sub);
+                const uint32_t key[4] = {e.x, e.y, e.z, e.w};
+                uint32_t c[4], inc[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + 4 * sub + u;
+                    const bool ok = j < nraw && (key[u] >> 24) >= thr;
+                    const uint32_t kk = j < nraw ? key[u] : 0u;
+                    c[u] = (uint32_t)xPath[kk & 0xFFF] | (uint32_t)yPath[(kk >> 12) & 0xFFF];
+                    inc[u] = ok ? 1u : 0u;
+                    bv[u] = ((kk >> 24) << 24) | (0xFFFFFFu - (uint32_t)(base + j));
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++)
+                    if (c[u] == c[u + 1]) { inc[u + 1] += inc[u]; bv[u + 1] = inc[u] ? (inc[u + 1] > inc[u] ? max(bv[u], bv[u + 1]) : bv[u]) : bv[u + 1]; inc[u] = 0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (inc[u]) {
+                        atomicAdd(&pyr[offDeep + (c[u] >> 1)], inc[u] << (16 * (c[u] & 1)));
+                        atomicMax(&bestP[offDeep + c[u]], bv[u]);
+                    }
+            }
+        }
+    } else {
     uint32_t nkey[4];
     if (iLo + 4 * tid < iHi) load_keys4(keys, iLo + 4 * tid, n, nkey);
     for (int i0 = iLo + 4 * tid; i0 < iHi; i0 += 4 * OCT_T) {
@@ -224,6 +292,7 @@ __device__ __forceinline__ void octree_pyr_body(
                 if (CB) atomicMax(&bestP[offDeep + c[u]], bv[u]);
             }
     }
+    }   // !fused
     __syncthreads();
     if (MODE == 1) {   // partial histogram -> global; the last workgroup to arrive carries on with the sum of all K
         const int deepWords = ((nIni << (2 * Dm)) + 1) >> 1;
@@ -437,6 +506,36 @@ __device__ __forceinline__ void octree_pyr_body(
         if (sh_abort) {   // counts deeper than the pyramid are needed: this block redoes its level with the exact form (same LDS, carved anew)
             if (tid == 0) { fallback[b * nlevels + l] = 1; if (MODE == 1) bstate[2] = -1; }   // (a record: tests look at it; MODE 2 skips the level)
             __syncthreads();
+            if (fused) {   // the exact form sweeps the compacted keys: this block gathers its level (what k_gather does for a whole batch)
+                uint32_t *dstBase = src.candOut + (size_t)b * keysPerImg + g.keyOff;
+                for (int i = tid; i < g.ncells; i += OCT_T) cellOff[i] = (int)fCnt[i];
+                __syncthreads();
+                array_scan_excl(cellOff, g.ncells, wsumF);
+                const int sub = tid & 15, gshift = tid & 48;
+                for (int c0 = 0; c0 < g.ncells; c0 += OCT_T / 16) {
+                    const int cell = c0 + (tid >> 4);
+                    const bool live = cell < g.ncells;
+                    const uint32_t rw = live ? fRaw[cell] : 0u;
+                    const int nraw = (int)(rw & 0x7FFFFFFFu);
+                    const uint32_t thr = (rw >> 31) ? (uint32_t)src.iniTh : (uint32_t)src.minTh;
+                    const uint32_t *sp2 = fSlots + (size_t)min(cell, g.ncells - 1) * g.capc;
+                    uint32_t *dst = dstBase + (live ? cellOff[cell] : 0);
+                    int keptc = 0;
+                    const int rounds = (g.capc + 63) / 64;   // uniform bound (the ballots need every lane; entries past a list are masked)
+                    for (int r = 0; r < rounds; r++) {
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; k4++) {
+                            const int j = 64 * r + sub + 16 * k4;
+                            const uint32_t v4 = j < nraw ? sp2[j] : 0u;
+                            const bool keep = j < nraw && (v4 >> 24) >= thr;
+                            const uint32_t m = (uint32_t)(__ballot(keep) >> gshift) & 0xFFFFu;
+                            if (keep) dst[keptc + __popc(m & ((1u << sub) - 1u))] = v4;
+                            keptc += __popc(m);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
             octree_exact_level(geom, nlevels, cand, nodeOf, keysPerImg, candCnt, lvlKp, lvlKpCap, lvlCnt, tab, capMax, pow2cap, scratchInts,
                                dbgStopExact, l, b);
             return;
@@ -456,7 +555,16 @@ __device__ __forceinline__ void octree_pyr_body(
         for (int k = tid; k < Lout; k += OCT_T) {
             const int d = (int)(nid[k] >> 28);
             const uint32_t v = bestP[(uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u) + (nid[k] & 0x0FFFFFFFu)];
-            okp[k] = keys[0xFFFFFFu - (v & 0xFFFFFFu)];
+            const int idx = (int)(0xFFFFFFu - (v & 0xFFFFFFu));
+            if (fused) {   // raw index -> (cell, position): the last cell whose first raw index is <= idx
+                int lo = 0, hi = g.ncells;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (cellOff[mid] <= idx) lo = mid; else hi = mid;
+                }
+                okp[k] = fSlots[(size_t)lo * g.capc + (idx - cellOff[lo])];
+            } else
+                okp[k] = keys[idx];
         }
         if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; fallback[b * nlevels + l] = 0; }
         return;
@@ -559,7 +667,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
     const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand, size_t keysPerImg,
     const int32_t *__restrict__ candCnt, uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
     const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback, int dbgStop,
-    uint16_t *__restrict__ nodeOf, int scratchInts, int dbgStopExact, unsigned bigMask, int l0) {
+    uint16_t *__restrict__ nodeOf, int scratchInts, int dbgStopExact, unsigned bigMask, int l0, OctSrc src) {
     const int l = l0 + (int)blockIdx.y, b = blockIdx.x;  // level-major: large levels start first (l0: first level of a group launch)
     if ((bigMask >> l) & 1u) return;             // shared by several workgroups: k_octree_big
     // A level is ONE workgroup walking a serial chain: when other kernels share its CU (the pyramid built ahead, the stereo
@@ -567,7 +675,7 @@ __global__ __launch_bounds__(OCT_T) void k_octree_pyr(
     __builtin_amdgcn_s_setprio(3);
     OctBig none = {};
     octree_pyr_body<0>(geom, nlevels, cand, keysPerImg, candCnt, lvlKp, lvlKpCap, lvlCnt, tab, capMax, pow2cap, pyrWords, fallback, dbgStop,
-                       nodeOf, scratchInts, dbgStopExact, l, b, 0, 0, none);
+                       nodeOf, scratchInts, dbgStopExact, l, b, 0, 0, none, src);
 }
 template <int MODE>
 __global__ __launch_bounds__(OCT_T) void k_octree_big(
@@ -580,13 +688,15 @@ __global__ __launch_bounds__(OCT_T) void k_octree_big(
         // the first launch also carries the levels that one workgroup handles alone (grid y = nBig .. nlevels-1, slice 0 only):
         // they run beside the large levels' histograms and passes instead of in a launch of their own
         if (slice != 0) return;
+        OctSrc nosrc = {};
         octree_pyr_body<0>(geom, nlevels, cand, keysPerImg, candCnt, lvlKp, lvlKpCap, lvlCnt, tab, capMax, pow2cap, pyrWords, fallback, 0,
-                           nodeOf, scratchInts, 0, big.levelOf[blockIdx.y], b, 0, 0, big);
+                           nodeOf, scratchInts, 0, big.levelOf[blockIdx.y], b, 0, 0, big, nosrc);
         return;
     }
     const int bigIdx = blockIdx.y;
+    OctSrc nosrc2 = {};
     octree_pyr_body<MODE>(geom, nlevels, cand, keysPerImg, candCnt, lvlKp, lvlKpCap, lvlCnt, tab, capMax, pow2cap, pyrWords, fallback, 0,
-                          nodeOf, scratchInts, 0, big.levelOf[bigIdx], b, slice, bigIdx, big);
+                          nodeOf, scratchInts, 0, big.levelOf[bigIdx], b, slice, bigIdx, big, nosrc2);
 }
 template __global__ void k_octree_big<1>(const LevelGeom *, int, const uint32_t *, size_t, const int32_t *, uint32_t *, int, int32_t *,
                                          const int32_t *, int, int, int, int32_t *, uint16_t *, int, OctBig);

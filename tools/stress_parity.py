@@ -58,7 +58,7 @@ for it in range(N):
         continue
     ex = pkg.ORBextractor(nf, sf, nl, ini, mn)
     for variant, knobs in (("default", ()), ("strips", ((6, 3),)), ("strips+multi-wg quad-tree", ((6, 3), (4, 2))),
-                           ("strips+row pre-test", ((6, 3), (16, 2)))):
+                           ("strips+row pre-test", ((6, 3), (16, 2))), ("k_gather + compacted keys", ((18, 1),))):
         for k, v in knobs:
             pkg.lib().orbx_debug_set(k, v)
         try:
