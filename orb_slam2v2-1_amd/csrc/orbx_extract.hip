@@ -655,6 +655,30 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     // (seen as 0.30 instead of 0.27 ms in one run out of four).  An empty kernel orders the stamp behind the wait.
     if (profFast && skipPyr && g_debug[12] == 0) hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, st);
     if (profFast) ORBX_HIP(hipEventRecord(ev[1], st));
+    // decisions of the quad-tree stage that the FAST stage needs to know
+    // developer knob 4: 0 default, 1 = the exact form alone, 2 = EVERY level by the multi-workgroup form, 3 = none
+    const bool usePyr = g_debug[4] != 1;
+    const bool multiWg = g_debug[4] == 2 || (g_debug[4] != 3 && B <= 4 && h->octBigMask != 0);
+    // Fused: k_octree_pyr reads the FAST stage's cell lists in place (no k_gather launch, no compacted key array: -35 us per
+    // 128 images 1241x376, -200 us per 64 images 1920x1080 in the pipelined step).  Not for the multi-workgroup form, the exact
+    // form alone and the phase-stop knobs, which sweep the compacted array (developer knob 18 = 1: never fused).
+    const bool fused = usePyr && !multiWg && g_debug[7] == 0 && g_debug[1] == 0 && g_debug[18] != 1;
+    const int sparsePerCell = g_debug[16] == 2 ? 1 << 20 : ORBX_SPARSE_PER_CELL;
+    OctSrc osrc = {};
+    if (fused) {
+        osrc.cellCnt = v.cellCnt; osrc.cellRaw = v.cellRaw; osrc.slots = v.slots; osrc.slotsPerImg = h->slotsPerImg;
+        osrc.totalCells = h->totalCells; osrc.iniTh = h->ini_th; osrc.minTh = h->min_th; osrc.candCntOut = v.candCnt;
+        osrc.sparseFlag = v.sparse; osrc.sparsePerCell = sparsePerCell; osrc.candOut = v.cand;
+        h->candStale = std::max(h->candStale, v.b0 + B);
+    }
+    int pow2 = 1;
+    while (pow2 < h->maxNodeCap) pow2 <<= 1;
+    int maxCellsL = 0;
+    for (int l = 0; l < nl; l++) maxCellsL = std::max(maxCellsL, h->geom[l].ncells);
+    const int scratch = std::max(4 * h->maxNodeCap, maxCellsL + 1);
+    const size_t ldsOct = std::max(h->octPyrLdsBytes, h->octLdsBytes);
+    const bool wideOct = g_debug[11] == 0 ? h->octBigMask != 0 : g_debug[11] == 2;
+    int earlyLv = 0;   // > 0: the strips of the levels [0, earlyLv) are launched first and their quad-tree starts beside the FAST of the rest
     {   // K2
         // developer knob 6: 1 = every level by k_fast_cells (compile-time tile strides), 2 = ... with run-time strides
         // a strip is a longer job than a cell (a wave walks ~33 rows): with few images the one-wave-per-cell kernel finishes
@@ -664,10 +688,42 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
         if (strips) {
             StripBases sb;
             for (int l = 0; l <= ORBX_MAX_LEVELS; l++) sb.v[l] = h->stripBase[l];
-            hipLaunchKernelGGL(k_fast_strips, dim3((h->totalStrips + FAST_WAVES - 1) / FAST_WAVES, B), dim3(64 * FAST_WAVES), 0, st,
-                               v.pyr, h->pyrImgBytes, h->d_geom, nl, h->totalStrips, h->totalCells, v.cellCnt, v.cellRaw,
-                               v.slots, h->slotsPerImg, h->ini_th, h->min_th, sb,
-                               g_debug[16] == 1 ? (const int32_t *)nullptr : v.sparse);   // developer knob 16: 1 = never pre-test, 2 = always
+            const int32_t *spf = g_debug[16] == 1 ? (const int32_t *)nullptr : v.sparse;   // developer knob 16: 1 = never pre-test, 2 = always
+            // Early quad-tree (developer knob 19: a >= 2 = levels [0, a); default 0 = off): the quad-tree of the large levels is ONE
+            // workgroup per level walking a serial chain - the critical path behind FAST.  Their strips go first, in a launch of their
+            // own, and their quad-tree starts on a second stream as soon as that launch is done, beside the FAST of the remaining
+            // levels.  Parity-tested and MEASURED SLOWER at every size (64 stereo frames 1241x376: 0.635 -> 0.649 ms per step with
+            // a = 2, 0.657 with a = 3; 2000 features 0.838 -> 0.874; 1920x1080 x 64 1.254 -> 1.274; 752x480 0.599 -> 0.607): FAST loses to
+            // the quad-tree workgroups what the shorter chain behind it gains, plus two cross-stream events.  Off by default.
+            const int ea = g_debug[19];
+            if (fused && !prof && g_debug[19] >= 2 && g_debug[15] < 2 && h->lastChunks == 1 && B >= 8 && nl > ea &&
+                (h->stripLevels & ((1u << ea) - 1u)) == (1u << ea) - 1u && h->d_dbgBlur == nullptr)
+                earlyLv = ea;
+            const int sA = earlyLv ? h->stripBase[earlyLv] : 0;
+            if (earlyLv) {
+                hipLaunchKernelGGL(k_fast_strips, dim3((sA + FAST_WAVES - 1) / FAST_WAVES, B), dim3(64 * FAST_WAVES), 0, st,
+                                   v.pyr, h->pyrImgBytes, h->d_geom, nl, sA, h->totalCells, v.cellCnt, v.cellRaw,
+                                   v.slots, h->slotsPerImg, h->ini_th, h->min_th, sb, spf, 0);
+                hipStream_t s2 = h->side[1];
+                ORBX_HIP(hipEventRecord(h->evGather, st));
+                ORBX_HIP(hipStreamWaitEvent(s2, h->evGather, 0));
+                if (wideOct) {
+                    ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_pyr_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsOct));
+                    hipLaunchKernelGGL(k_octree_pyr_wide, dim3(B, earlyLv), dim3(OCT_T_WIDE), ldsOct, s2, h->d_geom, nl, v.cand, h->keysPerImg, v.candCnt,
+                                       v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords, v.octFallback, 0, v.nodeOf,
+                                       scratch, 0, 0u, 0, osrc);
+                } else {
+                    ORBX_HIP(hipFuncSetAttribute((const void *)k_octree_pyr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsOct));
+                    hipLaunchKernelGGL(k_octree_pyr, dim3(B, earlyLv), dim3(OCT_T), ldsOct, s2, h->d_geom, nl, v.cand, h->keysPerImg, v.candCnt,
+                                       v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords, v.octFallback, 0, v.nodeOf,
+                                       scratch, 0, 0u, 0, osrc);
+                }
+                ORBX_HIP(hipEventRecord(h->evOctA, s2));
+            }
+            if (h->totalStrips > sA)
+                hipLaunchKernelGGL(k_fast_strips, dim3((h->totalStrips - sA + FAST_WAVES - 1) / FAST_WAVES, B), dim3(64 * FAST_WAVES), 0, st,
+                                   v.pyr, h->pyrImgBytes, h->d_geom, nl, h->totalStrips, h->totalCells, v.cellCnt, v.cellRaw,
+                                   v.slots, h->slotsPerImg, h->ini_th, h->min_th, sb, spf, sA);
         }
         if (stripLevels != (1u << nl) - 1u) {   // levels with wider cells (the coarsest ones of small images)
             dim3 grid((h->totalCells + FAST_WAVES - 1) / FAST_WAVES, B);
@@ -690,32 +746,13 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     const bool gate = h->pfUsed && evPyrDone == nullptr;   // a pyramid built ahead starts behind this FAST stage (knob 10: 1 behind the quad-tree, 2 behind the descriptors)
     if (gate && g_debug[10] == 0) ORBX_HIP(hipEventRecord(h->evFastDone, st));
     {   // K3
-        int pow2 = 1;
-        while (pow2 < h->maxNodeCap) pow2 <<= 1;
-        int maxCells = 0;
-        for (int l = 0; l < nl; l++) maxCells = std::max(maxCells, h->geom[l].ncells);
-        const int scratch = std::max(4 * h->maxNodeCap, maxCells + 1);
-        // developer knob 4: 0 default, 1 = the exact form alone, 2 = EVERY level by the multi-workgroup form, 3 = none
-        const bool usePyr = g_debug[4] != 1;
-        const int sparsePerCell = g_debug[16] == 2 ? 1 << 20 : ORBX_SPARSE_PER_CELL;
-        // Fused: k_octree_pyr reads the FAST stage's cell lists in place (no k_gather launch, no compacted key array: -35 us per
-        // 128 images 1241x376, -200 us per 64 images 1920x1080 in the pipelined step).  Not for the multi-workgroup form, the exact
-        // form alone and the phase-stop knobs, which sweep the compacted array (developer knob 18 = 1: never fused).
-        const bool multiWg = g_debug[4] == 2 || (g_debug[4] != 3 && B <= 4 && h->octBigMask != 0);
-        const bool fused = usePyr && !multiWg && g_debug[7] == 0 && g_debug[1] == 0 && g_debug[18] != 1;
-        OctSrc osrc = {};
-        if (fused) {
-            osrc.cellCnt = v.cellCnt; osrc.cellRaw = v.cellRaw; osrc.slots = v.slots; osrc.slotsPerImg = h->slotsPerImg;
-            osrc.totalCells = h->totalCells; osrc.iniTh = h->ini_th; osrc.minTh = h->min_th; osrc.candCntOut = v.candCnt;
-            osrc.sparseFlag = v.sparse; osrc.sparsePerCell = sparsePerCell; osrc.candOut = v.cand;
-            h->candStale = std::max(h->candStale, v.b0 + B);
-        } else
+        if (!fused)
             hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
                                dim3(256), 0, st, h->d_geom, nl, h->totalCells, v.cellCnt, v.cellRaw, v.slots,
                                h->slotsPerImg, v.cand, h->keysPerImg, v.candCnt, h->ini_th, h->min_th, cb, v.sparse, sparsePerCell);
         // developer knob 15: a >= 2 = split call at level a (default 0: one launch sequence)
         aSplit = (usePyr && !prof && h->lastChunks == 1 && B >= 8 && g_debug[7] == 0 && g_debug[1] == 0 && g_debug[15] >= 2 &&
-                  !(g_debug[4] == 2 || (g_debug[4] != 3 && B <= 4 && h->octBigMask)) && h->d_dbgBlur == nullptr)
+                  !multiWg && h->d_dbgBlur == nullptr)
                      ? std::min(g_debug[15], nl - 1) : 0;   // (default: no split - measured slower)
         if (nl < 3) aSplit = 0;
         if (aSplit > 0) {   // scratch records of the levels [a, nl)
@@ -766,6 +803,12 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
                 ORBX_OCT_LAUNCH(k_octree_big<2>, k_octree_big_wide<2>, dim3(OCT_BIG_K, big.nBig, B), lds, h->d_geom, nl, v.cand, h->keysPerImg,
                                 v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2, h->octPyrWords,
                                 v.octFallback, v.nodeOf, scratch, big);
+            } else if (earlyLv > 0) {
+                // the quad-tree of the levels [0, earlyLv) is already running on the second stream (started behind their strips)
+                ORBX_OCT_LAUNCH(k_octree_pyr, k_octree_pyr_wide, dim3(B, nl - earlyLv), lds, h->d_geom, nl, v.cand,
+                                h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
+                                pow2, h->octPyrWords, v.octFallback, 0, v.nodeOf, scratch, 0, 0u, earlyLv, osrc);
+                ORBX_HIP(hipStreamWaitEvent(st, h->evOctA, 0));
             } else if (aSplit > 0) {
                 // Split call: the quad-tree of the large levels [0, a) - one workgroup per level walking a serial chain, the critical
                 // path of this stage - moves to a second stream, and the small levels [a, nl) go ahead on the caller's stream:

@@ -89,7 +89,7 @@ __global__ void k_pyr_pad(const uint8_t *img, int sstride, size_t simg, uint8_t 
 struct StripBases { int v[ORBX_MAX_LEVELS + 1]; };   // first strip of every level (levels with cells wider than 32 px own none)
 __global__ void k_fast_strips(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalStrips, int totalCells,
                               uint32_t *cellCnt, uint32_t *cellRaw, uint32_t *slots, size_t slotsPerImg, int iniTh, int minTh,
-                              StripBases sb, const int32_t *sparseFlag);                                                                    // orbx_fast.hip
+                              StripBases sb, const int32_t *sparseFlag, int strip0);                                                                    // orbx_fast.hip
 template <int ES_T>
 __global__ void k_fast_cells(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalCells,
                              uint32_t *cellCnt, uint32_t *cellRaw, uint32_t *slots, size_t slotsPerImg, int iniTh, int minTh, int ESrt,

@@ -334,13 +334,13 @@ __device__ __forceinline__ uint32_t dpp_row_shl1(uint32_t v) { return (uint32_t)
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels, int totalStrips,
     int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ cellRaw, uint32_t *__restrict__ slots, size_t slotsPerImg,
-    int iniTh, int minTh, StripBases sb, const int32_t *__restrict__ sparseFlag) {
+    int iniTh, int minTh, StripBases sb, const int32_t *__restrict__ sparseFlag, int strip0) {
     __shared__ __align__(16) uint32_t smem[FAST_WAVES * STRIP_SLOTS * STRIP_ES];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int bx, b;
     xcd_block_map(bx, b);
-    const int strip = bx * FAST_WAVES + wave;
-    if (strip >= totalStrips) return;   // wave-uniform; no block barrier in this kernel
+    const int strip = strip0 + bx * FAST_WAVES + wave;   // strip0: first strip of this launch (a call may launch the large levels' strips first)
+    if (strip >= totalStrips) return;   // wave-uniform; no block barrier in this kernel (totalStrips: end of this launch's range)
     int l = 0;
 #pragma unroll
     for (int i = 1; i < ORBX_MAX_LEVELS; i++) l += (i < nlevels && strip >= sb.v[i]) ? 1 : 0;

@@ -695,3 +695,50 @@ def test_fast_row_pretest_is_exact(pkg, oracle, synth, kind, mode):
     finally:
         pkg.lib().orbx_debug_set(6, 0)
         pkg.lib().orbx_debug_set(16, 0)
+
+
+@pytest.mark.parametrize("early", [0, 2, 3, 5])
+def test_early_quadtree_of_large_levels(pkg, oracle, synth, early):
+    """A batch that fills the GPU launches the strips of the levels [0, a) first and starts their quad-tree on a second stream beside
+    the FAST of the other levels (developer knob 19: 0 = off - the default, it measured slower - a >= 2 = on).  Same keypoints, order and descriptors - also for
+    natural (corner-sparse) frames whose levels fall back to the exact form inside the early launch, and on repeated calls."""
+    import torch
+    w, h, nf, B = 752, 480, 900, 10
+    imgs = np.stack([synth.frame(w, h, 90 + b) if b % 2 == 0 else synth.natural(w, h, 90 + b) for b in range(B)])
+    orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    exp = [orc.extract(imgs[b]) for b in range(B)]
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    ex(imgs[0])
+    cap = ex.max_keypoints()
+    d_imgs = torch.from_numpy(imgs).cuda()
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    pkg.lib().orbx_debug_set(19, early)
+    pkg.lib().orbx_debug_set(6, 3)          # strips for this small batch
+    try:
+        for rep in range(3):
+            ex.extract_batch_device(d_imgs.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)
+        torch.cuda.synchronize()
+        k = kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+        dd = desc.cpu().numpy()
+        for b in range(B):
+            ok, od = exp[b]
+            n = int(cnt[b])
+            assert n == len(ok), (early, b, n, len(ok))
+            got = np.frombuffer(k[b, :n].tobytes(), pkg.KP_DTYPE)
+            for f in ("x", "y", "size", "response", "octave", "class_id"):
+                np.testing.assert_array_equal(got[f], ok[f], err_msg="%s image %d" % (f, b))
+            np.testing.assert_array_equal(dd[b, :n], od)
+        for l in (0, 1, 4):                     # the compacted candidates are materialised on demand (k_gather) and still right
+            np.testing.assert_array_equal(ex.debug_level_points(l, 0, b=3), _cands_of(oracle, imgs[3], nf, l))
+    finally:
+        pkg.lib().orbx_debug_set(19, 0)
+        pkg.lib().orbx_debug_set(6, 0)
+
+
+def _cands_of(oracle, img, nf, l):
+    o = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    o.extract(img)
+    return _cands(o.level_candidates(l))
