@@ -376,7 +376,13 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  * key 7: stop k_octree_pyr after phase n; key 8: n >= 2 cuts a batch into n chunks (at most 4) whose kernels
  * overlap on the handle's side streams (measured: no gain, default one chunk); key 9: ignore pyramids built ahead; key 11: quad-tree kernels in
  * the 1024-thread build never (1) / always (2) instead of by image size; key 12: 1 = no ordering kernel in front of the FAST
- * stage's start event).
+ * stage's start event; keys 13 / 14: form of the Gaussian blur (orbx_debug_blurred_level below); key 15: a >= 2 = split call, the
+ * quad-tree of levels [0, a) on a second stream beside quad-tree + descriptors of the others; key 16: row pre-test of corner-sparse
+ * levels in k_fast_strips never (1) / on every level (2) instead of by the previous call's candidate density; key 17: 1 = the
+ * intra-device events keep their system-scope fence (read at orbx_create); key 18: 1 = k_gather + compacted key arrays instead of
+ * the quad-tree reading the FAST cell lists in place; key 19: a >= 2 = the strips of levels [0, a) launched first and their
+ * quad-tree started beside the FAST of the others.  Keys 13-19 select alternatives with identical results; 15 and 19 measured
+ * slower and are off by default, 18 = 1 is the round-2 path).
  * Never set in production: keys 0, 1 and 7 leave outputs incomplete; 2, 4, 5, 6 select an alternative
  * kernel with identical results (tests use them to cover those kernels). */
 int orbx_debug_set(int key, int value);
