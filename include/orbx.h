@@ -197,6 +197,15 @@ int orbm_stereo_batch_device_prev(orbx_extractor_t *hl, orbx_extractor_t *hr, in
                              const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
                              int cap, float mbf, float mb, float *d_uright, float *d_depth,
                              int32_t *d_nmatch, void *stream);
+/* One stereo frame, host to host, in ONE call: the stereo Frame constructor's ExtractORB(left) || ExtractORB(right) followed by
+ * ComputeStereoMatches (src/Frame.cc:78-84, 481-655).  Both images are extracted as one batch of two on h (a second extractor handle
+ * is not needed), matched on the device and everything comes down behind one synchronisation.  kl / dl / uright / depth: left
+ * keypoints, descriptors, mvuRight, mvDepth (cap entries each); kr / dr: right keypoints and descriptors; *nl, *nr, *nmatch counts.
+ * More than cap keypoints: clamped, ORBX_ERR_CAPACITY.  Empty image: ORBX_OK with zero counts.  Synchronous. */
+int orbx_stereo_frame(orbx_extractor_t *h, const uint8_t *left, const uint8_t *right, int w, int hgt, int stride,
+                      float mbf, float mb, int cap, orbx_keypoint_t *kl, uint8_t *dl, int *nl, orbx_keypoint_t *kr,
+                      uint8_t *dr, int *nr, float *uright, float *depth, int *nmatch);
+
 /* Host-buffer convenience for one frame (synchronous); pyramids come from hl / hr, which
  * must have just extracted the left / right image (image slot 0). */
 int orbm_stereo(orbx_extractor_t *hl, orbx_extractor_t *hr,

@@ -43,7 +43,7 @@ EXPORTS = [
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
     "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch", "orbx_debug_sincosf",
     "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels", "orbx_extract_batch_device_prefetch", "orbx_stream_wait_fast_stage", "orbx_side_stream", "orbm_stereo_batch_device_prev", "orbx_debug_blur_patches", "orbm_debug_features_in_area",
-    "orbx_debug_blurred_level", "orbx_side_stream_for",
+    "orbx_debug_blurred_level", "orbx_side_stream_for", "orbx_stereo_frame",
 ]
 
 
@@ -130,6 +130,8 @@ def lib():
     L.orbx_stream_wait_fast_stage.argtypes = [vp, vp]
     L.orbx_side_stream.argtypes = [vp]
     L.orbx_side_stream.restype = vp
+    L.orbx_stereo_frame.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, C.POINTER(i32), vp, vp, C.POINTER(i32), vp, vp,
+                                    C.POINTER(i32)]
     L.orbx_side_stream_for.argtypes = [vp, vp]
     L.orbx_side_stream_for.restype = vp
     L.orbx_pyramid_host.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
@@ -291,6 +293,23 @@ class ORBextractor:
     def side_stream(self):
         """hipStream_t of the handle's own side stream (orbx_side_stream)."""
         return self._L.orbx_side_stream(self._h)
+
+    def stereo_frame(self, left, right, mbf, mb):
+        """One stereo frame host to host in one call (orbx_stereo_frame): -> dict(kl, dl, kr, dr, uright, depth, nmatch)."""
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        assert left.shape == right.shape and left.ndim == 2
+        hgt, w = left.shape
+        cap = (self.max_keypoints() if self._shape == (hgt, w) else self.nfeatures + 3 * self.nlevels + 8 * 64) + 8
+        kl, kr = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
+        dl, dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+        ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        nl, nr, nm = C.c_int(), C.c_int(), C.c_int()
+        _check(self._L.orbx_stereo_frame(self._h, _p(left), _p(right), w, hgt, w, float(mbf), float(mb), cap, _p(kl), _p(dl), C.byref(nl),
+                                         _p(kr), _p(dr), C.byref(nr), _p(ur), _p(dp), C.byref(nm)))
+        self._shape = (hgt, w)
+        a, b = nl.value, nr.value
+        return {"kl": kl[:a].copy(), "dl": dl[:a].copy(), "kr": kr[:b].copy(), "dr": dr[:b].copy(), "uright": ur[:a].copy(),
+                "depth": dp[:a].copy(), "nmatch": nm.value}
 
     def side_stream_for(self, main_stream):
         """The side stream, probed (and replaced if need be) so that it does not share a hardware queue with main_stream."""

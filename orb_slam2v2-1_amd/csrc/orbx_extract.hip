@@ -149,6 +149,7 @@ extern "C" int orbx_destroy(orbx_extractor_t *h) {
     orbx_internal_free_stereo_scratch(h);
     free_plan(h);
     hipFree(h->d_in); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_dbgBlur);
+    hipFree(h->d_sfr); if (h->h_sfr) hipHostFree(h->h_sfr);
     if (h->h_kps) { hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); }
     for (int r = 0; r < ORBX_EV_RING; r++)
         for (int i = 0; i < ORBX_NUM_STAGES; i++) hipEventDestroy(h->ev[r][i]);
@@ -1115,6 +1116,73 @@ extern "C" int orbx_extract_batch(orbx_extractor_t *h, const uint8_t *const *img
             memcpy(desc + (size_t)b * cap * 32, h->h_desc + (size_t)b * dcap * 32, (size_t)32 * n);
         }
     }
+    return status;
+}
+
+// One stereo frame host to host in ONE call: what the reference's stereo Frame constructor does with two extractor threads and a CPU
+// matcher (src/Frame.cc:78-84: ExtractORB(0, imLeft) || ExtractORB(1, imRight), then ComputeStereoMatches, :481-655).  Both images
+// go up, are extracted as one batch of two on this handle (slots 0 / 1), matched on the device, and everything comes down behind ONE
+// synchronisation: no second extractor, no re-upload of the keypoints the extractor just produced.
+extern "C" int orbx_stereo_frame(orbx_extractor_t *h, const uint8_t *left, const uint8_t *right, int w, int hgt, int stride,
+                                 float mbf, float mb, int cap, orbx_keypoint_t *kl, uint8_t *dl, int *nl, orbx_keypoint_t *kr,
+                                 uint8_t *dr, int *nr, float *uright, float *depth, int *nmatch) {
+    if (!h || !kl || !dl || !nl || !kr || !dr || !nr || !uright || !depth || cap < 1) {
+        orbx_set_error("orbx_stereo_frame: bad arguments");
+        return ORBX_ERR_ARG;
+    }
+    *nl = 0; *nr = 0;
+    if (nmatch) *nmatch = 0;
+    if (!left || !right || w <= 0 || hgt <= 0) return ORBX_OK;   // empty image (:1046-1047)
+    if (stride < w) { orbx_set_error("stride < width"); return ORBX_ERR_ARG; }
+    ORBX_HIP(hipSetDevice(h->device));
+    int rc = ensure_plan(h, w, hgt, 2);
+    if (rc) return rc;
+    const size_t span = (size_t)stride * (hgt - 1) + w, img_bytes = (span + 255) & ~(size_t)255;
+    rc = ensure_staging(h, img_bytes * 2, 2, cap);
+    if (rc) return rc;
+    const int dcap = h->out_cap;
+    if (h->sfr_cap < dcap) {
+        hipFree(h->d_sfr); h->d_sfr = nullptr;
+        if (h->h_sfr) { hipHostFree(h->h_sfr); h->h_sfr = nullptr; }
+        h->sfr_cap = 0;
+        ORBX_HIP(hipMalloc(&h->d_sfr, sizeof(float) * (2 * (size_t)dcap + 4)));
+        ORBX_HIP(hipHostMalloc((void **)&h->h_sfr, sizeof(float) * (2 * (size_t)dcap + 4), hipHostMallocDefault));
+        h->sfr_cap = dcap;
+    }
+    hipStream_t st = h->stream;
+    ORBX_HIP(hipMemcpyAsync(h->d_in, left, span, hipMemcpyHostToDevice, st));
+    ORBX_HIP(hipMemcpyAsync(h->d_in + img_bytes, right, span, hipMemcpyHostToDevice, st));
+    rc = launch_pipeline(h, h->d_in, 2, w, hgt, stride, img_bytes, h->d_kps, h->d_desc, h->d_counts, dcap, st);
+    if (rc) return rc;
+    float *d_ur = h->d_sfr, *d_dp = h->d_sfr + dcap;
+    int32_t *d_nm = (int32_t *)(h->d_sfr + 2 * (size_t)dcap);
+    rc = orbm_stereo_batch_device(h, h, 1, 0, 1, h->d_kps, h->d_desc, h->d_counts, h->d_kps + dcap, h->d_desc + (size_t)dcap * 32,
+                                  h->d_counts + 1, dcap, mbf, mb, d_ur, d_dp, d_nm, st);
+    if (rc) return rc;
+    ORBX_HIP(hipMemcpyAsync(h->h_counts, h->d_counts, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipMemcpyAsync(h->h_kps, h->d_kps, sizeof(orbx_keypoint_t) * 2 * (size_t)dcap, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)32 * 2 * dcap, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipMemcpyAsync(h->h_sfr, h->d_sfr, sizeof(float) * (2 * (size_t)dcap + 4), hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
+    int status = ORBX_OK;
+    int n0 = h->h_counts[0], n1 = h->h_counts[1];
+    if (n0 > cap || n1 > cap) {
+        orbx_set_error("stereo frame produced %d / %d keypoints, cap %d", n0, n1, cap);
+        status = ORBX_ERR_CAPACITY;
+        n0 = std::min(n0, cap); n1 = std::min(n1, cap);
+    }
+    *nl = n0; *nr = n1;
+    if (n0 > 0) {
+        memcpy(kl, h->h_kps, sizeof(orbx_keypoint_t) * n0);
+        memcpy(dl, h->h_desc, (size_t)32 * n0);
+        memcpy(uright, h->h_sfr, sizeof(float) * n0);
+        memcpy(depth, h->h_sfr + dcap, sizeof(float) * n0);
+    }
+    if (n1 > 0) {
+        memcpy(kr, h->h_kps + dcap, sizeof(orbx_keypoint_t) * n1);
+        memcpy(dr, h->h_desc + (size_t)dcap * 32, (size_t)32 * n1);
+    }
+    if (nmatch) *nmatch = ((const int32_t *)(h->h_sfr + 2 * (size_t)dcap))[0];
     return status;
 }
 

@@ -95,6 +95,7 @@ struct orbx_extractor {
     uint8_t *d_in; size_t d_in_bytes;
     orbx_keypoint_t *d_kps; uint8_t *d_desc; int32_t *d_counts; int out_cap, out_B;
     orbx_keypoint_t *h_kps; uint8_t *h_desc; int32_t *h_counts;   // pinned mirrors of the three above
+    float *d_sfr; float *h_sfr; int sfr_cap;   // orbx_stereo_frame: mvuRight | mvDepth | nmatch of one frame (device + pinned mirror)
     uint8_t *d_dbgBlur; int dbgBlurCap;   // test hook: blurred 37x37 blocks of a single-image call (orbx_debug_blur_patches)
     hipStream_t stream;      // own stream
     hipStream_t side[ORBX_SIDE_STREAMS]; hipEvent_t evPyr[ORBX_MAX_CHUNKS], evJoin[ORBX_SIDE_STREAMS]; int lastChunks;   // chunk overlap (launch_pipeline)

@@ -714,6 +714,47 @@ int ComputeDistinctiveDescriptorsHIP(const std::vector<MapPoint *> &vpMapPoints,
     return n;
 }
 
+int ExtractStereoFrameHIP(Frame &F, const cv::Mat &imLeft, const cv::Mat &imRight) {
+    F.mvKeys.clear(); F.mvKeysRight.clear(); F.mDescriptors.release(); F.mDescriptorsRight.release();
+    F.mvuRight.clear(); F.mvDepth.clear(); F.N = 0;
+    if (!F.mpORBextractorLeft || !F.mpORBextractorLeft->ok() || imLeft.empty() || imRight.empty()) return 0;
+    if (imLeft.cols != imRight.cols || imLeft.rows != imRight.rows || imLeft.step != imRight.step) {
+        std::fprintf(stderr, "ExtractStereoFrame: left and right image differ in size or stride\n");
+        return -1;
+    }
+    orbx_extractor_t *h = F.mpORBextractorLeft->handle();
+    const int cap = orbx_max_keypoints(h) + 256;
+    std::vector<orbx_keypoint_t> kl(cap), kr(cap);
+    cv::Mat dl(cap, 32, CV_8U), dr(cap, 32, CV_8U);
+    std::vector<float> ur(cap), dp(cap);
+    int nl = 0, nr = 0, nm = 0;
+    if (orbx_stereo_frame(h, imLeft.ptr(0), imRight.ptr(0), imLeft.cols, imLeft.rows, (int)imLeft.step, F.mbf, F.mb, cap, kl.data(),
+                          dl.ptr(0), &nl, kr.data(), dr.ptr(0), &nr, ur.data(), dp.data(), &nm) != ORBX_OK) {
+        std::fprintf(stderr, "ExtractStereoFrame: %s\n", orbx_last_error());
+        return -1;
+    }
+    auto fill = [](const std::vector<orbx_keypoint_t> &src, const cv::Mat &dsrc, int n, std::vector<cv::KeyPoint> &keys, cv::Mat &desc) {
+        keys.reserve(n);
+        for (int i = 0; i < n; i++) {
+            const orbx_keypoint_t &s = src[i];
+            cv::KeyPoint kp;
+            kp.pt.x = s.x; kp.pt.y = s.y; kp.size = s.size; kp.angle = s.angle; kp.response = s.response;
+            kp.octave = s.octave; kp.class_id = s.class_id;
+            keys.push_back(kp);
+        }
+        if (n > 0) {
+            desc.create(n, 32, CV_8U);
+            for (int i = 0; i < n; i++) std::memcpy(desc.ptr(i), dsrc.ptr(i), 32);
+        }
+    };
+    fill(kl, dl, nl, F.mvKeys, F.mDescriptors);
+    fill(kr, dr, nr, F.mvKeysRight, F.mDescriptorsRight);
+    F.N = nl;                                         // :86
+    F.mvuRight.assign(ur.begin(), ur.begin() + nl);   // -1 where unmatched, as :483-484 initialise them
+    F.mvDepth.assign(dp.begin(), dp.begin() + nl);
+    return nm;
+}
+
 int ComputeStereoMatchesHIP(Frame &F) {
     const int N = F.N, Nr = (int)F.mvKeysRight.size();
     F.mvuRight = std::vector<float>(N, -1.0f);  // :483-484

@@ -82,6 +82,16 @@ protected:
 // Call it from Frame::ComputeStereoMatches() in place of the CPU body. Returns #matches (<0: error).
 int ComputeStereoMatchesHIP(Frame &F);
 
+// The stereo Frame constructor's feature part in ONE GPU call (src/Frame.cc:78-84 + 481-655): ExtractORB(0, imLeft),
+// ExtractORB(1, imRight) and ComputeStereoMatches.  Fills F.mvKeys / mDescriptors / mvKeysRight / mDescriptorsRight / N / mvuRight /
+// mvDepth exactly as the three reference calls do, from F.mpORBextractorLeft alone (both images go through that extractor as one
+// batch of two; the right extractor, its thread and the re-upload of the keypoints are not needed).  Replace
+//     thread threadLeft(&Frame::ExtractORB,this,0,imLeft); thread threadRight(&Frame::ExtractORB,this,1,imRight); ...join...
+//     N = mvKeys.size(); ... ComputeStereoMatches();
+// by   ExtractStereoFrameHIP(*this, imLeft, imRight);   (mbf / mb must be set: they are constructor arguments / :114).
+// Returns the number of stereo matches (< 0: error, outputs empty).
+int ExtractStereoFrameHIP(Frame &F, const cv::Mat &imLeft, const cv::Mat &imRight);
+
 // Tracking::SearchLocalPoints (src/Tracking.cc:1305-1339) from "Project points in frame" on: Frame::isInFrustum
 // (src/Frame.cc:284-340) of every local map point that was not seen in this frame and is not bad, then
 // ORBmatcher(nnratio).SearchByProjection(F, vpLocalMapPoints, th) — both in ONE GPU call.  Leaves on each point

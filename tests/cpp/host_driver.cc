@@ -430,6 +430,27 @@ int main(int argc, char **argv) {
         printf("%d %d\n", F.N, nm);
         return nm < 0 ? 5 : 0;
     }
+    if (mode == "stereoframe" && argc == 10) {   // the stereo Frame constructor's feature part in one GPU call
+        const int w = atoi(argv[4]), h = atoi(argv[5]), nf = atoi(argv[6]);
+        const float mbf = (float)atof(argv[7]), fx = (float)atof(argv[8]);
+        const std::string out = argv[9];
+        std::vector<unsigned char> l = slurp(argv[2]), r = slurp(argv[3]);
+        ORBextractor ex(nf, 1.2f, 8, 20, 7);
+        if (!ex.ok()) return 3;
+        Frame F;
+        F.mpORBextractorLeft = &ex; F.mpORBextractorRight = &ex;
+        Frame::fx = fx; F.mbf = mbf; F.mb = F.mbf / Frame::fx;  // src/Frame.cc:114
+        int nm = 0;
+        for (int rep = 0; rep < 2; rep++) nm = ExtractStereoFrameHIP(F, cv::Mat(h, w, CV_8UC1, l.data()), cv::Mat(h, w, CV_8UC1, r.data()));
+        dump_kps(out + ".kps", F.mvKeys);
+        dump(out + ".desc", F.mDescriptors.empty() ? NULL : F.mDescriptors.ptr(0), (size_t)F.mDescriptors.rows * 32);
+        dump_kps(out + ".kpsr", F.mvKeysRight);
+        dump(out + ".descr", F.mDescriptorsRight.empty() ? NULL : F.mDescriptorsRight.ptr(0), (size_t)F.mDescriptorsRight.rows * 32);
+        dump(out + ".uright", F.mvuRight.data(), F.mvuRight.size() * 4);
+        dump(out + ".depth", F.mvDepth.data(), F.mvDepth.size() * 4);
+        printf("%d %d %d\n", F.N, (int)F.mvKeysRight.size(), nm);
+        return nm < 0 ? 5 : 0;
+    }
     if (mode == "init" && argc == 8) {
         const int w = atoi(argv[4]), h = atoi(argv[5]), nf = atoi(argv[6]);
         const std::string out = argv[7];

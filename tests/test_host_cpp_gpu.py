@@ -67,6 +67,52 @@ def test_stereo_through_frame(driver, oracle, synth, tmp_path):
     np.testing.assert_array_equal(np.fromfile(str(tmp_path / "s.depth"), np.float32), odp)
 
 
+def test_stereo_frame_in_one_call(driver, oracle, synth, pkg, tmp_path):
+    """ExtractStereoFrameHIP (host/ORBmatcher.h) = the stereo Frame constructor's ExtractORB(left) || ExtractORB(right) +
+    ComputeStereoMatches (src/Frame.cc:78-84, 481-655) as ONE C-ABI call (orbx_stereo_frame): both key point sets, both descriptor
+    matrices, mvuRight, mvDepth and the match count equal the oracle's; the ctypes binding of the same entry point too, on a
+    corner-sparse pair and with an empty image."""
+    w, h, nf = 1241, 376, 2000
+    l, r = synth.stereo_pair_blocky(w, h, 25)
+    l.tofile(tmp_path / "l.raw"); r.tofile(tmp_path / "r.raw")
+    mbf, fx = 386.1448, 718.856
+    N, Nr, nm = _run(driver, "stereoframe", tmp_path / "l.raw", tmp_path / "r.raw", w, h, nf, mbf, fx, tmp_path / "f")
+
+    def ref(l, r):
+        ol, orr = oracle.Extractor(nf, 1.2, 8, 20, 7), oracle.Extractor(nf, 1.2, 8, 20, 7)
+        kl, dl = ol.extract(l); kr, dr = orr.extract(r)
+        mb = np.float32(mbf) / np.float32(fx)
+        on, our, odp = oracle.stereo_match(kl, dl, kr, dr, [ol.pyramid_level(i) for i in range(8)],
+                                           [orr.pyramid_level(i) for i in range(8)], ol.scale_factors, ol.inv_scale_factors, mbf, mb)
+        return kl, dl, kr, dr, on, our, odp
+    kl, dl, kr, dr, on, our, odp = ref(l, r)
+    assert (N, Nr, nm) == (len(kl), len(kr), on) and on > 100
+    for tag, k, d in (("", kl, dl), ("r", kr, dr)):
+        g = np.fromfile(str(tmp_path / ("f.kps" + tag)), np.uint8).reshape(-1, 28)
+        gk = np.frombuffer(g.tobytes(), pkg.KP_DTYPE)
+        for f in ("x", "y", "size", "response", "octave", "class_id"):
+            np.testing.assert_array_equal(gk[f], k[f], err_msg=tag + f)
+        np.testing.assert_allclose(gk["angle"], k["angle"], atol=1e-4, rtol=0)
+        np.testing.assert_array_equal(np.fromfile(str(tmp_path / ("f.desc" + tag)), np.uint8).reshape(-1, 32), d)
+    np.testing.assert_array_equal(np.fromfile(str(tmp_path / "f.uright"), np.float32), our)
+    np.testing.assert_array_equal(np.fromfile(str(tmp_path / "f.depth"), np.float32), odp)
+    # the same entry point through ctypes, on a corner-sparse pair (levels that fall back to the exact quad-tree) ...
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    l2, r2 = synth.natural_pair(w, h, 26)
+    kl, dl, kr, dr, on, our, odp = ref(l2, r2)
+    for rep in range(2):
+        f = ex.stereo_frame(l2, r2, mbf, float(np.float32(mbf) / np.float32(fx)))
+    assert (len(f["kl"]), len(f["kr"]), f["nmatch"]) == (len(kl), len(kr), on)
+    np.testing.assert_array_equal(f["kl"][["x", "y", "response", "octave"]], kl[["x", "y", "response", "octave"]])
+    np.testing.assert_array_equal(f["dl"], dl)
+    np.testing.assert_array_equal(f["dr"], dr)
+    np.testing.assert_array_equal(f["uright"], our)
+    np.testing.assert_array_equal(f["depth"], odp)
+    # ... and an image without key points: zero counts, no error (a flat image has no FAST corner)
+    f0 = ex.stereo_frame(np.full((h, w), 80, np.uint8), np.full((h, w), 80, np.uint8), mbf, 0.5)
+    assert (len(f0["kl"]), len(f0["kr"]), f0["nmatch"]) == (0, 0, 0)
+
+
 def test_search_for_initialization_through_frames(driver, oracle, synth, tmp_path):
     w, h, nf = 640, 480, 2000
     a = synth.frame(w, h, 23)

@@ -22,7 +22,7 @@ def test_chained_tracking_front_end(oracle, w, h, nf, T):
     step = 0.04
     frames, _ = synth.stereo_sequence(w, h, T, k=11, step=step)
     Ts = tc.poses(T, step)
-    chains = [tc.Chain(B(w, h, nf), w, h, nf) for B in (tc.OracleBackend, tc.GpuHostBackend, tc.GpuDeviceBackend)]
+    chains = [tc.Chain(B(w, h, nf), w, h, nf) for B in (tc.OracleBackend, tc.GpuHostBackend, tc.GpuStereoFrameBackend, tc.GpuDeviceBackend)]
     for t in range(T):
         snaps = [c.step(frames[t][0], frames[t][1], Ts[t]) for c in chains]
         for c in chains[1:]:

@@ -254,6 +254,16 @@ class GpuHostBackend:
                                             frame_mp, ext_obs, th, nnratio)
 
 
+class GpuStereoFrameBackend(GpuHostBackend):
+    """Host arrays in and out, the stereo frame in ONE call (orbx_stereo_frame = what host/ORBmatcher.h: ExtractStereoFrameHIP
+    gives the C++ Frame constructor): one extractor handle, no re-upload of the keypoints for the matcher."""
+    name = "gpu-host-1call"
+
+    def frame(self, left, right, mbf, mb):
+        f = self.exl.stereo_frame(left, right, mbf, mb)
+        return {"k": f["kl"], "d": f["dl"], "uright": f["uright"], "depth": f["depth"]}
+
+
 class GpuDeviceBackend(GpuHostBackend):
     """Left and right image through ONE handle (slots 0 / 1), stereo matcher and guided searches on the arrays the
     extractor left in HBM; only the results the host bookkeeping needs come down."""
