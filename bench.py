@@ -306,6 +306,40 @@ def measure_end_to_end(fe, left, right, steps, warmup, torch):
     return dt, last
 
 
+def tracking_front_end(nframes=16):
+    """BASELINE config 5's SHAPE without its dataset, optimiser and back-end (KITTI-00 and a vocabulary are not in the image): the
+    front-end of Tracking::Track in localisation mode chained over a synthetic 1241x376 stereo sequence, 2000 features per camera -
+    Frame(stereo), SearchByProjection(cur, last), SearchLocalPoints, key frames - with the state carried from frame to frame
+    (tests/tracking_chain.py).  Latency per frame of the device-resident chain, and the whole chain compared snapshot by snapshot with
+    the same chain on the CPU oracle (checker leg).  Replicas only: frame t needs frame t-1."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    tc = importlib.import_module("tracking_chain")
+    synth = importlib.import_module("orb_slam2v2-1_amd.synth")
+    w, h, nf, step = 1241, 376, 2000, 0.04
+    frames, _ = synth.stereo_sequence(w, h, nframes, k=11, step=step)
+    Ts = tc.poses(nframes, step)
+    dev = tc.Chain(tc.GpuDeviceBackend(w, h, nf), w, h, nf)
+    src = [(torch.from_numpy(l).pin_memory(), torch.from_numpy(r).pin_memory()) for l, r in frames]
+    for t in range(nframes):
+        dev.step(src[t][0], src[t][1], Ts[t])
+    orc = tc.Chain(tc.OracleBackend(w, h, nf), w, h, nf)
+    for t in range(nframes):
+        orc.step(frames[t][0], frames[t][1], Ts[t])
+    diff = tc.first_difference(orc.log, dev.log)
+    log = dev.log[4:]
+    med = lambda key: 1e3 * float(np.median([s[key] for s in log]))
+    tot = med("t_frame") + med("t_proj") + med("t_local")
+    return {"value": round(1e3 / tot, 1), "unit": "frames/s (one frame at a time)", "ms_per_frame": round(tot, 4),
+            "ms_frame_extract_stereo": round(med("t_frame"), 4), "ms_search_by_projection": round(med("t_proj"), 4),
+            "ms_search_local_points": round(med("t_local"), 4), "frames": nframes,
+            "projection_matches_median": int(np.median([s["proj_n"] for s in log])),
+            "verified": diff is None, "verified_note": ("every snapshot of %d chained frames (keypoints, descriptors, mvuRight, mvDepth, projection holders, "
+                                                        "frustum records, local-map holders, map) == the same chain on the CPU oracle" % nframes)
+            if diff is None else "chains diverge at frame %d, field %s" % diff,
+            "note": "config 5's shape on a synthetic sequence: no KITTI-00, no vocabulary, no optimiser (poses are the true ones); not ATE"}
+
+
 def verify_against_oracle(fe, last, seeds, frames, kind="dense"):
     """Checker leg (outside every timed region): frames `frames` of the last timed step against the CPU oracle: keypoint
     coordinates, sizes, responses, octaves, counts and descriptors bit for bit, angles within 1e-4 (north_star's float tolerance;
@@ -434,6 +468,7 @@ def main():
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short untimed-by-the-driver runs of the other north-star sizes (other_workloads block)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step")
+    ap.add_argument("--no-tracking", action="store_true", help="skip the chained tracking front-end block (config 5's shape)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-memory-to-host-memory pass (end_to_end block)")
     ap.add_argument("--verify-all-gathered", action="store_true",
                     help="N > 1: check EVERY frame of every rank in the all-gathered records of the last timed step against the oracle "
@@ -641,6 +676,11 @@ def main():
                         "buffers in HBM, downloads on a third stream, all overlapped with the kernels of the neighbouring batches; the host "
                         "waits for the results of step i - 3 before it submits batch i + 2; clock from the first upload to the last "
                         "result's arrival.  NOT the headline value (which starts with frames in HBM)"}
+        if world == 1 and not args.no_tracking and args.workload.startswith("kitti_stereo_1241x376_1000"):
+            try:
+                out["tracking_front_end"] = tracking_front_end()
+            except Exception as e:      # a broken side block must not take the headline line with it
+                out["tracking_front_end"] = {"error": repr(e)}
         if others:
             # the other north-star sizes, same definition of a step, short runs (not the headline; the driver times only `value`)
             del fe

@@ -9,7 +9,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out
 hb=$!
 trap "kill $hb 2>/dev/null" EXIT
 cd /tmp && export TMPDIR=/tmp
-common="--no-cpu-baseline --no-other-workloads --no-verify --no-end-to-end --gen-workers 1"
+common="--no-cpu-baseline --no-other-workloads --no-verify --no-end-to-end --no-tracking --gen-workers 1"
 rm -rf $out/prof_$tag
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$tag -- python3 $GRAFT_REPO_ROOT/bench.py $common --steps 40 --warmup 10 --ramp-steps 60 "$@" > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 cp $(ls $out/prof_$tag/*/*kernel_stats.csv | head -1) $out/${tag}_kernel_stats.csv
