@@ -999,7 +999,7 @@ extern "C" void *orbx_side_stream(orbx_extractor_t *h) { return h ? (void *)h->s
 // ~2 ms of nothing on one wave: the "busy" side of the queue probe below (constant 100 MHz counter)
 __global__ void k_spin(long long ticks) {
     const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    for (int i = 0; i < 100000 && wall_clock64() - t0 < ticks; i++) __builtin_amdgcn_s_sleep(32);   // bounded whatever the counter does
 }
 // true iff a command on `cand` starts while `busy` is still occupied, i.e. the two streams do not share a hardware queue
 static bool streams_independent(hipStream_t busy, hipStream_t cand, hipEvent_t eb, hipEvent_t ec) {
