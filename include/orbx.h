@@ -99,6 +99,12 @@ int orbx_extract_batch_device(orbx_extractor_t *h, const uint8_t *d_imgs, int B,
 int orbx_extract_batch_device_prefetch(orbx_extractor_t *h, const uint8_t *d_imgs, int B, int w, int hgt, int stride,
                                        size_t image_stride_bytes, void *side_stream);
 
+/* Two (default) or three pyramid buffers per handle.  With three, the pyramid built ahead gets a buffer of its own and the previous
+ * call's pyramid stays valid across orbx_extract_batch_device_prefetch, so the pattern below may issue the prefetch of batch i+1
+ * BEFORE orbm_stereo_batch_device_prev of batch i-1 on the side stream (the matcher then runs beside the descriptor kernel of batch i
+ * instead of beside its quad-tree: better when there are many keypoints per image).  Costs one more pyramid buffer of HBM. */
+int orbx_set_pyramid_buffers(orbx_extractor_t *h, int n);
+
 /* Orders `stream` behind the FAST stage of the extraction call issued last on h (the point the pyramid built ahead waits for).
  * With orbm_stereo_batch_device_prev this lets a throughput pipeline run the stereo matcher of batch i-1 beside the gather /
  * quad-tree / descriptor kernels of batch i:

@@ -43,7 +43,7 @@ EXPORTS = [
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
     "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch", "orbx_debug_sincosf",
     "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels", "orbx_extract_batch_device_prefetch", "orbx_stream_wait_fast_stage", "orbx_side_stream", "orbm_stereo_batch_device_prev", "orbx_debug_blur_patches", "orbm_debug_features_in_area",
-    "orbx_debug_blurred_level", "orbx_side_stream_for", "orbx_stereo_frame",
+    "orbx_debug_blurred_level", "orbx_side_stream_for", "orbx_stereo_frame", "orbx_set_pyramid_buffers",
 ]
 
 
@@ -132,6 +132,7 @@ def lib():
     L.orbx_side_stream.restype = vp
     L.orbx_stereo_frame.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, C.POINTER(i32), vp, vp, C.POINTER(i32), vp, vp,
                                     C.POINTER(i32)]
+    L.orbx_set_pyramid_buffers.argtypes = [vp, i32]
     L.orbx_side_stream_for.argtypes = [vp, vp]
     L.orbx_side_stream_for.restype = vp
     L.orbx_pyramid_host.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
@@ -310,6 +311,10 @@ class ORBextractor:
         a, b = nl.value, nr.value
         return {"kl": kl[:a].copy(), "dl": dl[:a].copy(), "kr": kr[:b].copy(), "dr": dr[:b].copy(), "uright": ur[:a].copy(),
                 "depth": dp[:a].copy(), "nmatch": nm.value}
+
+    def set_pyramid_buffers(self, n):
+        """2 (default) or 3 pyramid buffers (orbx_set_pyramid_buffers)."""
+        _check(self._L.orbx_set_pyramid_buffers(self._h, int(n)))
 
     def side_stream_for(self, main_stream):
         """The side stream, probed (and replaced if need be) so that it does not share a hardware queue with main_stream."""

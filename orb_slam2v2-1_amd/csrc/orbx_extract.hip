@@ -129,6 +129,7 @@ static void free_plan(orbx_extractor *h) {
     hipFree(h->d_cellRaw); h->d_cellRaw = nullptr;
     hipFree(h->d_octFallback); h->d_octFallback = nullptr;
     hipFree(h->d_pyrAlt); h->d_pyrAlt = nullptr; h->pyrAltBytes = 0; h->pfValid = 0; h->prevPyrValid = 0;
+    hipFree(h->d_pyrNext); h->d_pyrNext = nullptr; h->pyrNextBytes = 0;
     hipFree(h->d_blur); hipFree(h->d_blurAlt); h->d_blur = h->d_blurAlt = nullptr; h->blurBytes = h->blurAltBytes = 0; h->blurMaskLast = h->blurMaskAlt = 0;
     hipFree(h->d_octPart); hipFree(h->d_octLeaf); hipFree(h->d_octBest); hipFree(h->d_octState);
     h->d_octPart = nullptr; h->d_octLeaf = nullptr; h->d_octBest = nullptr; h->d_octState = nullptr;
@@ -938,12 +939,23 @@ extern "C" int orbx_extract_batch_device(orbx_extractor_t *h, const uint8_t *d_i
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream, as in every HIP API
     // the pyramid of exactly this batch was built ahead (orbx_extract_batch_device_prefetch): take that buffer, skip K1
-    const bool ahead = h->pfValid && h->d_pyrAlt && h->pfImgs == d_imgs && h->pfB == B && h->pfW == w && h->pfH == hgt && h->pfStride == stride &&
+    const bool three = h->pyrBuffers == 3;
+    const bool ahead = h->pfValid && (three ? h->d_pyrNext != nullptr : h->d_pyrAlt != nullptr) && h->pfImgs == d_imgs && h->pfB == B && h->pfW == w && h->pfH == hgt && h->pfStride == stride &&
                        h->pfImgStride == image_stride_bytes && g_debug[9] == 0;
     h->pfValid = 0;
     h->prevPyrValid = ahead ? 1 : 0;   // the buffers swap: the other one keeps the previous call's pyramid until the next one is built into it
     if (ahead) {
-        std::swap(h->d_pyr, h->d_pyrAlt);
+        if (three) {   // previous <- current <- next <- (old previous: its matcher was issued on the side stream before the next prefetch is)
+            if (h->pyrAltBytes < h->pyrImgBytes * (size_t)h->pB) {   // first rotation: the "previous" buffer does not exist yet
+                ORBX_HIP(hipStreamSynchronize(h->side[0]));
+                hipFree(h->d_pyrAlt); h->d_pyrAlt = nullptr;
+                ORBX_HIP(hipMalloc(&h->d_pyrAlt, h->pyrImgBytes * (size_t)h->pB));
+                h->pyrAltBytes = h->pyrImgBytes * (size_t)h->pB;
+            }
+            uint8_t *oldPrev = h->d_pyrAlt;
+            h->d_pyrAlt = h->d_pyr; h->d_pyr = h->d_pyrNext; h->d_pyrNext = oldPrev;
+        } else
+            std::swap(h->d_pyr, h->d_pyrAlt);
         std::swap(h->d_blur, h->d_blurAlt); std::swap(h->blurBytes, h->blurAltBytes); std::swap(h->blurMaskLast, h->blurMaskAlt);
         ORBX_HIP(hipStreamWaitEvent(st, h->evPrefetch, 0));
     }
@@ -960,24 +972,41 @@ extern "C" int orbx_extract_batch_device_prefetch(orbx_extractor_t *h, const uin
     int rc = ensure_plan(h, w, hgt, B);
     if (rc) return rc;
     const size_t need = h->pyrImgBytes * (size_t)h->pB;
-    if (h->pyrAltBytes < need) {
+    const bool three = h->pyrBuffers == 3;
+    uint8_t **tgt = three ? &h->d_pyrNext : &h->d_pyrAlt;
+    size_t *tgtBytes = three ? &h->pyrNextBytes : &h->pyrAltBytes;
+    if (*tgtBytes < need) {
         ORBX_HIP(hipStreamSynchronize(h->side[0]));
-        hipFree(h->d_pyrAlt); h->d_pyrAlt = nullptr; h->pyrAltBytes = 0;
-        ORBX_HIP(hipMalloc(&h->d_pyrAlt, need));
-        h->pyrAltBytes = need;
+        hipFree(*tgt); *tgt = nullptr; *tgtBytes = 0;
+        ORBX_HIP(hipMalloc(tgt, need));
+        *tgtBytes = need;
     }
     hipStream_t sd = side_stream ? (hipStream_t)side_stream : h->side[0];   // the caller's side stream (work it queued there comes first) or the handle's own
-    h->prevPyrValid = 0;
+    if (!three) h->prevPyrValid = 0;   // two buffers: the pyramid built ahead overwrites the previous one (three: it has a buffer of its own)
     (void)hipGetLastError();
     if (h->pfUsed && h->last_valid) ORBX_HIP(hipStreamWaitEvent(sd, h->evFastDone, 0));   // (the first time there is no such event yet: the
     else if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));             //  second buffer is new, wait for the handle to be idle)
     h->pfUsed = 1;
-    launch_pyramid(h, d_imgs, h->d_pyrAlt, B, stride, image_stride_bytes, sd);
-    rc = launch_blur(h, h->d_pyrAlt, &h->d_blurAlt, &h->blurAltBytes, 0, B, sd, &h->blurMaskAlt);
+    launch_pyramid(h, d_imgs, *tgt, B, stride, image_stride_bytes, sd);
+    rc = launch_blur(h, *tgt, &h->d_blurAlt, &h->blurAltBytes, 0, B, sd, &h->blurMaskAlt);
     if (rc) return rc;
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipEventRecord(h->evPrefetch, sd));
     h->pfValid = 1; h->pfImgs = d_imgs; h->pfB = B; h->pfW = w; h->pfH = hgt; h->pfStride = stride; h->pfImgStride = image_stride_bytes;
+    return ORBX_OK;
+}
+
+// Two (default) or three pyramid buffers.  With three, orbx_extract_batch_device_prefetch builds the next pyramid into a buffer of its
+// own and the previous call's pyramid stays valid, so a pipeline may issue the pyramid of batch i+1 BEFORE the matcher of batch i-1 on
+// its side stream (pipeline.FrontEnd(stereo_late=True): the matcher then runs beside the descriptor kernel instead of beside the
+// quad-tree).  The buffer the next prefetch overwrites is the one the matcher issued before it (same stream) has read.
+extern "C" int orbx_set_pyramid_buffers(orbx_extractor_t *h, int n) {
+    if (!h || (n != 2 && n != 3)) { orbx_set_error("orbx_set_pyramid_buffers: 2 or 3"); return ORBX_ERR_ARG; }
+    ORBX_HIP(hipSetDevice(h->device));
+    if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    for (int i = 0; i < ORBX_SIDE_STREAMS; i++) ORBX_HIP(hipStreamSynchronize(h->side[i]));
+    h->pyrBuffers = n;
+    h->pfValid = 0; h->prevPyrValid = 0;
     return ORBX_OK;
 }
 

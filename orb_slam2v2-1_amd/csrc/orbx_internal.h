@@ -105,6 +105,7 @@ struct orbx_extractor {
     uint8_t *d_blur, *d_blurAlt; size_t blurBytes, blurAltBytes; unsigned blurMaskLast, blurMaskAlt;
     // split call (launch_chunk): records of the small levels described ahead, and the events between the two streams
     orbx_keypoint_t *d_kpsB; uint8_t *d_descB; size_t splitBytes; hipEvent_t evGather, evOctA;
+    uint8_t *d_pyrNext; size_t pyrNextBytes; int pyrBuffers;   // three-buffer mode (orbx_set_pyramid_buffers): the pyramid built ahead gets a buffer of its own, the previous one survives it
     int prevPyrValid;   // d_pyrAlt still holds the pyramid of the call before the last one (orbm_stereo_batch_device_prev)
     hipEvent_t evFastDone, evPrefetch;
     hipStream_t last_stream; // stream of the last batch call (NULL is a stream too: the HIP default stream)

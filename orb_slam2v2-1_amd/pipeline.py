@@ -60,7 +60,8 @@ def independent_stream(dev, busy, ncand=8):
 
 class FrontEnd:
     def __init__(self, w, h, nfeatures, stereo, B, device_index=0, nbuf=3, streams=1, world=1, gather=False,
-                 gather_via_host=False, mbf=KITTI_BF, fx=KITTI_FX, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, prefetch=True, lag_stereo=True):
+                 gather_via_host=False, mbf=KITTI_BF, fx=KITTI_FX, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, prefetch=True, lag_stereo=True,
+                 stereo_late=None):
         if not torch.cuda.is_available():
             raise RuntimeError("orb_slam2v2-1_amd.pipeline.FrontEnd needs a GPU: the HIP path has no CPU fallback")
         self.w, self.h, self.nf, self.stereo, self.B = w, h, nfeatures, stereo, B
@@ -80,6 +81,13 @@ class FrontEnd:
         main0 = torch.cuda.current_stream(self.dev)
         self._side_raw = self.ex.side_stream_for(main0.cuda_stream) if (prefetch and self.S == 1) else self.ex.side_stream()
         self.side = torch.cuda.ExternalStream(self._side_raw, device=self.dev) if self.lag else None
+        # Order of the two side-stream jobs behind FAST(i).  Default: matcher(i-1), then pyramid(i+1) - the matcher beside the quad-tree, the
+        # pyramid beside the descriptors.  stereo_late: pyramid(i+1) first, then matcher(i-1) (three pyramid buffers) - the matcher beside the
+        # descriptor kernel; pays when that kernel is long (many keypoints per image): None = by the feature budget.
+        self.late = bool(self.lag and (nfeatures >= 1500 if stereo_late is None else stereo_late))
+        if self.late:
+            self.ex.set_pyramid_buffers(3)
+        self._ev_late = None           # event behind the last late matcher: the next FAST waits for it (FAST always runs alone)
         self._pend = None              # (buffer set, step) whose matcher has not been issued yet
         self._ev_side = {}             # buffer set -> event behind its matcher on the side stream
         self.streams = [torch.cuda.current_stream(self.dev)] + [torch.cuda.Stream(self.dev) for _ in range(self.S - 1)]
@@ -236,6 +244,8 @@ class FrontEnd:
             self._flush() if self.lag else None
         elif j in self._ev_side:
             stream.wait_event(self._ev_side.pop(j))     # the matcher that last wrote buffer set j (nbuf steps ago) is long done
+        if lag and self._ev_late is not None:
+            stream.wait_event(self._ev_late)            # late order: the previous step's matcher is the last job of the side stream
         exi.extract_batch_device(self._imgs(i), self.nimg, w, h, w, w * h, r.kps[j].data_ptr(), r.desc[j].data_ptr(),
                                  r.cnt[j].data_ptr(), cap, st)
         if hs is not None:
@@ -250,15 +260,21 @@ class FrontEnd:
                 hs.ev_main[j].record(stream)
         if lag:
             sd = self.side.cuda_stream
+            if self.late:
+                exi.stream_wait_fast_stage(sd)
+                self._prefetch_next(exi, i, self.side)      # three buffers: the previous pyramid survives this one
             if self._pend is not None:
                 pj, pstep = self._pend
-                exi.stream_wait_fast_stage(sd)
+                if not self.late:
+                    exi.stream_wait_fast_stage(sd)
                 self._match(exi, pj, sd, prev=True)       # step i-1: its pyramid is the buffer the call above swapped out
                 self._publish_side(pj, pstep)
                 ev = torch.cuda.Event()
                 ev.record(self.side)
                 self._ev_side[pj] = ev
-            self._prefetch_next(exi, i, self.side)          # behind the matcher: it reads that buffer
+                self._ev_late = ev if self.late else None
+            if not self.late:
+                self._prefetch_next(exi, i, self.side)      # behind the matcher: it reads that buffer
             self._pend = (j, i)
             return j
         if self.prefetch:

@@ -66,7 +66,7 @@ def test_bench_step_three_handles_three_streams_one_thread():
     _run_stereo(1241, 376, 1000, 16, seed0=200, streams=3, steps=20)
 
 
-@pytest.mark.parametrize("mode", ["pipelined", "pyramid_ahead_only", "plain"])
+@pytest.mark.parametrize("mode", ["pipelined", "pipelined_late", "pyramid_ahead_only", "plain"])
 def test_bench_step_rotating_batches(mode):
     """The software-pipelined step (pyramid of step i+1 and stereo matcher of step i-1 on the side stream beside the tail of step
     i) over THREE different resident batches and the handle's TWO pyramid buffers, seven steps without a host synchronisation:
@@ -74,8 +74,9 @@ def test_bench_step_rotating_batches(mode):
     Every result still resident at the end (steps 4, 5, 6 = batches 1, 2, 0) must equal the oracle of ITS batch."""
     pl, ref = _pipeline(), _ref()
     w, h, nf, B, nsets, steps = 752, 480, 600, 6, 3, 7
-    fe = pl.FrontEnd(w, h, nf, True, B, prefetch=(mode != "plain"), lag_stereo=(mode == "pipelined"))
-    assert fe.lag == (mode == "pipelined")
+    # pipelined_late: the pyramid of step i+1 is issued BEFORE the matcher of step i-1 on the side stream (three pyramid buffers)
+    fe = pl.FrontEnd(w, h, nf, True, B, prefetch=(mode != "plain"), lag_stereo=mode.startswith("pipelined"), stereo_late=(mode == "pipelined_late"))
+    assert fe.lag == mode.startswith("pipelined") and fe.late == (mode == "pipelined_late")
     exps = [ref.run_pool(ref.stereo_frame, [(w, h, nf, 700 + 50 * s + i, fe.mbf, fe.mb) for i in range(B)]) for s in range(nsets)]
     fe.upload(np.stack([e["left"] for e in exps[0]]), np.stack([e["right"] for e in exps[0]]))
     for s in range(1, nsets):
@@ -99,7 +100,7 @@ def test_bench_step_rotating_batches(mode):
     assert not bad, "\n".join(bad[:20])
 
 
-@pytest.mark.parametrize("mode", ["pipelined", "pyramid_ahead_only", "plain"])
+@pytest.mark.parametrize("mode", ["pipelined", "pipelined_late", "pyramid_ahead_only", "plain"])
 def test_host_streaming_rotating_batches(mode):
     """End to end from host memory (FrontEnd.enable_host_streaming): THREE different batches in pinned host memory arrive by
     asynchronous copies on an upload stream into three image buffers while other batches compute, results leave on a download
@@ -109,7 +110,7 @@ def test_host_streaming_rotating_batches(mode):
     import torch
     pl, ref = _pipeline(), _ref()
     w, h, nf, B, nsets, steps = 752, 480, 600, 6, 3, 8
-    fe = pl.FrontEnd(w, h, nf, True, B, prefetch=(mode != "plain"), lag_stereo=(mode == "pipelined"))
+    fe = pl.FrontEnd(w, h, nf, True, B, prefetch=(mode != "plain"), lag_stereo=mode.startswith("pipelined"), stereo_late=(mode == "pipelined_late"))
     exps = [ref.run_pool(ref.stereo_frame, [(w, h, nf, 1700 + 50 * s + i, fe.mbf, fe.mb) for i in range(B)]) for s in range(nsets)]
     fe.upload(np.stack([e["left"] for e in exps[0]]), np.stack([e["right"] for e in exps[0]]))
     fe.enable_host_streaming()

@@ -14,7 +14,8 @@ else:
     L, R = np.stack([synth.frame(w, h, i) for i in range(B)]), None
 for v in vals:
     pkg.lib().orbx_debug_set(knob, v)
-    fe = pl.FrontEnd(w, h, nf, bool(stereo), B).upload(L, R)
+    late = os.environ.get("LATE")
+    fe = pl.FrontEnd(w, h, nf, bool(stereo), B, stereo_late=None if late is None else bool(int(late))).upload(L, R)
     best = 1e9
     for rep in range(3):
         for i in range(10):
