@@ -119,7 +119,18 @@ class ResultRing:
     def publish(self, j, step=None):
         if not self.gather:
             return
-        pack_records(self.kps[j][:self.B], self.desc[j][:self.B], self.ur[j], self.dp[j], self.cnt[j][:self.B], out=self.pack[j])
+        self.pack_set(j)
+        self.gather_set(j, step)
+
+    def pack_set(self, j):
+        """ONE pack kernel (current stream): the B frame records of set j -> pack[j]."""
+        if self.gather:
+            pack_records(self.kps[j][:self.B], self.desc[j][:self.B], self.ur[j], self.dp[j], self.cnt[j][:self.B], out=self.pack[j])
+
+    def gather_set(self, j, step=None):
+        """ONE all-gather of pack[j] (asynchronous; ordered behind the current stream's work)."""
+        if not self.gather:
+            return
         if self.via_host:
             g, _ = all_gather_records(self.pack[j].cpu())
             self.gath[j].copy_(g)

@@ -87,6 +87,7 @@ class FrontEnd:
         self.late = bool(self.lag and (nfeatures >= 1500 if stereo_late is None else stereo_late))
         if self.late:
             self.ex.set_pyramid_buffers(3)
+        self._coll = None              # torch-native stream the all-gather of the pipelined mode is issued from (N > 1)
         self._ev_late = None           # event behind the last late matcher: the next FAST waits for it (FAST always runs alone)
         self._pend = None              # (buffer set, step) whose matcher has not been issued yet
         self._ev_side = {}             # buffer set -> event behind its matcher on the side stream
@@ -144,7 +145,16 @@ class FrontEnd:
         itself runs on the backend's own stream and overlaps whatever follows)."""
         if self.ring.gather:
             with torch.cuda.stream(self.side):
-                self.ring.publish(j, step)
+                self.ring.pack_set(j)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            # the collective is issued from a stream torch created itself (the side stream is the handle's, wrapped as an external
+            # stream: fine for kernels, but the backend's stream bookkeeping is best left to a native one)
+            if self._coll is None:
+                self._coll = torch.cuda.Stream(self.dev)
+            self._coll.wait_event(ev)
+            with torch.cuda.stream(self._coll):
+                self.ring.gather_set(j, step)
 
     # ---- end to end from host memory (src/ros_stereo.cc:133, src/Frame.cc:78-81: the reference receives its images on the host)
     def enable_host_streaming(self, nimgbuf=3):
