@@ -1071,6 +1071,8 @@ extern "C" void *orbx_side_stream_for(orbx_extractor_t *h, void *main_stream) {
         }
         for (hipStream_t c : tried) hipStreamDestroy(c);
         if (found) {
+            if (h->st_stream == h->side[0]) h->st_stream = nullptr;       // (nothing may keep the handle of the stream that goes away)
+            if (h->last_valid && h->last_stream == h->side[0]) h->last_valid = 0;
             hipStreamDestroy(h->side[0]);
             h->side[0] = found;
             h->pfValid = 0; h->prevPyrValid = 0;
