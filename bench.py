@@ -380,16 +380,16 @@ def verify_gathered(fe, gath, ranks, frames_of_rank, kind="dense"):
     if held != step:
         return ["buffer set %d holds the gathered records of step %s, expected step %d" % (j, held, step)], 0
     g = {k: v.cpu().numpy() for k, v in rec.items()}
-    B, cap, nchk = fe.B, fe.cap, 0
+    gB, cap, nchk = fe.ring.gB, fe.cap, 0
     jobs, where = [], []
     for r in ranks:
-        for b in frames_of_rank(B):
+        for b in frames_of_rank(r["frames_per_step"]):
             seed = r["first_seed"] + b
             jobs.append((fe.w, fe.h, fe.nf, seed, fe.mbf, fe.mb, kind) if fe.stereo else (fe.w, fe.h, fe.nf, seed, kind))
             where.append((r["rank"], b))
     exp = ref.run_pool(ref.stereo_frame if fe.stereo else ref.mono_frame, jobs)
     for (rk, b), e in zip(where, exp):
-        row = rk * B + b
+        row = rk * gB + b
         n = int(g["counts"][row])
         if n < 0 or n > cap:
             bad.append("rank %d frame %d: count %d" % (rk, b, n))
@@ -450,6 +450,39 @@ def roofline_block(fe, m, workload, B, value, world, traffic_lookup=True):
     return roof, navg
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without an outer launcher: start the N ranks as CHILD processes of torch.distributed.run (one
+    per GPU, rendezvous on 127.0.0.1 at a free port) with this command line, relay what they print - rank 0's single JSON line
+    goes to stdout as it arrives - and return their exit code.  Nothing in this process has touched the GPU (numpy only), and it
+    is never replaced by another program: the ranks are children, the parent waits.  Under an outer torch.distributed.run
+    (WORLD_SIZE / RANK set) main() never comes here."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    try:
+        for line in p.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        rc = p.wait()
+    except BaseException:
+        p.terminate()           # the exact child this process started (its ranks die with the launcher)
+        try:
+            p.wait(30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+        raise
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -491,6 +524,8 @@ def main():
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N > 1 on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))     # plain `python bench.py --gpus N`: this process only starts the ranks (no GPU call before)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -558,17 +593,13 @@ def main():
         else:
             dist.init_process_group("gloo")
     gather = world > 1 and not args.no_gather
-    if gather and strong:
-        # the all-gather is a fixed-shape collective: every rank contributes the same number of records
-        sizes = [batching.shard_range(args.total_frames, r, world) for r in range(world)]
-        if len({b - a for a, b in sizes}) != 1:
-            if rank == 0:
-                print("bench.py: --total-frames must be a multiple of the rank count when results are all-gathered", file=sys.stderr)
-            sys.exit(2)
+    # the all-gather is a fixed-shape collective: every rank contributes as many record rows as the LARGEST block holds (a batch that
+    # does not divide by the rank count leaves blocks that differ by one frame; the short blocks' last row stays empty)
+    gB = max(b - a for a, b in (batching.shard_range(args.total_frames, r, world) for r in range(world))) if strong else B
 
     S = max(1, args.streams)
     fe = pipeline.FrontEnd(w, h, nf, stereo, B, device_index=dev_index, nbuf=3, streams=S, world=world, gather=gather,
-                           gather_via_host=(args.backend != "nccl"), prefetch=not args.no_prefetch, lag_stereo=not args.no_lag_stereo)
+                           gather_via_host=(args.backend != "nccl"), prefetch=not args.no_prefetch, lag_stereo=not args.no_lag_stereo, gather_B=gB)
     fe.upload(left, right)
     m = measure(fe, args.steps, args.warmup, args.ramp_steps, world, dist, dev, torch)
     dt, stage_ms = m["dt"], m["stage_ms"]

@@ -89,9 +89,13 @@ class ResultRing:
         ring.drain()             # wait for every outstanding all-gather
     Frames are the first B images of a set (a stereo pair's right image sits at slot B + b and is not exchanged)."""
 
-    def __init__(self, nbuf, B, nimg, cap, device, world=1, gather=False, blocking_via_host=False):
+    def __init__(self, nbuf, B, nimg, cap, device, world=1, gather=False, blocking_via_host=False, gather_B=None):
         self.nbuf, self.B, self.nimg, self.cap, self.world = nbuf, B, nimg, cap, world
         self.gather = gather and world > 1
+        # rows every rank contributes to the fixed-shape collective: the LARGEST block of any rank when a batch does not divide
+        # evenly (shard_range: sizes differ by at most one); a smaller block leaves its last row zero (count 0)
+        self.gB = B if gather_B is None else int(gather_B)
+        assert self.gB >= B
         self.via_host = blocking_via_host   # rehearsal on a box with fewer GPUs than ranks: gloo moves host memory
         z = lambda shape, dt: [torch.zeros(shape, dtype=dt, device=device) for _ in range(nbuf)]
         self.kps, self.desc, self.cnt = z((nimg, cap, 7), torch.float32), z((nimg, cap, 32), torch.uint8), z((nimg,), torch.int32)
@@ -101,8 +105,8 @@ class ResultRing:
         self._pending = [None] * nbuf
         if self.gather:
             rb = record_bytes(cap)
-            self.pack = z((B, rb), torch.uint8)
-            self.gath = z((world * B, rb), torch.uint8)
+            self.pack = z((self.gB, rb), torch.uint8)
+            self.gath = z((world * self.gB, rb), torch.uint8)
 
     def acquire(self, i):
         j = i % self.nbuf
@@ -125,7 +129,7 @@ class ResultRing:
     def pack_set(self, j):
         """ONE pack kernel (current stream): the B frame records of set j -> pack[j]."""
         if self.gather:
-            pack_records(self.kps[j][:self.B], self.desc[j][:self.B], self.ur[j], self.dp[j], self.cnt[j][:self.B], out=self.pack[j])
+            pack_records(self.kps[j][:self.B], self.desc[j][:self.B], self.ur[j], self.dp[j], self.cnt[j][:self.B], out=self.pack[j][:self.B])
 
     def gather_set(self, j, step=None):
         """ONE all-gather of pack[j] (asynchronous; ordered behind the current stream's work)."""
@@ -143,5 +147,6 @@ class ResultRing:
             self._finish(j)
 
     def gathered(self, j):
-        """dict(kps, desc, uright, depth, counts) of ALL ranks' frames of the step held by set j (after acquire/drain)."""
+        """dict(kps, desc, uright, depth, counts) of ALL ranks' frames of the step held by set j (after acquire/drain); rank r's
+        frames are rows [r * gB, r * gB + its block size)."""
         return unpack_records(self.gath[j], self.cap)

@@ -61,7 +61,7 @@ def independent_stream(dev, busy, ncand=8):
 class FrontEnd:
     def __init__(self, w, h, nfeatures, stereo, B, device_index=0, nbuf=3, streams=1, world=1, gather=False,
                  gather_via_host=False, mbf=KITTI_BF, fx=KITTI_FX, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, prefetch=True, lag_stereo=True,
-                 stereo_late=None):
+                 stereo_late=None, gather_B=None):
         if not torch.cuda.is_available():
             raise RuntimeError("orb_slam2v2-1_amd.pipeline.FrontEnd needs a GPU: the HIP path has no CPU fallback")
         self.w, self.h, self.nf, self.stereo, self.B = w, h, nfeatures, stereo, B
@@ -95,7 +95,7 @@ class FrontEnd:
         self.d_imgs = None
         self.cap = None
         self.ring = None
-        self._ring_args = (max(nbuf, self.S), world, gather, gather_via_host)
+        self._ring_args = (max(nbuf, self.S), world, gather, gather_via_host, gather_B)
         self._hs = None                # host-streaming state (enable_host_streaming)
 
     def upload(self, left, right=None):
@@ -107,9 +107,9 @@ class FrontEnd:
         self.cap = self.ex.max_keypoints()
         self.d_imgs = torch.from_numpy(np.ascontiguousarray(imgs)).to(self.dev)
         self.d_sets = [self.d_imgs]
-        nbuf, world, gather, via_host = self._ring_args
+        nbuf, world, gather, via_host, gB = self._ring_args
         self.ring = ResultRing(nbuf, self.B, self.nimg, self.cap, self.dev, world=world, gather=gather,
-                               blocking_via_host=via_host)
+                               blocking_via_host=via_host, gather_B=gB)
         return self
 
     def upload_more(self, left, right=None):

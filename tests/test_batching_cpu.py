@@ -149,3 +149,67 @@ def test_result_ring_single_rank_is_a_no_op_exchange():
     assert j == 2
     ring.publish(j, 5)
     ring.drain()
+
+
+def _uneven_worker(rank, world, port, total, q):
+    """A batch that does not divide by the rank count (shard_range blocks of 3 and 2 frames): every rank contributes gB = 3 record
+    rows, the short block's last row stays empty, rank r's frames are rows [r * gB, r * gB + its block)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cap, nbuf = 13, 2
+        blocks = [batching.shard_range(total, r, world) for r in range(world)]
+        gB = max(b - a for a, b in blocks)
+        s, e = blocks[rank]
+        B = e - s
+        ring = batching.ResultRing(nbuf, B, B, cap, torch.device("cpu"), world=world, gather=True, gather_B=gB)
+        j = ring.acquire(0)
+        kps, desc, ur, dp, cnt = _fake(list(range(s, e)), cap)
+        ring.kps[j].copy_(kps); ring.desc[j].copy_(desc); ring.ur[j].copy_(ur); ring.dp[j].copy_(dp); ring.cnt[j].copy_(cnt)
+        ring.publish(j, 0)
+        ring.drain()
+        u = ring.gathered(j)
+        ok = u["counts"].shape[0] == world * gB
+        for r, (a, b) in enumerate(blocks):
+            exp = _fake(list(range(a, b)), cap)
+            rows = slice(r * gB, r * gB + (b - a))
+            ok = ok and all(torch.equal(u[k][rows], x) for k, x in zip(("kps", "desc", "uright", "depth", "counts"), exp))
+            ok = ok and bool((u["counts"][r * gB + (b - a):(r + 1) * gB] == 0).all())
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_result_ring_uneven_blocks_world2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, total = 2, 5
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_bench_launches_its_own_ranks_without_an_outer_launcher():
+    """`python bench.py --gpus 2` (no torch.distributed.run around it, the shape of the driver's one-GPU command) must start its two
+    ranks itself and relay their exit code.  Without a GPU every rank stops at "no GPU visible" (exit code 3) - AFTER the launch,
+    which is what this CPU test can see: the old behaviour was exit code 2 with a usage message before anything ran."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: tests/test_multirank_gpu.py runs the real thing")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                        "--batch", "2", "--no-cpu-baseline", "--gen-workers", "1", "--workload", "mono_640x480_1000feat"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert "launch with torch.distributed.run" not in p.stderr
+    assert p.stderr.count("no GPU visible") == 2, p.stderr[-3000:]        # both ranks ran main() up to the GPU check
+    assert p.returncode != 0 and p.returncode != 2

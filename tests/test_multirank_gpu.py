@@ -61,3 +61,27 @@ def test_headline_step_two_ranks_same_pipeline_as_one():
     assert out["verified"] is True, out["verified_note"]
     assert out["gathered_verified"] is True, out["gathered_verified_note"]
     assert out["gathered_verified_note"].startswith("32 frames"), out["gathered_verified_note"]
+
+
+def test_bench_self_launch_two_ranks():
+    """`python3 bench.py --gpus 2 ...` with NO launcher around it (the shape of the driver's one-GPU command): bench.py starts its
+    own ranks as children before anything touches the GPU and relays rank 0's single JSON line.  The batch of 33 frames does not
+    divide by two: blocks of 17 and 16 frames travel through the fixed-shape collective as 17 rows per rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--ramp-steps", "0", "--gen-workers", "6"]
+    p = subprocess.run(cmd + ["--batch", "8"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
+    assert p.returncode == 0, "bench.py failed (%d)\n%s\n%s" % (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["world_size_observed"] == 2
+    assert out["verified"] is True and out["gathered_verified"] is True, (out["verified_note"], out["gathered_verified_note"])
+    # uneven strong-scaling batch through the same self-launch
+    p = subprocess.run(cmd + ["--workload", "mono_640x480_1000feat", "--total-frames", "33", "--verify-all-gathered"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
+    assert p.returncode == 0, "bench.py failed (%d)\n%s\n%s" % (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert [r["frames_per_step"] for r in out["config"]["ranks"]] == [17, 16] and out["config"]["total_frames_per_step"] == 33
+    assert out["gathered_verified"] is True and out["gathered_verified_note"].startswith("33 frames"), out["gathered_verified_note"]
