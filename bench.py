@@ -520,9 +520,14 @@ def main():
                     help="after the measurement, an extra pass of K steps alternating over 3 handles on 3 streams; its throughput "
                          "is reported beside the headline value (\"overlapped\").  Off by default so that the kernel launches of "
                          "the default command are all single-stream (rocprof averages = the reported kernel duration)")
+    ap.add_argument("--handle-options", default="", help="k=v[,k=v...]: orbx_set_option(k, v) on every extractor handle of this run (ORBX_OPT_* of "
+                    "include/orbx.h: alternative kernels with identical results); recorded in config.handle_options")
+    ap.add_argument("--gauss-flavour", default=os.environ.get("ORBX_TEST_GAUSS_FLAVOUR", "half_up"), choices=["half_up", "sse2"],
+                    help="orbx_flavour_t.gauss_rounding of the handles AND of the oracle that checks them (default: half_up)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N > 1 on a box with fewer GPUs than ranks")
     args = ap.parse_args()
+    os.environ["ORBX_TEST_GAUSS_FLAVOUR"] = args.gauss_flavour      # the oracle that checks the run, spawned workers and ranks included
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus))     # plain `python bench.py --gpus N`: this process only starts the ranks (no GPU call before)
@@ -572,9 +577,12 @@ def main():
     pkg = importlib.import_module("orb_slam2v2-1_amd")
     pipeline = importlib.import_module("orb_slam2v2-1_amd.pipeline")
     pkg.lib()  # fails loudly if the HIP library is missing
-    for kv in os.environ.get("ORBX_BENCH_KNOBS", "").split(","):   # developer knobs for A/B runs, e.g. ORBX_BENCH_KNOBS=12=1
+    handle_options = {}
+    for kv in args.handle_options.split(","):   # A/B runs: per-handle options of include/orbx.h for every handle this run creates
         if "=" in kv:
-            pkg.lib().orbx_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
+            handle_options[int(kv.split("=")[0])] = int(kv.split("=")[1])
+            pkg.set_default_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
+    pkg.default_gauss_flavour = args.gauss_flavour
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -673,7 +681,8 @@ def main():
                                       else "pyramid of the next step built ahead (orbx_extract_batch_device_prefetch)") if fe.prefetch else "none",
                        "parallelism": "frames sharded over %d GPU(s)%s" % (world, ", results all-gathered (%s)" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal") if gather else ""),
                        "world_size_observed": world_seen, "ranks": ranks,
-                       "avg_keypoints_per_image": round(navg, 1)},
+                       "avg_keypoints_per_image": round(navg, 1), "gauss_flavour": args.gauss_flavour,
+                       "handle_options": handle_options},
             "roofline": roof,
             "long_run": None if m.get("long_run") is None else {
                 "steps": m["long_run"][0], "value": round(B * m["long_run"][0] / m["long_run"][1], 2), "unit": "frames/s",
@@ -738,9 +747,9 @@ def main():
                                 "verified": None if args.no_verify else not obad}
                 if okind == "natural":
                     # the corner-sparse workload with and without k_fast_strips' exact row pre-test (developer knob 16 = 1: off)
-                    pkg.lib().orbx_debug_set(16, 1)
+                    pkg.set_default_option(16, 1)
                     om2 = measure(ofe, osteps, 5, 20, 1, dist, dev, torch)
-                    pkg.lib().orbx_debug_set(16, 0)
+                    pkg.set_default_option(16, 0)
                     ow_out[name].update({
                         "corner_fraction_note": "2-5 % of the pixels are FAST corners at t = 7 (dense workloads: 33-53 %)",
                         "fast_ms_with_row_pretest": round(om["fast_ms"], 4), "fast_ms_without": round(om2["fast_ms"], 4),

@@ -53,6 +53,26 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
                 int device, orbx_extractor_t **out);
 int orbx_destroy(orbx_extractor_t *h);
 
+/* Flavour of the OpenCV primitives behind the reference's calls.  The reference does not contain them (OpenCV, version unpinned:
+ * CMakeLists.txt:52-58, README "2.4.11 and 3.2") and ships no vectors, so where OpenCV itself computes a primitive in two ways the
+ * choice is a property of the reference BUILD this library stands in for.  It is fixed when the handle is created and never changes
+ * afterwards (orbx_get_flavour reads it back); orbx_create = every field 0.
+ *   gauss_rounding - cv::GaussianBlur(7x7, sigma 2) on 8U (src/ORBextractor.cc:1085-1086), rounding of the column pass, OpenCV <= 3.3:
+ *     ORBX_GAUSS_ROUND_HALF_UP  (sum + 2^15) >> 16 on every column: the scalar FixedPtCastEx (builds without SSE2 / NEON column code)
+ *     ORBX_GAUSS_ROUND_SSE2     x86 builds (SSE2 is baseline on x86-64): SymmColumnVec_32s8u rounds the columns x < (w & ~3) of a
+ *                               level half to EVEN (_mm_cvtps_epi32); the last w % 4 columns take the scalar half-up code.
+ *   The two differ at ~1 pixel in 131 072 (sum mod 65536 == 32768 with an even quotient).  Which one a given reference build
+ *   follows is reported by the reference-vector consumer (tests/golden/README.md); both are hypotheses until vectors exist. */
+#define ORBX_GAUSS_ROUND_HALF_UP 0
+#define ORBX_GAUSS_ROUND_SSE2 1
+typedef struct {
+    int32_t gauss_rounding;   /* ORBX_GAUSS_ROUND_* */
+    int32_t reserved[7];      /* must be 0 */
+} orbx_flavour_t;
+int orbx_create_flavoured(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
+                          int device, const orbx_flavour_t *flavour, orbx_extractor_t **out);
+int orbx_get_flavour(const orbx_extractor_t *h, orbx_flavour_t *out);
+
 /* GetLevels / GetScaleFactor(s) / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares (include/ORBextractor.h:62-83); arrays of nlevels floats,
  * any may be NULL.  features_per_level / umax expose mnFeaturesPerLevel and umax[16]. */
@@ -151,7 +171,7 @@ int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, int stage, in
 #define ORBX_NUM_STAGES 5
 /* Stage [1] is k_fast_strips (one wave per strip of four cells; levels whose cells are at most 32 px wide, batches that fill
  * the GPU) and / or k_fast_cells (one wave per cell; the other levels, small batches): which of them a batch of B images of
- * the planned size runs.  Same results either way.  A call is ONE chunk by default (developer knob 8 cuts a batch into up to
+ * the planned size runs.  Same results either way.  A call is ONE chunk by default (ORBX_OPT_CHUNKS cuts a batch into up to
  * four chunks whose kernels overlap on the handle's side streams; the call keeps its stream semantics); the events of stage
  * [1] bracket the first chunk's launch, which covers *images_per_launch images (= B by default). */
 int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, int *cells, int *images_per_launch);
@@ -382,25 +402,55 @@ int orbm_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const 
 int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, int npoints, int32_t *best_row,
                                  int32_t *best_median, int device);
 
-/* Developer knobs for kernel ablation timing (key 0: stop k_fast_cells after phase n; 0 = off;
- * key 1: stop k_octree early; key 2: force the exact one-workgroup matcher kernels;
- * key 3: pyramid tile size; key 4: 1 = quad-tree by k_octree alone, without the count pyramid, 2 = every level by the
- * multi-workgroup form k_octree_big (default: levels with >= 600 FAST cells when the batch is at most 4 images), 3 = no level by it;
- * key 5: 1 = pyramid by the one-launch fused kernel, 3 = levels 3.. by it (default: one launch per level); key 6: 1 = every level's FAST by k_fast_cells (one wave per cell) instead of
- * k_fast_strips, 2 = ... with run-time tile strides, 3 = k_fast_strips even for a small batch (default: by batch size);
- * key 7: stop k_octree_pyr after phase n; key 8: n >= 2 cuts a batch into n chunks (at most 4) whose kernels
- * overlap on the handle's side streams (measured: no gain, default one chunk); key 9: ignore pyramids built ahead; key 11: quad-tree kernels in
- * the 1024-thread build never (1) / always (2) instead of by image size; key 12: 1 = no ordering kernel in front of the FAST
- * stage's start event; keys 13 / 14: form of the Gaussian blur (orbx_debug_blurred_level below); key 15: a >= 2 = split call, the
- * quad-tree of levels [0, a) on a second stream beside quad-tree + descriptors of the others; key 16: row pre-test of corner-sparse
- * levels in k_fast_strips never (1) / on every level (2) instead of by the previous call's candidate density; key 17: 1 = the
- * intra-device events keep their system-scope fence (read at orbx_create); key 18: 1 = k_gather + compacted key arrays instead of
- * the quad-tree reading the FAST cell lists in place; key 19: a >= 2 = the strips of levels [0, a) launched first and their
- * quad-tree started beside the FAST of the others.  Keys 13-19 select alternatives with identical results; 15 and 19 measured
- * slower and are off by default, 18 = 1 is the round-2 path).
- * Never set in production: keys 0, 1 and 7 leave outputs incomplete; 2, 4, 5, 6 select an alternative
- * kernel with identical results (tests use them to cover those kernels). */
-int orbx_debug_set(int key, int value);
+/* Per-handle options: which of several kernels / launch arrangements with IDENTICAL results a handle uses.  State of the handle
+ * (no process-global switch exists: two handles on two threads may run with different options); set between calls, from the thread
+ * that issues the handle's calls.  Defaults (every value 0) are the measured-fastest choices; the tests use the others to cover
+ * every kernel against the oracle.  Unknown keys / values: ORBX_ERR_ARG.
+ *   ORBX_OPT_PYR_TILE      3   tile size of the fused pyramid kernel at the coarsest level (0 = 64; takes effect at the next plan)
+ *   ORBX_OPT_OCTREE_FORM   4   1 = quad-tree by the exact form alone, 2 = every level by the multi-workgroup form, 3 = no level by it
+ *                              (default: levels with >= 600 FAST cells when the batch is at most 4 images)
+ *   ORBX_OPT_PYRAMID_FORM  5   1 = pyramid by the one-launch fused kernel, 3 = levels 3.. by it (default: one launch per level)
+ *   ORBX_OPT_FAST_FORM     6   1 = every level's FAST by k_fast_cells, 2 = ... with run-time tile strides, 3 = k_fast_strips even for
+ *                              a small batch (default: by batch size)
+ *   ORBX_OPT_CHUNKS        8   n >= 2: a batch is cut into n chunks (<= 4) on the handle's side streams (default one)
+ *   ORBX_OPT_IGNORE_AHEAD  9   1 = pyramids built ahead are ignored
+ *   ORBX_OPT_PREFETCH_GATE 10  where a pyramid built ahead may start: 0 behind FAST, 1 behind the quad-tree, 2 behind the descriptors
+ *   ORBX_OPT_OCTREE_WIDTH  11  quad-tree kernels in the 1024-thread build never (1) / always (2) (default: by image size)
+ *   ORBX_OPT_NO_ORDER_KERNEL 12  1 = no ordering kernel in front of the FAST stage's start event
+ *   ORBX_OPT_BLUR_FORM     13  1 = no level blurred as a whole, 2 = every level (orbx_debug_blurred_level); 14 = the rule's threshold
+ *   ORBX_OPT_SPLIT_CALL    15  a >= 2: quad-tree of levels [0, a) on a second stream beside quad-tree + descriptors of the others
+ *   ORBX_OPT_ROW_PRETEST   16  corner-sparse FAST path of k_fast_strips never (1) / on every level (2) (default: by the previous
+ *                              call's candidate density)
+ *   ORBX_OPT_GATHER        18  1 = k_gather + compacted key arrays instead of the quad-tree reading the FAST cell lists in place
+ *   ORBX_OPT_EARLY_OCTREE  19  a >= 2: strips of levels [0, a) launched first, their quad-tree beside the FAST of the others
+ *   ORBX_OPT_SPARSE_FORM   20  corner-sparse levels: 0 = compaction kernel (score only the pixels that pass the five-pixel bound),
+ *                              1 = row skip inside k_fast_strips
+ * Keys 0, 1 and 7 (stop a kernel after phase n: outputs incomplete) exist only in a library built with -DORBX_DEVELOPER
+ * (tools/octree_phase_probe.py); the default build refuses them. */
+#define ORBX_OPT_PYR_TILE 3
+#define ORBX_OPT_OCTREE_FORM 4
+#define ORBX_OPT_PYRAMID_FORM 5
+#define ORBX_OPT_FAST_FORM 6
+#define ORBX_OPT_CHUNKS 8
+#define ORBX_OPT_IGNORE_AHEAD 9
+#define ORBX_OPT_PREFETCH_GATE 10
+#define ORBX_OPT_OCTREE_WIDTH 11
+#define ORBX_OPT_NO_ORDER_KERNEL 12
+#define ORBX_OPT_BLUR_FORM 13
+#define ORBX_OPT_BLUR_THRESHOLD 14
+#define ORBX_OPT_SPLIT_CALL 15
+#define ORBX_OPT_ROW_PRETEST 16
+#define ORBX_OPT_GATHER 18
+#define ORBX_OPT_EARLY_OCTREE 19
+#define ORBX_OPT_SPARSE_FORM 20
+#define ORBX_NUM_OPTIONS 32
+int orbx_set_option(orbx_extractor_t *h, int key, int value);
+int orbx_get_option(const orbx_extractor_t *h, int key, int *value);
+/* The guided-search matchers keep their scratch per host thread, and so their one option: ORBM_OPT_EXACT_KERNELS = 1 makes the
+ * calling thread's matcher calls take the exact one-workgroup kernels instead of candidate search + speculative resolution
+ * (identical results; the tests run both).  Thread-local. */
+#define ORBM_OPT_EXACT_KERNELS 2
+int orbm_set_thread_option(int key, int value);
 /* Test hooks for two rows of the scope table that have no output of their own.
  * orbx_debug_blur_patches (a8, cv::GaussianBlur 7x7 sigma 2 - fused into the descriptor kernel, never stored): enable = 1, then
  * orbx_extract of ONE image with cap <= the handle's keypoint bound, then out != NULL fetches the 37x37 blurred block around each
@@ -412,8 +462,8 @@ int orbx_debug_blur_patches(orbx_extractor_t *h, int enable, uint8_t *out, int n
 /* a8, the other form: levels whose keypoint budget makes per-keypoint blurring the more expensive way are blurred as a whole by
  * k_blur_levels and the descriptor kernel only gathers (src/ORBextractor.cc:1083-1090 does exactly this for every level).
  * *mask_out (may be NULL) = levels of the last call that took this form (bit l); dst != NULL fetches level `level` of image b
- * (inner ROI, dst_stride bytes per row) - ORBX_ERR_ARG when that level is not in the mask.  Developer knob 13 (orbx_debug_set):
- * 1 = no level, 2 = every level; knob 14 = the rule's threshold in percent (level-wide iff nfeatures_l * 37^2 * 100 >=
+ * (inner ROI, dst_stride bytes per row) - ORBX_ERR_ARG when that level is not in the mask.  ORBX_OPT_BLUR_FORM (orbx_set_option):
+ * 1 = no level, 2 = every level; ORBX_OPT_BLUR_THRESHOLD = the rule's threshold in percent (level-wide iff nfeatures_l * 37^2 * 100 >=
  * thr * w_l * h_l).  Results never depend on the form. */
 int orbx_debug_blurred_level(orbx_extractor_t *h, int b, int level, uint8_t *dst, int dst_stride, unsigned *mask_out);
 int orbm_debug_features_in_area(const orbx_keypoint_t *kun, int n, const orbm_grid_geom_t *g, float x, float y, float r,

@@ -103,6 +103,13 @@ def lib():
         L.oracle_fast_detect.argtypes = [vp, i32, i32, i32, i32, vp, i32]
         L.oracle_resize_linear.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32]
         L.oracle_gaussian_blur7.argtypes = [vp, i32, i32, i32, vp, i32]
+        L.oracle_gaussian_blur7_flavour.argtypes = [vp, i32, i32, i32, vp, i32, i32]
+        L.oracle_set_gauss_flavour.restype = i32
+        L.oracle_set_gauss_flavour.argtypes = [vp, i32]
+        L.oracle_gauss_round_half_even.restype = i32
+        L.oracle_gauss_round_half_even.argtypes = [i32]
+        L.oracle_gauss_round_sse2_literal.restype = i32
+        L.oracle_gauss_round_sse2_literal.argtypes = [i32] * 7
         L.oracle_distribute_octtree.restype = i32
         L.oracle_distribute_octtree.argtypes = [vp, i32, i32, i32, i32, vp, i32]
         L.oracle_hamming.restype = i32
@@ -174,14 +181,26 @@ def _arr(ptr, n, dtype):
     return np.frombuffer(buf, dtype=dtype, count=n).copy()
 
 
+GAUSS_FLAVOURS = {"half_up": 0, "sse2": 1}
+# flavour an Extractor takes when it is not told (tests that run the whole parity suite under the other flavour set this
+# together with the HIP wrapper's default)
+# (ORBX_TEST_GAUSS_FLAVOUR in the environment: the same switch as the HIP wrapper's, inherited by spawned workers)
+default_gauss_flavour = os.environ.get("ORBX_TEST_GAUSS_FLAVOUR", "half_up")
+
+
 class Extractor:
     """CPU oracle of ORBextractor (reference: include/ORBextractor.h:45-111)."""
 
-    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, gauss=None):
+        """gauss: flavour of cv::GaussianBlur's column rounding, "half_up" (scalar FixedPtCastEx, the default) or "sse2"
+        (SymmColumnVec_32s8u: round half to even for the columns x < (w & ~3)); None = default_gauss_flavour."""
         self.L = lib()
         self.h = self.L.oracle_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
         if not self.h:
             raise ValueError("bad extractor arguments")
+        self.gauss = default_gauss_flavour if gauss is None else gauss
+        if self.L.oracle_set_gauss_flavour(self.h, GAUSS_FLAVOURS[self.gauss]):
+            raise ValueError("bad gauss flavour %r" % (self.gauss,))
         self.nfeatures, self.nlevels = nfeatures, nlevels
 
     def __del__(self):
@@ -299,10 +318,10 @@ def resize_linear(src, dw, dh):
     return dst
 
 
-def gaussian_blur7(src):
+def gaussian_blur7(src, gauss="half_up"):
     src = np.ascontiguousarray(src, np.uint8)
     dst = np.zeros_like(src)
-    lib().oracle_gaussian_blur7(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), src.shape[1])
+    lib().oracle_gaussian_blur7_flavour(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), src.shape[1], GAUSS_FLAVOURS[gauss])
     return dst
 
 

@@ -73,6 +73,16 @@ int oracle_fast_detect(const uint8_t *img, int stride, int w, int h, int thresho
 void oracle_resize_linear(const uint8_t *src, int sw, int sh, int sstride,
                           uint8_t *dst, int dw, int dh, int dstride);
 void oracle_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride);
+/* Flavours of the column-pass rounding of cv::GaussianBlur on 8U (OpenCV <= 3.3 filter.cpp; see orb_oracle_extract.c):
+ * HALF_UP = the scalar FixedPtCastEx everywhere (the default, what rounds 1-3 encoded), SSE2 = SymmColumnVec_32s8u's
+ * round-half-to-even for the columns x < (w & ~3), scalar for the tail.  Both are hypotheses until reference vectors arrive. */
+#define ORACLE_GAUSS_HALF_UP 0
+#define ORACLE_GAUSS_SSE2 1
+void oracle_gaussian_blur7_flavour(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride, int flavour);
+int oracle_set_gauss_flavour(orb_oracle_t *o, int flavour);
+int oracle_get_gauss_flavour(const orb_oracle_t *o);
+int oracle_gauss_round_half_even(int sum);
+int oracle_gauss_round_sse2_literal(int s0, int s1, int s2, int s3, int s4, int s5, int s6);
 /* DistributeOctTree on a candidate list (coords relative to minBorder); region size
  * width x height = (maxX-minX) x (maxY-minY). Returns number of selected, in list order. */
 int oracle_distribute_octtree(const oracle_cand_t *cands, int n, int width, int height, int N,

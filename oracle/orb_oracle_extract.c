@@ -25,6 +25,7 @@ static const int8_t k_pattern[1024] = {
 
 struct orb_oracle {
     int nfeatures, nlevels, ini_th, min_th;
+    int gauss_flavour;   /* ORACLE_GAUSS_*: column rounding of cv::GaussianBlur (oracle_set_gauss_flavour) */
     double scale_factor; /* member is double: include/ORBextractor.h:98 */
     float sf[MAX_LEVELS], isf[MAX_LEVELS], sig2[MAX_LEVELS], isig2[MAX_LEVELS];
     int32_t nfeat[MAX_LEVELS];
@@ -95,6 +96,12 @@ static void free_frame_state(orb_oracle_t *o) {
         free(o->sel[l]); o->sel[l] = NULL; o->nsel[l] = 0;
     }
 }
+int oracle_set_gauss_flavour(orb_oracle_t *o, int flavour) {
+    if (!o || (flavour != ORACLE_GAUSS_HALF_UP && flavour != ORACLE_GAUSS_SSE2)) return -1;
+    o->gauss_flavour = flavour;
+    return 0;
+}
+int oracle_get_gauss_flavour(const orb_oracle_t *o) { return o->gauss_flavour; }
 void oracle_destroy(orb_oracle_t *o) { if (o) { free_frame_state(o); free(o); } }
 
 const float *oracle_scale_factors(const orb_oracle_t *o) { return o->sf; }
@@ -317,10 +324,45 @@ static void gauss7_fixed(int k[7]) {
         k[i] = oracle_cv_round((double)cf[i] * 256.0);
     }
 }
-void oracle_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride) {
+/* Column-pass rounding, the one step of this primitive that OpenCV <= 3.3 implements twice (filter.cpp):
+ *   ORACLE_GAUSS_HALF_UP (0)  FixedPtCastEx<int, uchar>: (sum + 2^15) >> 16 - the scalar code, used for EVERY column by a build
+ *                             without SSE2 (or with NEON, whose SymmColumnVec_32s8u is not covered here);
+ *   ORACLE_GAUSS_SSE2    (1)  SymmColumnVec_32s8u on x86 (SSE2 is baseline on x86-64): the columns x < (w & ~3) go through float -
+ *                             int32 row sums -> float, times the float kernel k/65536, summed in float (exact below 256: every
+ *                             partial sum is a multiple of 2^-16 under 2^8), _mm_cvtps_epi32 = ROUND-HALF-TO-EVEN, signed then
+ *                             unsigned saturating packs; the last w % 4 columns fall through to the scalar FixedPtCastEx.
+ * The two differ exactly where sum mod 65536 == 32768 and sum >> 16 is even (~1 pixel in 131 072).  Written from memory of the
+ * 2.4.11 / 3.2 sources [external, unverified here: parity unpinned]; which one a given reference build follows is what
+ * oracle.refvec.compare reports from the per-level blur checksums. */
+static inline int gauss_col_sum(const int *tmp, const int k[7], int x, int y, int w, int h) {
+    int acc = 0;
+    for (int i = -3; i <= 3; i++) acc += k[i + 3] * tmp[(size_t)reflect101(y + i, h) * w + x];
+    return acc;
+}
+#if defined(__SSE2__)
+#include <emmintrin.h>
+/* the literal vector path for four columns x .. x+3 of row y: products and sums in float, cvtps (MXCSR default: nearest even) */
+static void gauss_col_sse2_4(const int *tmp, const int k[7], int x, int y, int w, int h, uint8_t out[4]) {
+    float kf[4];
+    for (int i = 0; i <= 3; i++) kf[i] = (float)k[3 + i] * (1.f / 65536.f);   /* _kernel.convertTo(kernel, CV_32F, 1./(1 << bits)) */
+    const int *S0 = tmp + (size_t)y * w + x;
+    __m128 s = _mm_mul_ps(_mm_cvtepi32_ps(_mm_loadu_si128((const __m128i *)S0)), _mm_set1_ps(kf[0]));   /* delta = 0 */
+    for (int i = 1; i <= 3; i++) {
+        const int *Sp = tmp + (size_t)reflect101(y + i, h) * w + x, *Sm = tmp + (size_t)reflect101(y - i, h) * w + x;
+        const __m128i xs = _mm_add_epi32(_mm_loadu_si128((const __m128i *)Sp), _mm_loadu_si128((const __m128i *)Sm));
+        s = _mm_add_ps(s, _mm_mul_ps(_mm_cvtepi32_ps(xs), _mm_set1_ps(kf[i])));
+    }
+    __m128i r = _mm_cvtps_epi32(s);
+    r = _mm_packs_epi32(r, r);
+    r = _mm_packus_epi16(r, r);
+    const int v = _mm_cvtsi128_si32(r);
+    memcpy(out, &v, 4);
+}
+#endif
+void oracle_gaussian_blur7_flavour(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride, int flavour) {
     int k[7];
     gauss7_fixed(k);
-    int *tmp = (int *)malloc(sizeof(int) * (size_t)w * h);
+    int *tmp = (int *)malloc(sizeof(int) * ((size_t)w * h + 4));
     for (int y = 0; y < h; y++) {
         const uint8_t *s = src + (size_t)y * sstride;
         for (int x = 0; x < w; x++) {
@@ -329,14 +371,48 @@ void oracle_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_
             tmp[(size_t)y * w + x] = acc;
         }
     }
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) {
-            int acc = 0;
-            for (int i = -3; i <= 3; i++) acc += k[i + 3] * tmp[(size_t)reflect101(y + i, h) * w + x];
+    const int wv = flavour == ORACLE_GAUSS_SSE2 ? (w & ~3) : 0;   /* columns the vector path takes */
+    for (int y = 0; y < h; y++) {
+        int x = 0;
+        for (; x < wv; x += 4) {
+#if defined(__SSE2__)
+            gauss_col_sse2_4(tmp, k, x, y, w, h, dst + (size_t)y * dstride + x);
+#else
+            for (int j = 0; j < 4; j++) {   /* the closed form of the float path: round half to even, saturate */
+                const int acc = gauss_col_sum(tmp, k, x + j, y, w, h);
+                const int r = (acc + 32767 + ((acc >> 16) & 1)) >> 16;
+                dst[(size_t)y * dstride + x + j] = (uint8_t)(r > 255 ? 255 : r);
+            }
+#endif
+        }
+        for (; x < w; x++) {
+            int acc = gauss_col_sum(tmp, k, x, y, w, h);
             acc = (acc + (1 << 15)) >> 16;
             dst[(size_t)y * dstride + x] = (uint8_t)(acc > 255 ? 255 : acc < 0 ? 0 : acc);
         }
+    }
     free(tmp);
+}
+void oracle_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride) {
+    oracle_gaussian_blur7_flavour(src, w, h, sstride, dst, dstride, ORACLE_GAUSS_HALF_UP);
+}
+/* the integer closed form of the SSE2 column rounding (what the HIP kernels compute); tests compare it with the literal path */
+int oracle_gauss_round_half_even(int sum) { const int r = (sum + 32767 + ((sum >> 16) & 1)) >> 16; return r > 255 ? 255 : r; }
+int oracle_gauss_round_sse2_literal(int s0, int s1, int s2, int s3, int s4, int s5, int s6) {
+    /* seven int32 row sums of one column -> the byte the vector path stores (same arithmetic as gauss_col_sse2_4) */
+#if defined(__SSE2__)
+    int k[7];
+    gauss7_fixed(k);
+    int col[7 * 4] = {0};
+    const int sv[7] = {s0, s1, s2, s3, s4, s5, s6};
+    for (int i = 0; i < 7; i++) col[i * 4] = sv[i];
+    uint8_t out[4];
+    gauss_col_sse2_4(col, k, 0, 3, 4, 7, out);
+    return out[0];
+#else
+    (void)s0; (void)s1; (void)s2; (void)s3; (void)s4; (void)s5; (void)s6;
+    return -1;
+#endif
 }
 
 /* ------------------------------------------------------------ quad-tree */
@@ -642,7 +718,7 @@ int oracle_extract(orb_oracle_t *o, const uint8_t *img, int w, int h, int stride
         double tb = now_s(); o->stage_s[3] += tb - ta;
         if (o->nsel[l] == 0) continue;
         o->blur[l] = (uint8_t *)malloc((size_t)lw * lh);
-        oracle_gaussian_blur7(inner, lw, lh, ps, o->blur[l], lw);
+        oracle_gaussian_blur7_flavour(inner, lw, lh, ps, o->blur[l], lw, o->gauss_flavour);
         double tc = now_s(); o->stage_s[4] += tc - tb;
         for (int k = 0; k < o->nsel[l]; k++) {
             oracle_kp_t *kp = &kps[off + k];

@@ -36,7 +36,7 @@ EXPORTS = [
     "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_tables",
     "orbx_max_keypoints", "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_device",
     "orbx_pyramid_host", "orbx_pyramid_device", "orbx_debug_level_points", "orbx_set_profiling",
-    "orbx_get_stage_ms", "orbx_debug_set", "orbm_hamming", "orbm_hamming_matrix_device", "orbm_stereo_batch_device",
+    "orbx_get_stage_ms", "orbx_create_flavoured", "orbx_get_flavour", "orbx_set_option", "orbx_get_option", "orbm_set_thread_option", "orbm_hamming", "orbm_hamming_matrix_device", "orbm_stereo_batch_device",
     "orbm_stereo", "orbm_search_for_initialization", "orbm_search_by_projection_mp",
     "orbm_search_by_projection_frame", "orbm_match_windows", "orbm_best_in_windows", "orbm_distinctive_descriptors", "orbm_predict_scale_thresholds", "orbm_is_in_frustum",
     "orbm_search_local_points", "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_transform",
@@ -71,6 +71,33 @@ def grid_geom(w, h):
     g.inv_w = np.float32(64) / np.float32(w)
     g.inv_h = np.float32(48) / np.float32(h)
     return g
+
+
+class Flavour(C.Structure):
+    """orbx_flavour_t: which OpenCV build the handle stands in for (include/orbx.h)."""
+    _fields_ = [("gauss_rounding", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+GAUSS_FLAVOURS = {"half_up": 0, "sse2": 1}
+# What an ORBextractor takes when its constructor is not told.  HARNESS state of this Python module (the library itself has no
+# process-global switch: flavour and options are per handle): the parity suite is run under both flavours by changing this and the
+# oracle's default together, and the tests that cover an alternative kernel set a default option around the code under test.
+# ORBX_TEST_GAUSS_FLAVOUR=sse2 in the environment runs a whole test / bench session (spawned oracle workers included) under the
+# other flavour.
+default_gauss_flavour = os.environ.get("ORBX_TEST_GAUSS_FLAVOUR", "half_up")
+_default_options = {}
+_live = None
+
+
+def set_default_option(key, value):
+    """Option `key` of every ORBextractor created from now on AND of the live ones (value 0 = the library default)."""
+    if value:
+        _default_options[int(key)] = int(value)
+    else:
+        _default_options.pop(int(key), None)
+    for e in list(_live or ()):
+        if getattr(e, "_h", None):
+            e.set_option(key, value)
 
 
 _lib = None
@@ -118,6 +145,11 @@ def lib():
     L.orbx_create.restype = i32
     L.orbx_create.argtypes = [i32, f32, i32, i32, i32, i32, C.POINTER(vp)]
     L.orbx_destroy.argtypes = [vp]
+    L.orbx_create_flavoured.argtypes = [i32, f32, i32, i32, i32, i32, C.POINTER(Flavour), C.POINTER(vp)]
+    L.orbx_get_flavour.argtypes = [vp, C.POINTER(Flavour)]
+    L.orbx_set_option.argtypes = [vp, i32, i32]
+    L.orbx_get_option.argtypes = [vp, i32, C.POINTER(i32)]
+    L.orbm_set_thread_option.argtypes = [i32, i32]
     L.orbx_get_levels.argtypes = [vp]
     L.orbx_get_scale_factor.restype = f32
     L.orbx_get_scale_factor.argtypes = [vp]
@@ -206,14 +238,39 @@ class ORBextractor:
     argument of the reference is ignored there (src/ORBextractor.cc:1043) and absent here.
     """
 
-    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device=0):
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device=0, gauss=None):
+        """gauss: "half_up" / "sse2" = orbx_flavour_t.gauss_rounding (include/orbx.h); None = default_gauss_flavour."""
+        global _live
         self._L = lib()
         h = C.c_void_p()
-        _check(self._L.orbx_create(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST),
-                                   int(minThFAST), int(device), C.byref(h)))
+        self.gauss = default_gauss_flavour if gauss is None else gauss
+        fl = Flavour()
+        fl.gauss_rounding = GAUSS_FLAVOURS[self.gauss]
+        _check(self._L.orbx_create_flavoured(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST),
+                                             int(minThFAST), int(device), C.byref(fl), C.byref(h)))
         self._h = h
         self.nfeatures, self.nlevels, self.device = int(nfeatures), int(nlevels), int(device)
         self._shape = None
+        if _live is None:
+            import weakref
+            _live = weakref.WeakSet()
+        _live.add(self)
+        for k, v in _default_options.items():
+            self.set_option(k, v)
+
+    def set_option(self, key, value):
+        """orbx_set_option: per-handle choice among kernels / arrangements with identical results (ORBX_OPT_* of include/orbx.h)."""
+        _check(self._L.orbx_set_option(self._h, int(key), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int(0)
+        _check(self._L.orbx_get_option(self._h, int(key), C.byref(v)))
+        return v.value
+
+    def flavour(self):
+        fl = Flavour()
+        _check(self._L.orbx_get_flavour(self._h, C.byref(fl)))
+        return {v: k for k, v in GAUSS_FLAVOURS.items()}[fl.gauss_rounding]
 
     def close(self):
         if getattr(self, "_h", None):

@@ -124,7 +124,8 @@ __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) { return (uint32_t
 __device__ __forceinline__ uint32_t dpp_wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
 
 __global__ __launch_bounds__(256) void k_blur_levels(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, size_t pyrImgBytes,
-                                                     const LevelGeom *__restrict__ geom, int nlevels, int totalTiles, BlurPlan bp) {
+                                                     const LevelGeom *__restrict__ geom, int nlevels, int totalTiles, BlurPlan bp,
+                                                     int gaussRounding) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int bx, b;
     xcd_block_map(bx, b);
@@ -207,15 +208,26 @@ __global__ __launch_bounds__(256) void k_blur_levels(const uint8_t *__restrict__
     }
     uint8_t *dst = blur + (size_t)b * pyrImgBytes + g.poff;
     const bool col_ok = D <= DL;
+    // column rounding (orbx_flavour_t): half up = + 2^15; SSE2 = half to even for the level's columns x < (w & ~3):
+    // + 32767 + bit 16 of the sum (a v_bfe whose WIDTH is 0 for the other columns)
+    uint32_t rc[4], bw[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int x = 4 * D + q - ORBX_EDGE;
+        const bool even = gaussRounding == ORBX_GAUSS_ROUND_SSE2 && x < (g.w & ~3);
+        rc[q] = even ? 32767u : 32768u;
+        bw[q] = even ? 1u : 0u;
+    }
 #pragma unroll
     for (int r = 0; r < BLUR_R; r++) {
         uint32_t a[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            uint32_t s = udot2_u16_acc(pr[r][q], W01, 1u << 15);
+            uint32_t s = udot2_u16_acc(pr[r][q], W01, 0u);
             s = udot2_u16_acc(pr[r + 2][q], W23, s);
             s = udot2_u16_acc(pr[r + 4][q], W45, s);
             s = udot2_u16_acc(pr[r + 5][q], W6, s);
+            s = s + __builtin_amdgcn_ubfe(s, 16u, bw[q]) + rc[q];
             a[q] = min(s, 0xFFFFFFu);   // the taps sum to 257: a saturated neighbourhood reaches 257 * 65535 + 2^15 > 2^24 (-> 255)
         }
         const uint32_t out = __builtin_amdgcn_perm(a[1], a[0], 0x0c0c0602u) | __builtin_amdgcn_perm(a[3], a[2], 0x06020c0cu);
@@ -224,6 +236,7 @@ __global__ __launch_bounds__(256) void k_blur_levels(const uint8_t *__restrict__
     }
 }
 
+template <int GAUSS>
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
     const uint32_t *__restrict__ lvlKp, int lvlKpCap, const int32_t *__restrict__ lvlCnt,
@@ -457,9 +470,19 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
 #pragma unroll
         for (int k = 0; k < 19; k++) T[k] = col[k * TSTRIDE4];
         const uint32_t W01 = 18u | (34u << 16), W23 = 49u | (55u << 16), W45 = 49u | (34u << 16);
+        // column rounding of the flavour (include/orbx.h): half up = the 2^15 the sums start from; SSE2 = round half to EVEN for the
+        // level's columns x < (w & ~3) - sum + 32767 + bit 16 of the sum, the bit taken by a v_bfe whose WIDTH is 0 for the
+        // columns of the scalar tail (which keep + 2^15).  Blurred column c of the block is level column cx - 18 + c.
+        uint32_t rc0 = 0, rc1 = 0, bw0 = 0, bw1 = 0;
+        if (GAUSS == ORBX_GAUSS_ROUND_SSE2) {
+            const int x0 = cx - ORBX_DESC_R + 2 * cp, wv = g.w & ~3;
+            bw0 = x0 < wv ? 1u : 0u; bw1 = x0 + 1 < wv ? 1u : 0u;
+            rc0 = 32768u - bw0; rc1 = 32768u - bw1;
+        }
+        constexpr uint32_t A_INIT = GAUSS == ORBX_GAUSS_ROUND_SSE2 ? 0u : 1u << 15;
 #pragma unroll
         for (int rr = 0; rr < 13; rr++) {
-            uint32_t a0 = 1u << 15, a1 = 1u << 15;
+            uint32_t a0 = A_INIT, a1 = A_INIT;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const uint32_t w = k == 0 ? W01 : k == 1 ? W23 : W45;
@@ -469,6 +492,10 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
             // 7th tap = high half of pair[rr+5] = (row rr+5, row rr+6), a pair the next output row needs anyway
             a0 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 6], T[rr + 5], 0x05040100u), 18u << 16, a0);
             a1 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 6], T[rr + 5], 0x07060302u), 18u << 16, a1);
+            if (GAUSS == ORBX_GAUSS_ROUND_SSE2) {
+                a0 = a0 + __builtin_amdgcn_ubfe(a0, 16u, bw0) + rc0;
+                a1 = a1 + __builtin_amdgcn_ubfe(a1, 16u, bw1) + rc1;
+            }
             a0 = min(a0, 0xFFFFFFu);   // the taps sum to 257: a saturated patch reaches 257 * 65535 + 2^15 > 2^24 (-> 255)
             a1 = min(a1, 0xFFFFFFu);
             if (rr < nr) *(uint16_t *)(Bl + (r0 + rr) * BSTRIDE + 2 * cp) = (uint16_t)__builtin_amdgcn_perm(a1, a0, 0x0c0c0602u);
@@ -518,6 +545,11 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
         kps[oi] = kp;
     }
 }
+
+template __global__ void k_describe<ORBX_GAUSS_ROUND_HALF_UP>(const uint8_t *, size_t, const LevelGeom *, int, const uint32_t *, int, const int32_t *,
+                                                              orbx_keypoint_t *, uint8_t *, int32_t *, int, uint8_t *, const uint8_t *, unsigned, DescGroup);
+template __global__ void k_describe<ORBX_GAUSS_ROUND_SSE2>(const uint8_t *, size_t, const LevelGeom *, int, const uint32_t *, int, const int32_t *,
+                                                           orbx_keypoint_t *, uint8_t *, int32_t *, int, uint8_t *, const uint8_t *, unsigned, DescGroup);
 
 // ---- test hook: the device's cosf / sinf restatement on an array of angles (tests compare it with the oracle's and with
 // the host libm over the whole angle domain; a descriptor only ever exercises the angles its keypoints happen to have)

@@ -40,8 +40,27 @@ extern "C" int orbx_thread_release_scratch(void) {
     return ORBX_OK;
 }
 
-int g_debug[32] = {0};
-extern "C" int orbx_debug_set(int key, int value) { if (key < 0 || key >= 32) return ORBX_ERR_ARG; g_debug[key] = value; return ORBX_OK; }
+// Per-handle options (include/orbx.h): which of several kernels / launch arrangements with identical results the handle uses.
+// There is no process-global switch.  Keys 0, 1, 7 stop a kernel after phase n (ablation timing; outputs incomplete) and exist only
+// in a developer build (-DORBX_DEVELOPER).
+extern "C" int orbx_set_option(orbx_extractor_t *h, int key, int value) {
+    static const signed char maxv[ORBX_NUM_OPTIONS] = {/*0*/ -1, -1, -2, 64, 3, 3, 3, -1, ORBX_MAX_CHUNKS, 1, 2, 2, 1, 2, 127, ORBX_MAX_LEVELS,
+                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 1, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
+    if (!h || key < 0 || key >= ORBX_NUM_OPTIONS || maxv[key] == -2) { orbx_set_error("orbx_set_option: unknown key %d", key); return ORBX_ERR_ARG; }
+#ifdef ORBX_DEVELOPER
+    if (maxv[key] == -1) { if (value < 0) return ORBX_ERR_ARG; h->opt[key] = value; return ORBX_OK; }
+#else
+    if (maxv[key] == -1) { orbx_set_error("orbx_set_option: key %d needs a library built with -DORBX_DEVELOPER", key); return ORBX_ERR_ARG; }
+#endif
+    if (value < 0 || (key != ORBX_OPT_BLUR_THRESHOLD && value > maxv[key])) { orbx_set_error("orbx_set_option: key %d does not take %d", key, value); return ORBX_ERR_ARG; }
+    h->opt[key] = value;
+    return ORBX_OK;
+}
+extern "C" int orbx_get_option(const orbx_extractor_t *h, int key, int *value) {
+    if (!h || !value || key < 0 || key >= ORBX_NUM_OPTIONS) return ORBX_ERR_ARG;
+    *value = h->opt[key];
+    return ORBX_OK;
+}
 
 // ------------------------------------------------------------------------------------
 // host side
@@ -55,8 +74,22 @@ static short sat_short_round(float v) {
 
 extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th,
                            int device, orbx_extractor_t **out) {
+    return orbx_create_flavoured(nfeatures, scale_factor, nlevels, ini_th, min_th, device, nullptr, out);
+}
+extern "C" int orbx_get_flavour(const orbx_extractor_t *h, orbx_flavour_t *out) {
+    if (!h || !out) return ORBX_ERR_ARG;
+    *out = h->flavour;
+    return ORBX_OK;
+}
+extern "C" int orbx_create_flavoured(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th,
+                                     int device, const orbx_flavour_t *flavour, orbx_extractor_t **out) {
     if (!out) { orbx_set_error("orbx_create: out is NULL"); return ORBX_ERR_ARG; }
     *out = nullptr;
+    if (flavour) {
+        bool ok = flavour->gauss_rounding == ORBX_GAUSS_ROUND_HALF_UP || flavour->gauss_rounding == ORBX_GAUSS_ROUND_SSE2;
+        for (int i = 0; i < 7; i++) ok = ok && flavour->reserved[i] == 0;
+        if (!ok) { orbx_set_error("orbx_create_flavoured: unknown flavour (gauss_rounding=%d)", flavour->gauss_rounding); return ORBX_ERR_ARG; }
+    }
     if (nfeatures < 1 || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || !(scale_factor > 1.0f) || ini_th < 0 ||
         min_th < 0 || ini_th > 255 || min_th > 255) {
         orbx_set_error("orbx_create: bad arguments (nfeatures=%d scale=%f nlevels=%d ini=%d min=%d)", nfeatures,
@@ -75,6 +108,7 @@ extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int i
     memset(h, 0, sizeof(*h));
     h->nfeatures = nfeatures; h->nlevels = nlevels; h->ini_th = ini_th; h->min_th = min_th;
     h->device = device; h->scale_factor = scale_factor;
+    if (flavour) h->flavour = *flavour;
     // scale tables (:415-431)
     h->sf[0] = 1.0f; h->sig2[0] = 1.0f;
     for (int i = 1; i < nlevels; i++) {
@@ -112,11 +146,11 @@ extern "C" int orbx_create(int nfeatures, float scale_factor, int nlevels, int i
     }
     for (int i = 0; i < ORBX_MAX_CHUNKS; i++) ORBX_HIP(hipEventCreateWithFlags(&h->evPyr[i], hipEventDisableTiming));
     // evFastDone orders the side stream's kernels behind FAST for SPEED only (they touch nothing FAST reads or writes): no memory fence
-    // is needed when it fires.  Developer knob 17 = 1 keeps the default (system-scope) fence.
-    ORBX_HIP(hipEventCreateWithFlags(&h->evFastDone, hipEventDisableTiming | (g_debug[17] == 1 ? 0u : hipEventDisableSystemFence)));
+    // is needed when it fires.
+    ORBX_HIP(hipEventCreateWithFlags(&h->evFastDone, hipEventDisableTiming | hipEventDisableSystemFence));
     ORBX_HIP(hipEventCreateWithFlags(&h->evGather, hipEventDisableTiming));
     ORBX_HIP(hipEventCreateWithFlags(&h->evOctA, hipEventDisableTiming));
-    ORBX_HIP(hipEventCreateWithFlags(&h->evPrefetch, hipEventDisableTiming | (g_debug[17] == 1 ? 0u : hipEventDisableSystemFence)));   // consumer: a kernel of the same device
+    ORBX_HIP(hipEventCreateWithFlags(&h->evPrefetch, hipEventDisableTiming | hipEventDisableSystemFence));   // consumer: a kernel of the same device
     for (int r = 0; r < ORBX_EV_RING; r++)
         // timing-only events: no system-scope fence (cache write-back + invalidate) when they complete — with the default
         // flags every stage boundary of a profiled batch cost ~5 us of idle GPU, which the step time then contained
@@ -379,7 +413,7 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     }
     {   // fused-pyramid tile spans, per axis: own_l partitions level l, comp_l = own_l + needs of comp_{l+1}
         const int Lc = h->nlevels - 1;
-        int T = (int)lrintf((g_debug[3] > 0 ? (float)g_debug[3] : 64.0f) / h->sf[Lc]);
+        int T = (int)lrintf((h->opt[3] > 0 ? (float)h->opt[3] : 64.0f) / h->sf[Lc]);
         T = std::max(4, std::min(64, (T + 2) & ~3));
         int maxDim = 0, maxPar = 0;
         for (int axis = 0; axis < 2; axis++) {
@@ -539,12 +573,12 @@ __global__ void k_nop() {}
 static unsigned blur_plan(const orbx_extractor *h, BlurPlan &bp, int &totalTiles) {
     unsigned mask = 0;
     totalTiles = 0;
-    const long thr = g_debug[14] > 0 ? g_debug[14] : ORBX_BLUR_THR;
+    const long thr = h->opt[14] > 0 ? h->opt[14] : ORBX_BLUR_THR;
     for (int l = 0; l <= ORBX_MAX_LEVELS; l++) {
         bp.tileBase[l] = totalTiles;
         if (l >= h->nlevels) continue;
         const LevelGeom &g = h->geom[l];
-        const bool on = g_debug[13] == 2 || (g_debug[13] == 0 && (long)g.N * 1369 * 100 >= thr * (long)g.w * g.h);
+        const bool on = h->opt[13] == 2 || (h->opt[13] == 0 && (long)g.N * 1369 * 100 >= thr * (long)g.w * g.h);
         bp.tilesX[l] = 0;
         if (!on) continue;
         mask |= 1u << l;
@@ -574,13 +608,14 @@ static int launch_blur(orbx_extractor *h, const uint8_t *pyr, uint8_t **blurBuf,
     int rc = ensure_blur(h, blurBuf, blurBytes);
     if (rc) return rc;
     const size_t off = (size_t)b0 * h->pyrImgBytes;   // images [b0, b0 + B) of both buffers
-    hipLaunchKernelGGL(k_blur_levels, dim3((tiles + 3) / 4, B), dim3(256), 0, st, pyr + off, *blurBuf + off, h->pyrImgBytes, h->d_geom, h->nlevels, tiles, bp);
+    hipLaunchKernelGGL(k_blur_levels, dim3((tiles + 3) / 4, B), dim3(256), 0, st, pyr + off, *blurBuf + off, h->pyrImgBytes, h->d_geom, h->nlevels, tiles, bp,
+                       h->flavour.gauss_rounding);
     return ORBX_OK;
 }
 
 // K1: ComputePyramid of B images into pyr.  Developer knob 5: 0 / 2 = one launch per level (the default), 1 = every level in the
 // fused launch, 3 = hybrid.
-static bool pyramid_fused_all(const orbx_extractor *h) { return g_debug[5] == 1 || h->scale_factor > 3.0; }
+static bool pyramid_fused_all(const orbx_extractor *h) { return h->opt[5] == 1 || h->scale_factor > 3.0; }
 static void launch_pyramid(orbx_extractor *h, const uint8_t *d_imgs, uint8_t *pyr, int B, int stride, size_t img_stride, hipStream_t st) {
     const int nl = h->nlevels;
     if (pyramid_fused_all(h)) {   // writes every frame itself (a lane's two source byte pairs fit 8 bytes only up to scale 3)
@@ -594,7 +629,7 @@ static void launch_pyramid(orbx_extractor *h, const uint8_t *d_imgs, uint8_t *py
     // image 193 us per orbx_extract call against 184 us with seven launches (the chain's five barriers and its generic per-pixel
     // indexing cost more than five ~4-us launches), and for a batch it spends five times the instructions per pixel while the
     // pyramid runs beside VALU-bound kernels.
-    const bool hybrid = g_debug[5] == 3;
+    const bool hybrid = h->opt[5] == 3;
     const int lastSingle = hybrid ? std::min(2, nl - 1) : nl - 1;
     const LevelGeom &g0 = h->geom[0];
     hipLaunchKernelGGL(k_pyr_pad<true>, dim3(((g0.pstride >> 4) * g0.prows + 255) / 256, 1, B), dim3(256), 0, st, d_imgs, stride,
@@ -655,17 +690,17 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     // With the pyramid built ahead nothing but a stream wait (for that pyramid) sits in front of the FAST launch, and a timing
     // event recorded right behind a pending wait can be stamped before the wait is over: the bracket then reads wait + FAST
     // (seen as 0.30 instead of 0.27 ms in one run out of four).  An empty kernel orders the stamp behind the wait.
-    if (profFast && skipPyr && g_debug[12] == 0) hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, st);
+    if (profFast && skipPyr && h->opt[12] == 0) hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, st);
     if (profFast) ORBX_HIP(hipEventRecord(ev[1], st));
     // decisions of the quad-tree stage that the FAST stage needs to know
     // developer knob 4: 0 default, 1 = the exact form alone, 2 = EVERY level by the multi-workgroup form, 3 = none
-    const bool usePyr = g_debug[4] != 1;
-    const bool multiWg = g_debug[4] == 2 || (g_debug[4] != 3 && B <= 4 && h->octBigMask != 0);
+    const bool usePyr = h->opt[4] != 1;
+    const bool multiWg = h->opt[4] == 2 || (h->opt[4] != 3 && B <= 4 && h->octBigMask != 0);
     // Fused: k_octree_pyr reads the FAST stage's cell lists in place (no k_gather launch, no compacted key array: -35 us per
     // 128 images 1241x376, -200 us per 64 images 1920x1080 in the pipelined step).  Not for the multi-workgroup form, the exact
     // form alone and the phase-stop knobs, which sweep the compacted array (developer knob 18 = 1: never fused).
-    const bool fused = usePyr && !multiWg && g_debug[7] == 0 && g_debug[1] == 0 && g_debug[18] != 1;
-    const int sparsePerCell = g_debug[16] == 2 ? 1 << 20 : ORBX_SPARSE_PER_CELL;
+    const bool fused = usePyr && !multiWg && h->opt[7] == 0 && h->opt[1] == 0 && h->opt[18] != 1;
+    const int sparsePerCell = h->opt[16] == 2 ? 1 << 20 : ORBX_SPARSE_PER_CELL;
     OctSrc osrc = {};
     if (fused) {
         osrc.cellCnt = v.cellCnt; osrc.cellRaw = v.cellRaw; osrc.slots = v.slots; osrc.slotsPerImg = h->slotsPerImg;
@@ -679,26 +714,26 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     for (int l = 0; l < nl; l++) maxCellsL = std::max(maxCellsL, h->geom[l].ncells);
     const int scratch = std::max(4 * h->maxNodeCap, maxCellsL + 1);
     const size_t ldsOct = std::max(h->octPyrLdsBytes, h->octLdsBytes);
-    const bool wideOct = g_debug[11] == 0 ? h->octBigMask != 0 : g_debug[11] == 2;
+    const bool wideOct = h->opt[11] == 0 ? h->octBigMask != 0 : h->opt[11] == 2;
     int earlyLv = 0;   // > 0: the strips of the levels [0, earlyLv) are launched first and their quad-tree starts beside the FAST of the rest
     {   // K2
         // developer knob 6: 1 = every level by k_fast_cells (compile-time tile strides), 2 = ... with run-time strides
         // a strip is a longer job than a cell (a wave walks ~33 rows): with few images the one-wave-per-cell kernel finishes
         // sooner (13 vs 29 us for one 1241x376 image); once the strips fill the GPU they win (2.5 vs 3.1 us per image).  Same results.
-        const bool strips = h->totalStrips > 0 && (g_debug[6] == 0 ? (size_t)h->totalStrips * B >= 4096 : g_debug[6] == 3);
+        const bool strips = h->totalStrips > 0 && (h->opt[6] == 0 ? (size_t)h->totalStrips * B >= 4096 : h->opt[6] == 3);
         const unsigned stripLevels = strips ? h->stripLevels : 0u;
         if (strips) {
             StripBases sb;
             for (int l = 0; l <= ORBX_MAX_LEVELS; l++) sb.v[l] = h->stripBase[l];
-            const int32_t *spf = g_debug[16] == 1 ? (const int32_t *)nullptr : v.sparse;   // developer knob 16: 1 = never pre-test, 2 = always
+            const int32_t *spf = h->opt[16] == 1 ? (const int32_t *)nullptr : v.sparse;   // developer knob 16: 1 = never pre-test, 2 = always
             // Early quad-tree (developer knob 19: a >= 2 = levels [0, a); default 0 = off): the quad-tree of the large levels is ONE
             // workgroup per level walking a serial chain - the critical path behind FAST.  Their strips go first, in a launch of their
             // own, and their quad-tree starts on a second stream as soon as that launch is done, beside the FAST of the remaining
             // levels.  Parity-tested and MEASURED SLOWER at every size (64 stereo frames 1241x376: 0.635 -> 0.649 ms per step with
             // a = 2, 0.657 with a = 3; 2000 features 0.838 -> 0.874; 1920x1080 x 64 1.254 -> 1.274; 752x480 0.599 -> 0.607): FAST loses to
             // the quad-tree workgroups what the shorter chain behind it gains, plus two cross-stream events.  Off by default.
-            const int ea = g_debug[19];
-            if (fused && !prof && g_debug[19] >= 2 && g_debug[15] < 2 && h->lastChunks == 1 && B >= 8 && nl > ea &&
+            const int ea = h->opt[19];
+            if (fused && !prof && h->opt[19] >= 2 && h->opt[15] < 2 && h->lastChunks == 1 && B >= 8 && nl > ea &&
                 (h->stripLevels & ((1u << ea) - 1u)) == (1u << ea) - 1u && h->d_dbgBlur == nullptr)
                 earlyLv = ea;
             const int sA = earlyLv ? h->stripBase[earlyLv] : 0;
@@ -733,8 +768,8 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     hipLaunchKernelGGL(k_fast_cells<EST>, grid, dim3(64 * FAST_WAVES), (size_t)h->fastLdsPerWave * FAST_WAVES, st,  \
                        v.pyr, h->pyrImgBytes, h->d_geom, nl, h->totalCells, v.cellCnt, v.cellRaw, v.slots, \
                        h->slotsPerImg, h->ini_th, h->min_th, h->fastTileStride, h->fastScoreStride, h->fastTileRows, \
-                       h->fastLdsPerWave, g_debug[0], cb, stripLevels)
-            const int es = (h->fastScoreStride == h->fastTileStride - 8 && g_debug[6] != 2) ? h->fastTileStride : 0;
+                       h->fastLdsPerWave, h->opt[0], cb, stripLevels)
+            const int es = (h->fastScoreStride == h->fastTileStride - 8 && h->opt[6] != 2) ? h->fastTileStride : 0;
             switch (es) {   // the strides of the usual 30-px cell grids; anything else takes the run-time-stride instance
             case 44: ORBX_LAUNCH_FAST(44); break;
             case 48: ORBX_LAUNCH_FAST(48); break;
@@ -746,16 +781,16 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     }
     if (profFast) ORBX_HIP(hipEventRecord(ev[2], st));
     const bool gate = h->pfUsed && evPyrDone == nullptr;   // a pyramid built ahead starts behind this FAST stage (knob 10: 1 behind the quad-tree, 2 behind the descriptors)
-    if (gate && g_debug[10] == 0) ORBX_HIP(hipEventRecord(h->evFastDone, st));
+    if (gate && h->opt[10] == 0) ORBX_HIP(hipEventRecord(h->evFastDone, st));
     {   // K3
         if (!fused)
             hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
                                dim3(256), 0, st, h->d_geom, nl, h->totalCells, v.cellCnt, v.cellRaw, v.slots,
                                h->slotsPerImg, v.cand, h->keysPerImg, v.candCnt, h->ini_th, h->min_th, cb, v.sparse, sparsePerCell);
         // developer knob 15: a >= 2 = split call at level a (default 0: one launch sequence)
-        aSplit = (usePyr && !prof && h->lastChunks == 1 && B >= 8 && g_debug[7] == 0 && g_debug[1] == 0 && g_debug[15] >= 2 &&
+        aSplit = (usePyr && !prof && h->lastChunks == 1 && B >= 8 && h->opt[7] == 0 && h->opt[1] == 0 && h->opt[15] >= 2 &&
                   !multiWg && h->d_dbgBlur == nullptr)
-                     ? std::min(g_debug[15], nl - 1) : 0;   // (default: no split - measured slower)
+                     ? std::min(h->opt[15], nl - 1) : 0;   // (default: no split - measured slower)
         if (nl < 3) aSplit = 0;
         if (aSplit > 0) {   // scratch records of the levels [a, nl)
             const size_t need = (size_t)h->pB * cap * 60;
@@ -773,7 +808,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             // The multi-workgroup form shortens ONE image's critical path (a 1920x1080 level 0: 195 us alone in its workgroup); a
             // batch already fills the GPU with one workgroup per (image, level), and the extra hand-offs then cost more than they save
             // (batch 32 of 1920x1080: 274 us against 215), so it is taken for small batches only.  Same results either way.
-            const unsigned bigMask = g_debug[4] == 2 ? (1u << nl) - 1u : (g_debug[4] == 3 || B > 4) ? 0u : h->octBigMask;
+            const unsigned bigMask = h->opt[4] == 2 ? (1u << nl) - 1u : (h->opt[4] == 3 || B > 4) ? 0u : h->octBigMask;
             OctBig big = {};
             // the kernels index this scratch by the chunk-local image: chunks that run side by side on two streams get disjoint slots
             big.part = h->d_octPart + v.octSlot0 * OCT_BIG_K * (size_t)h->octDeepMax; big.leaf = h->d_octLeaf + v.octSlot0 * (size_t)h->octPyrWords;
@@ -781,7 +816,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             big.K = OCT_BIG_K; big.deepMax = h->octDeepMax; big.pyrMax = h->octPyrWords;
             for (int l = 0; l < nl; l++) if ((bigMask >> l) & 1u) big.levelOf[big.nBig++] = l;
             // 1024-thread instances for images with a large level (>= 600 FAST cells; developer knob 11: 1 = never, 2 = always)
-            const bool wide = g_debug[11] == 0 ? h->octBigMask != 0 : g_debug[11] == 2;
+            const bool wide = h->opt[11] == 0 ? h->octBigMask != 0 : h->opt[11] == 2;
 #define ORBX_OCT_LAUNCH_ON(STREAM, KERN, KERNW, GRID, LDS, ...)                                                            \
     do {                                                                                                                \
         if (wide) {                                                                                                     \
@@ -793,7 +828,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
         }                                                                                                               \
     } while (0)
 #define ORBX_OCT_LAUNCH(KERN, KERNW, GRID, LDS, ...) ORBX_OCT_LAUNCH_ON(st, KERN, KERNW, GRID, LDS, __VA_ARGS__)
-            if (big.nBig > 0 && g_debug[7] == 0 && g_debug[1] == 0) {
+            if (big.nBig > 0 && h->opt[7] == 0 && h->opt[1] == 0) {
                 // large levels: K workgroups histogram, the last one to arrive runs the passes; the same launch carries the other
                 // levels (one workgroup each, listed behind the large ones) ...
                 int nall = big.nBig;
@@ -829,20 +864,21 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             } else {   // no large level (or a phase-stop knob is set): one workgroup per level, one launch
                 ORBX_OCT_LAUNCH(k_octree_pyr, k_octree_pyr_wide, dim3(B, nl), lds, h->d_geom, nl, v.cand,
                                 h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
-                                pow2, h->octPyrWords, v.octFallback, g_debug[7], v.nodeOf, scratch, g_debug[1], 0u, 0, osrc);
+                                pow2, h->octPyrWords, v.octFallback, h->opt[7], v.nodeOf, scratch, h->opt[1], 0u, 0, osrc);
             }
         } else {        // developer knob 4 = 1: the exact form alone
-            const bool wide = g_debug[11] == 0 ? h->octBigMask != 0 : g_debug[11] == 2;
+            const bool wide = h->opt[11] == 0 ? h->octBigMask != 0 : h->opt[11] == 2;
             ORBX_OCT_LAUNCH(k_octree, k_octree_wide, dim3(B, nl), h->octLdsBytes, h->d_geom, nl, v.cand, v.nodeOf,
                             h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap, pow2,
-                            scratch, g_debug[1]);
+                            scratch, h->opt[1]);
 #undef ORBX_OCT_LAUNCH
 #undef ORBX_OCT_LAUNCH_ON
         }
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[3], st));
-    if (gate && g_debug[10] == 1) ORBX_HIP(hipEventRecord(h->evFastDone, st));
-    {   // K4
+    if (gate && h->opt[10] == 1) ORBX_HIP(hipEventRecord(h->evFastDone, st));
+    {   // K4 (one instance per flavour of the Gaussian's column rounding: the default pays nothing for the other)
+        const auto kDesc = h->flavour.gauss_rounding == ORBX_GAUSS_ROUND_SSE2 ? k_describe<ORBX_GAUSS_ROUND_SSE2> : k_describe<ORBX_GAUSS_ROUND_HALF_UP>;
         const uint8_t *blurp = h->blurMaskLast ? h->d_blur + (size_t)v.b0 * h->pyrImgBytes : nullptr;
         if (aSplit > 0) {
             int boundA = 0, boundB = 0;
@@ -852,31 +888,31 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             uint8_t *dB = h->d_descB + (size_t)v.b0 * cap * 32;
             const int nbB = (maxoB + DESC_WAVES - 1) / DESC_WAVES, nbA = (maxoA + DESC_WAVES - 1) / DESC_WAVES;
             const DescGroup gB = {aSplit, nl, 0, nbB, nullptr, nullptr};
-            hipLaunchKernelGGL(k_describe, dim3(nbB, B), dim3(64 * DESC_WAVES), 0, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
+            hipLaunchKernelGGL(kDesc, dim3(nbB, B), dim3(64 * DESC_WAVES), 0, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
                                v.lvlKp, h->lvlKpCap, v.lvlCnt, kB, dB, d_counts, cap, (uint8_t *)nullptr, blurp, h->blurMaskLast, gB);
             ORBX_HIP(hipStreamWaitEvent(st, h->evOctA, 0));
             const DescGroup gA = {0, aSplit, 1, nbA, kB, dB};
-            hipLaunchKernelGGL(k_describe, dim3(nbA + (maxoB + DESC_COPY_PER_BLOCK - 1) / DESC_COPY_PER_BLOCK, B), dim3(64 * DESC_WAVES), 0, st,
+            hipLaunchKernelGGL(kDesc, dim3(nbA + (maxoB + DESC_COPY_PER_BLOCK - 1) / DESC_COPY_PER_BLOCK, B), dim3(64 * DESC_WAVES), 0, st,
                                v.pyr, h->pyrImgBytes, h->d_geom, nl, v.lvlKp, h->lvlKpCap, v.lvlCnt, d_kps, d_desc, d_counts, cap,
                                (uint8_t *)nullptr, blurp, h->blurMaskLast, gA);
         } else {
             const int maxo = std::min(cap, h->max_kp);
             dim3 grid((maxo + DESC_WAVES - 1) / DESC_WAVES, B);
             const DescGroup gAll = {0, nl, 1, (int)grid.x, nullptr, nullptr};
-            hipLaunchKernelGGL(k_describe, grid, dim3(64 * DESC_WAVES), 0, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
+            hipLaunchKernelGGL(kDesc, grid, dim3(64 * DESC_WAVES), 0, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
                                v.lvlKp, h->lvlKpCap, v.lvlCnt, d_kps, d_desc, d_counts, cap, h->d_dbgBlur, blurp, h->blurMaskLast, gAll);
         }
     }
     if (prof) ORBX_HIP(hipEventRecord(ev[4], st));
-    if (gate && g_debug[10] == 2) ORBX_HIP(hipEventRecord(h->evFastDone, st));
+    if (gate && h->opt[10] == 2) ORBX_HIP(hipEventRecord(h->evFastDone, st));
     return ORBX_OK;
 }
 
 // Chunks a batch of B images is cut into (developer knob 8; default ONE).  The one rule for launch_pipeline and orbx_fast_kernels.
-static int chunk_count(int B, bool prof, bool skipPyr) {
-    int nch = g_debug[8] <= 1 ? 1 : std::min(g_debug[8], ORBX_MAX_CHUNKS);
+static int chunk_count(const orbx_extractor *h, int B, bool prof, bool skipPyr) {
+    int nch = h->opt[8] <= 1 ? 1 : std::min(h->opt[8], ORBX_MAX_CHUNKS);
     nch = std::min(nch, B);
-    if (prof || skipPyr || g_debug[0] || g_debug[1] || g_debug[7]) nch = 1;
+    if (prof || skipPyr || h->opt[0] || h->opt[1] || h->opt[7]) nch = 1;
     return nch;
 }
 
@@ -899,7 +935,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
     }
     // developer knob 8: n >= 2 = n chunks (default: one - measured on 64 stereo frames, two chunks: 773 us against 742, the
     // latency-bound gather / quad-tree do not shrink with the chunk and the pyramid slows the FAST it overlaps by as much as it gains).
-    const int nch = chunk_count(B, prof, skipPyr);
+    const int nch = chunk_count(h, B, prof, skipPyr);
     h->lastChunks = nch;
     h->candStale = 0;
     h->prevPyrValid = skipPyr ? 1 : 0;   // d_pyr is overwritten unless this call took a pyramid built ahead (then d_pyrAlt keeps the previous one)
@@ -941,7 +977,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor_t *h, const uint8_t *d_i
     // the pyramid of exactly this batch was built ahead (orbx_extract_batch_device_prefetch): take that buffer, skip K1
     const bool three = h->pyrBuffers == 3;
     const bool ahead = h->pfValid && (three ? h->d_pyrNext != nullptr : h->d_pyrAlt != nullptr) && h->pfImgs == d_imgs && h->pfB == B && h->pfW == w && h->pfH == hgt && h->pfStride == stride &&
-                       h->pfImgStride == image_stride_bytes && g_debug[9] == 0;
+                       h->pfImgStride == image_stride_bytes && h->opt[9] == 0;
     h->pfValid = 0;
     h->prevPyrValid = ahead ? 1 : 0;   // the buffers swap: the other one keeps the previous call's pyramid until the next one is built into it
     if (ahead) {
@@ -1341,10 +1377,10 @@ extern "C" int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, in
 extern "C" int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, int *cells, int *images_per_launch) {
     if (!h || h->pw == 0 || B < 1) { orbx_set_error("orbx_fast_kernels: no plan yet"); return ORBX_ERR_ARG; }
     // the last call's own chunk count when it was a batch of this size (it knows whether its pyramid was built ahead), else the rule
-    const int nch = (h->last_valid && h->lastB == B) ? h->lastChunks : chunk_count(B, h->profiling == 1, false);
+    const int nch = (h->last_valid && h->lastB == B) ? h->lastChunks : chunk_count(h, B, h->profiling == 1, false);
     B = B / nch;                                   // the first chunk is the one whose FAST stage carries the events
     if (images_per_launch) *images_per_launch = B;
-    const bool st = h->totalStrips > 0 && (g_debug[6] == 0 ? (size_t)h->totalStrips * B >= 4096 : g_debug[6] == 3);
+    const bool st = h->totalStrips > 0 && (h->opt[6] == 0 ? (size_t)h->totalStrips * B >= 4096 : h->opt[6] == 3);
     const unsigned lv = st ? h->stripLevels : 0u;
     if (strips) *strips = st ? 1 : 0;
     if (cells) *cells = lv != (1u << h->nlevels) - 1u ? 1 : 0;

@@ -68,7 +68,7 @@ struct DescGroup {
 #define BLUR_SRC (BLUR_R + 6)    // source rows a tile reads
 struct BlurPlan { int tileBase[ORBX_MAX_LEVELS + 1]; int tilesX[ORBX_MAX_LEVELS]; };   // tiles of the levels blurred as a whole (others own none)
 __global__ void k_blur_levels(const uint8_t *pyr, uint8_t *blur, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalTiles,
-                              BlurPlan bp);                                                                                        // orbx_describe.hip
+                              BlurPlan bp, int gaussRounding);                                                                                        // orbx_describe.hip
 struct CellBases { int v[ORBX_MAX_LEVELS + 1]; };
 __device__ __forceinline__ int level_of_cell(const CellBases &cb, int nlevels, int gc) {
     int l = 0;
@@ -136,6 +136,7 @@ __global__ void k_octree_big_wide(const LevelGeom *geom, int nlevels, const uint
 __global__ void k_octree_wide(const LevelGeom *geom, int nlevels, const uint32_t *cand, uint16_t *nodeOf, size_t keysPerImg,
                               const int32_t *candCnt, uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax,
                               int pow2cap, int scratchInts, int dbgStop);
+template <int GAUSS>   // ORBX_GAUSS_ROUND_*: column rounding of the fused Gaussian (orbx_flavour_t)
 __global__ void k_describe(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, const uint32_t *lvlKp,
                            int lvlKpCap, const int32_t *lvlCnt, orbx_keypoint_t *kps, uint8_t *desc, int32_t *counts,
                            int cap, uint8_t *dbgBlur, const uint8_t *blur, unsigned blurMask, DescGroup grp);                                                                             // orbx_describe.hip

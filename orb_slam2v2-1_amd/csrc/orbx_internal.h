@@ -64,6 +64,8 @@ struct orbx_extractor {
     int32_t nfeat[ORBX_MAX_LEVELS];
     int32_t umax[16];
     int max_kp;  // nfeatures + 3*nlevels (+ roots) upper bound per image
+    orbx_flavour_t flavour;          // which OpenCV build the handle stands in for (orbx_create_flavoured); fixed for the handle's life
+    int opt[ORBX_NUM_OPTIONS];       // per-handle options (orbx_set_option): alternative kernels / arrangements with identical results
 
     // plan (depends on image size / batch capacity)
     int pw, ph, pB;  // planned image size and batch capacity (0 = none)
@@ -163,7 +165,7 @@ int fast_best_in_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const 
                          int32_t *best_dist, int device);
 int fast_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, int npoints, int32_t *best_row,
                                  int32_t *best_median, int device);
-extern int g_debug[32];  // developer knobs (orbx_debug_set); [2] != 0 forces the exact one-workgroup matcher kernels
+extern thread_local int t_matchExact;   // orbm_set_thread_option(ORBM_OPT_EXACT_KERNELS): this thread's guided searches take the exact one-workgroup kernels
 
 // XCD-aware block -> (image, block-in-image) map for grids of (blocks per image, images).  Workgroups are dealt round-robin
 // to the 8 XCDs in linear-id order and every XCD has its own L2, so with the identity map neighbouring blocks - which

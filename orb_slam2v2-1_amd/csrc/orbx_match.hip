@@ -16,6 +16,14 @@
 #include <algorithm>
 #include <vector>
 
+// orbm_set_thread_option (include/orbx.h): like the matchers' scratch, their one option is per host thread - no process-global state
+thread_local int t_matchExact = 0;
+extern "C" int orbm_set_thread_option(int key, int value) {
+    if (key != ORBM_OPT_EXACT_KERNELS || (value != 0 && value != 1)) { orbx_set_error("orbm_set_thread_option: key %d / value %d", key, value); return ORBX_ERR_ARG; }
+    t_matchExact = value;
+    return ORBX_OK;
+}
+
 extern "C" int orbm_hamming(const uint8_t *a, const uint8_t *b) {
     if (!a || !b) return ORBX_ERR_ARG;
     int d = 0;
@@ -724,7 +732,7 @@ extern "C" int orbm_search_for_initialization(const orbx_keypoint_t *k1, const u
     }
     *nmatches = 0;
     if (n1 == 0) return ORBX_OK;
-    if (!g_debug[2] && n2 > 0) {
+    if (!t_matchExact && n2 > 0) {
         const int frc = fast_search_for_initialization(k1, d1, n1, k2, d2, n2, g2, prev_matched, matches12, window, nnratio,
                                                        check_orientation, device, nmatches);
         if (frc <= 0) return frc;  // done or error; > 0: exact fallback below
@@ -875,7 +883,7 @@ static int search_local_points_impl(const orbx_keypoint_t *kun, const uint8_t *d
     if (n == 0) return fast_is_in_frustum(pts, m, Tcw16, cam, g, viewing_cos_limit, thresholds, nlevels, proj_out, device);
     FrustumArgs w = {pts, Tcw16, cam, viewing_cos_limit, thresholds};
     int frc = ORBX_FAST_FALLBACK_RC;
-    if (!g_debug[2])
+    if (!t_matchExact)
         frc = fast_search_by_projection_mp(kun, desc, uright, n, g, scale_factors, nlevels, nullptr, mp_desc, m, frame_mp, ext_obs,
                                            th, nnratio, device, nmatches, &w, proj_out, dev);
     else {
@@ -923,7 +931,7 @@ extern "C" int orbm_search_by_projection_mp(const orbx_keypoint_t *kun, const ui
             orbx_set_error("map point %d: level %d out of range", i, mps[i].level);
             return ORBX_ERR_ARG;
         }
-    if (!g_debug[2]) {
+    if (!t_matchExact) {
         const int frc = fast_search_by_projection_mp(kun, desc, uright, n, g, scale_factors, nlevels, mps, mp_desc, m,
                                                      frame_mp, ext_obs, th, nnratio, device, nmatches);
         if (frc <= 0) return frc;
@@ -1098,7 +1106,7 @@ static int search_by_projection_frame_impl(const orbx_keypoint_t *kun, const uin
             orbx_set_error("last point %d: octave %d out of range", i, last[i].octave);
             return ORBX_ERR_ARG;
         }
-    if (!g_debug[2]) {
+    if (!t_matchExact) {
         const int frc = fast_search_by_projection_frame(kun, desc, uright, n, g, scale_factors, nlevels, cam, Tcw_cur16,
                                                         Tcw_last16, last, last_desc, nlast, cur_mp, ext_obs, th, mono,
                                                         check_orientation, device, nmatches, dev);
@@ -1275,7 +1283,7 @@ extern "C" int orbm_match_windows(const orbx_keypoint_t *kun, const uint8_t *des
     if (n == 0 || m == 0) return ORBX_OK;
     for (int i = 0; i < n; i++)
         if (holder[i] < -2 || holder[i] >= m) { orbx_set_error("holder[%d] = %d out of range", i, holder[i]); return ORBX_ERR_ARG; }
-    if (!g_debug[2]) {
+    if (!t_matchExact) {
         const int frc = fast_match_windows(kun, desc, uright, n, g, g_assign ? g_assign : g, queries, query_desc, m, holder, ext_blocks, max_dist,
                                            check_orientation, device, nmatches);
         if (frc <= 0) return frc;

@@ -151,11 +151,11 @@ def test_batch_chunking_does_not_change_results(chunks):
     chunk, so off by default): per-image results must not depend on it, uneven chunk sizes included (26 images in 3 or 4
     chunks), and the stereo matcher behind it must see finished arrays."""
     pkg = importlib.import_module(PKG)
-    pkg.lib().orbx_debug_set(8, chunks)
+    pkg.set_default_option(8, chunks)
     try:
         _run_stereo(752, 480, 700, 13, seed0=400, steps=3)
     finally:
-        pkg.lib().orbx_debug_set(8, 0)
+        pkg.set_default_option(8, 0)
 
 
 def test_pyramid_built_ahead_is_used_only_for_the_same_batch():

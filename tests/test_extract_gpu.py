@@ -24,11 +24,11 @@ def test_staged_parity(pkg, oracle, synth, w, h, nf, fast_kernel):
     ok, od = None, None
     orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
     ok, od = orc.extract(img)
-    pkg.lib().orbx_debug_set(6, 3 if fast_kernel == "strips" else 0)
+    pkg.set_default_option(6, 3 if fast_kernel == "strips" else 0)
     try:
         gk, gd = ex(img)
     finally:
-        pkg.lib().orbx_debug_set(6, 0)
+        pkg.set_default_option(6, 0)
     for l in range(8):
         np.testing.assert_array_equal(ex.pyramid_level(l, padded=True), orc.pyramid_level(l, padded=True),
                                       err_msg="pyramid level %d" % l)
@@ -65,7 +65,7 @@ def _compare(pkg, oracle, img, nf, sf=1.2, nl=8, ini=20, mn=7):
     ex = pkg.ORBextractor(nf, sf, nl, ini, mn)
     orc = oracle.Extractor(nf, sf, nl, ini, mn)
     ok, od = orc.extract(img)
-    knob = pkg.lib().orbx_debug_set
+    knob = pkg.set_default_option
     if _KNOB6[0] == 0:
         knob(6, 3)
         try:
@@ -292,7 +292,7 @@ def _pyr(oracle, img, nf, level):
 def test_fused_pyramid_kernel(pkg, oracle, synth):
     """k_pyramid_fused (all levels in one launch) is kept as the alternative to the level-per-launch
     pyramid (and is used for scale factors > 3): same bytes, frame included."""
-    pkg.lib().orbx_debug_set(5, 1)
+    pkg.set_default_option(5, 1)
     try:
         _compare(pkg, oracle, synth.frame(752, 480, 82), 1000)
         img = synth.frame(641, 479, 83)
@@ -303,7 +303,7 @@ def test_fused_pyramid_kernel(pkg, oracle, synth):
         for lvl in range(8):
             np.testing.assert_array_equal(ex.pyramid_level(lvl, padded=True), o.pyramid_level(lvl, padded=True), err_msg=str(lvl))
     finally:
-        pkg.lib().orbx_debug_set(5, 0)
+        pkg.set_default_option(5, 0)
 
 
 @pytest.mark.parametrize("knob", [2, 3])
@@ -311,7 +311,7 @@ def test_pyramid_forms_agree(pkg, oracle, synth, knob):
     """Developer knob 5: 2 = one launch per level (the default), 3 = the hybrid (levels 1, 2 per launch, levels 3.. chained
     through LDS in ONE launch; measured slower, kept as a tested alternative): every level byte for byte, frame included,
     for an odd size, a 3-, 4- and a 10-level pyramid, and the key points behind them."""
-    pkg.lib().orbx_debug_set(5, knob)
+    pkg.set_default_option(5, knob)
     try:
         for (w, h, nl, sf, seed) in ((641, 479, 8, 1.2, 84), (1241, 376, 8, 1.2, 85), (500, 400, 4, 1.3, 86), (900, 700, 10, 1.2, 87), (320, 240, 3, 1.2, 88)):
             img = synth.frame(w, h, seed)
@@ -324,7 +324,7 @@ def test_pyramid_forms_agree(pkg, oracle, synth, knob):
                 np.testing.assert_array_equal(ex.pyramid_level(lvl, padded=True), o.pyramid_level(lvl, padded=True), err_msg=str((w, h, nl, lvl)))
             ex.close()
     finally:
-        pkg.lib().orbx_debug_set(5, 0)
+        pkg.set_default_option(5, 0)
 
 
 def test_small_budget_many_roots(pkg, oracle, synth):
@@ -342,12 +342,12 @@ def test_large_scale_factor(pkg, oracle, synth):
 
 def test_quadtree_sweep_kernel_alone(pkg, oracle, synth):
     """k_octree (one key sweep per pass) is the exact fallback of k_octree_pyr: run it alone."""
-    pkg.lib().orbx_debug_set(4, 1)
+    pkg.set_default_option(4, 1)
     try:
         _compare(pkg, oracle, synth.frame(752, 480, 80), 1000)
         _compare(pkg, oracle, synth.frame(640, 480, 81), 2000)
     finally:
-        pkg.lib().orbx_debug_set(4, 0)
+        pkg.set_default_option(4, 0)
 
 
 def test_quadtree_multi_workgroup_form(pkg, oracle, synth):
@@ -360,7 +360,7 @@ def test_quadtree_multi_workgroup_form(pkg, oracle, synth):
     clustered[200:280, 260:380] = rng.integers(0, 256, (80, 120), dtype=np.uint8)   # all keys in one corner of the tree
     flat = np.full((480, 640), 77, np.uint8)                                          # no keys at all
     for knob in (2, 3):
-        pkg.lib().orbx_debug_set(4, knob)
+        pkg.set_default_option(4, knob)
         try:
             _compare(pkg, oracle, synth.frame(1241, 376, 96), 1000)
             _compare(pkg, oracle, synth.frame(640, 480, 97), 2000)
@@ -378,7 +378,7 @@ def test_quadtree_multi_workgroup_form(pkg, oracle, synth):
                     assert res[i][0].tobytes() == ok.tobytes() or (len(res[i][0]) == len(ok) and (res[i][1] == od).all()
                                                                      and (res[i][0]["x"] == ok["x"]).all() and (res[i][0]["y"] == ok["y"]).all())
         finally:
-            pkg.lib().orbx_debug_set(4, 0)
+            pkg.set_default_option(4, 0)
     _compare(pkg, oracle, synth.frame(1920, 1080, 99), 4000)     # default rule: a single image, the larger levels take the multi-workgroup form
 
 
@@ -390,8 +390,8 @@ def test_quadtree_workgroup_width(pkg, oracle, synth, wide, form):
     rng = np.random.default_rng(195)
     clustered = np.full((480, 640), 128, np.uint8)
     clustered[200:280, 260:380] = rng.integers(0, 256, (80, 120), dtype=np.uint8)
-    pkg.lib().orbx_debug_set(11, wide)
-    pkg.lib().orbx_debug_set(4, form)
+    pkg.set_default_option(11, wide)
+    pkg.set_default_option(4, form)
     try:
         _compare(pkg, oracle, synth.frame(1241, 376, 196), 2000)
         _compare(pkg, oracle, clustered, 1000)
@@ -399,8 +399,8 @@ def test_quadtree_workgroup_width(pkg, oracle, synth, wide, form):
         _compare(pkg, oracle, synth.frame(1920, 1080, 197), 4000)
         _compare(pkg, oracle, rng.integers(0, 256, (376, 620), dtype=np.uint8), 3000)
     finally:
-        pkg.lib().orbx_debug_set(11, 0)
-        pkg.lib().orbx_debug_set(4, 0)
+        pkg.set_default_option(11, 0)
+        pkg.set_default_option(4, 0)
 
 
 def test_fast_cell_kernel_instances(pkg, oracle, synth):
@@ -409,14 +409,14 @@ def test_fast_cell_kernel_instances(pkg, oracle, synth):
     with compile-time tile strides (44/48/52 dwords), 2 = the run-time-stride instance that serves every other configuration
     (reached naturally by 60-px-tall single-cell levels, stride 60)."""
     for knob in (1, 2):
-        pkg.lib().orbx_debug_set(6, knob)
+        pkg.set_default_option(6, knob)
         _KNOB6[0] = knob
         try:
             _compare(pkg, oracle, synth.frame(752, 480, 85), 1000)
             _compare(pkg, oracle, synth.frame(1241, 376, 86), 1000)
         finally:
             _KNOB6[0] = 0
-            pkg.lib().orbx_debug_set(6, 0)
+            pkg.set_default_option(6, 0)
     _compare(pkg, oracle, synth.frame(1241, 376, 86), 1000)
     _compare(pkg, oracle, synth.frame(333, 211, 87), 300, sf=1.3, nl=5)
 
@@ -567,7 +567,7 @@ def test_blur_forms_agree_with_oracle(pkg, oracle, synth, form, w, h, nf, kind):
     orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
     ok, od = orc.extract(img)
     ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
-    pkg.lib().orbx_debug_set(13, form)
+    pkg.set_default_option(13, form)
     try:
         gk, gd = ex(img)
         mask = ex.blurred_mask()
@@ -577,7 +577,7 @@ def test_blur_forms_agree_with_oracle(pkg, oracle, synth, form, w, h, nf, kind):
                 np.testing.assert_array_equal(ex.blurred_level(l), orc.blurred_level(l), err_msg="blurred level %d" % l)
         k2, d2, patches = ex.debug_blur_patches(img)     # the 37x37 blocks as k_describe saw them, whatever their source
     finally:
-        pkg.lib().orbx_debug_set(13, 0)
+        pkg.set_default_option(13, 0)
     assert len(gk) == len(ok) and len(ok) > 100
     for f in ("x", "y", "size", "response", "octave", "class_id"):
         np.testing.assert_array_equal(gk[f], ok[f], err_msg=f)
@@ -601,12 +601,12 @@ def test_blur_form_rule_and_batch(pkg, oracle, synth):
     for nf, thr in ((1000, 0), (1000, 60), (2500, 120), (400, 250)):
         orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
         ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
-        pkg.lib().orbx_debug_set(14, thr)
+        pkg.set_default_option(14, thr)
         try:
             res = ex.extract_batch(imgs)
             mask = ex.blurred_mask()
         finally:
-            pkg.lib().orbx_debug_set(14, 0)
+            pkg.set_default_option(14, 0)
         nfl = orc.features_per_level
         orc.extract(imgs[0])
         want = 0
@@ -638,7 +638,7 @@ def test_split_call_level_groups(pkg, oracle, synth, split):
     ex(imgs[0])
     d_imgs = torch.from_numpy(imgs).cuda()
     st = torch.cuda.current_stream().cuda_stream
-    pkg.lib().orbx_debug_set(15, split)
+    pkg.set_default_option(15, split)
     try:
         for cap in (ex.max_keypoints(), 700, 150):
             kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
@@ -659,7 +659,7 @@ def test_split_call_level_groups(pkg, oracle, synth, split):
                 np.testing.assert_allclose(got["angle"], ok["angle"][:n], atol=1e-4, rtol=0)
                 np.testing.assert_array_equal(dd[b, :n], od[:n])
     finally:
-        pkg.lib().orbx_debug_set(15, 0)
+        pkg.set_default_option(15, 0)
 
 
 @pytest.mark.parametrize("kind", ["natural", "dense", "flat_with_one_blob"])
@@ -681,8 +681,8 @@ def test_fast_row_pretest_is_exact(pkg, oracle, synth, kind, mode):
     orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
     ok, od = orc.extract(img)
     ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
-    pkg.lib().orbx_debug_set(6, 3)       # the strip kernel for a single image
-    pkg.lib().orbx_debug_set(16, mode)
+    pkg.set_default_option(6, 3)       # the strip kernel for a single image
+    pkg.set_default_option(16, mode)
     try:
         for rep in range(3):
             gk, gd = ex(img)
@@ -693,8 +693,8 @@ def test_fast_row_pretest_is_exact(pkg, oracle, synth, kind, mode):
             np.testing.assert_array_equal(gk[["x", "y", "response", "octave"]], ok[["x", "y", "response", "octave"]])
             np.testing.assert_array_equal(gd, od)
     finally:
-        pkg.lib().orbx_debug_set(6, 0)
-        pkg.lib().orbx_debug_set(16, 0)
+        pkg.set_default_option(6, 0)
+        pkg.set_default_option(16, 0)
 
 
 @pytest.mark.parametrize("early", [0, 2, 3, 5])
@@ -715,8 +715,8 @@ def test_early_quadtree_of_large_levels(pkg, oracle, synth, early):
     desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
     cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    pkg.lib().orbx_debug_set(19, early)
-    pkg.lib().orbx_debug_set(6, 3)          # strips for this small batch
+    pkg.set_default_option(19, early)
+    pkg.set_default_option(6, 3)          # strips for this small batch
     try:
         for rep in range(3):
             ex.extract_batch_device(d_imgs.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)
@@ -734,8 +734,8 @@ def test_early_quadtree_of_large_levels(pkg, oracle, synth, early):
         for l in (0, 1, 4):                     # the compacted candidates are materialised on demand (k_gather) and still right
             np.testing.assert_array_equal(ex.debug_level_points(l, 0, b=3), _cands_of(oracle, imgs[3], nf, l))
     finally:
-        pkg.lib().orbx_debug_set(19, 0)
-        pkg.lib().orbx_debug_set(6, 0)
+        pkg.set_default_option(19, 0)
+        pkg.set_default_option(6, 0)
 
 
 def _cands_of(oracle, img, nf, l):

@@ -80,9 +80,9 @@ def test_stereo_edge_cases(pkg, oracle, synth):
 def matcher_path(request, pkg):
     """Both implementations of the guided searches: parallel candidates + speculative
     resolution (default) and the exact one-workgroup kernels it falls back to."""
-    pkg.lib().orbx_debug_set(2, 1 if request.param == "exact" else 0)
+    pkg.lib().orbm_set_thread_option(2, 1 if request.param == "exact" else 0)
     yield request.param
-    pkg.lib().orbx_debug_set(2, 0)
+    pkg.lib().orbm_set_thread_option(2, 0)
 
 
 def test_search_for_initialization(pkg, oracle, synth, matcher_path):
@@ -289,9 +289,9 @@ def test_match_windows_generic_paths_agree(pkg, oracle, synth, matcher_path):
     qd = d ^ (rng.integers(0, 256, d.shape, dtype=np.uint8) & rng.integers(0, 256, d.shape, dtype=np.uint8) &
               rng.integers(0, 256, d.shape, dtype=np.uint8))
     holder = np.full(n, -1, np.int32)
-    pkg.lib().orbx_debug_set(2, 1)
+    pkg.lib().orbm_set_thread_option(2, 1)
     en, eh = pkg.match_windows(k, d, uright, pkg.grid_geom(w, h), q, qd, holder, None, 100, True)
-    pkg.lib().orbx_debug_set(2, 0 if matcher_path == "fast" else 1)
+    pkg.lib().orbm_set_thread_option(2, 0 if matcher_path == "fast" else 1)
     gn, gh = pkg.match_windows(k, d, uright, pkg.grid_geom(w, h), q, qd, holder, None, 100, True)
     assert gn == en > 100
     np.testing.assert_array_equal(gh, eh)

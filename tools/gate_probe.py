@@ -11,7 +11,7 @@ pairs = [synth.stereo_pair(w, h, i) for i in range(B)]
 L = np.stack([p[0] for p in pairs])
 R = np.stack([p[1] for p in pairs])
 for name, pf, knob in (("no prefetch", False, 0), ("behind FAST", True, 0), ("behind quad-tree", True, 1), ("behind descriptors", True, 2)):
-    pkg.lib().orbx_debug_set(10, knob)
+    pkg.set_default_option(10, knob)
     fe = pl.FrontEnd(w, h, nf, True, B, prefetch=pf).upload(L, R)
     best = 1e9
     for rep in range(3):

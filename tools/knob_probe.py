@@ -13,7 +13,7 @@ if stereo:
 else:
     L, R = np.stack([synth.frame(w, h, i) for i in range(B)]), None
 for v in vals:
-    pkg.lib().orbx_debug_set(knob, v)
+    pkg.set_default_option(knob, v)
     late = os.environ.get("LATE")
     fe = pl.FrontEnd(w, h, nf, bool(stereo), B, stereo_late=None if late is None else bool(int(late))).upload(L, R)
     best = 1e9
@@ -28,4 +28,4 @@ for v in vals:
         best = min(best, (time.perf_counter() - t) / 40)
     print("knob %d = %d: %.4f ms/step  %.0f per s" % (knob, v, best * 1e3, B / best), flush=True)
     del fe
-pkg.lib().orbx_debug_set(knob, 0)
+pkg.set_default_option(knob, 0)

@@ -10,10 +10,10 @@ w, h, nf, stop = (int(x) for x in sys.argv[1:5])
 ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
 img = synth.frame(w, h, 5)
 ex(img)
-pkg.lib().orbx_debug_set(7, stop)
+pkg.set_default_option(7, stop)
 for _ in range(20):
     try:
         ex(img)
     except Exception:
         pass
-pkg.lib().orbx_debug_set(7, 0)
+pkg.set_default_option(7, 0)

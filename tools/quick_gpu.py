@@ -13,7 +13,7 @@ else:
     imgs = synth.batch(w, h, 8, 0)
 imgs = np.concatenate([imgs] * ((B + 7) // 8))[:B]
 import os as _os
-if _os.environ.get("PYR_T"): pkg.lib().orbx_debug_set(3, int(_os.environ["PYR_T"]))
+if _os.environ.get("PYR_T"): pkg.set_default_option(3, int(_os.environ["PYR_T"]))
 ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
 k, d = ex(imgs[0])
 print("single:", len(k), k[:3], d[0][:8])
@@ -40,7 +40,7 @@ print("stage ms [pyr, fast, octree, describe, total]:", ex.stage_ms())
 print("counts", cnt[:8].tolist())
 if len(sys.argv) > 2 and sys.argv[2] == "ablate_oct":
     for ph in (1, 2, 3, 4, 5, 6, 7, 0):
-        pkg.lib().orbx_debug_set(1, ph)
+        pkg.set_default_option(1, ph)
         ex.set_profiling(True)
         for it in range(5):
             ex.extract_batch_device(timg.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)
@@ -48,7 +48,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "ablate_oct":
         print("octree dbgStop", ph, "stage ms", ex.stage_ms()[0])
 if len(sys.argv) > 2 and sys.argv[2] == "ablate":
     for ph in (1, 2, 3, 0):
-        pkg.lib().orbx_debug_set(0, ph)
+        pkg.set_default_option(0, ph)
         ex.set_profiling(True)
         for it in range(5):
             ex.extract_batch_device(timg.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)

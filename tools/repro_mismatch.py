@@ -12,7 +12,7 @@ orc = oracle.Extractor(nf, sf, nl, ini, mn)
 ok, od = orc.extract(img)
 for dbg in ([], [(4, 1)], [(5, 1)]):
     for k, v in dbg:
-        pkg.lib().orbx_debug_set(k, v)
+        pkg.set_default_option(k, v)
     ex = pkg.ORBextractor(nf, sf, nl, ini, mn)
     gk, gd = ex(img)
     print("debug", dbg, "gpu", len(gk), "oracle", len(ok))
@@ -30,5 +30,5 @@ for dbg in ([], [(4, 1)], [(5, 1)]):
         print("  level %d: pyramid %s  cand %d/%d %s  kept %d/%d %s  N=%d" % (l, "ok" if (pg == po).all() else "DIFF", len(cg), len(co),
               "ok" if same_c else "DIFF", len(kg), len(ko), "ok" if same_k else "DIFF", orc.features_per_level[l] if hasattr(orc, "features_per_level") else -1))
     for k, v in dbg:
-        pkg.lib().orbx_debug_set(k, 0)
+        pkg.set_default_option(k, 0)
     ex.close()

@@ -6,7 +6,7 @@ pkg = importlib.import_module("orb_slam2v2-1_amd")
 synth = importlib.import_module("orb_slam2v2-1_amd.synth")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 if len(sys.argv) > 3:
-    pkg.lib().orbx_debug_set(int(sys.argv[2]), int(sys.argv[3]))   # developer knob, e.g. 5 1 = fused pyramid kernel, 4 3 = no multi-workgroup quad-tree
+    pkg.set_default_option(int(sys.argv[2]), int(sys.argv[3]))   # developer knob, e.g. 5 1 = fused pyramid kernel, 4 3 = no multi-workgroup quad-tree
 for w, h, nf in ((1241, 376, 1000), (1241, 376, 2000), (1920, 1080, 4000)):
     ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
     img = synth.frame(w, h, 5)

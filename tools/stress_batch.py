@@ -50,14 +50,14 @@ for it in range(N):
     cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     for k, v in knobs:
-        pkg.lib().orbx_debug_set(k, v)
+        pkg.set_default_option(k, v)
     try:
         for rep in range(2):
             ex.extract_batch_device(d_imgs.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)
         torch.cuda.synchronize()
     finally:
         for k, v in knobs:
-            pkg.lib().orbx_debug_set(k, 0)
+            pkg.set_default_option(k, 0)
     kk = kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
     dd = desc.cpu().numpy()
     for b in range(B):

@@ -40,7 +40,7 @@ for rd in range(1, rounds + 1):
         cases.append(("bow[%s]" % v, "fast", lambda v=v: T.test_search_by_bow(pkg, oracle, bow, v)))
     cases.append(("triangulation", "fast", lambda: T.test_search_for_triangulation(pkg, oracle, bow)))
     for name, path, fn in cases:
-        pkg.lib().orbx_debug_set(2, 1 if path == "exact" else 0)
+        pkg.lib().orbm_set_thread_option(2, 1 if path == "exact" else 0)
         try:
             fn()
         except AssertionError as e:
@@ -55,7 +55,7 @@ for rd in range(1, rounds + 1):
             print("ERROR round", rd, name)
             traceback.print_exc(limit=2)
         finally:
-            pkg.lib().orbx_debug_set(2, 0)
+            pkg.lib().orbm_set_thread_option(2, 0)
 np.random.default_rng = orig_rng
 print("matcher stress: %d rounds, %d failures, %.1f s" % (rounds, bad, time.time() - t0))
 sys.exit(1 if bad else 0)

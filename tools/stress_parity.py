@@ -60,14 +60,14 @@ for it in range(N):
     for variant, knobs in (("default", ()), ("strips", ((6, 3),)), ("strips+multi-wg quad-tree", ((6, 3), (4, 2))),
                            ("strips+row pre-test", ((6, 3), (16, 2))), ("k_gather + compacted keys", ((18, 1),))):
         for k, v in knobs:
-            pkg.lib().orbx_debug_set(k, v)
+            pkg.set_default_option(k, v)
         try:
             gk, gd = ex(img)
             if variant.endswith("pre-test"):
                 gk, gd = ex(img)     # the second call runs under the verdicts the first one left (every level pre-tested)
         finally:
             for k, v in knobs:
-                pkg.lib().orbx_debug_set(k, 0)
+                pkg.set_default_option(k, 0)
         same = len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and gd.tobytes() == od.tobytes()
         if not same:
             bad += 1
