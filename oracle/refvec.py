@@ -85,8 +85,9 @@ def _xyr(c):
     return np.stack([c["x"], c["y"], c["score"]], 1).astype("<i4") if len(c) else np.zeros((0, 3), "<i4")
 
 
-def oracle_vectors(case, force_full=None):
-    """What the ORACLE produces for `case`, under the key set of dump_reference_vectors.cc -> dict of arrays."""
+def oracle_vectors(case, force_full=None, gauss=None):
+    """What the ORACLE produces for `case`, under the key set of dump_reference_vectors.cc -> dict of arrays.
+    gauss: flavour of the Gaussian's column rounding ("half_up" / "sse2"; None = the oracle's default)."""
     import oracle
     name, w, h, nf, stereo, seed, kind, full = case
     full = full if force_full is None else force_full
@@ -97,7 +98,7 @@ def oracle_vectors(case, force_full=None):
     out[p + "meta_f"] = np.array([SCALE, KITTI_FX, KITTI_BF], "<f4")
     out[p + "info"] = np.frombuffer(b"producer=oracle (NOT reference output)", np.uint8)
     out[p + "image_crc"] = np.array([crc(left)] + ([crc(right)] if stereo else []), "<f8")
-    ex = oracle.Extractor(nf, SCALE, NLEVELS, INI_TH, MIN_TH)
+    ex = oracle.Extractor(nf, SCALE, NLEVELS, INI_TH, MIN_TH, gauss=gauss)
     k, d = ex.extract(left)
     out[p + "scale_factors"] = np.asarray(ex.scale_factors, "<f4")
     out[p + "features_per_level"] = np.asarray(ex.features_per_level, "<i4")
@@ -123,7 +124,7 @@ def oracle_vectors(case, force_full=None):
     out[p + "keypoints"] = np.frombuffer(k.tobytes(), np.uint8).reshape(len(k), 28)
     out[p + "descriptors"] = d
     if stereo:
-        exr = oracle.Extractor(nf, SCALE, NLEVELS, INI_TH, MIN_TH)
+        exr = oracle.Extractor(nf, SCALE, NLEVELS, INI_TH, MIN_TH, gauss=gauss)
         kr, dr = exr.extract(right)
         out[p + "keypoints_right"] = np.frombuffer(kr.tobytes(), np.uint8).reshape(len(kr), 28)
         out[p + "descriptors_right"] = dr
@@ -193,7 +194,7 @@ def compare(ref, got):
         elif leaf == "crc":
             d = [i for i in range(len(r)) if r[i] != g[i]]
             if d:
-                bad.append((key, stage, "checksum(s) %s differ ([0] level, [1] padded, [2] blurred): re-dump the case with full=1 "
+                bad.append((key, stage, "checksum(s) %s differ ([0] level, [1] padded, [2] blurred - [2] alone: try the other gauss flavour): re-dump the case with full=1 "
                                         "in the manifest to see the pixels" % d))
         elif r.dtype.kind == "f":
             if r.tobytes() != g.tobytes():
@@ -205,6 +206,30 @@ def compare(ref, got):
             else:
                 bad.append((key, stage, "%d values differ" % int((r != g).sum())))
     return bad, ncmp, missing
+
+
+def identify_flavour(ref, produce):
+    """Which flavour of the unpinned OpenCV decisions a reference vector file follows.  produce(flavour) -> the arrays a backend
+    (oracle or HIP) gives for the file's case under that flavour.  The flavours differ in the blurred pixels only (per-level
+    `crc`[2] / `blur`) and in whatever descriptor bits those pixels decide, so a file whose other stages agree names its flavour by
+    the blur checksums.  -> (flavour whose every compared key agrees or None, {flavour: (bad, ncmp, missing)}, verdict text)."""
+    import oracle
+    res = {}
+    for fl in oracle.GAUSS_FLAVOURS:
+        res[fl] = compare(ref, produce(fl))
+    clean = [fl for fl, (bad, _, _) in res.items() if not bad]
+    if clean:
+        both = len(clean) == len(res)
+        return clean[0], res, ("reference agrees with EVERY flavour (no pixel of this case sits on a rounding tie)" if both else
+                               "reference follows flavour %r of cv::GaussianBlur's column rounding" % clean[0])
+
+    def blur_only(bad):
+        return all(k.rsplit("/", 1)[1] in ("blur", "crc", "descriptors", "descriptors_right") and (k.rsplit("/", 1)[1] != "crc" or "[2]" in d)
+                   for k, _, d in bad)
+    hint = [fl for fl, (bad, _, _) in res.items() if blur_only(bad)]
+    return None, res, ("no flavour reproduces the reference" + (
+        "; with %s only the blurred pixels / descriptors differ: a THIRD variant of GaussianBlur (OpenCV >= 3.4.1 bit-exact path, IPP, NEON?)"
+        % " and ".join(repr(h) for h in hint) if hint else "; stages in front of the blur differ too (see the first stage listed)"))
 
 
 def case_of_file(ref):

@@ -5,20 +5,27 @@
 #include <cassert>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace ORB_SLAM2 {
 
 static_assert(sizeof(orbx_keypoint_t) == 28, "cv::KeyPoint wire layout");
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST,
-                           int device)
+                           int device, const orbx_flavour_t *flavour)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST),
       minThFAST(_minThFAST), mpHandle(nullptr), mbMaterializePyramid(true) {
     if (device < 0) {
         const char *e = std::getenv("ORBX_DEVICE");
         device = e ? std::atoi(e) : 0;
     }
-    if (orbx_create(nfeatures, _scaleFactor, nlevels, iniThFAST, minThFAST, device, &mpHandle) != ORBX_OK) {
+    orbx_flavour_t fl = {};
+    if (flavour) fl = *flavour;
+    else if (const char *g = std::getenv("ORBX_GAUSS_ROUNDING")) {
+        if (!std::strcmp(g, "sse2")) fl.gauss_rounding = ORBX_GAUSS_ROUND_SSE2;
+        else if (std::strcmp(g, "half_up")) std::fprintf(stderr, "ORBextractor: ORBX_GAUSS_ROUNDING=%s ignored (half_up | sse2)\n", g);
+    }
+    if (orbx_create_flavoured(nfeatures, _scaleFactor, nlevels, iniThFAST, minThFAST, device, &fl, &mpHandle) != ORBX_OK) {
         std::fprintf(stderr, "ORBextractor: %s\n", orbx_last_error());  // the reference logs with cerr too
         mpHandle = nullptr;
         return;

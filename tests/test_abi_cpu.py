@@ -95,3 +95,31 @@ def test_predict_scale_threshold_table(oracle):
             expect = L.oracle_predict_scale_ratio(float(r), float(log_sf), nl)
             got = int((np.float32(r) >= thr).sum())
             assert got == expect, (sf, float(r))
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree exists in the build container only")
+@pytest.mark.parametrize("src", ["ORBVocabulary.cc", "ORBmatcher.cc"])
+def test_dbow2_integration_branch_compiles_against_the_reference_headers(src):
+    """host/ORBVocabulary.h's ORBX_HAVE_DBOW2 branch takes BowVector / FeatureVector from the reference's own Thirdparty/DBoW2
+    instead of the local restatement: it must keep compiling against those headers (syntax + types only, nothing is built).
+    The ORBX_HAVE_OPENCV / ORBX_HAVE_ORBSLAM2 branches and tools/refvec/dump_reference_vectors.cc need OpenCV headers, which
+    this image does not have (tests/golden/README.md lists what they rely on)."""
+    import subprocess
+    host = os.path.join(ROOT, "orb_slam2v2-1_amd", "host")
+    p = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-DORBX_HAVE_DBOW2", "-I" + REF, "-I" + os.path.join(ROOT, "include"),
+                        "-I" + host, os.path.join(host, src)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+
+
+def test_default_build_has_no_process_global_switch(pkg):
+    """no global mutable state.  The library exports no orbx_debug_* setter; kernel selection is per handle
+    (orbx_set_option), the matchers' one option per thread (orbm_set_thread_option), and phase-stop keys need -DORBX_DEVELOPER."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    syms = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert "orbx_set_option" in syms and "orbm_set_thread_option" in syms
+    assert not [s for s in syms if s.startswith("orbx_debug_set") or s == "g_debug"], syms
+    assert "ORBX_BENCH_KNOBS" not in open(os.path.join(ROOT, "bench.py")).read()

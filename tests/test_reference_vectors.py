@@ -97,22 +97,50 @@ def test_consumer_end_to_end_on_oracle_written_vectors(tmp_path, case_name):
         assert [b[0] for b in bad] == [p + key], (key, _format(bad))
 
 
+def test_consumer_names_the_flavour_a_file_follows(tmp_path):
+    """A vector file written under one flavour of the Gaussian's column rounding is reported as following THAT flavour (not as a
+    bare mismatch), from the per-level blur checksums; a third variant is reported as such."""
+    rv = _refvec()
+    case = next(c for c in rv.CASES if c[0] == "euroc_752x480_1000")
+    vecs = {fl: rv.oracle_vectors(case, gauss=fl) for fl in ("half_up", "sse2")}
+    differ = [k for k in vecs["half_up"] if k.endswith("/crc") and not np.array_equal(vecs["half_up"][k], vecs["sse2"][k])]
+    assert differ, "the case must hold at least one rounding tie"
+    for fl in ("half_up", "sse2"):
+        path = str(tmp_path / ("ref_%s.orbvec" % fl))
+        rv.write(path, vecs[fl])
+        got, res, verdict = rv.identify_flavour(rv.read(path), lambda g: vecs[g])
+        assert got == fl and repr(fl) in verdict, verdict
+        other = "sse2" if fl == "half_up" else "half_up"
+        assert {k.rsplit("/", 1)[1] for k, _, _ in res[other][0]} <= {"crc", "descriptors", "descriptors_right"}
+    third = dict(vecs["half_up"])
+    a = third[differ[0]].copy(); a[2] += 7; third[differ[0]] = a          # blurred pixels that follow neither flavour
+    got, _, verdict = rv.identify_flavour(third, lambda g: vecs[g])
+    assert got is None and "THIRD variant" in verdict, verdict
+
+
 def test_reference_vectors_pin_the_oracle():
     files = _reference_files()
     if not files:
         pytest.skip(NO_VECTORS)
     rv = _refvec()
-    report = []
+    report, followed = [], set()
     for f in files:
         ref = rv.read(f)
         case = rv.case_of_file(ref)
         info = bytes(ref[case[0] + "/info"]).decode()
         assert "producer=reference" in info, "%s was not written by the reference dump program (%s)" % (f, info)
         assert rv.check_inputs(ref, case), "%s: computed on different pixels than the committed synthetic case" % f
-        bad, ncmp, missing = rv.compare(ref, rv.oracle_vectors(case, force_full=int(ref[case[0] + "/meta"][7])))
-        assert not missing, missing
-        if bad:
-            report.append("%s (%s):\n%s" % (os.path.basename(f), info, _format(bad)))
+        full = int(ref[case[0] + "/meta"][7])
+        flavour, res, verdict = rv.identify_flavour(ref, lambda fl: rv.oracle_vectors(case, force_full=full, gauss=fl))
+        print("%s: %s" % (os.path.basename(f), verdict))
+        assert not any(missing for _, _, missing in res.values())
+        if flavour is None:
+            report.append("%s (%s): %s\n%s" % (os.path.basename(f), info, verdict, "\n".join(
+                "-- flavour %s:\n%s" % (fl, _format(bad)) for fl, (bad, _, _) in res.items())))
+        else:
+            followed.add(flavour if "EVERY" not in verdict else None)
+    followed.discard(None)
+    assert len(followed) <= 1, "reference files follow different flavours: %s" % sorted(followed)
     assert not report, "the CPU oracle disagrees with the reference:\n" + "\n".join(report)
 
 
@@ -128,9 +156,11 @@ def test_reference_vectors_pin_the_hip_path():
         ref = rv.read(f)
         case = rv.case_of_file(ref)
         assert "producer=reference" in bytes(ref[case[0] + "/info"]).decode()
-        bad, ncmp, missing = be.compare_hip(ref, be.hip_vectors(case))
-        if bad:
-            report.append("%s:\n%s" % (os.path.basename(f), _format(bad)))
+        flavour, res, verdict = rv.identify_flavour(ref, lambda fl: be.hip_vectors(case, gauss=fl))
+        print("%s: HIP path: %s" % (os.path.basename(f), verdict))
+        if flavour is None:
+            report.append("%s: %s\n%s" % (os.path.basename(f), verdict, "\n".join(
+                "-- flavour %s:\n%s" % (fl, _format(bad)) for fl, (bad, _, _) in res.items())))
     assert not report, "the HIP path disagrees with the reference:\n" + "\n".join(report)
 
 
@@ -147,5 +177,12 @@ def test_consumer_hip_backend_on_oracle_written_vectors(tmp_path, case_name):
     bad, ncmp, missing = be.compare_hip(ref, be.hip_vectors(case))
     assert not bad, _format(bad)
     assert ncmp >= 8 * 3 + 5
+    # a file written under the OTHER flavour is recognised as such by oracle and HIP path alike (the quantised case has ties)
+    if case_name == "tiny_320x240_500":
+        for fl in ("half_up", "sse2"):
+            rv.write(path, rv.oracle_vectors(case, gauss=fl))
+            ref = rv.read(path)
+            got_fl, _, verdict = rv.identify_flavour(ref, lambda g: be.hip_vectors(case, gauss=g))
+            assert got_fl is not None, verdict
     # what the HIP path cannot show (primitives it never materialises) is exactly this:
-    assert {m.rsplit("/", 1)[1] for m in missing} <= {"fast20", "fast7", "octree_direct", "pyramid", "padded", "blur"}, missing
+    assert {m.rsplit("/", 1)[1] for m in missing} <= {"fast20", "fast7", "octree_direct"}, missing
