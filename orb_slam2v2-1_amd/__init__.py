@@ -226,6 +226,15 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+def blur_reach_mask():
+    """[37, 37] bool: the pixels of a keypoint's blurred block a descriptor tap can reach - the rounded rotation of a pattern point
+    with x^2 + y^2 <= 338 satisfies (|row| - 1/2)^2 + (|col| - 1/2)^2 <= 338 (+ 2 of slack), 1133 of 1369 pixels.  The fused blur of
+    the descriptor kernel computes nothing else, and ORBextractor.debug_blur_patches reports the rest as 0."""
+    d = np.abs(np.arange(-18, 19))
+    t = np.where(d > 0, 2 * d - 1, 0)
+    return (t[:, None] ** 2 + t[None, :] ** 2) <= 4 * 340
+
+
 def device_count():
     return lib().orbx_device_count()
 

@@ -5,9 +5,6 @@
 #include <float.h>
 // ------------------------------------------------------------------------------------
 // constant tables
-__constant__ int8_t c_pattern[1024] = {
-#include "../../include/orb_pattern_31.inc"
-};
 // The other two tables of the path live in the code that uses them: umax (IC_Angle disc, :454-469) inside make_ic_tab,
 // the 7-tap sigma=2 Gaussian in 8-bit fixed point {18, 34, 49, 55, 49, 34, 18} (cvRound(k*256), sum 257) as the packed
 // weights of k_describe's two blur passes.
@@ -29,11 +26,81 @@ __constant__ int8_t c_pattern[1024] = {
 #define TROWS PROWS
 #define TCOLS (2 * ORBX_DESC_R + 1)  // 37
 #define TGROUPS 10               // horizontal pass: 10 groups of 4 outputs per row (cols 0..39)
-#define TSTRIDE4 20              // dwords per row of the u16 intermediate (40 columns)
 #define BSTRIDE 40
-// patch | pad | horizontal-pass intermediate (+ 2 rows of slack: the vertical pass of the last row segment reads rows 43, 44
-// and ignores them).  The blurred 37x40 block OVERLAYS the patch, which nobody reads after the horizontal pass.
-#define DESC_LDS_PER_WAVE (PROWS * PSTRIDE + PPAD + (TROWS + 2) * TSTRIDE4 * 4)
+// The horizontal pass leaves its u16 sums TRANSPOSED: column c of the block is a run of TCS bytes, row r at byte 2r, so that a
+// dword holds the rows (2p, 2p+1) of one column - the pair one v_dot2_u32_u16 of the vertical pass multiplies with two taps (the
+// first version kept rows of 40 columns and re-paired consecutive rows with 46 v_perm per lane).  23 dwords per column: odd, so
+// neighbouring columns start in different banks.
+#define TCS 92
+#define TT_BYTES (4 * TGROUPS * TCS)
+// patch | pad | transposed horizontal-pass intermediate.  The blurred 37x40 block OVERLAYS the patch, which nobody reads after the
+// horizontal pass.  (The gather form of a level blurred as a whole keeps its 37 rows of 40 bytes where the intermediate would be.)
+#define DESC_LDS_PER_WAVE (PROWS * PSTRIDE + PPAD + TT_BYTES)
+static_assert(DESC_WAVES * DESC_LDS_PER_WAVE <= 160 * 1024 / 7, "seven workgroups per CU");
+static_assert(TT_BYTES >= TCOLS * BSTRIDE + 4, "gather form: the blurred block sits where the intermediate would be");
+
+// Which pixels of the 37x37 blurred block a descriptor can read at all.  A tap is (cvRound(x*b + y*a), cvRound(x*a - y*b)) of a
+// pattern point with x^2 + y^2 <= 338 (src/ORBextractor.cc:119-120, 150-408): the rotated point lies on a circle of radius
+// <= 18.39, so the rounded tap (i, j) satisfies (|i| - 1/2)^2 + (|j| - 1/2)^2 <= 338 (+ 2 of slack for the float arithmetic):
+// a disc of 1133 of the 1369 pixels.  Both blur passes skip what lies outside it: c_reach.hh[c] = largest |row offset| column
+// c - 18 needs, the item list of the horizontal pass (370 of 430 (row, column group) items: six rounds of the wave instead of
+// seven) and the (column pair, first row) of every lane of the vertical pass (runs of 12 rows instead of 3 x 13 for every pair).
+// Everything outside the disc holds whatever the skipped work would have overwritten: no tap reads it.
+#define DESC_H_ITERS 6
+#define DESC_V_ROWS 12
+struct DescReach { uint8_t hh[40]; uint16_t hitem[DESC_H_ITERS * 64]; uint16_t vlane[64]; int nh, nv; };
+constexpr DescReach make_desc_reach() {
+    DescReach t{};
+    for (int c = 0; c < 40; c++) {
+        int best = -1;
+        const int ax = c < TCOLS ? (c > ORBX_DESC_R ? c - ORBX_DESC_R : ORBX_DESC_R - c) : 99;
+        for (int d = 0; d <= ORBX_DESC_R; d++) {
+            const int tx = ax > 0 ? 2 * ax - 1 : 0, ty = d > 0 ? 2 * d - 1 : 0;
+            if (tx * tx + ty * ty <= 4 * (338 + 2)) best = d;
+        }
+        t.hh[c] = (uint8_t)(best < 0 ? 0 : best);
+        if (c >= TCOLS) t.hh[c] = 0;
+    }
+    int n = 0;
+    for (int r = 0; r < PROWS; r++) {   // intermediate row r (row offset r - 21) is needed by column c iff |r - 21| <= hh[c] + 3
+        int g0 = 99, g1 = -1;
+        for (int c = 0; c < TCOLS; c++) {
+            const int dy = r > PR ? r - PR : PR - r;
+            if (dy <= t.hh[c] + 3) { if ((c >> 2) < g0) g0 = c >> 2; if ((c >> 2) > g1) g1 = c >> 2; }
+        }
+        for (int g = g0; g <= g1; g++) t.hitem[n++] = (uint16_t)(r | (g << 8));
+    }
+    t.nh = n;
+    for (int i = n; i < DESC_H_ITERS * 64; i++) t.hitem[i] = t.hitem[n - 1];   // spare slots redo the last item (same values)
+    int m = 0;
+    for (int cp = 0; cp < 19; cp++) {   // column pair (2cp, 2cp+1): rows 18 - h .. 18 + h, h = the taller of the two
+        const int h = t.hh[2 * cp] > t.hh[2 * cp + 1] ? t.hh[2 * cp] : t.hh[2 * cp + 1];
+        const int top = (ORBX_DESC_R - h) & ~1, bot = ORBX_DESC_R + h;
+        for (int r0 = top; r0 <= bot; r0 += DESC_V_ROWS) {
+            const int rs = r0 + DESC_V_ROWS > TCOLS + 1 ? TCOLS + 1 - DESC_V_ROWS : r0;   // even; the last run may overlap the one before
+            t.vlane[m < 64 ? m : 63] = (uint16_t)(cp | (rs << 8));
+            m++;
+        }
+    }
+    t.nv = m;
+    for (int i = m; i < 64; i++) t.vlane[i] = t.vlane[m - 1];
+    return t;
+}
+__constant__ const DescReach c_reach = make_desc_reach();
+static_assert(make_desc_reach().nh <= DESC_H_ITERS * 64 && make_desc_reach().nh > (DESC_H_ITERS - 1) * 64, "horizontal pass: rounds of the wave");
+static_assert(make_desc_reach().nv <= 64, "vertical pass: one run of rows per lane");
+// the rBRIEF pattern as floats (the rotation runs in float: src/ORBextractor.cc:119-120): no integer -> float conversions per tap
+__constant__ float c_patternf[1024] = {
+#include "../../include/orb_pattern_31.inc"
+};
+// tools/phase_count.py: with -DORBX_PHASE_MARKERS the kernel carries assembler comments at its phase boundaries, and the per-phase
+// instruction mix is counted from the disassembly (the hot path is straight-line: every loop is unrolled).  Never in the product
+// build: a volatile asm statement is a scheduling barrier.
+#ifdef ORBX_PHASE_MARKERS
+#define PHASE(name) asm volatile("; ORBX_PHASE " name)
+#else
+#define PHASE(name)
+#endif
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     // cv::fastAtan2 of OpenCV 2.4.11 / 3.2 (scalar path)
@@ -237,7 +304,7 @@ __global__ __launch_bounds__(256) void k_blur_levels(const uint8_t *__restrict__
 }
 
 template <int GAUSS>
-__global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
+__global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_describe(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
     const uint32_t *__restrict__ lvlKp, int lvlKpCap, const int32_t *__restrict__ lvlCnt,
     orbx_keypoint_t *__restrict__ kps, uint8_t *__restrict__ desc, int32_t *__restrict__ counts, int cap, uint8_t *__restrict__ dbgBlur,
@@ -247,6 +314,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     int bx, b;
     xcd_block_map(bx, b);   // all patches of an image are read through ONE L2
     int o = bx * DESC_WAVES + wave;
+    PHASE("locate");
     // locate (level, k) of output ordinal o: level-major concatenation (:1076-1104)
     int l = 0, base = 0, total = 0, obefore = 0;
     {   // lane i < nlevels holds the count of level i: ONE load, a 4-step prefix sum, a ballot (not nlevels dependent loads)
@@ -286,11 +354,17 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     const int cx = (int)(key & 0xFFF) + ORBX_MINB, cy = (int)((key >> 12) & 0xFFF) + ORBX_MINB;
     const int score = (int)(key >> 24);
 
+    PHASE("stage");
     // table entries of this lane, requested before the patch so that their latency is hidden behind the staging
     // (the 4 x 64 pattern pairs of the four ballot rounds, IC_Angle byte weights)
-    uint32_t pat[4];
+    typedef float float4v __attribute__((ext_vector_type(4)));
+    float4v pat[4];    // (x0, y0, x1, y1) of this lane's pair in each of the four ballot rounds
 #pragma unroll
-    for (int r = 0; r < 4; r++) pat[r] = ((const uint32_t *)c_pattern)[r * 64 + lane];
+    for (int r = 0; r < 4; r++) pat[r] = ((const float4v *)c_patternf)[r * 64 + lane];
+    uint32_t hitem[DESC_H_ITERS];   // this lane's (row | column group << 8) in each round of the horizontal pass
+#pragma unroll
+    for (int it = 0; it < DESC_H_ITERS; it++) hitem[it] = c_reach.hitem[it * 64 + lane];
+    const uint32_t vlane = c_reach.vlane[lane];   // (column pair | first row << 8) of the vertical pass
     uint32_t icm[4], icw[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) { icm[j] = c_ic.m[lane][j]; icw[j] = c_ic.w[lane][j]; }
@@ -309,7 +383,12 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     // The 19-px REFLECT_101 frame of the levels >= 1 is only ever read HERE, by the few keypoints closer than PR to a
     // level's edge (the frame of level 0 comes with the copy of the input).  Those keypoints mirror the coordinates
     // themselves, so the pipeline never writes the frames of levels >= 1 (orbx_pyramid_host writes them on demand).
+#ifdef ORBX_PHASE_MARKERS   // the counted build keeps the hot path only: no edge keypoint, no level-wide blur, no test hook
+    const bool edge = false;
+    blurMask = 0; dbgBlur = nullptr;
+#else
     const bool edge = l > 0 && (cx < PR || cy < PR || cx + PR >= g.w || cy + PR >= g.h);   // wave-uniform
+#endif
     // Level blurred as a whole by k_blur_levels (levels whose keypoints' 37x37 blocks add up to more pixels than the level has):
     // stage the 31 rows of the IC_Angle disc from the level and the 37x37 block from the blurred level; no blur passes here.
     const bool pre = (blurMask >> l) & 1u;                                                  // wave-uniform
@@ -381,6 +460,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     wave_sync();
     // pixel (cx-21+c, cy-21+r) is byte P[r*48 + sh + c], r,c in [0,43)
 
+    PHASE("ic_angle");
     // ---- IC_Angle: two lanes per row v of the radius-15 disc (u = -15..0 | 1..15)
     int m10 = 0, m01 = 0;
     {   // all 64 lanes: the table weights of lanes 62, 63 are zero (their row, v = 16, lies inside the patch)
@@ -411,6 +491,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
     // 7-tap sum over bytes o .. o+6 of those 16 bytes, o = sh + j.  Instead of realigning the DATA (9 v_alignbyte per
     // group) the WEIGHTS are shifted: W[j] = taps << 8*o as a 128-bit constant, wave-uniform (scalar registers), and the
     // sum is a v_dot4_u32_u8 per dword the window can touch - 13 dot products per group, no alignment instructions.
+    PHASE("horizontal");
     const uint8_t *Bl0 = Bl;           // blurred pixel (cx - 18 + c, cy - 18 + r) = Bl0[r * BSTRIDE + c]
     if (pre) Bl0 = (const uint8_t *)Tm + shB;
     else {
@@ -425,21 +506,12 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
             for (int m = 0; m < 4; m++) Wt[jj][m] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> (32 * m)));
         }
     }
-    // item i = lane + 64 * it is group cg = i % 10 of row r = i / 10: the store address is linear in i (a row of the
-    // intermediate is 10 groups x 8 B), the load address advances by 6 rows + 4 groups per step with a carry into the row
-    int hcg = lane % TGROUPS;
-    const uint8_t *hlp = P + (lane / TGROUPS) * PSTRIDE + 4 * hcg;
-    constexpr int H_ITERS = (TROWS * TGROUPS + 63) / 64;
+    // round `it`: this lane's item (row r, column group cg) of the list c_reach.hitem - only what lies inside the disc
+    uint8_t *Tt = (uint8_t *)Tm;
 #pragma unroll
-    for (int it = 0; it < H_ITERS; it++) {
-        const uint32_t *pr = (const uint32_t *)hlp;                      // dwords cg .. cg+3 hold bytes 4cg .. 4cg+15
-        {   // next item of this lane: +64 = 6 rows + 4 groups
-            hcg += 64 % TGROUPS;
-            const bool carry = hcg >= TGROUPS;
-            hcg -= carry ? TGROUPS : 0;
-            hlp += (64 / TGROUPS) * PSTRIDE + 4 * (64 % TGROUPS) + (carry ? PSTRIDE - 4 * TGROUPS : 0);
-        }
-        if ((it + 1) * 64 > TROWS * TGROUPS && it * 64 + lane >= TROWS * TGROUPS) continue;   // tail of the last step
+    for (int it = 0; it < DESC_H_ITERS; it++) {
+        const uint32_t r = hitem[it] & 0xFFu, cg = hitem[it] >> 8;
+        const uint32_t *pr = (const uint32_t *)(P + r * PSTRIDE + 4 * cg);   // dwords cg .. cg+3 hold bytes 4cg .. 4cg+15
         const uint32_t d0 = pr[0], d1 = pr[1], d2 = pr[2], d3 = pr[3];
         uint32_t oo[4];
 #pragma unroll
@@ -450,26 +522,25 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
             if (jj == 3) acc = __builtin_amdgcn_udot4(d3, Wt[jj][3], acc, false);
             oo[jj] = acc;
         }
-        uint2 st;
-        st.x = oo[0] | (oo[1] << 16);
-        st.y = oo[2] | (oo[3] << 16);
-        *(uint2 *)((uint8_t *)Tm + 8 * (it * 64 + lane)) = st;   // = Tm + r * TSTRIDE4 + cg * 2 (TSTRIDE4 = 2 * TGROUPS)
-    }
-    static_assert(TSTRIDE4 == 2 * TGROUPS, "the horizontal pass stores at a linear address");
-    wave_sync();
-
-    // ---- vertical pass: lane = (column pair, row segment of 13 output rows).  A dword of the intermediate holds the u16
-    // values of two columns; v_perm re-pairs two consecutive ROWS of one column, so that one v_dot2_u32_u16 applies two
-    // taps: out[r] = (18,34).pair[r] + (49,55).pair[r+2] + (49,34).pair[r+4] + (0,18).pair[r+5] + 2^15, and the rounded bytes of
-    // both columns leave through one more v_perm (byte 2 of the sums clamped to 2^24 - 1).
-    if (lane < 60) {
-        const int cp = lane % 20, seg = lane / 20;
-        const int r0 = seg * 13, nr = seg == 2 ? 11 : 13;
-        const uint32_t *col = Tm + r0 * TSTRIDE4 + cp;
-        uint32_t T[19];   // rows r0 .. r0+18; for the last segment rows 43, 44 are the slack rows: read, never used by a stored output
+        uint16_t *dst = (uint16_t *)(Tt + cg * (4 * TCS) + 2 * r);   // column 4cg + jj, row r: four 16-bit stores off one address
 #pragma unroll
-        for (int k = 0; k < 19; k++) T[k] = col[k * TSTRIDE4];
-        const uint32_t W01 = 18u | (34u << 16), W23 = 49u | (55u << 16), W45 = 49u | (34u << 16);
+        for (int jj = 0; jj < 4; jj++) dst[jj * (TCS / 2)] = (uint16_t)oo[jj];
+    }
+    wave_sync();
+    PHASE("vertical");
+
+    // ---- vertical pass: lane = (column pair, run of DESC_V_ROWS rows starting at an even row).  A dword of the transposed
+    // intermediate holds rows (2p, 2p+1) of one column, so every output is four v_dot2_u32_u16 on dwords as they come from LDS:
+    //   even row r: (18,34).pair[r/2] + (49,55).pair[r/2+1] + (49,34).pair[r/2+2] + (18, 0).pair[r/2+3]
+    //   odd  row r: ( 0,18).pair[(r-1)/2] + (34,49).pair[..+1] + (55,49).pair[..+2] + (34,18).pair[..+3]
+    // and the rounded bytes of both columns leave through one v_perm (byte 2 of the sums clamped to 2^24 - 1).
+    {
+        const int cp = (int)(vlane & 0xFFu), r0 = (int)(vlane >> 8);
+        const uint32_t *col = (const uint32_t *)(Tt + (2 * cp) * TCS) + (r0 >> 1);
+        constexpr int NP = DESC_V_ROWS / 2 + 3;   // row pairs a run touches
+        uint32_t A[NP], B[NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++) { A[k] = col[k]; B[k] = col[k + TCS / 4]; }
         // column rounding of the flavour (include/orbx.h): half up = the 2^15 the sums start from; SSE2 = round half to EVEN for the
         // level's columns x < (w & ~3) - sum + 32767 + bit 16 of the sum, the bit taken by a v_bfe whose WIDTH is 0 for the
         // columns of the scalar tail (which keep + 2^15).  Blurred column c of the block is level column cx - 18 + c.
@@ -480,56 +551,63 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(
             rc0 = 32768u - bw0; rc1 = 32768u - bw1;
         }
         constexpr uint32_t A_INIT = GAUSS == ORBX_GAUSS_ROUND_SSE2 ? 0u : 1u << 15;
+        constexpr uint32_t WE[4] = {18u | (34u << 16), 49u | (55u << 16), 49u | (34u << 16), 18u};
+        constexpr uint32_t WO[4] = {18u << 16, 34u | (49u << 16), 55u | (49u << 16), 34u | (18u << 16)};
+        uint8_t *out = Bl + r0 * BSTRIDE + 2 * cp;
 #pragma unroll
-        for (int rr = 0; rr < 13; rr++) {
+        for (int i = 0; i < DESC_V_ROWS; i++) {
             uint32_t a0 = A_INIT, a1 = A_INIT;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const uint32_t w = k == 0 ? W01 : k == 1 ? W23 : W45;
-                a0 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 2 * k + 1], T[rr + 2 * k], 0x05040100u), w, a0);
-                a1 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 2 * k + 1], T[rr + 2 * k], 0x07060302u), w, a1);
+            for (int k = 0; k < 4; k++) {
+                const uint32_t w = (i & 1) ? WO[k] : WE[k];
+                a0 = udot2_u16_acc(A[(i >> 1) + k], w, a0);
+                a1 = udot2_u16_acc(B[(i >> 1) + k], w, a1);
             }
-            // 7th tap = high half of pair[rr+5] = (row rr+5, row rr+6), a pair the next output row needs anyway
-            a0 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 6], T[rr + 5], 0x05040100u), 18u << 16, a0);
-            a1 = udot2_u16_acc(__builtin_amdgcn_perm(T[rr + 6], T[rr + 5], 0x07060302u), 18u << 16, a1);
             if (GAUSS == ORBX_GAUSS_ROUND_SSE2) {
                 a0 = a0 + __builtin_amdgcn_ubfe(a0, 16u, bw0) + rc0;
                 a1 = a1 + __builtin_amdgcn_ubfe(a1, 16u, bw1) + rc1;
             }
             a0 = min(a0, 0xFFFFFFu);   // the taps sum to 257: a saturated patch reaches 257 * 65535 + 2^15 > 2^24 (-> 255)
             a1 = min(a1, 0xFFFFFFu);
-            if (rr < nr) *(uint16_t *)(Bl + (r0 + rr) * BSTRIDE + 2 * cp) = (uint16_t)__builtin_amdgcn_perm(a1, a0, 0x0c0c0602u);
+            *(uint16_t *)(out + i * BSTRIDE) = (uint16_t)__builtin_amdgcn_perm(a1, a0, 0x0c0c0602u);   // rows r0 .. r0+11 <= 37: inside the block's 38 x 40 bytes
         }
     }
     wave_sync();
     }   // !pre
 
-    if (dbgBlur) {   // test hook (wave-uniform, NULL in production): the 37x37 blurred block around the keypoint, rows of 37 bytes
+    PHASE("brief");
+    if (dbgBlur) {   // test hook (wave-uniform, NULL in production): the 37x37 blurred block around the keypoint, rows of 37 bytes;
+        // pixels no tap can reach (outside the disc of c_reach) are reported as 0 - the fused form never computes them
         uint8_t *o37 = dbgBlur + ((size_t)b * cap + o) * (TCOLS * TCOLS);
-        for (int i = lane; i < TCOLS * TCOLS; i += 64) o37[i] = Bl0[(i / TCOLS) * BSTRIDE + i % TCOLS];
+        for (int i = lane; i < TCOLS * TCOLS; i += 64) {
+            const int rr = i / TCOLS, cc = i % TCOLS, dy = rr > ORBX_DESC_R ? rr - ORBX_DESC_R : ORBX_DESC_R - rr;
+            o37[i] = dy <= c_reach.hh[cc] ? Bl0[rr * BSTRIDE + cc] : (uint8_t)0;
+        }
     }
     // ---- steered BRIEF: 4 rounds x 64 pairs, one ballot = 8 descriptor bytes
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ang = angle * factorPI;
     float ca, sa;
     sincosf_glibc(ang, sa, ca);
-    const uint8_t *Bc = Bl0 + ORBX_DESC_R * BSTRIDE + ORBX_DESC_R;
+    // LDS byte address of the block's centre as a float (exact: far below 2^24); a tap's address is then ONE float multiply-add of
+    // its rounded coordinates - cvRound(row) * 40 + (cvRound(col) + centre), every term a small integer - and one conversion
+    const float centre = (float)(int)(uint32_t)(uintptr_t)(Bl0 - smem + ORBX_DESC_R * BSTRIDE + ORBX_DESC_R);
     unsigned long long bits[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const uint32_t pq = pat[r];   // (x0, y0, x1, y1) as signed bytes
-        const float x0 = (float)(int8_t)(pq & 0xFF), y0 = (float)(int8_t)((pq >> 8) & 0xFF), x1 = (float)(int8_t)((pq >> 16) & 0xFF),
-                    y1 = (float)(int8_t)(pq >> 24);
+        const float x0 = pat[r].x, y0 = pat[r].y, x1 = pat[r].z, y1 = pat[r].w;
         // (x*sa + y*ca, x*ca - y*sa) on the packed-f32 pipe: two multiplies and one add per point, each rounded on its own
         // exactly like the scalar form (no contraction)
         typedef float float2v __attribute__((ext_vector_type(2)));
         const float2v sc = {sa, ca}, cs = {ca, -sa};
         const float2v p0 = (float2v){x0, x0} * sc + (float2v){y0, y0} * cs;
         const float2v p1 = (float2v){x1, x1} * sc + (float2v){y1, y1} * cs;
-        const int t0 = Bc[__float2int_rn(p0.x) * BSTRIDE + __float2int_rn(p0.y)];
-        const int t1 = Bc[__float2int_rn(p1.x) * BSTRIDE + __float2int_rn(p1.y)];
+        const int i0 = (int)__builtin_fmaf(__builtin_rintf(p0.x), (float)BSTRIDE, __builtin_rintf(p0.y) + centre);
+        const int i1 = (int)__builtin_fmaf(__builtin_rintf(p1.x), (float)BSTRIDE, __builtin_rintf(p1.y) + centre);
+        const int t0 = smem[i0], t1 = smem[i1];
         bits[r] = __ballot(t0 < t1);
     }
+    PHASE("store");
     const size_t oi = (size_t)b * cap + (o - obefore);   // a launch that starts behind level 0 fills the scratch arrays from their start
     if (lane < 4) ((unsigned long long *)(desc + oi * 32))[lane] = bits[lane];
     if (lane == 0) {

@@ -499,6 +499,8 @@ def test_blurred_patches_direct(pkg, oracle, synth):
     for _ in range(400):
         x, y = rng.integers(0, 636), rng.integers(0, 476)
         sat[y:y + rng.integers(2, 40), x:x + rng.integers(2, 40)] = 255 if rng.random() < 0.5 else 0
+    reach = pkg.blur_reach_mask()
+    assert reach.sum() == 1133 and reach[18].all() and reach[:, 18].all() and not reach[0, 0]
     for img, nf in ((synth.frame(752, 480, 70), 1000), (sat, 800)):
         ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
         orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
@@ -517,8 +519,11 @@ def test_blurred_patches_direct(pkg, oracle, synth):
             inside = (ys[:, None] >= 0) & (ys[:, None] < h) & (xs[None, :] >= 0) & (xs[None, :] < w)
             nedge += int(not inside.all())
             want = bl[np.clip(ys, 0, h - 1)[:, None], np.clip(xs, 0, w - 1)[None, :]]
-            # pixels of the block outside the level are never read by a descriptor tap: compare what lies inside
+            # pixels of the block outside the level are never read by a descriptor tap, nor are those outside the disc the
+            # rotated pattern can reach (the kernel does not compute them and the hook reports 0): compare the rest
+            inside &= reach
             assert (patches[i][inside] == want[inside]).all(), "keypoint %d level %d" % (i, l)
+            assert not patches[i][~reach].any()
         assert len(k) > 500
 
 
@@ -590,7 +595,7 @@ def test_blur_forms_agree_with_oracle(pkg, oracle, synth, form, w, h, nf, kind):
         bl = orc.blurred_level(l)
         cx = int(round(float(k2["x"][i]) * float(isf[l]))) if l else int(k2["x"][i])
         cy = int(round(float(k2["y"][i]) * float(isf[l]))) if l else int(k2["y"][i])
-        np.testing.assert_array_equal(patches[i], bl[cy - 18:cy + 19, cx - 18:cx + 19], err_msg="keypoint %d level %d" % (i, l))
+        np.testing.assert_array_equal(patches[i], bl[cy - 18:cy + 19, cx - 18:cx + 19] * pkg.blur_reach_mask(), err_msg="keypoint %d level %d" % (i, l))
 
 
 def test_blur_form_rule_and_batch(pkg, oracle, synth):

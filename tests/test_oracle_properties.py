@@ -226,3 +226,26 @@ def test_vocabulary_transform_hand_built(oracle):
     assert list(bw) == [0, 3]
     np.testing.assert_array_equal(bv, np.array([4.0, 8.0]) / 12.0)   # 2+2 and 4+4, L1-normalised
     assert fv == {1: [0, 3], 2: [1, 4]}                       # the stopped feature 2 is in neither vector
+
+
+def test_descriptor_taps_stay_inside_the_reach_disc(oracle, pkg):
+    """The fused blur of the HIP descriptor kernel computes only the pixels of a keypoint's 37x37 block that a tap can reach
+    (pkg.blur_reach_mask: (|row| - 1/2)^2 + (|col| - 1/2)^2 <= 340).  Every tap of every pattern point at 36 000 angles, computed
+    the way src/ORBextractor.cc:113-120 does (float products, cvRound), lies inside it - and the disc is tight: the taps reach its
+    rim."""
+    import re
+    txt = open(__import__("os").path.join(__import__("os").path.dirname(__file__), "..", "include", "orb_pattern_31.inc")).read()
+    txt = re.sub(r"//.*", "", txt)
+    pat = np.array([int(v) for v in re.findall(r"-?\d+", txt)], np.float32).reshape(-1, 2)
+    assert pat.shape == (512, 2) and int((pat ** 2).sum(1).max()) == 338
+    reach = pkg.blur_reach_mask()
+    hit = np.zeros((37, 37), bool)
+    ang = (np.arange(36000, dtype=np.float32) * np.float32(0.01)) * np.float32(np.pi / 180.0)
+    a, b = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+    for x, y in pat:
+        row = np.rint(x * b + y * a).astype(int)      # float32 products and sum, round half to even (cvRound)
+        col = np.rint(x * a - y * b).astype(int)
+        assert np.abs(row).max() <= 18 and np.abs(col).max() <= 18
+        hit[row + 18, col + 18] = True
+    assert not (hit & ~reach).any()
+    assert hit[reach].mean() > 0.97     # nearly every pixel of the disc is read at some angle
