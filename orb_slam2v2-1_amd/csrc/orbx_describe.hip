@@ -48,7 +48,8 @@ static_assert(TT_BYTES >= TCOLS * BSTRIDE + 4, "gather form: the blurred block s
 // Everything outside the disc holds whatever the skipped work would have overwritten: no tap reads it.
 #define DESC_H_ITERS 6
 #define DESC_V_ROWS 12
-struct DescReach { uint8_t hh[40]; uint16_t hitem[DESC_H_ITERS * 64]; uint16_t vlane[64]; int nh, nv; };
+// hitem = byte offset of the item's 16 source bytes in the patch | byte offset of its first output in the transposed intermediate << 16
+struct DescReach { uint8_t hh[40]; uint32_t hitem[DESC_H_ITERS * 64]; uint16_t vlane[64]; int nh, nv; };
 constexpr DescReach make_desc_reach() {
     DescReach t{};
     for (int c = 0; c < 40; c++) {
@@ -68,7 +69,7 @@ constexpr DescReach make_desc_reach() {
             const int dy = r > PR ? r - PR : PR - r;
             if (dy <= t.hh[c] + 3) { if ((c >> 2) < g0) g0 = c >> 2; if ((c >> 2) > g1) g1 = c >> 2; }
         }
-        for (int g = g0; g <= g1; g++) t.hitem[n++] = (uint16_t)(r | (g << 8));
+        for (int g = g0; g <= g1; g++) t.hitem[n++] = (uint32_t)(r * PSTRIDE + 4 * g) | ((uint32_t)(g * (4 * TCS) + 2 * r) << 16);
     }
     t.nh = n;
     for (int i = n; i < DESC_H_ITERS * 64; i++) t.hitem[i] = t.hitem[n - 1];   // spare slots redo the last item (same values)
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void k_blur_levels(const uint8_t *__restrict__
     }
 }
 
-template <int GAUSS>
+template <int GAUSS, bool SPLIT>
 __global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_describe(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
     const uint32_t *__restrict__ lvlKp, int lvlKpCap, const int32_t *__restrict__ lvlCnt,
@@ -317,35 +318,43 @@ __global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu
     PHASE("locate");
     // locate (level, k) of output ordinal o: level-major concatenation (:1076-1104)
     int l = 0, base = 0, total = 0, obefore = 0;
-    {   // lane i < nlevels holds the count of level i: ONE load, a 4-step prefix sum, a ballot (not nlevels dependent loads)
+    {   // lane i < nlevels holds the count of level i: ONE load, a prefix sum inside the first DPP row (16 lanes >= ORBX_MAX_LEVELS:
+        // four row_shr additions, no LDS round trips), a ballot
+        static_assert(ORBX_MAX_LEVELS <= 16, "the level counts fit one DPP row");
         const int c = lane < nlevels ? lvlCnt[b * nlevels + lane] : 0;
         int inc = c;
-#pragma unroll
-        for (int d = 1; d < ORBX_MAX_LEVELS; d <<= 1) {
-            const int t = __shfl_up(inc, d);
-            if (lane >= d) inc += t;
-        }
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);   // row_shr:1
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);   // row_shr:2
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);   // row_shr:4
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);   // row_shr:8
         total = __builtin_amdgcn_readlane(inc, ORBX_MAX_LEVELS - 1);
-        if (grp.writeCounts && bx == 0 && threadIdx.x == 0) counts[b] = min(total, cap);
-        // keypoints in front of this launch's first level (0 for a launch that starts at level 0; the scratch arrays of the later
-        // levels are indexed from their own first keypoint)
-        const int before = grp.lvBegin > 0 ? __builtin_amdgcn_readlane(inc, max(grp.lvBegin - 1, 0)) : 0;
-        if (bx >= grp.copyBlock0) {
-            // move the records of the levels [lvEnd, nlevels) from the scratch arrays to their place behind this launch's levels
-            const int cA = __builtin_amdgcn_readlane(inc, grp.lvEnd - 1), cB = total - cA;
-            const int t = threadIdx.x, i = (bx - grp.copyBlock0) * DESC_COPY_PER_BLOCK + (t >> 4), part = t & 15;
-            if (i < cB && cA + i < cap && part < 15) {
-                const size_t si = (size_t)b * cap + i, di = (size_t)b * cap + cA + i;
-                if (part < 7) ((uint32_t *)(kps + di))[part] = ((const uint32_t *)(grp.kpsScratch + si))[part];
-                else ((uint32_t *)(desc + di * 32))[part - 7] = ((const uint32_t *)(grp.descScratch + si * 32))[part - 7];
+        if (SPLIT) {
+            if (grp.writeCounts && bx == 0 && threadIdx.x == 0) counts[b] = min(total, cap);
+            // keypoints in front of this launch's first level (0 for a launch that starts at level 0; the scratch arrays of the later
+            // levels are indexed from their own first keypoint)
+            const int before = grp.lvBegin > 0 ? __builtin_amdgcn_readlane(inc, max(grp.lvBegin - 1, 0)) : 0;
+            if (bx >= grp.copyBlock0) {
+                // move the records of the levels [lvEnd, nlevels) from the scratch arrays to their place behind this launch's levels
+                const int cA = __builtin_amdgcn_readlane(inc, grp.lvEnd - 1), cB = total - cA;
+                const int t = threadIdx.x, i = (bx - grp.copyBlock0) * DESC_COPY_PER_BLOCK + (t >> 4), part = t & 15;
+                if (i < cB && cA + i < cap && part < 15) {
+                    const size_t si = (size_t)b * cap + i, di = (size_t)b * cap + cA + i;
+                    if (part < 7) ((uint32_t *)(kps + di))[part] = ((const uint32_t *)(grp.kpsScratch + si))[part];
+                    else ((uint32_t *)(desc + di * 32))[part - 7] = ((const uint32_t *)(grp.descScratch + si * 32))[part - 7];
+                }
+                return;
             }
-            return;
+            o += before;   // ordinal over all levels
+            obefore = before;
+            const unsigned long long hit = __ballot(lane >= grp.lvBegin && lane < grp.lvEnd && o < inc);
+            if (!hit || o - before >= cap) return;  // wave-uniform
+            l = __builtin_ctzll(hit);
+        } else {   // the usual launch: every level, into the caller's arrays
+            if (bx == 0 && threadIdx.x == 0) counts[b] = min(total, cap);
+            const unsigned long long hit = __ballot(lane < nlevels && o < inc);
+            if (!hit || o >= cap) return;  // wave-uniform
+            l = __builtin_ctzll(hit);
         }
-        o += before;   // ordinal over all levels
-        obefore = before;
-        const unsigned long long hit = __ballot(lane >= grp.lvBegin && lane < grp.lvEnd && o < inc);
-        if (!hit || o - before >= cap) return;  // wave-uniform
-        l = __builtin_ctzll(hit);
         base = __builtin_amdgcn_readlane(inc - c, l);
     }
     l = __builtin_amdgcn_readfirstlane(l);
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu
     float4v pat[4];    // (x0, y0, x1, y1) of this lane's pair in each of the four ballot rounds
 #pragma unroll
     for (int r = 0; r < 4; r++) pat[r] = ((const float4v *)c_patternf)[r * 64 + lane];
-    uint32_t hitem[DESC_H_ITERS];   // this lane's (row | column group << 8) in each round of the horizontal pass
+    uint32_t hitem[DESC_H_ITERS];   // this lane's item (source offset | destination offset << 16) in each round of the horizontal pass
 #pragma unroll
     for (int it = 0; it < DESC_H_ITERS; it++) hitem[it] = c_reach.hitem[it * 64 + lane];
     const uint32_t vlane = c_reach.vlane[lane];   // (column pair | first row << 8) of the vertical pass
@@ -510,8 +519,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu
     uint8_t *Tt = (uint8_t *)Tm;
 #pragma unroll
     for (int it = 0; it < DESC_H_ITERS; it++) {
-        const uint32_t r = hitem[it] & 0xFFu, cg = hitem[it] >> 8;
-        const uint32_t *pr = (const uint32_t *)(P + r * PSTRIDE + 4 * cg);   // dwords cg .. cg+3 hold bytes 4cg .. 4cg+15
+        const uint32_t *pr = (const uint32_t *)(P + (hitem[it] & 0xFFFFu));   // row r, dwords cg .. cg+3 = bytes 4cg .. 4cg+15
         const uint32_t d0 = pr[0], d1 = pr[1], d2 = pr[2], d3 = pr[3];
         uint32_t oo[4];
 #pragma unroll
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu
             if (jj == 3) acc = __builtin_amdgcn_udot4(d3, Wt[jj][3], acc, false);
             oo[jj] = acc;
         }
-        uint16_t *dst = (uint16_t *)(Tt + cg * (4 * TCS) + 2 * r);   // column 4cg + jj, row r: four 16-bit stores off one address
+        uint16_t *dst = (uint16_t *)(Tt + (hitem[it] >> 16));   // column 4cg + jj, row r: four 16-bit stores off one address
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) dst[jj * (TCS / 2)] = (uint16_t)oo[jj];
     }
@@ -548,11 +556,14 @@ __global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu
         if (GAUSS == ORBX_GAUSS_ROUND_SSE2) {
             const int x0 = cx - ORBX_DESC_R + 2 * cp, wv = g.w & ~3;
             bw0 = x0 < wv ? 1u : 0u; bw1 = x0 + 1 < wv ? 1u : 0u;
-            rc0 = 32768u - bw0; rc1 = 32768u - bw1;
+            rc0 = (32768u - bw0) << 8; rc1 = (32768u - bw1) << 8;
         }
-        constexpr uint32_t A_INIT = GAUSS == ORBX_GAUSS_ROUND_SSE2 ? 0u : 1u << 15;
-        constexpr uint32_t WE[4] = {18u | (34u << 16), 49u | (55u << 16), 49u | (34u << 16), 18u};
-        constexpr uint32_t WO[4] = {18u << 16, 34u | (49u << 16), 55u | (49u << 16), 34u | (18u << 16)};
+        // The taps carry a factor 256, so a sum S is held as 256 S and the CLAMP bit of v_dot2_u32_u16 saturates it at 2^32 - exactly
+        // where the rounded byte would pass 255 (the taps add up to 257: a saturated patch reaches 257 * 65535 + 2^15 > 2^24); every
+        // term is non-negative, so saturating the partial sums saturates the total.  The result byte is bits 31:24: no v_min.
+        constexpr uint32_t A_INIT = GAUSS == ORBX_GAUSS_ROUND_SSE2 ? 0u : 1u << 23;
+        constexpr uint32_t WE[4] = {(18u | (34u << 16)) << 8, (49u | (55u << 16)) << 8, (49u | (34u << 16)) << 8, 18u << 8};
+        constexpr uint32_t WO[4] = {18u << 24, (34u | (49u << 16)) << 8, (55u | (49u << 16)) << 8, (34u | (18u << 16)) << 8};
         uint8_t *out = Bl + r0 * BSTRIDE + 2 * cp;
 #pragma unroll
         for (int i = 0; i < DESC_V_ROWS; i++) {
@@ -560,16 +571,14 @@ __global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t w = (i & 1) ? WO[k] : WE[k];
-                a0 = udot2_u16_acc(A[(i >> 1) + k], w, a0);
-                a1 = udot2_u16_acc(B[(i >> 1) + k], w, a1);
+                a0 = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, A[(i >> 1) + k]), __builtin_bit_cast(ushort2v, w), a0, true);
+                a1 = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, B[(i >> 1) + k]), __builtin_bit_cast(ushort2v, w), a1, true);
             }
-            if (GAUSS == ORBX_GAUSS_ROUND_SSE2) {
-                a0 = a0 + __builtin_amdgcn_ubfe(a0, 16u, bw0) + rc0;
-                a1 = a1 + __builtin_amdgcn_ubfe(a1, 16u, bw1) + rc1;
+            if (GAUSS == ORBX_GAUSS_ROUND_SSE2) {   // + (32767 + bit 16 of S) << 8, saturating
+                a0 = __builtin_elementwise_add_sat(a0, (__builtin_amdgcn_ubfe(a0, 24u, bw0) << 8) + rc0);
+                a1 = __builtin_elementwise_add_sat(a1, (__builtin_amdgcn_ubfe(a1, 24u, bw1) << 8) + rc1);
             }
-            a0 = min(a0, 0xFFFFFFu);   // the taps sum to 257: a saturated patch reaches 257 * 65535 + 2^15 > 2^24 (-> 255)
-            a1 = min(a1, 0xFFFFFFu);
-            *(uint16_t *)(out + i * BSTRIDE) = (uint16_t)__builtin_amdgcn_perm(a1, a0, 0x0c0c0602u);   // rows r0 .. r0+11 <= 37: inside the block's 38 x 40 bytes
+            *(uint16_t *)(out + i * BSTRIDE) = (uint16_t)__builtin_amdgcn_perm(a1, a0, 0x0c0c0703u);   // rows r0 .. r0+11 <= 37: inside the block's 38 x 40 bytes
         }
     }
     wave_sync();
@@ -624,10 +633,13 @@ __global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu
     }
 }
 
-template __global__ void k_describe<ORBX_GAUSS_ROUND_HALF_UP>(const uint8_t *, size_t, const LevelGeom *, int, const uint32_t *, int, const int32_t *,
-                                                              orbx_keypoint_t *, uint8_t *, int32_t *, int, uint8_t *, const uint8_t *, unsigned, DescGroup);
-template __global__ void k_describe<ORBX_GAUSS_ROUND_SSE2>(const uint8_t *, size_t, const LevelGeom *, int, const uint32_t *, int, const int32_t *,
-                                                           orbx_keypoint_t *, uint8_t *, int32_t *, int, uint8_t *, const uint8_t *, unsigned, DescGroup);
+#define ORBX_DESC_INSTANCE(G, S)                                                                                                             \
+    template __global__ void k_describe<G, S>(const uint8_t *, size_t, const LevelGeom *, int, const uint32_t *, int, const int32_t *, \
+                                              orbx_keypoint_t *, uint8_t *, int32_t *, int, uint8_t *, const uint8_t *, unsigned, DescGroup);
+ORBX_DESC_INSTANCE(ORBX_GAUSS_ROUND_HALF_UP, false)
+ORBX_DESC_INSTANCE(ORBX_GAUSS_ROUND_HALF_UP, true)
+ORBX_DESC_INSTANCE(ORBX_GAUSS_ROUND_SSE2, false)
+ORBX_DESC_INSTANCE(ORBX_GAUSS_ROUND_SSE2, true)
 
 // ---- test hook: the device's cosf / sinf restatement on an array of angles (tests compare it with the oracle's and with
 // the host libm over the whole angle domain; a descriptor only ever exercises the angles its keypoints happen to have)

@@ -878,7 +878,9 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     if (prof) ORBX_HIP(hipEventRecord(ev[3], st));
     if (gate && h->opt[10] == 1) ORBX_HIP(hipEventRecord(h->evFastDone, st));
     {   // K4 (one instance per flavour of the Gaussian's column rounding: the default pays nothing for the other)
-        const auto kDesc = h->flavour.gauss_rounding == ORBX_GAUSS_ROUND_SSE2 ? k_describe<ORBX_GAUSS_ROUND_SSE2> : k_describe<ORBX_GAUSS_ROUND_HALF_UP>;
+        const bool sse2 = h->flavour.gauss_rounding == ORBX_GAUSS_ROUND_SSE2;
+        const auto kDesc = aSplit > 0 ? (sse2 ? k_describe<ORBX_GAUSS_ROUND_SSE2, true> : k_describe<ORBX_GAUSS_ROUND_HALF_UP, true>)
+                                      : (sse2 ? k_describe<ORBX_GAUSS_ROUND_SSE2, false> : k_describe<ORBX_GAUSS_ROUND_HALF_UP, false>);
         const uint8_t *blurp = h->blurMaskLast ? h->d_blur + (size_t)v.b0 * h->pyrImgBytes : nullptr;
         if (aSplit > 0) {
             int boundA = 0, boundB = 0;

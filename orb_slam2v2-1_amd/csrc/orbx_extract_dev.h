@@ -136,7 +136,7 @@ __global__ void k_octree_big_wide(const LevelGeom *geom, int nlevels, const uint
 __global__ void k_octree_wide(const LevelGeom *geom, int nlevels, const uint32_t *cand, uint16_t *nodeOf, size_t keysPerImg,
                               const int32_t *candCnt, uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax,
                               int pow2cap, int scratchInts, int dbgStop);
-template <int GAUSS>   // ORBX_GAUSS_ROUND_*: column rounding of the fused Gaussian (orbx_flavour_t)
+template <int GAUSS, bool SPLIT>   // ORBX_GAUSS_ROUND_*: column rounding of the fused Gaussian (orbx_flavour_t); SPLIT: a launch of a split call (DescGroup)
 __global__ void k_describe(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, const uint32_t *lvlKp,
                            int lvlKpCap, const int32_t *lvlCnt, orbx_keypoint_t *kps, uint8_t *desc, int32_t *counts,
                            int cap, uint8_t *dbgBlur, const uint8_t *blur, unsigned blurMask, DescGroup grp);                                                                             // orbx_describe.hip
