@@ -425,6 +425,8 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  *   ORBX_OPT_EARLY_OCTREE  19  a >= 2: strips of levels [0, a) launched first, their quad-tree beside the FAST of the others
  *   ORBX_OPT_SPARSE_FORM   20  corner-sparse levels: 0 = compaction kernel (score only the pixels that pass the five-pixel bound),
  *                              1 = row skip inside k_fast_strips
+ *   ORBX_OPT_DESC_LDS_PAD  21  KB of unused LDS per k_describe workgroup: fewer of them resident per CU, more wave slots for the
+ *                              kernels of a neighbouring stream (tuning of the pipelined step; default 0)
  * Keys 0, 1 and 7 (stop a kernel after phase n: outputs incomplete) exist only in a library built with -DORBX_DEVELOPER
  * (tools/octree_phase_probe.py); the default build refuses them. */
 #define ORBX_OPT_PYR_TILE 3
@@ -443,6 +445,7 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
 #define ORBX_OPT_GATHER 18
 #define ORBX_OPT_EARLY_OCTREE 19
 #define ORBX_OPT_SPARSE_FORM 20
+#define ORBX_OPT_DESC_LDS_PAD 21
 #define ORBX_NUM_OPTIONS 32
 int orbx_set_option(orbx_extractor_t *h, int key, int value);
 int orbx_get_option(const orbx_extractor_t *h, int key, int *value);

@@ -45,7 +45,7 @@ extern "C" int orbx_thread_release_scratch(void) {
 // in a developer build (-DORBX_DEVELOPER).
 extern "C" int orbx_set_option(orbx_extractor_t *h, int key, int value) {
     static const signed char maxv[ORBX_NUM_OPTIONS] = {/*0*/ -1, -1, -2, 64, 3, 3, 3, -1, ORBX_MAX_CHUNKS, 1, 2, 2, 1, 2, 127, ORBX_MAX_LEVELS,
-                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 1, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
+                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 1, 100, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
     if (!h || key < 0 || key >= ORBX_NUM_OPTIONS || maxv[key] == -2) { orbx_set_error("orbx_set_option: unknown key %d", key); return ORBX_ERR_ARG; }
 #ifdef ORBX_DEVELOPER
     if (maxv[key] == -1) { if (value < 0) return ORBX_ERR_ARG; h->opt[key] = value; return ORBX_OK; }
@@ -140,6 +140,10 @@ extern "C" int orbx_create_flavoured(int nfeatures, float scale_factor, int nlev
     }
     h->max_kp = 0;
     ORBX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    // host-mapped word the quad-tree kernels store a call's sequence number into when they flag a corner-sparse level (launch_chunk)
+    ORBX_HIP(hipHostMalloc((void **)&h->h_sparseSeen, sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    *h->h_sparseSeen = -(1 << 30);
+    ORBX_HIP(hipHostGetDevicePointer((void **)&h->d_sparseSeen, h->h_sparseSeen, 0));
     for (int i = 0; i < ORBX_SIDE_STREAMS; i++) {
         ORBX_HIP(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
         ORBX_HIP(hipEventCreateWithFlags(&h->evJoin[i], hipEventDisableTiming));
@@ -185,6 +189,7 @@ extern "C" int orbx_destroy(orbx_extractor_t *h) {
     free_plan(h);
     hipFree(h->d_in); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_dbgBlur);
     hipFree(h->d_sfr); if (h->h_sfr) hipHostFree(h->h_sfr);
+    if (h->h_sparseSeen) hipHostFree(h->h_sparseSeen);
     if (h->h_kps) { hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); }
     for (int r = 0; r < ORBX_EV_RING; r++)
         for (int i = 0; i < ORBX_NUM_STAGES; i++) hipEventDestroy(h->ev[r][i]);
@@ -706,6 +711,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
         osrc.cellCnt = v.cellCnt; osrc.cellRaw = v.cellRaw; osrc.slots = v.slots; osrc.slotsPerImg = h->slotsPerImg;
         osrc.totalCells = h->totalCells; osrc.iniTh = h->ini_th; osrc.minTh = h->min_th; osrc.candCntOut = v.candCnt;
         osrc.sparseFlag = v.sparse; osrc.sparsePerCell = sparsePerCell; osrc.candOut = v.cand;
+        osrc.sparseSeen = h->d_sparseSeen; osrc.callSeq = h->callSeq;
         h->candStale = std::max(h->candStale, v.b0 + B);
     }
     int pow2 = 1;
@@ -715,6 +721,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     const int scratch = std::max(4 * h->maxNodeCap, maxCellsL + 1);
     const size_t ldsOct = std::max(h->octPyrLdsBytes, h->octLdsBytes);
     const bool wideOct = h->opt[11] == 0 ? h->octBigMask != 0 : h->opt[11] == 2;
+    bool compact = false;   // the compaction kernel takes the corner-sparse (image, level)s of the strip levels
     int earlyLv = 0;   // > 0: the strips of the levels [0, earlyLv) are launched first and their quad-tree starts beside the FAST of the rest
     {   // K2
         // developer knob 6: 1 = every level by k_fast_cells (compile-time tile strides), 2 = ... with run-time strides
@@ -725,7 +732,15 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
         if (strips) {
             StripBases sb;
             for (int l = 0; l <= ORBX_MAX_LEVELS; l++) sb.v[l] = h->stripBase[l];
-            const int32_t *spf = h->opt[16] == 1 ? (const int32_t *)nullptr : v.sparse;   // developer knob 16: 1 = never pre-test, 2 = always
+            const int32_t *spf = h->opt[16] == 1 ? (const int32_t *)nullptr : v.sparse;   // ORBX_OPT_ROW_PRETEST: 1 = never the sparse path, 2 = always
+            // Corner-sparse (image, level)s - flagged by the previous call's quad-tree - leave the strip kernel and are done by the
+            // compaction form of the cell kernel (below).  That costs a launch whose waves all return at once when nothing is flagged,
+            // so it is added only while the handle has recently met a sparse level: the quad-tree stores the call's sequence number
+            // into a host-mapped word when it flags one (a hint that lags by the calls in flight; a wrong hint costs speed only,
+            // because both kernels take the SAME device flags).  ORBX_OPT_SPARSE_FORM = 1: the round-3 form (rows skipped inside
+            // the strip kernel).
+            compact = spf != nullptr && h->opt[20] == 0 &&
+                      (h->opt[16] == 2 || (h->h_sparseSeen && h->callSeq - *(volatile int32_t *)h->h_sparseSeen <= 16));
             // Early quad-tree (developer knob 19: a >= 2 = levels [0, a); default 0 = off): the quad-tree of the large levels is ONE
             // workgroup per level walking a serial chain - the critical path behind FAST.  Their strips go first, in a launch of their
             // own, and their quad-tree starts on a second stream as soon as that launch is done, beside the FAST of the remaining
@@ -733,14 +748,14 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             // a = 2, 0.657 with a = 3; 2000 features 0.838 -> 0.874; 1920x1080 x 64 1.254 -> 1.274; 752x480 0.599 -> 0.607): FAST loses to
             // the quad-tree workgroups what the shorter chain behind it gains, plus two cross-stream events.  Off by default.
             const int ea = h->opt[19];
-            if (fused && !prof && h->opt[19] >= 2 && h->opt[15] < 2 && h->lastChunks == 1 && B >= 8 && nl > ea &&
+            if (fused && !prof && !compact && h->opt[19] >= 2 && h->opt[15] < 2 && h->lastChunks == 1 && B >= 8 && nl > ea &&
                 (h->stripLevels & ((1u << ea) - 1u)) == (1u << ea) - 1u && h->d_dbgBlur == nullptr)
                 earlyLv = ea;
             const int sA = earlyLv ? h->stripBase[earlyLv] : 0;
             if (earlyLv) {
                 hipLaunchKernelGGL(k_fast_strips, dim3((sA + FAST_WAVES - 1) / FAST_WAVES, B), dim3(64 * FAST_WAVES), 0, st,
                                    v.pyr, h->pyrImgBytes, h->d_geom, nl, sA, h->totalCells, v.cellCnt, v.cellRaw,
-                                   v.slots, h->slotsPerImg, h->ini_th, h->min_th, sb, spf, 0);
+                                   v.slots, h->slotsPerImg, h->ini_th, h->min_th, sb, spf, 0, compact ? 1 : 0);
                 hipStream_t s2 = h->side[1];
                 ORBX_HIP(hipEventRecord(h->evGather, st));
                 ORBX_HIP(hipStreamWaitEvent(s2, h->evGather, 0));
@@ -760,24 +775,33 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             if (h->totalStrips > sA)
                 hipLaunchKernelGGL(k_fast_strips, dim3((h->totalStrips - sA + FAST_WAVES - 1) / FAST_WAVES, B), dim3(64 * FAST_WAVES), 0, st,
                                    v.pyr, h->pyrImgBytes, h->d_geom, nl, h->totalStrips, h->totalCells, v.cellCnt, v.cellRaw,
-                                   v.slots, h->slotsPerImg, h->ini_th, h->min_th, sb, spf, sA);
+                                   v.slots, h->slotsPerImg, h->ini_th, h->min_th, sb, spf, sA, compact ? 1 : 0);
         }
-        if (stripLevels != (1u << nl) - 1u) {   // levels with wider cells (the coarsest ones of small images)
-            dim3 grid((h->totalCells + FAST_WAVES - 1) / FAST_WAVES, B);
-#define ORBX_LAUNCH_FAST(EST)                                                                                         \
-    hipLaunchKernelGGL(k_fast_cells<EST>, grid, dim3(64 * FAST_WAVES), (size_t)h->fastLdsPerWave * FAST_WAVES, st,  \
+        dim3 grid((h->totalCells + FAST_WAVES - 1) / FAST_WAVES, B);
+        const int es = (h->fastScoreStride == h->fastTileStride - 8 && h->opt[6] != 2) ? h->fastTileStride : 0;
+#define ORBX_LAUNCH_FAST(EST, SP, LDSW)                                                                                  \
+    hipLaunchKernelGGL((k_fast_cells<EST, SP>), grid, dim3(64 * FAST_WAVES), (size_t)(LDSW) * FAST_WAVES, st,              \
                        v.pyr, h->pyrImgBytes, h->d_geom, nl, h->totalCells, v.cellCnt, v.cellRaw, v.slots, \
                        h->slotsPerImg, h->ini_th, h->min_th, h->fastTileStride, h->fastScoreStride, h->fastTileRows, \
-                       h->fastLdsPerWave, h->opt[0], cb, stripLevels)
-            const int es = (h->fastScoreStride == h->fastTileStride - 8 && h->opt[6] != 2) ? h->fastTileStride : 0;
-            switch (es) {   // the strides of the usual 30-px cell grids; anything else takes the run-time-stride instance
-            case 44: ORBX_LAUNCH_FAST(44); break;
-            case 48: ORBX_LAUNCH_FAST(48); break;
-            case 52: ORBX_LAUNCH_FAST(52); break;
-            default: ORBX_LAUNCH_FAST(0); break;
+                       (LDSW), h->opt[0], cb, stripLevels, v.sparse)
+        if (compact) {   // the flagged (image, level)s of the strip levels: + the queue of 16-bit entries behind a wave's tiles
+            const int ldsw = h->fastLdsPerWave + ((32 * h->fastTileRows + 15) & ~15);
+            switch (es) {
+            case 44: ORBX_LAUNCH_FAST(44, true, ldsw); break;
+            case 48: ORBX_LAUNCH_FAST(48, true, ldsw); break;
+            case 52: ORBX_LAUNCH_FAST(52, true, ldsw); break;
+            default: ORBX_LAUNCH_FAST(0, true, ldsw); break;
             }
-#undef ORBX_LAUNCH_FAST
         }
+        if (stripLevels != (1u << nl) - 1u) {   // levels with wider cells (the coarsest ones of small images)
+            switch (es) {   // the strides of the usual 30-px cell grids; anything else takes the run-time-stride instance
+            case 44: ORBX_LAUNCH_FAST(44, false, h->fastLdsPerWave); break;
+            case 48: ORBX_LAUNCH_FAST(48, false, h->fastLdsPerWave); break;
+            case 52: ORBX_LAUNCH_FAST(52, false, h->fastLdsPerWave); break;
+            default: ORBX_LAUNCH_FAST(0, false, h->fastLdsPerWave); break;
+            }
+        }
+#undef ORBX_LAUNCH_FAST
     }
     if (profFast) ORBX_HIP(hipEventRecord(ev[2], st));
     const bool gate = h->pfUsed && evPyrDone == nullptr;   // a pyramid built ahead starts behind this FAST stage (knob 10: 1 behind the quad-tree, 2 behind the descriptors)
@@ -786,7 +810,8 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
         if (!fused)
             hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
                                dim3(256), 0, st, h->d_geom, nl, h->totalCells, v.cellCnt, v.cellRaw, v.slots,
-                               h->slotsPerImg, v.cand, h->keysPerImg, v.candCnt, h->ini_th, h->min_th, cb, v.sparse, sparsePerCell);
+                               h->slotsPerImg, v.cand, h->keysPerImg, v.candCnt, h->ini_th, h->min_th, cb, v.sparse, sparsePerCell,
+                               h->d_sparseSeen, h->callSeq);
         // developer knob 15: a >= 2 = split call at level a (default 0: one launch sequence)
         aSplit = (usePyr && !prof && h->lastChunks == 1 && B >= 8 && h->opt[7] == 0 && h->opt[1] == 0 && h->opt[15] >= 2 &&
                   !multiWg && h->d_dbgBlur == nullptr)
@@ -879,6 +904,9 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     if (gate && h->opt[10] == 1) ORBX_HIP(hipEventRecord(h->evFastDone, st));
     {   // K4 (one instance per flavour of the Gaussian's column rounding: the default pays nothing for the other)
         const bool sse2 = h->flavour.gauss_rounding == ORBX_GAUSS_ROUND_SSE2;
+        // ORBX_OPT_DESC_LDS_PAD (KB): unused dynamic LDS per workgroup = fewer resident k_describe workgroups per CU, i.e. wave slots
+        // left for the pyramid kernels that run beside it in a pipelined step (tuning only)
+        const size_t descPad = (size_t)h->opt[21] * 1024;
         const auto kDesc = aSplit > 0 ? (sse2 ? k_describe<ORBX_GAUSS_ROUND_SSE2, true> : k_describe<ORBX_GAUSS_ROUND_HALF_UP, true>)
                                       : (sse2 ? k_describe<ORBX_GAUSS_ROUND_SSE2, false> : k_describe<ORBX_GAUSS_ROUND_HALF_UP, false>);
         const uint8_t *blurp = h->blurMaskLast ? h->d_blur + (size_t)v.b0 * h->pyrImgBytes : nullptr;
@@ -890,18 +918,18 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             uint8_t *dB = h->d_descB + (size_t)v.b0 * cap * 32;
             const int nbB = (maxoB + DESC_WAVES - 1) / DESC_WAVES, nbA = (maxoA + DESC_WAVES - 1) / DESC_WAVES;
             const DescGroup gB = {aSplit, nl, 0, nbB, nullptr, nullptr};
-            hipLaunchKernelGGL(kDesc, dim3(nbB, B), dim3(64 * DESC_WAVES), 0, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
+            hipLaunchKernelGGL(kDesc, dim3(nbB, B), dim3(64 * DESC_WAVES), descPad, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
                                v.lvlKp, h->lvlKpCap, v.lvlCnt, kB, dB, d_counts, cap, (uint8_t *)nullptr, blurp, h->blurMaskLast, gB);
             ORBX_HIP(hipStreamWaitEvent(st, h->evOctA, 0));
             const DescGroup gA = {0, aSplit, 1, nbA, kB, dB};
-            hipLaunchKernelGGL(kDesc, dim3(nbA + (maxoB + DESC_COPY_PER_BLOCK - 1) / DESC_COPY_PER_BLOCK, B), dim3(64 * DESC_WAVES), 0, st,
+            hipLaunchKernelGGL(kDesc, dim3(nbA + (maxoB + DESC_COPY_PER_BLOCK - 1) / DESC_COPY_PER_BLOCK, B), dim3(64 * DESC_WAVES), descPad, st,
                                v.pyr, h->pyrImgBytes, h->d_geom, nl, v.lvlKp, h->lvlKpCap, v.lvlCnt, d_kps, d_desc, d_counts, cap,
                                (uint8_t *)nullptr, blurp, h->blurMaskLast, gA);
         } else {
             const int maxo = std::min(cap, h->max_kp);
             dim3 grid((maxo + DESC_WAVES - 1) / DESC_WAVES, B);
             const DescGroup gAll = {0, nl, 1, (int)grid.x, nullptr, nullptr};
-            hipLaunchKernelGGL(kDesc, grid, dim3(64 * DESC_WAVES), 0, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
+            hipLaunchKernelGGL(kDesc, grid, dim3(64 * DESC_WAVES), descPad, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
                                v.lvlKp, h->lvlKpCap, v.lvlCnt, d_kps, d_desc, d_counts, cap, h->d_dbgBlur, blurp, h->blurMaskLast, gAll);
         }
     }
@@ -940,6 +968,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
     const int nch = chunk_count(h, B, prof, skipPyr);
     h->lastChunks = nch;
     h->candStale = 0;
+    h->callSeq++;
     h->prevPyrValid = skipPyr ? 1 : 0;   // d_pyr is overwritten unless this call took a pyramid built ahead (then d_pyrAlt keeps the previous one)
     h->framesStale = (!pyramid_fused_all(h) && h->nlevels > 1) ? B : 0;   // frames of levels >= 1: written on demand (ensure_frames)
     int b0 = 0;
@@ -1340,7 +1369,7 @@ static int ensure_cand(orbx_extractor *h) {
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B), dim3(256), 0, h->last_stream,
                        h->d_geom, nl, h->totalCells, h->d_cellCnt, h->d_cellRaw, h->d_slots, h->slotsPerImg, h->d_cand, h->keysPerImg,
-                       h->d_candCnt, h->ini_th, h->min_th, cb, (int32_t *)nullptr, 0);
+                       h->d_candCnt, h->ini_th, h->min_th, cb, (int32_t *)nullptr, 0, (int32_t *)nullptr, 0);
     ORBX_HIP(hipGetLastError());
     h->candStale = 0;
     return ORBX_OK;

@@ -89,14 +89,15 @@ __global__ void k_pyr_pad(const uint8_t *img, int sstride, size_t simg, uint8_t 
 struct StripBases { int v[ORBX_MAX_LEVELS + 1]; };   // first strip of every level (levels with cells wider than 32 px own none)
 __global__ void k_fast_strips(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalStrips, int totalCells,
                               uint32_t *cellCnt, uint32_t *cellRaw, uint32_t *slots, size_t slotsPerImg, int iniTh, int minTh,
-                              StripBases sb, const int32_t *sparseFlag, int strip0);                                                                    // orbx_fast.hip
-template <int ES_T>
+                              StripBases sb, const int32_t *sparseFlag, int strip0, int skipSparse);                                                                    // orbx_fast.hip
+template <int ES_T, bool SPARSE>   // SPARSE: the compaction form for the flagged (image, level)s of the strip levels
 __global__ void k_fast_cells(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalCells,
                              uint32_t *cellCnt, uint32_t *cellRaw, uint32_t *slots, size_t slotsPerImg, int iniTh, int minTh, int ESrt,
-                             int SSrt, int tileRows, int ldsPerWave, int phaseLimit, CellBases cb, unsigned stripLevels);  // orbx_fast.hip
+                             int SSrt, int tileRows, int ldsPerWave, int phaseLimit, CellBases cb, unsigned stripLevels,
+                             const int32_t *sparseFlag);  // orbx_fast.hip
 __global__ void k_gather(const LevelGeom *geom, int nlevels, int totalCells, const uint32_t *cellCnt, const uint32_t *cellRaw,
                          const uint32_t *slots, size_t slotsPerImg, uint32_t *cand, size_t keysPerImg, int32_t *candCnt, int iniTh,
-                         int minTh, CellBases cb, int32_t *sparseFlag, int sparsePerCell);                                                               // orbx_fast.hip
+                         int minTh, CellBases cb, int32_t *sparseFlag, int sparsePerCell, int32_t *sparseSeen, int callSeq);                                                               // orbx_fast.hip
 struct OctBig {   // multi-workgroup quad-tree of large levels (orbx_octree.hip)
     uint32_t *part, *leaf, *best;
     int32_t *state;
@@ -112,6 +113,8 @@ struct OctSrc {
     int32_t *candCntOut;     // kept keys per (image, level): what k_gather would have written
     int32_t *sparseFlag;     // verdict for the next call's FAST stage (may be NULL)
     int sparsePerCell;
+    int32_t *sparseSeen;     // host-mapped word: the sequence number of the last call that found a corner-sparse level (may be NULL)
+    int callSeq;
     uint32_t *candOut;       // compacted keys, written only by a level that falls back to the exact form
 };
 __global__ void k_octree_pyr(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,

@@ -120,11 +120,23 @@ __device__ __forceinline__ void fast_nms_pair(const uint8_t *Sc, int SS, int cw,
 // ES_T != 0: the tile strides are compile-time constants (pair tile ES_T dwords, score tile ES_T - 8 bytes), so every LDS
 // address of the ring / NMS reads is ONE base register + an immediate offset; with run-time strides the score loop spent
 // 21 of its 150 VALU instructions per pixel pair on address arithmetic.  ES_T == 0: run-time strides (any configuration).
-template <int ES_T>
+//
+// SPARSE (round 4): the same kernel for the corner-sparse levels of the strip kernel's range (cells up to 32 px wide whose
+// (image slot, level) the previous call flagged: a few candidates per cell, the regime of real footage).  There the 76-operation
+// score is wasted on most pixels, and skipping it lane by lane saves nothing (an instruction issues for the whole wave), so the
+// work is COMPACTED: (1) every pixel pair goes through the exact five-pixel bound on score + 1 (every nine-arc of the ring holds
+// r[0] or r[8] and r[4] or r[12]; the necessary condition cv::FAST itself tests first), 9 packed operations instead of 76; (2) the
+// pairs that can reach min(iniTh, minTh) are appended to an LDS queue in row-major order (ballot prefix); (3) the queue is scored
+// 64 pairs at a time with per-lane ring addressing, the scores scattered into the zeroed score tile; (4) the 3x3 suppression and
+// the ordered emission run over the queue entries only.  A pair that fails the bound has a score below both thresholds: the dense
+// form writes 0 for it as well, so the score tile - and everything behind it - is identical.  sparseFlag selects the cells:
+// SPARSE instances take the flagged (image, level)s of stripLevels, k_fast_strips (skipSparse) leaves exactly those alone.
+template <int ES_T, bool SPARSE>
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
     int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ cellRaw, uint32_t *__restrict__ slots, size_t slotsPerImg,
-    int iniTh, int minTh, int ESrt, int SSrt, int tileRows, int ldsPerWave, int phaseLimit, CellBases cb, unsigned stripLevels) {
+    int iniTh, int minTh, int ESrt, int SSrt, int tileRows, int ldsPerWave, int phaseLimit, CellBases cb, unsigned stripLevels,
+    const int32_t *__restrict__ sparseFlag) {
     const int ES = ES_T ? ES_T : ESrt, SS = ES_T ? ES_T - 8 : SSrt;
     extern __shared__ __align__(16) uint8_t smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -133,7 +145,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     const int gc = bx * FAST_WAVES + wave;
     if (gc >= totalCells) return;  // wave-uniform; the kernel uses no block barrier
     const int l = level_of_cell(cb, nlevels, gc);
-    if ((stripLevels >> l) & 1u) return;   // this level's cells are k_fast_strips' (cells up to 32 px wide)
+    if (SPARSE) {   // the flagged (image, level)s of the strip kernel's levels, nothing else
+        if (!((stripLevels >> l) & 1u) || __builtin_amdgcn_readfirstlane(sparseFlag[b * nlevels + l]) == 0) return;
+    } else if ((stripLevels >> l) & 1u) return;   // this level's cells are k_fast_strips' (cells up to 32 px wide)
     const LevelGeom g = geom[l];
     const int c = gc - g.cellBase;
     const int ci = c / g.nCols, cj = c - ci * g.nCols;
@@ -200,6 +214,33 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
 
     const int tlo = max(min(iniTh, minTh), 0);
     const int pw2 = (cw + 1) >> 1;
+    // SPARSE: queue of the pairs that pass the bound, (row << 4 | pair) as 16-bit entries behind the score tile (capacity: every pair)
+    uint16_t *Q = (uint16_t *)(smem + (size_t)wave * ldsPerWave + (size_t)ES * tileRows * 4 + (((size_t)SS * (tileRows - 4) + 15) & ~(size_t)15));
+    int nQ = 0;
+    if (SPARSE) {   // (cells of the strip levels: pw2 <= 16)
+        const int j = lane & 15, r4 = lane >> 4;
+        const half2v tl2 = __builtin_bit_cast(half2v, (uint32_t)tlo * 0x00010001u);
+        const uint32_t vmask = (2 * j < cw ? 0xFFFFu : 0u) | (2 * j + 1 < cw ? 0xFFFF0000u : 0u);
+        const uint32_t *q = E + (r4 + 3) * ES + 2 * j + 3 + sh;
+        for (int r0 = 0; r0 < ch; r0 += 4, q += 4 * ES) {
+            const int py = r0 + r4;
+            // (rows past the cell: the window rows exist in the tile's allocation, the verdict is masked)
+            const half2v v = __builtin_bit_cast(half2v, q[0]), a0 = __builtin_bit_cast(half2v, q[3 * ES]), a4 = __builtin_bit_cast(half2v, q[3]),
+                         a8 = __builtin_bit_cast(half2v, q[-3 * ES]), a12 = __builtin_bit_cast(half2v, q[-3]);
+            const half2v ub = __builtin_elementwise_minimum(__builtin_elementwise_maximum(a0, a8), __builtin_elementwise_maximum(a4, a12)) - v;
+            const half2v ud = v - __builtin_elementwise_maximum(__builtin_elementwise_minimum(a0, a8), __builtin_elementwise_minimum(a4, a12));
+            const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_maximum(ub, ud), tl2) - tl2) & vmask;
+            const bool pass = u != 0 && py < ch;   // U > min(iniTh, minTh) for one of the pair's pixels inside the evaluated area
+            const unsigned long long m = __ballot(pass);
+            if (pass) Q[nQ + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)((py << 4) | j);
+            nQ += __popcll(m);
+        }
+        wave_sync();
+        for (int base = 0; base < nQ; base += 64) {
+            const uint32_t e = Q[min(base + lane, nQ - 1)];   // lanes past the end redo the last entry (same values)
+            fast_score_pair(E, ES, sh, Sc, SS, tlo, cw, (int)(e >> 4), 2 * (int)(e & 15u));
+        }
+    } else
     // scores, two pixels per lane.  Cells up to 32 px wide (the rule) use a fixed lane -> (row mod 4,
     // pair) map: no per-iteration index arithmetic; wider cells walk a flat pair index.
     if (pw2 <= 16) {
@@ -224,7 +265,23 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     uint32_t *Lst = E;
     bool anyIni = false;
     int nL = 0;
-    if (pw2 <= 16) {
+    if (SPARSE) {   // only a queued pair can hold a survivor; the queue is in row-major order, so the list is too
+        for (int base = 0; base < nQ; base += 64) {
+            bool k0 = false, k1 = false;
+            int v0 = 0, v1 = 0;
+            const uint32_t e = Q[min(base + lane, nQ - 1)];
+            const int py = (int)(e >> 4), px = 2 * (int)(e & 15u);
+            if (base + lane < nQ) fast_nms_pair(Sc, SS, cw, py, px, k0, k1, v0, v1);
+            k0 = k0 && v0 > 0;   // (a pair queued for its other pixel: a zero score is no strict maximum of anything it would be emitted for)
+            k1 = k1 && v1 > 0;
+            anyIni |= (__ballot((k0 && v0 >= iniTh) || (k1 && v1 >= iniTh)) != 0ull);
+            const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1), lt = (1ull << lane) - 1ull;
+            int pos = nL + __popcll(m0 & lt) + __popcll(m1 & lt);
+            if (k0) Lst[pos++] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)v0 << 16);
+            if (k1) Lst[pos] = (uint32_t)(px + 1) | ((uint32_t)py << 8) | ((uint32_t)v1 << 16);
+            nL += __popcll(m0) + __popcll(m1);
+        }
+    } else if (pw2 <= 16) {
         // fixed lane -> (row mod 4, pair) map as in the score phase: column, byte selectors and the keep-mask of the odd
         // pixel are loop invariants, a row step is one address add, and the iniTh test is ONE ballot after the loop
         const int j = lane & 15, px = 2 * j, r4 = lane >> 4;
@@ -334,7 +391,7 @@ __device__ __forceinline__ uint32_t dpp_row_shl1(uint32_t v) { return (uint32_t)
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels, int totalStrips,
     int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ cellRaw, uint32_t *__restrict__ slots, size_t slotsPerImg,
-    int iniTh, int minTh, StripBases sb, const int32_t *__restrict__ sparseFlag, int strip0) {
+    int iniTh, int minTh, StripBases sb, const int32_t *__restrict__ sparseFlag, int strip0, int skipSparse) {
     __shared__ __align__(16) uint32_t smem[FAST_WAVES * STRIP_SLOTS * STRIP_ES];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int bx, b;
@@ -348,6 +405,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
     // Corner-sparse level (the previous call found few candidates in this image slot's level, k_gather leaves the verdict): every
     // row is first put through a cheap bound on the score and scored only if some pixel of the wave's 128 can reach the threshold.
     const bool pretest = sparseFlag != nullptr && __builtin_amdgcn_readfirstlane(sparseFlag[b * nlevels + l]) != 0;   // wave-uniform
+    if (pretest && skipSparse) return;   // this (image, level) is the compaction kernel's (k_fast_cells<.., true> of the same call)
     const int s = strip - sb.v[l];
     const int ng = (g.nCols + 3) >> 2;
     const int ci = s / ng, cj0 = 4 * (s - ci * ng);
@@ -525,7 +583,8 @@ __global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ ge
                                                 const uint32_t *__restrict__ cellCnt, const uint32_t *__restrict__ cellRaw,
                                                 const uint32_t *__restrict__ slots, size_t slotsPerImg,
                                                 uint32_t *__restrict__ cand, size_t keysPerImg, int32_t *__restrict__ candCnt,
-                                                int iniTh, int minTh, CellBases cb, int32_t *__restrict__ sparseFlag, int sparsePerCell) {
+                                                int iniTh, int minTh, CellBases cb, int32_t *__restrict__ sparseFlag, int sparsePerCell,
+                                                int32_t *__restrict__ sparseSeen, int callSeq) {
     __shared__ int wsum[4], ccnt[GATHER_CELLS_PER_BLOCK], clvl[GATHER_CELLS_PER_BLOCK];
     const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
     int bx, b;
@@ -571,7 +630,11 @@ __global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ ge
         candCnt[b * nlevels + l] = off + cn;
         // verdict for the NEXT call's FAST stage on this image slot: a level with few candidates per cell is put through the
         // row pre-test of k_fast_strips (speed only, never results)
-        if (sparseFlag) sparseFlag[b * nlevels + l] = (off + cn) < sparsePerCell * ncells ? 1 : 0;
+        if (sparseFlag) {
+            const int sparse = (off + cn) < sparsePerCell * ncells ? 1 : 0;
+            sparseFlag[b * nlevels + l] = sparse;
+            if (sparse && sparseSeen) __hip_atomic_store(sparseSeen, callSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     uint32_t *dst = cand + (size_t)b * keysPerImg + keyOff + off;
     const int gshift = (tid & 48);   // my group's 16 lanes inside the wave's ballot
@@ -591,11 +654,15 @@ __global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ ge
     }
 }
 
-// the tile strides of the usual 30-px cell grids + the run-time-stride instance
-#define ORBX_FAST_INSTANCE(EST)                                                                                              \
-    template __global__ void k_fast_cells<EST>(const uint8_t *, size_t, const LevelGeom *, int, int, uint32_t *, uint32_t *, \
-                                               uint32_t *, size_t, int, int, int, int, int, int, int, CellBases, unsigned)
-ORBX_FAST_INSTANCE(0);
-ORBX_FAST_INSTANCE(44);
-ORBX_FAST_INSTANCE(48);
-ORBX_FAST_INSTANCE(52);
+// the tile strides of the usual 30-px cell grids + the run-time-stride instance, each in the dense and the compaction form
+#define ORBX_FAST_INSTANCE(EST, SP)                                                                                              \
+    template __global__ void k_fast_cells<EST, SP>(const uint8_t *, size_t, const LevelGeom *, int, int, uint32_t *, uint32_t *, \
+                                                   uint32_t *, size_t, int, int, int, int, int, int, int, CellBases, unsigned, const int32_t *)
+ORBX_FAST_INSTANCE(0, false);
+ORBX_FAST_INSTANCE(44, false);
+ORBX_FAST_INSTANCE(48, false);
+ORBX_FAST_INSTANCE(52, false);
+ORBX_FAST_INSTANCE(0, true);
+ORBX_FAST_INSTANCE(44, true);
+ORBX_FAST_INSTANCE(48, true);
+ORBX_FAST_INSTANCE(52, true);

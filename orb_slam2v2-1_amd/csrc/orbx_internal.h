@@ -92,6 +92,7 @@ struct orbx_extractor {
     int32_t *d_candCnt, *d_lvlCnt;
     int candStale;       // > 0: the compacted key arrays (d_cand / d_candCnt of every level) of that many images were not written by the last call
                          // (k_octree_pyr read the cell lists in place); k_gather materialises them on demand (test hooks)
+    int32_t *h_sparseSeen, *d_sparseSeen; int callSeq;   // host-mapped word: sequence number of the last call that flagged a corner-sparse level
     int32_t *d_sparse;   // [B][nlevels] verdict of the last call: level with few FAST candidates (k_gather writes, k_fast_strips of the next call reads)
     // staging for the host API
     uint8_t *d_in; size_t d_in_bytes;

@@ -219,7 +219,13 @@ __device__ __forceinline__ void octree_pyr_body(
         if (tid == 0) {
             cellOff[g.ncells] = rawTotal;
             src.candCntOut[b * nlevels + l] = sh_kept;
-            if (src.sparseFlag) src.sparseFlag[b * nlevels + l] = sh_kept < src.sparsePerCell * g.ncells ? 1 : 0;   // verdict for the next call's FAST
+            if (src.sparseFlag) {   // verdict for the next call's FAST
+                const int sparse = sh_kept < src.sparsePerCell * g.ncells ? 1 : 0;
+                src.sparseFlag[b * nlevels + l] = sparse;
+                // the host learns (late, never needed for correctness) that calls on this handle meet corner-sparse levels: it then adds
+                // the compaction kernel's launch to the FAST stage
+                if (sparse && src.sparseSeen) __hip_atomic_store(src.sparseSeen, src.callSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         __syncthreads();
         // one sweep over the cell lists: 16 lanes per cell, a lane owns four CONSECUTIVE entries (one 16-byte load; a cell's slot block

@@ -81,10 +81,12 @@ class FrontEnd:
         main0 = torch.cuda.current_stream(self.dev)
         self._side_raw = self.ex.side_stream_for(main0.cuda_stream) if (prefetch and self.S == 1) else self.ex.side_stream()
         self.side = torch.cuda.ExternalStream(self._side_raw, device=self.dev) if self.lag else None
-        # Order of the two side-stream jobs behind FAST(i).  Default: matcher(i-1), then pyramid(i+1) - the matcher beside the quad-tree, the
-        # pyramid beside the descriptors.  stereo_late: pyramid(i+1) first, then matcher(i-1) (three pyramid buffers) - the matcher beside the
-        # descriptor kernel; pays when that kernel is long (many keypoints per image): None = by the feature budget.
-        self.late = bool(self.lag and (nfeatures >= 1500 if stereo_late is None else stereo_late))
+        # Order of the two side-stream jobs behind FAST(i).  stereo_late (the default since round 4): pyramid(i+1) first, then matcher(i-1)
+        # (three pyramid buffers) - the pyramid starts beside the quad-tree, the matcher runs beside the descriptor kernel, the next FAST
+        # waits for it.  stereo_late = False: matcher(i-1), then pyramid(i+1) - the matcher beside the quad-tree, the pyramid beside the
+        # descriptors (two buffers).  Measured per 64-frame step, round 4 (descriptor kernel 133 us alone): 1000 features 0.613 -> 0.607 ms,
+        # round 3 (165 us): 2000 features 76.6 -> 77.6 k frames/s, 1000 features no difference.
+        self.late = bool(self.lag and (True if stereo_late is None else stereo_late))
         if self.late:
             self.ex.set_pyramid_buffers(3)
         self._coll = None              # torch-native stream the all-gather of the pipelined mode is issued from (N > 1)

@@ -667,39 +667,77 @@ def test_split_call_level_groups(pkg, oracle, synth, split):
         pkg.set_default_option(15, 0)
 
 
-@pytest.mark.parametrize("kind", ["natural", "dense", "flat_with_one_blob"])
-@pytest.mark.parametrize("mode", [2, 0, 1], ids=["pretest_forced", "pretest_by_density", "pretest_off"])
-def test_fast_row_pretest_is_exact(pkg, oracle, synth, kind, mode):
-    """k_fast_strips' early-out for corner-sparse levels: a five-pixel upper bound of the score decides per row of 128 pixels
-    whether the score is computed at all (developer knob 16: 2 = every level pre-tested, 1 = never, 0 = by the candidate density
-    the previous call found).  FAST candidates per level (order included), keypoints and descriptors must equal the oracle's on
-    corner-sparse scenes, on the dense benchmark frames (where nearly every row passes the pre-test) and on an image whose rows are
-    mostly skipped; the second call on a handle is the one that sees the first call's verdicts."""
+@pytest.mark.parametrize("kind", ["natural", "dense", "flat_with_one_blob", "noise"])
+@pytest.mark.parametrize("form", [0, 1], ids=["compaction", "row_skip"])
+@pytest.mark.parametrize("mode", [2, 0, 1], ids=["sparse_forced", "sparse_by_density", "sparse_off"])
+def test_fast_row_pretest_is_exact(pkg, oracle, synth, kind, mode, form):
+    """The FAST stage's paths for corner-sparse levels.  A five-pixel upper bound of the score (every nine-arc of the ring holds
+    r[0] or r[8] and r[4] or r[12]) decides where the 76-operation score is computed at all: ORBX_OPT_SPARSE_FORM 0 (default) = the
+    compaction form of the cell kernel (pairs that pass are queued and scored 64 at a time, suppression over the queue), 1 = rows of
+    128 pixels skipped inside k_fast_strips; ORBX_OPT_ROW_PRETEST 2 = every level takes the sparse path, 1 = none, 0 = by the candidate
+    density the previous call found.  FAST candidates per level (order included), keypoints and descriptors must equal the oracle's
+    on corner-sparse scenes, on the dense benchmark frames and on uniform noise (where nearly every pair passes the bound and the
+    queue holds the whole cell) and on an image most of whose pairs fail; the second call on a handle is the one that sees the
+    first call's verdicts."""
     w, h, nf = 1241, 376, 1000
     if kind == "natural":
         img = synth.natural(w, h, 7)
     elif kind == "dense":
         img = synth.frame(w, h, 7)
+    elif kind == "noise":
+        img = np.random.default_rng(5).integers(0, 256, (h, w), dtype=np.uint8)
     else:
         img = np.full((h, w), 90, np.uint8)
         img[150:230, 500:640] = synth.frame(140, 80, 3)
     orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
     ok, od = orc.extract(img)
     ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
-    pkg.set_default_option(6, 3)       # the strip kernel for a single image
-    pkg.set_default_option(16, mode)
-    try:
-        for rep in range(3):
-            gk, gd = ex(img)
-            for l in range(8):
-                np.testing.assert_array_equal(ex.debug_level_points(l, 0), _cands(orc.level_candidates(l)),
-                                              err_msg="FAST candidates level %d call %d" % (l, rep))
-            assert len(gk) == len(ok)
+    ex.set_option(6, 3)       # the strip kernel for a single image
+    ex.set_option(16, mode)
+    ex.set_option(20, form)
+    for rep in range(3):
+        gk, gd = ex(img)
+        for l in range(8):
+            np.testing.assert_array_equal(ex.debug_level_points(l, 0), _cands(orc.level_candidates(l)),
+                                          err_msg="FAST candidates level %d call %d" % (l, rep))
+        assert len(gk) == len(ok)
+        np.testing.assert_array_equal(gk[["x", "y", "response", "octave"]], ok[["x", "y", "response", "octave"]])
+        np.testing.assert_array_equal(gd, od)
+
+
+def test_sparse_and_dense_images_in_one_batch(pkg, oracle, synth):
+    """A batch whose image slots alternate between corner-sparse and dense scenes, three calls on the same slots and then the
+    slots swapped: the strip kernel and the compaction kernel share each call's levels by the previous call's verdicts (per image
+    slot and level), every image equals the oracle in every call - also right after the swap, when every verdict is wrong."""
+    import torch
+    w, h, nf, B = 752, 480, 900, 10
+    imgs = np.stack([synth.natural(w, h, 40 + b) if b % 2 else synth.frame(w, h, 40 + b) for b in range(B)])
+    orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    exp = [orc.extract(imgs[b]) for b in range(B)]
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    ex.set_option(6, 3)
+    ex(imgs[0])
+    cap = ex.max_keypoints()
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    order = list(range(B))
+    for call in range(6):
+        if call == 3:
+            order = order[1:] + order[:1]          # sparse scenes into the slots flagged dense and the other way round
+        d_imgs = torch.from_numpy(imgs[order]).cuda()
+        ex.extract_batch_device(d_imgs.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)
+        torch.cuda.synchronize()
+        n = cnt.cpu().numpy()
+        K = kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+        D = desc.cpu().numpy()
+        for s, b in enumerate(order):
+            ok, od = exp[b]
+            assert n[s] == len(ok), (call, s, b)
+            gk = np.frombuffer(K[s, :n[s]].tobytes(), pkg.KP_DTYPE)
             np.testing.assert_array_equal(gk[["x", "y", "response", "octave"]], ok[["x", "y", "response", "octave"]])
-            np.testing.assert_array_equal(gd, od)
-    finally:
-        pkg.set_default_option(6, 0)
-        pkg.set_default_option(16, 0)
+            np.testing.assert_array_equal(D[s, :n[s]], od)
 
 
 @pytest.mark.parametrize("early", [0, 2, 3, 5])
