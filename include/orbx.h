@@ -423,8 +423,9 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  *                              call's candidate density)
  *   ORBX_OPT_GATHER        18  1 = k_gather + compacted key arrays instead of the quad-tree reading the FAST cell lists in place
  *   ORBX_OPT_EARLY_OCTREE  19  a >= 2: strips of levels [0, a) launched first, their quad-tree beside the FAST of the others
- *   ORBX_OPT_SPARSE_FORM   20  corner-sparse levels: 0 = compaction kernel (score only the pixels that pass the five-pixel bound),
- *                              1 = row skip inside k_fast_strips
+ *   ORBX_OPT_SPARSE_FORM   20  corner-sparse levels: 0 = rows of 128 pixels that cannot hold a corner are skipped inside k_fast_strips
+ *                              (default), 1 = k_fast_strips_sparse (the pixel pairs that pass the five-pixel bound are queued and
+ *                              scored 64 at a time), 2 = the same compaction inside the cell kernel; 1 and 2 measured no faster
  *   ORBX_OPT_DESC_LDS_PAD  21  KB of unused LDS per k_describe workgroup: fewer of them resident per CU, more wave slots for the
  *                              kernels of a neighbouring stream (tuning of the pipelined step; default 0)
  * Keys 0, 1 and 7 (stop a kernel after phase n: outputs incomplete) exist only in a library built with -DORBX_DEVELOPER

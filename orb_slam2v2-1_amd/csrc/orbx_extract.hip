@@ -45,7 +45,7 @@ extern "C" int orbx_thread_release_scratch(void) {
 // in a developer build (-DORBX_DEVELOPER).
 extern "C" int orbx_set_option(orbx_extractor_t *h, int key, int value) {
     static const signed char maxv[ORBX_NUM_OPTIONS] = {/*0*/ -1, -1, -2, 64, 3, 3, 3, -1, ORBX_MAX_CHUNKS, 1, 2, 2, 1, 2, 127, ORBX_MAX_LEVELS,
-                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 1, 100, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
+                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 100, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
     if (!h || key < 0 || key >= ORBX_NUM_OPTIONS || maxv[key] == -2) { orbx_set_error("orbx_set_option: unknown key %d", key); return ORBX_ERR_ARG; }
 #ifdef ORBX_DEVELOPER
     if (maxv[key] == -1) { if (value < 0) return ORBX_ERR_ARG; h->opt[key] = value; return ORBX_OK; }
@@ -711,7 +711,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
         osrc.cellCnt = v.cellCnt; osrc.cellRaw = v.cellRaw; osrc.slots = v.slots; osrc.slotsPerImg = h->slotsPerImg;
         osrc.totalCells = h->totalCells; osrc.iniTh = h->ini_th; osrc.minTh = h->min_th; osrc.candCntOut = v.candCnt;
         osrc.sparseFlag = v.sparse; osrc.sparsePerCell = sparsePerCell; osrc.candOut = v.cand;
-        osrc.sparseSeen = h->d_sparseSeen; osrc.callSeq = h->callSeq;
+        osrc.sparseSeen = h->opt[20] != 0 ? h->d_sparseSeen : nullptr; osrc.callSeq = h->callSeq;   // (the hint only serves the compaction forms)
         h->candStale = std::max(h->candStale, v.b0 + B);
     }
     int pow2 = 1;
@@ -733,13 +733,13 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             StripBases sb;
             for (int l = 0; l <= ORBX_MAX_LEVELS; l++) sb.v[l] = h->stripBase[l];
             const int32_t *spf = h->opt[16] == 1 ? (const int32_t *)nullptr : v.sparse;   // ORBX_OPT_ROW_PRETEST: 1 = never the sparse path, 2 = always
-            // Corner-sparse (image, level)s - flagged by the previous call's quad-tree - leave the strip kernel and are done by the
-            // compaction form of the cell kernel (below).  That costs a launch whose waves all return at once when nothing is flagged,
-            // so it is added only while the handle has recently met a sparse level: the quad-tree stores the call's sequence number
+            // ORBX_OPT_SPARSE_FORM 1 / 2 (alternatives, measured no faster than the default row skip inside the strip kernel - DESIGN.md
+            // section 5): the corner-sparse (image, level)s - flagged by the previous call's quad-tree - leave the strip kernel and are done
+            // by a compaction kernel (below).  That costs a launch whose waves all return at once when nothing is flagged, so it is added
+            // only while the handle has recently met a sparse level: the quad-tree of image slot 0 stores the call's sequence number
             // into a host-mapped word when it flags one (a hint that lags by the calls in flight; a wrong hint costs speed only,
-            // because both kernels take the SAME device flags).  ORBX_OPT_SPARSE_FORM = 1: the round-3 form (rows skipped inside
-            // the strip kernel).
-            compact = spf != nullptr && h->opt[20] == 0 &&
+            // because both kernels take the SAME device flags).
+            compact = spf != nullptr && h->opt[20] != 0 &&
                       (h->opt[16] == 2 || (h->h_sparseSeen && h->callSeq - *(volatile int32_t *)h->h_sparseSeen <= 16));
             // Early quad-tree (developer knob 19: a >= 2 = levels [0, a); default 0 = off): the quad-tree of the large levels is ONE
             // workgroup per level walking a serial chain - the critical path behind FAST.  Their strips go first, in a launch of their
@@ -784,7 +784,13 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
                        v.pyr, h->pyrImgBytes, h->d_geom, nl, h->totalCells, v.cellCnt, v.cellRaw, v.slots, \
                        h->slotsPerImg, h->ini_th, h->min_th, h->fastTileStride, h->fastScoreStride, h->fastTileRows, \
                        (LDSW), h->opt[0], cb, stripLevels, v.sparse)
-        if (compact) {   // the flagged (image, level)s of the strip levels: + the queue of 16-bit entries behind a wave's tiles
+        if (compact && h->opt[20] == 1) {   // the flagged (image, level)s: the strip kernel's compaction twin
+            StripBases sb;
+            for (int l = 0; l <= ORBX_MAX_LEVELS; l++) sb.v[l] = h->stripBase[l];
+            hipLaunchKernelGGL(k_fast_strips_sparse, dim3((h->totalStrips + FAST_WAVES - 1) / FAST_WAVES, B), dim3(64 * FAST_WAVES), 0, st,
+                               v.pyr, h->pyrImgBytes, h->d_geom, nl, h->totalStrips, h->totalCells, v.cellCnt, v.cellRaw,
+                               v.slots, h->slotsPerImg, h->ini_th, h->min_th, sb, v.sparse);
+        } else if (compact) {   // ORBX_OPT_SPARSE_FORM = 2: the cell kernel's compaction form (+ the queue of 16-bit entries behind a wave's tiles)
             const int ldsw = h->fastLdsPerWave + ((32 * h->fastTileRows + 15) & ~15);
             switch (es) {
             case 44: ORBX_LAUNCH_FAST(44, true, ldsw); break;
@@ -811,7 +817,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             hipLaunchKernelGGL(k_gather, dim3((h->totalCells + GATHER_CELLS_PER_BLOCK - 1) / GATHER_CELLS_PER_BLOCK, B),
                                dim3(256), 0, st, h->d_geom, nl, h->totalCells, v.cellCnt, v.cellRaw, v.slots,
                                h->slotsPerImg, v.cand, h->keysPerImg, v.candCnt, h->ini_th, h->min_th, cb, v.sparse, sparsePerCell,
-                               h->d_sparseSeen, h->callSeq);
+                               h->opt[20] != 0 ? h->d_sparseSeen : (int32_t *)nullptr, h->callSeq);
         // developer knob 15: a >= 2 = split call at level a (default 0: one launch sequence)
         aSplit = (usePyr && !prof && h->lastChunks == 1 && B >= 8 && h->opt[7] == 0 && h->opt[1] == 0 && h->opt[15] >= 2 &&
                   !multiWg && h->d_dbgBlur == nullptr)

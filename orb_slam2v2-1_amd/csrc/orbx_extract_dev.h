@@ -90,6 +90,9 @@ struct StripBases { int v[ORBX_MAX_LEVELS + 1]; };   // first strip of every lev
 __global__ void k_fast_strips(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalStrips, int totalCells,
                               uint32_t *cellCnt, uint32_t *cellRaw, uint32_t *slots, size_t slotsPerImg, int iniTh, int minTh,
                               StripBases sb, const int32_t *sparseFlag, int strip0, int skipSparse);                                                                    // orbx_fast.hip
+__global__ void k_fast_strips_sparse(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalStrips, int totalCells,
+                                     uint32_t *cellCnt, uint32_t *cellRaw, uint32_t *slots, size_t slotsPerImg, int iniTh, int minTh,
+                                     StripBases sb, const int32_t *sparseFlag);                                                               // orbx_fast.hip
 template <int ES_T, bool SPARSE>   // SPARSE: the compaction form for the flagged (image, level)s of the strip levels
 __global__ void k_fast_cells(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalCells,
                              uint32_t *cellCnt, uint32_t *cellRaw, uint32_t *slots, size_t slotsPerImg, int iniTh, int minTh, int ESrt,

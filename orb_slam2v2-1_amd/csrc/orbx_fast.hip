@@ -574,6 +574,222 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
 }
 
 // ------------------------------------------------------------------------------------
+// K2s: the strip kernel for CORNER-SPARSE levels (a few FAST candidates per cell: real footage; the (image slot, level)s the
+// previous call's quad-tree flagged).  Same wave = strip of four cells, same lane = pixel pair, same suppression in registers and
+// same ordered emission as k_fast_strips - but the 76-operation score is computed only where it can matter, and COMPACTED:
+//   * every pair of a row goes through the five-pixel bound on score + 1 (every nine-arc of the ring holds r[0] or r[8] and r[4]
+//     or r[12]: the necessary condition cv::FAST itself tests first; exact - a pair that fails it has a score below both thresholds,
+//     is never emitted and never beats a pixel that is, so its score may be taken as 0);
+//   * the pairs that pass are appended to an LDS queue (ballot prefix), eight evaluated rows at a time; the queue is then scored
+//     64 pairs per round with per-lane ring addresses - skipping the score lane by lane would save nothing, an instruction issues for
+//     the whole wave - and the scores land in a sparse tile (one dword per lane and row, zeroed by the pre-test);
+//   * the suppression / emission of the block's rows then runs exactly as in k_fast_strips with the row's scores read from the tile.
+// The window rows are kept as BYTES (a ring of 16 rows + a mirror of its first six, so that any seven consecutive rows are one
+// base address + immediates): 6.2 KB of LDS per wave.  A packed pixel pair (two 16-bit halves, the f16-denormal trick of
+// fast_ring_score) costs one 16-bit LDS read and one v_perm (lds_pair).
+#define SP_RS 144          // ring row stride in bytes (>= 3 + 4 * 32 + 6 + 4)
+#define SP_SLOTS 16
+#define SP_MIRROR 6
+#define SP_K 8             // evaluated rows per block
+#define SP_LDS_PER_WAVE ((SP_SLOTS + SP_MIRROR) * SP_RS + SP_K * 64 * 2 + SP_K * 64 * 2 + 16)
+// packed pixel pair (p[0] | p[1] << 16) from two neighbouring ring bytes: two ds_read_u8 and one v_lshl_or.  Measured alternatives:
+// ONE unaligned ds_read_u16 + v_perm made the kernel 4x slower (0.95 instead of 0.21 ms per 128 images: misaligned LDS accesses
+// are replayed), and ds_read_u8_d16 + ds_read_u8_d16_hi - which would build the pair in the LDS unit with no VALU work - ZERO the
+// other half of the register on gfx950 (d16 loads keep it only without SRAM ECC): the first version read 0 in every low half.
+__device__ __forceinline__ uint32_t lds_pair(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 16); }
+
+__global__ __launch_bounds__(64 * FAST_WAVES) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_fast_strips_sparse(
+    const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels, int totalStrips,
+    int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ cellRaw, uint32_t *__restrict__ slots, size_t slotsPerImg,
+    int iniTh, int minTh, StripBases sb, const int32_t *__restrict__ sparseFlag) {
+    __shared__ __align__(16) uint8_t smem[FAST_WAVES * SP_LDS_PER_WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int bx, b;
+    xcd_block_map(bx, b);
+    const int strip = bx * FAST_WAVES + wave;
+    if (strip >= totalStrips) return;   // wave-uniform; no block barrier in this kernel
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < ORBX_MAX_LEVELS; i++) l += (i < nlevels && strip >= sb.v[i]) ? 1 : 0;
+    if (__builtin_amdgcn_readfirstlane(sparseFlag[b * nlevels + l]) == 0) return;   // k_fast_strips' (wave-uniform)
+    const LevelGeom g = geom[l];
+    const int s = strip - sb.v[l];
+    const int ng = (g.nCols + 3) >> 2;
+    const int ci = s / ng, cj0 = 4 * (s - ci * ng);
+    const int c = lane >> 4, j = lane & 15, cj = cj0 + c;
+    const bool exists = cj < g.nCols;
+    const int maxBX = g.w - ORBX_MINB, maxBY = g.h - ORBX_MINB;
+    const int iniY = ORBX_MINB + ci * g.hCell, Xs = ORBX_MINB + cj0 * g.wCell;
+    const int th = min(iniY + g.hCell + 6, maxBY) - iniY, ch = th - 6;          // FAST sub-image rows, evaluated rows
+    const int cw = exists ? min(g.wCell, maxBX - (ORBX_MINB + cj * g.wCell) - 6) : 0;   // evaluated columns of MY cell (<= 0: skipped, :803-804)
+    const int cw0 = min(g.wCell, maxBX - Xs - 6);                               // ... of the strip's first cell (wave-uniform)
+    const size_t cellIdx = (size_t)b * totalCells + g.cellBase + ci * g.nCols + cj;
+    if (iniY >= maxBY - 3 || ch <= 0 || cw0 <= 0) {   // skipped rows (:794-795) / nothing to evaluate
+        if (j == 0 && exists) { cellCnt[cellIdx] = 0; cellRaw[cellIdx] = 0; }
+        return;
+    }
+    const int cjL = min(cj0 + 3, g.nCols - 1);
+    const int tws = min(ORBX_MINB + cjL * g.wCell + g.wCell + 6, maxBX) - Xs;   // strip window width: its cells' windows overlap by 6 px
+
+    uint8_t *Rg = smem + wave * SP_LDS_PER_WAVE;                              // ring [16 + 6][SP_RS] bytes
+    uint16_t *Tile = (uint16_t *)(Rg + (SP_SLOTS + SP_MIRROR) * SP_RS);        // [SP_K][64] scores (+1, <= 255) of a block's rows, two bytes per lane
+    uint16_t *Q = (uint16_t *)(Tile + SP_K * 64);                             // [SP_K * 64] entries: row-in-block << 8 | lane << 2 | valid pixels
+    uint32_t *RowHit = (uint32_t *)(Q + SP_K * 64);                           // bit r: row r of the block holds a score >= min(iniTh, minTh)
+    const size_t a = (size_t)(ORBX_EDGE + iniY) * g.pstride + ORBX_EDGE + Xs;
+    const int sh = (int)(a & 3);
+    const uint8_t *src = pyr + (size_t)b * pyrImgBytes + g.poff + (a - sh);
+    const int nd = (sh + tws + 3) >> 2;                       // aligned source dwords per window row (<= 36)
+    const int qi = min(lane, nd - 1);                         // lanes past the row repeat its last item (same value, same address)
+    const uint32_t loff = (uint32_t)qi * 4u;
+    const int chS = __builtin_amdgcn_readfirstlane(ch), thS = __builtin_amdgcn_readfirstlane(th), pstrideS = __builtin_amdgcn_readfirstlane(g.pstride);
+    auto load_row = [&](int r) -> uint32_t {
+        const uint32_t ro = (uint32_t)(min(r, thS - 1) * pstrideS);
+        return *(const uint32_t *)(src + ro + loff);          // scalar row base + 32-bit lane offset
+    };
+    auto write_row = [&](int r, uint32_t d) {                 // window row r -> ring slot r & 15 (+ its mirror behind the ring)
+        const int slot = r & (SP_SLOTS - 1);
+        *(uint32_t *)(Rg + slot * SP_RS + loff) = d;
+        if (slot < SP_MIRROR) *(uint32_t *)(Rg + (slot + SP_SLOTS) * SP_RS + loff) = d;   // wave-uniform
+    };
+    {   // window rows 0..13 = the first block's
+        uint32_t d[SP_K + 6];
+#pragma unroll
+        for (int r = 0; r < SP_K + 6; r++) d[r] = load_row(r);
+#pragma unroll
+        for (int r = 0; r < SP_K + 6; r++) write_row(r, d[r]);
+    }
+    wave_sync();
+
+    const int tlo = max(min(iniTh, minTh), 0), thi = max(iniTh, minTh);
+    const int i0 = c * g.wCell + 3 + 2 * j;                   // strip column of my pair's first pixel
+    const uint8_t *myCol = Rg + sh + i0;                      // my pair in ring slot 0
+    const uint32_t vbits = (2 * j < cw ? 1u : 0u) | (2 * j + 1 < cw ? 2u : 0u);
+    const uint32_t vmask = (vbits & 1u ? 0xFFFFu : 0u) | (vbits & 2u ? 0xFFFF0000u : 0u);
+    const uint32_t ltc = (1u << j) - 1u;
+    const int cs = 16 * c;   // my cell's 16 lanes inside a ballot
+    const half2v tl2 = __builtin_bit_cast(half2v, (uint32_t)tlo * 0x00010001u);
+    const uint32_t x0 = (uint32_t)(cj * g.wCell + 3 + 2 * j), ybase = (uint32_t)(ci * g.hCell + 3);
+    uint32_t *lvlSlots = slots + (size_t)b * slotsPerImg + g.slotOff;
+    const uint32_t cellOff = (uint32_t)((ci * g.nCols + cj) * g.capc);
+    const uint32_t wCellS = (uint32_t)__builtin_amdgcn_readfirstlane(g.wCell);
+    uint32_t S1 = 0, H1 = 0, H2 = 0, LR1 = 0;
+    uint32_t nRaw = 0, nHi = 0;
+    uint32_t hitPrev = 0;   // the last row of the previous block held a score above the threshold
+    // suppression verdict for row y-1 from the scores S of row y (identical to k_fast_strips' rowstep behind its score)
+    auto nms_row = [&](uint32_t S, uint32_t &kpOut, uint32_t &sOut) {
+        const uint32_t Lp = __builtin_amdgcn_perm(S, dpp_row_shr1(S), 0x05040302u);
+        const uint32_t Rp = __builtin_amdgcn_perm(dpp_row_shl1(S), S, 0x05040302u);
+        const half2v Lh = __builtin_bit_cast(half2v, Lp), Rh = __builtin_bit_cast(half2v, Rp), Sh = __builtin_bit_cast(half2v, S);
+        const uint32_t H0 = __builtin_bit_cast(uint32_t, pk_max3(Lh, Sh, Rh));
+        const uint32_t LR0 = __builtin_bit_cast(uint32_t, pk_max3(Lh, Rh, tl2));
+        const half2v nb = pk_max3(__builtin_bit_cast(half2v, H2), __builtin_bit_cast(half2v, H0), __builtin_bit_cast(half2v, LR1));
+        kpOut = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, S1) - nb);
+        sOut = S1;
+        S1 = S; H2 = H1; H1 = H0; LR1 = LR0;
+    };
+    auto emit_pair = [&](int y, uint32_t kpA, uint32_t sA, uint32_t kpB, uint32_t sB) {   // verdicts for rows y - 1 (A) and y (B)
+        const short2v fa = __builtin_bit_cast(short2v, kpA), fb = __builtin_bit_cast(short2v, kpB);
+        const bool inA = fa.x > 0 || fa.y > 0, inB = fb.x > 0 || fb.y > 0;
+        const unsigned long long mA = __ballot(inA), mB = __ballot(inB);
+        if (mA | mB) {   // wave-uniform
+            const uint32_t aA = (uint32_t)(mA >> cs) & 0xFFFFu, aB = (uint32_t)(mB >> cs) & 0xFFFFu;
+            const bool second = inB ? fb.y > 0 : fa.y > 0;
+            const uint32_t sv = inB ? sB : sA;
+            const uint32_t sc = second ? sv >> 16 : sv & 0xFFFFu;
+            const uint32_t pos = cellOff + nRaw + (inB ? __popc(aA) + __popc(aB & ltc) : __popc(aA & ltc));
+            if (inA || inB)
+                lvlSlots[pos] = (sc << 24) + (second ? x0 + 1u : x0) + ((ybase + (uint32_t)(y - 1) + (inB ? 1u : 0u)) << 12) - (1u << 24);
+            nHi += (inA || inB) && sc > (uint32_t)thi ? 1u : 0u;
+            nRaw += __popc(aA) + __popc(aB);
+        }
+    };
+
+    for (int yv = 0; yv <= chS; yv += SP_K) {
+        const int y0 = __builtin_amdgcn_readfirstlane(yv);
+        // the next block's new window rows (y0 + 14 .. y0 + 21) go in flight now and into the ring behind this block's scoring
+        uint32_t pre[SP_K];
+#pragma unroll
+        for (int r = 0; r < SP_K; r++) pre[r] = load_row(y0 + SP_K + 6 + r);
+        // ---- pre-test of the block's rows, queue of the pairs that pass, zeroed tile
+        int nQ = 0;
+        if (lane == 0) *RowHit = 0;
+#pragma unroll
+        for (int r = 0; r < SP_K; r++) {
+            Tile[r * 64 + lane] = 0;
+            if (y0 + r < chS) {   // wave-uniform
+                const uint8_t *ar = myCol + ((y0 + r) & (SP_SLOTS - 1)) * SP_RS;   // window row y0 + r (= ring row of dy = -3)
+                const uint32_t v = lds_pair(ar + 3 * SP_RS), a0 = lds_pair(ar + 6 * SP_RS), a8 = lds_pair(ar),
+                               a4 = lds_pair(ar + 3 * SP_RS + 3), a12 = lds_pair(ar + 3 * SP_RS - 3);
+                const half2v vh = __builtin_bit_cast(half2v, v), h0 = __builtin_bit_cast(half2v, a0), h4 = __builtin_bit_cast(half2v, a4),
+                             h8 = __builtin_bit_cast(half2v, a8), h12 = __builtin_bit_cast(half2v, a12);
+                const half2v ub = __builtin_elementwise_minimum(__builtin_elementwise_maximum(h0, h8), __builtin_elementwise_maximum(h4, h12)) - vh;
+                const half2v ud = vh - __builtin_elementwise_maximum(__builtin_elementwise_minimum(h0, h8), __builtin_elementwise_minimum(h4, h12));
+                const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_maximum(ub, ud), tl2) - tl2) & vmask;
+                const bool pass = u != 0;   // U > min(iniTh, minTh) for one of my two pixels inside the evaluated area
+                const unsigned long long m = __ballot(pass);
+                if (pass) Q[nQ + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                              (uint16_t)((r << 8) | (lane << 2) | (int)vbits);
+                nQ += __popcll(m);
+            }
+        }
+        wave_sync();
+        // ---- the queue, 64 pairs per round: the full score with per-lane ring addresses
+        for (int base = 0; base < nQ; base += 64) {
+            const uint32_t e = Q[min(base + lane, nQ - 1)];   // lanes past the end redo the last entry (same value to the same place)
+            const uint32_t er = e >> 8, el = (e >> 2) & 63u, ev = e & 3u;
+            // ring address of the entry's pair at window row y0 + er: its lane's column + its row's slot (the mirror makes the seven
+            // rows contiguous: one address + immediates)
+            const uint8_t *ea = Rg + sh + 3 + (el >> 4) * wCellS + 2u * (el & 15u) + (((uint32_t)y0 + er) & (SP_SLOTS - 1)) * SP_RS;
+            const uint32_t vv = lds_pair(ea + 3 * SP_RS);
+            uint32_t rr[16];
+            rr[0] = lds_pair(ea + 6 * SP_RS);       rr[1] = lds_pair(ea + 6 * SP_RS + 1);  rr[2] = lds_pair(ea + 5 * SP_RS + 2);
+            rr[3] = lds_pair(ea + 4 * SP_RS + 3);   rr[4] = lds_pair(ea + 3 * SP_RS + 3);  rr[5] = lds_pair(ea + 2 * SP_RS + 3);
+            rr[6] = lds_pair(ea + 1 * SP_RS + 2);   rr[7] = lds_pair(ea + 1);              rr[8] = lds_pair(ea);
+            rr[9] = lds_pair(ea - 1);               rr[10] = lds_pair(ea + 1 * SP_RS - 2); rr[11] = lds_pair(ea + 2 * SP_RS - 3);
+            rr[12] = lds_pair(ea + 3 * SP_RS - 3);  rr[13] = lds_pair(ea + 4 * SP_RS - 3); rr[14] = lds_pair(ea + 5 * SP_RS - 2);
+            rr[15] = lds_pair(ea + 6 * SP_RS - 1);
+            const half2v best = fast_ring_score(vv, rr);
+            const uint32_t em = (ev & 1u ? 0xFFFFu : 0u) | (ev & 2u ? 0xFFFF0000u : 0u);
+            const uint32_t S = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(best, (half2v){(_Float16)0, (_Float16)0})) & em;
+            Tile[er * 64 + el] = (uint16_t)__builtin_amdgcn_perm(0u, S, 0x0c0c0200u);   // (lo, hi) -> two bytes
+            // rows that hold a score + 1 above min(iniTh, minTh): only they (and their neighbours) need the suppression below
+            const uint32_t over = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_bit_cast(half2v, S), tl2) - tl2);
+            if (over != 0) __hip_atomic_fetch_or(RowHit, 1u << er, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        wave_sync();
+        // ---- the new window rows take the slots of rows this block is done with
+#pragma unroll
+        for (int r = 0; r < SP_K; r++)
+            if (y0 + SP_K + 6 + r < thS) write_row(y0 + SP_K + 6 + r, pre[r]);   // wave-uniform
+        // ---- suppression + ordered emission, rows y0 .. y0 + 7 (rows past the cell are all-zero: the last verdicts).  A row without
+        // a score above the threshold can neither hold a survivor nor beat one (the threshold rides along as a neighbour), i.e. it
+        // may be taken as all-zero: a pair of rows is processed only if one of them or the row above holds such a score - in
+        // corner-sparse scenes most do not - and otherwise just leaves the state of two zero rows behind.
+        const uint32_t hits = ((uint32_t)__builtin_amdgcn_readfirstlane((int)*RowHit) << 1) | hitPrev;   // bit r + 1: row y0 + r, bit 0: row y0 - 1
+        hitPrev = (hits >> SP_K) & 1u;
+#pragma unroll
+        for (int r = 0; r < SP_K; r += 2) {
+            if (y0 + r <= chS) {   // wave-uniform
+                if ((hits >> r) & 7u) {   // rows y0 + r - 1, y0 + r, y0 + r + 1 (wave-uniform)
+                    uint32_t kpA, sA, kpB, sB;
+                    nms_row(__builtin_amdgcn_perm(0u, (uint32_t)Tile[r * 64 + lane], 0x0c010c00u), kpA, sA);         // scores of row y0 + r: verdict for row y0 + r - 1
+                    nms_row(__builtin_amdgcn_perm(0u, (uint32_t)Tile[(r + 1) * 64 + lane], 0x0c010c00u), kpB, sB);   // verdict for row y0 + r
+                    emit_pair(y0 + r, kpA, sA, kpB, sB);
+                } else { S1 = 0; H1 = 0; H2 = 0; LR1 = __builtin_bit_cast(uint32_t, tl2); }
+            }
+        }
+        wave_sync();
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) nHi += __shfl_xor(nHi, o);
+    if (j == 0 && exists) {
+        const uint32_t nA = iniTh >= minTh ? nHi : nRaw, nB = iniTh >= minTh ? nRaw : nHi;
+        cellCnt[cellIdx] = min(nA ? nA : nB, (uint32_t)g.capc);
+        cellRaw[cellIdx] = min(nRaw, (uint32_t)g.capc) | (nA ? 0x80000000u : 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // K2c: the cell lists -> the level's key array in vToDistributeKeys order (:789-828), applying the per-cell threshold
 // (cellRaw bit 31: some survivor reached iniTh -> keep score >= iniTh, else score >= minTh).  A block = 16 consecutive cells,
 // 16 lanes per cell.  A cell's place in its level's array = number of kept keys of the level's earlier cells: the cells before
@@ -633,7 +849,7 @@ __global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ ge
         if (sparseFlag) {
             const int sparse = (off + cn) < sparsePerCell * ncells ? 1 : 0;
             sparseFlag[b * nlevels + l] = sparse;
-            if (sparse && sparseSeen) __hip_atomic_store(sparseSeen, callSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (sparse && b == 0 && sparseSeen) __hip_atomic_store(sparseSeen, callSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     uint32_t *dst = cand + (size_t)b * keysPerImg + keyOff + off;

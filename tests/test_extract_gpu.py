@@ -668,13 +668,13 @@ def test_split_call_level_groups(pkg, oracle, synth, split):
 
 
 @pytest.mark.parametrize("kind", ["natural", "dense", "flat_with_one_blob", "noise"])
-@pytest.mark.parametrize("form", [0, 1], ids=["compaction", "row_skip"])
+@pytest.mark.parametrize("form", [0, 1, 2], ids=["row_skip", "strip_compaction", "cell_compaction"])
 @pytest.mark.parametrize("mode", [2, 0, 1], ids=["sparse_forced", "sparse_by_density", "sparse_off"])
 def test_fast_row_pretest_is_exact(pkg, oracle, synth, kind, mode, form):
     """The FAST stage's paths for corner-sparse levels.  A five-pixel upper bound of the score (every nine-arc of the ring holds
-    r[0] or r[8] and r[4] or r[12]) decides where the 76-operation score is computed at all: ORBX_OPT_SPARSE_FORM 0 (default) = the
-    compaction form of the cell kernel (pairs that pass are queued and scored 64 at a time, suppression over the queue), 1 = rows of
-    128 pixels skipped inside k_fast_strips; ORBX_OPT_ROW_PRETEST 2 = every level takes the sparse path, 1 = none, 0 = by the candidate
+    r[0] or r[8] and r[4] or r[12]) decides where the 76-operation score is computed at all: ORBX_OPT_SPARSE_FORM 0 (default) = rows
+    of 128 pixels skipped inside k_fast_strips, 1 = k_fast_strips_sparse (pairs that pass are queued and scored 64 at a time), 2 = the
+    same compaction inside the cell kernel; ORBX_OPT_ROW_PRETEST 2 = every level takes the sparse path, 1 = none, 0 = by the candidate
     density the previous call found.  FAST candidates per level (order included), keypoints and descriptors must equal the oracle's
     on corner-sparse scenes, on the dense benchmark frames and on uniform noise (where nearly every pair passes the bound and the
     queue holds the whole cell) and on an image most of whose pairs fail; the second call on a handle is the one that sees the
@@ -705,7 +705,8 @@ def test_fast_row_pretest_is_exact(pkg, oracle, synth, kind, mode, form):
         np.testing.assert_array_equal(gd, od)
 
 
-def test_sparse_and_dense_images_in_one_batch(pkg, oracle, synth):
+@pytest.mark.parametrize("form", [0, 1, 2], ids=["row_skip", "strip_compaction", "cell_compaction"])
+def test_sparse_and_dense_images_in_one_batch(pkg, oracle, synth, form):
     """A batch whose image slots alternate between corner-sparse and dense scenes, three calls on the same slots and then the
     slots swapped: the strip kernel and the compaction kernel share each call's levels by the previous call's verdicts (per image
     slot and level), every image equals the oracle in every call - also right after the swap, when every verdict is wrong."""
@@ -716,6 +717,7 @@ def test_sparse_and_dense_images_in_one_batch(pkg, oracle, synth):
     exp = [orc.extract(imgs[b]) for b in range(B)]
     ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
     ex.set_option(6, 3)
+    ex.set_option(20, form)
     ex(imgs[0])
     cap = ex.max_keypoints()
     kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
