@@ -61,7 +61,7 @@ def independent_stream(dev, busy, ncand=8):
 class FrontEnd:
     def __init__(self, w, h, nfeatures, stereo, B, device_index=0, nbuf=3, streams=1, world=1, gather=False,
                  gather_via_host=False, mbf=KITTI_BF, fx=KITTI_FX, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, prefetch=True, lag_stereo=True,
-                 stereo_late=None, gather_B=None):
+                 stereo_late=None, gather_B=None, two_side=None):
         if not torch.cuda.is_available():
             raise RuntimeError("orb_slam2v2-1_amd.pipeline.FrontEnd needs a GPU: the HIP path has no CPU fallback")
         self.w, self.h, self.nf, self.stereo, self.B = w, h, nfeatures, stereo, B
@@ -89,6 +89,11 @@ class FrontEnd:
         self.late = bool(self.lag and (True if stereo_late is None else stereo_late))
         if self.late:
             self.ex.set_pyramid_buffers(3)
+        # two_side: the matcher of step i-1 on a SECOND side stream, started behind FAST(i) like the pyramid of step i+1 (three pyramid
+        # buffers): the matcher beside the quad-tree, the pyramid beside quad-tree + descriptors, neither behind the other
+        import os as _os
+        self.two_side = bool(self.late and (int(_os.environ.get("ORBX_TWO_SIDE", "0")) if two_side is None else two_side))
+        self.side2 = independent_stream(self.dev, [main0, self.side]) if self.two_side else None
         self._coll = None              # torch-native stream the all-gather of the pipelined mode is issued from (N > 1)
         self._ev_late = None           # event behind the last late matcher: the next FAST waits for it (FAST always runs alone)
         self._pend = None              # (buffer set, step) whose matcher has not been issued yet
@@ -142,14 +147,15 @@ class FrontEnd:
         self._publish_side(j, step)
         main.wait_stream(self.side)
 
-    def _publish_side(self, j, step):
+    def _publish_side(self, j, step, side=None):
         """N > 1: records of buffer set j packed and all-gathered right behind its matcher, in side-stream order (the collective
         itself runs on the backend's own stream and overlaps whatever follows)."""
+        side = self.side if side is None else side
         if self.ring.gather:
-            with torch.cuda.stream(self.side):
+            with torch.cuda.stream(side):
                 self.ring.pack_set(j)
                 ev = torch.cuda.Event()
-                ev.record(self.side)
+                ev.record(side)
             # the collective is issued from a stream torch created itself (the side stream is the handle's, wrapped as an external
             # stream: fine for kernels, but the backend's stream bookkeeping is best left to a native one)
             if self._coll is None:
@@ -277,12 +283,13 @@ class FrontEnd:
                 self._prefetch_next(exi, i, self.side)      # three buffers: the previous pyramid survives this one
             if self._pend is not None:
                 pj, pstep = self._pend
-                if not self.late:
-                    exi.stream_wait_fast_stage(sd)
-                self._match(exi, pj, sd, prev=True)       # step i-1: its pyramid is the buffer the call above swapped out
-                self._publish_side(pj, pstep)
+                ms = self.side2 if self.two_side else self.side
+                if not self.late or self.two_side:
+                    exi.stream_wait_fast_stage(ms.cuda_stream)
+                self._match(exi, pj, ms.cuda_stream, prev=True)       # step i-1: its pyramid is the buffer the call above swapped out
+                self._publish_side(pj, pstep, ms)
                 ev = torch.cuda.Event()
-                ev.record(self.side)
+                ev.record(ms)
                 self._ev_side[pj] = ev
                 self._ev_late = ev if self.late else None
             if not self.late:

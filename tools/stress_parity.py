@@ -1,8 +1,9 @@
 """Randomised parity stress: python tools/stress_parity.py [N] [seed] — GPU extractor vs CPU oracle on
 random sizes / budgets / thresholds / image statistics (not part of the pytest suite).  Every configuration runs three times:
-the default kernel choice of a single image (k_fast_cells, one-workgroup quad-tree), the strip FAST kernel forced (developer
-knob 6 = 3), strips + the multi-workgroup quad-tree on every level (knob 4 = 2), and strips with the row pre-test of corner-sparse
-levels forced on every level (knob 16 = 2)."""
+the default kernel choice of a single image (k_fast_cells, one-workgroup quad-tree), the strip FAST kernel forced (option 6 = 3),
+strips + the multi-workgroup quad-tree on every level (option 4 = 2), strips with the sparse path forced on every level (option
+16 = 2) in its three forms (row skip, strip compaction, cell compaction: option 20), k_gather + compacted keys, and - against the
+oracle of that flavour - a handle of the SSE2 flavour of the Gaussian's column rounding."""
 import sys, os, importlib, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -57,22 +58,28 @@ for it in range(N):
     except RuntimeError:
         continue
     ex = pkg.ORBextractor(nf, sf, nl, ini, mn)
+    ok2, od2 = oracle.Extractor(nf, sf, nl, ini, mn, gauss="sse2").extract(img)
+    ex2 = pkg.ORBextractor(nf, sf, nl, ini, mn, gauss="sse2")
     for variant, knobs in (("default", ()), ("strips", ((6, 3),)), ("strips+multi-wg quad-tree", ((6, 3), (4, 2))),
-                           ("strips+row pre-test", ((6, 3), (16, 2))), ("k_gather + compacted keys", ((18, 1),))):
+                           ("strips+row skip pre-test", ((6, 3), (16, 2))), ("strips+strip compaction pre-test", ((6, 3), (16, 2), (20, 1))),
+                           ("strips+cell compaction pre-test", ((6, 3), (16, 2), (20, 2))), ("k_gather + compacted keys", ((18, 1),)),
+                           ("sse2 flavour", ())):
+        e, wk, wd = (ex2, ok2, od2) if variant.startswith("sse2") else (ex, ok, od)
         for k, v in knobs:
-            pkg.set_default_option(k, v)
+            e.set_option(k, v)
         try:
-            gk, gd = ex(img)
+            gk, gd = e(img)
             if variant.endswith("pre-test"):
-                gk, gd = ex(img)     # the second call runs under the verdicts the first one left (every level pre-tested)
+                gk, gd = e(img)     # the second call runs under the verdicts the first one left (every level on the sparse path)
         finally:
             for k, v in knobs:
-                pkg.set_default_option(k, 0)
-        same = len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and gd.tobytes() == od.tobytes()
+                e.set_option(k, 0)
+        same = len(gk) == len(wk) and gk.tobytes() == wk.tobytes() and gd.tobytes() == wd.tobytes()
         if not same:
             bad += 1
             print("MISMATCH", variant, it, w, h, nf, sf, nl, ini, mn, kind, len(gk), len(ok), flush=True)
     ex.close()
+    ex2.close()
     if it % 100 == 99:
         print("  ... %d configs, %d mismatches, %.0f s" % (it + 1, bad, time.time() - t0), flush=True)
 print("stress: %d configs, %d mismatches, %.1f s" % (N, bad, time.time() - t0))
