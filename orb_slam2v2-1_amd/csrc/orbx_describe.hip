@@ -29,10 +29,12 @@
 #define BSTRIDE 40
 // The horizontal pass leaves its u16 sums TRANSPOSED: column c of the block is a run of TCS bytes, row r at byte 2r, so that a
 // dword holds the rows (2p, 2p+1) of one column - the pair one v_dot2_u32_u16 of the vertical pass multiplies with two taps (the
-// first version kept rows of 40 columns and re-paired consecutive rows with 46 v_perm per lane).  23 dwords per column: odd, so
-// neighbouring columns start in different banks.
-#define TCS 92
-#define TT_BYTES (4 * TGROUPS * TCS)
+// first version kept rows of 40 columns and re-paired consecutive rows with 46 v_perm per lane).  The four columns of a group are
+// contiguous (22 dwords each); the groups start at c_reach.gbase - a few dwords apart, chosen with the lanes' order in the vertical
+// pass by a bank model (tools/desc_lds_layout.py) so that the 16-bit stores of the horizontal pass and the dword reads of the
+// vertical pass spread over the 32 banks: modelled 300 -> 216 LDS cycles per keypoint for the two passes.
+#define TCS 88
+#define TT_BYTES 3680
 // patch | pad | transposed horizontal-pass intermediate.  The blurred 37x40 block OVERLAYS the patch, which nobody reads after the
 // horizontal pass.  (The gather form of a level blurred as a whole keeps its 37 rows of 40 bytes where the intermediate would be.)
 #define DESC_LDS_PER_WAVE (PROWS * PSTRIDE + PPAD + TT_BYTES)
@@ -49,7 +51,11 @@ static_assert(TT_BYTES >= TCOLS * BSTRIDE + 4, "gather form: the blurred block s
 #define DESC_H_ITERS 6
 #define DESC_V_ROWS 12
 // hitem = byte offset of the item's 16 source bytes in the patch | byte offset of its first output in the transposed intermediate << 16
-struct DescReach { uint8_t hh[40]; uint32_t hitem[DESC_H_ITERS * 64]; uint16_t vlane[64]; int nh, nv; };
+// vlane = column pair | first row << 8 | byte offset of the pair's first column at that row << 16
+struct DescReach { uint8_t hh[40]; uint32_t hitem[DESC_H_ITERS * 64]; uint32_t vlane[64]; int nh, nv, cover; };
+constexpr int kDescGbase[TGROUPS] = {0, 89, 181, 275, 369, 461, 552, 643, 734, 828};                 // dword offset of every group of four columns (tools/desc_lds_layout.py)
+constexpr signed char kDescVlane[64][2] = {{7, 26}, {12, 12}, {12, 26}, {6, 12}, {5, 0}, {7, 12}, {2, 26}, {11, 26}, {7, 0}, {3, 14}, {7, 24}, {8, 0}, {9, 12}, {10, 24}, {8, 12}, {16, 4}, {10, 12}, {13, 12}, {18, 24}, {8, 26}, {5, 24}, {8, 24}, {13, 0}, {5, 12}, {15, 4}, {18, 24}, {9, 26}, {9, 0}, {11, 12}, {9, 24}, {6, 26}, {12, 24}, {3, 26}, {18, 12}, {18, 24}, {0, 10}, {15, 16}, {4, 26}, {10, 0}, {16, 16}, {4, 2}, {12, 0}, {2, 16}, {6, 24}, {4, 14}, {1, 18}, {14, 14}, {6, 0}, {14, 2}, {14, 26}, {0, 22}, {13, 24}, {16, 26}, {11, 24}, {3, 2}, {10, 26}, {11, 0}, {17, 20}, {18, 24}, {15, 26}, {18, 24}, {1, 6}, {2, 4}, {17, 8}};   // (column pair, first row) of every lane of the vertical pass (same tool)
+static_assert(4 * (kDescGbase[TGROUPS - 1] + 4 * (TCS / 4)) <= TT_BYTES, "transposed intermediate");
 constexpr DescReach make_desc_reach() {
     DescReach t{};
     for (int c = 0; c < 40; c++) {
@@ -69,27 +75,38 @@ constexpr DescReach make_desc_reach() {
             const int dy = r > PR ? r - PR : PR - r;
             if (dy <= t.hh[c] + 3) { if ((c >> 2) < g0) g0 = c >> 2; if ((c >> 2) > g1) g1 = c >> 2; }
         }
-        for (int g = g0; g <= g1; g++) t.hitem[n++] = (uint32_t)(r * PSTRIDE + 4 * g) | ((uint32_t)(g * (4 * TCS) + 2 * r) << 16);
+        for (int g = g0; g <= g1; g++) t.hitem[n++] = (uint32_t)(r * PSTRIDE + 4 * g) | ((uint32_t)(4 * kDescGbase[g] + 2 * r) << 16);
     }
     t.nh = n;
     for (int i = n; i < DESC_H_ITERS * 64; i++) t.hitem[i] = t.hitem[n - 1];   // spare slots redo the last item (same values)
-    int m = 0;
-    for (int cp = 0; cp < 19; cp++) {   // column pair (2cp, 2cp+1): rows 18 - h .. 18 + h, h = the taller of the two
+    // the vertical pass: lane -> (column pair, run of DESC_V_ROWS rows from an even row), in the order the bank model chose; `cover`
+    // counts the pixels of the disc that some run computes (checked below: all 1133 - a column pair needs rows 18 - h .. 18 + h, h = the
+    // taller of its two columns)
+    int cover = 0;
+    for (int cp = 0; cp < 19; cp++) {
         const int h = t.hh[2 * cp] > t.hh[2 * cp + 1] ? t.hh[2 * cp] : t.hh[2 * cp + 1];
-        const int top = (ORBX_DESC_R - h) & ~1, bot = ORBX_DESC_R + h;
-        for (int r0 = top; r0 <= bot; r0 += DESC_V_ROWS) {
-            const int rs = r0 + DESC_V_ROWS > TCOLS + 1 ? TCOLS + 1 - DESC_V_ROWS : r0;   // even; the last run may overlap the one before
-            t.vlane[m < 64 ? m : 63] = (uint16_t)(cp | (rs << 8));
-            m++;
+        for (int r = ORBX_DESC_R - h; r <= ORBX_DESC_R + h; r++) {
+            bool hit = false;
+            for (int i = 0; i < 64; i++) hit = hit || (kDescVlane[i][0] == cp && r >= kDescVlane[i][1] && r < kDescVlane[i][1] + DESC_V_ROWS);
+            cover += hit ? 1 : 0;
         }
+        cover -= 2 * h + 1;   // (0 when every row is covered)
+    }
+    t.cover = cover;
+    int m = 0;
+    for (int i = 0; i < 64; i++) {
+        const int cp = kDescVlane[i][0], r0 = kDescVlane[i][1];
+        if (cp < 0 || cp > 18 || r0 < 0 || (r0 & 1) || r0 + DESC_V_ROWS > TCOLS + 1) { m = 999; break; }
+        const int c0 = 2 * cp;
+        t.vlane[i] = (uint32_t)cp | ((uint32_t)r0 << 8) | ((uint32_t)(4 * (kDescGbase[c0 >> 2] + (c0 & 3) * (TCS / 4)) + 2 * r0) << 16);
+        m++;
     }
     t.nv = m;
-    for (int i = m; i < 64; i++) t.vlane[i] = t.vlane[m - 1];
     return t;
 }
 __constant__ const DescReach c_reach = make_desc_reach();
 static_assert(make_desc_reach().nh <= DESC_H_ITERS * 64 && make_desc_reach().nh > (DESC_H_ITERS - 1) * 64, "horizontal pass: rounds of the wave");
-static_assert(make_desc_reach().nv <= 64, "vertical pass: one run of rows per lane");
+static_assert(make_desc_reach().nv == 64 && make_desc_reach().cover == 0, "vertical pass: the runs of the 64 lanes cover the disc");
 // the rBRIEF pattern as floats (the rotation runs in float: src/ORBextractor.cc:119-120): no integer -> float conversions per tap
 __constant__ float c_patternf[1024] = {
 #include "../../include/orb_pattern_31.inc"
@@ -543,8 +560,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu
     //   odd  row r: ( 0,18).pair[(r-1)/2] + (34,49).pair[..+1] + (55,49).pair[..+2] + (34,18).pair[..+3]
     // and the rounded bytes of both columns leave through one v_perm (byte 2 of the sums clamped to 2^24 - 1).
     {
-        const int cp = (int)(vlane & 0xFFu), r0 = (int)(vlane >> 8);
-        const uint32_t *col = (const uint32_t *)(Tt + (2 * cp) * TCS) + (r0 >> 1);
+        const int cp = (int)(vlane & 0xFFu), r0 = (int)((vlane >> 8) & 0xFFu);
+        const uint32_t *col = (const uint32_t *)(Tt + (vlane >> 16));   // rows (r0, r0 + 1) of column 2cp; column 2cp + 1 follows TCS bytes behind
         constexpr int NP = DESC_V_ROWS / 2 + 3;   // row pairs a run touches
         uint32_t A[NP], B[NP];
 #pragma unroll
