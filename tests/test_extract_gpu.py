@@ -308,12 +308,13 @@ def test_fused_pyramid_kernel(pkg, oracle, synth):
 
 @pytest.mark.parametrize("knob", [2, 3])
 def test_pyramid_forms_agree(pkg, oracle, synth, knob):
-    """Developer knob 5: 2 = one launch per level (the default), 3 = the hybrid (levels 1, 2 per launch, levels 3.. chained
+    """ORBX_OPT_PYRAMID_FORM: 2 = one launch per level (the default), 3 = the hybrid (levels 1, 2 per launch, levels 3.. chained
     through LDS in ONE launch; measured slower, kept as a tested alternative): every level byte for byte, frame included,
-    for an odd size, a 3-, 4- and a 10-level pyramid, and the key points behind them."""
+    for odd sizes, a 3-, 4- and a 10-level pyramid, scale factors 1.1 to 1.7, and the key points behind them."""
     pkg.set_default_option(5, knob)
     try:
-        for (w, h, nl, sf, seed) in ((641, 479, 8, 1.2, 84), (1241, 376, 8, 1.2, 85), (500, 400, 4, 1.3, 86), (900, 700, 10, 1.2, 87), (320, 240, 3, 1.2, 88)):
+        for (w, h, nl, sf, seed) in ((641, 479, 8, 1.2, 84), (1241, 376, 8, 1.2, 85), (500, 400, 4, 1.3, 86), (900, 700, 10, 1.2, 87), (320, 240, 3, 1.2, 88),
+                                     (1023, 517, 5, 1.5, 89), (770, 431, 9, 1.1, 90), (258, 255, 6, 1.2, 91), (1000, 600, 3, 1.7, 92)):
             img = synth.frame(w, h, seed)
             ex = pkg.ORBextractor(500, sf, nl, 20, 7)
             k, d = ex(img)
