@@ -121,10 +121,14 @@ __device__ __forceinline__ uint2 stereo_right_record(const StereoLevels &lv, con
     o.y = __float_as_uint(kp.x);
     return o;
 }
-// Row bins for the candidate search (the reference's vRowIndices, :495-508, at a coarser grain): bins of BH rows,
-// BH = a power of two >= the tallest row band, so a right keypoint's band touches at most two bins and a left
-// keypoint only looks at the right keypoints of ITS bin (a few hundred) instead of all of them.
+// Row bins for the candidate search (the reference's vRowIndices, :495-508, at a coarser grain): bins of BH rows, BH a power of
+// two chosen so that the tallest row band touches at most ST_MAX_SPAN bins (BH = 4 rows for the usual 8 levels x 1.2: a band is
+// <= 18 rows); a right keypoint is entered in every bin its band touches and a left keypoint only looks at the right keypoints of
+// ITS bin.  Round 4: rounds 1-3 used BH >= the tallest band (32 rows: at most two bins per keypoint, ~125 candidates per left
+// keypoint at 1000 features, ~250 at 2000 - two to four rounds of the 64-lane candidate test); with 4-row bins a left keypoint tests
+// ~35 / ~65 entries: one round (k_stereo_match 44 -> see DESIGN.md section 6).
 #define ST_MAX_BINS 512
+#define ST_MAX_SPAN 6     // bin entries per right keypoint at most (the item array holds ST_MAX_SPAN * cap entries per frame)
 __global__ __launch_bounds__(256) void k_stereo_bins(StereoLevels lv, const orbx_keypoint_t *__restrict__ kr,
                                                      uint2 *__restrict__ rc, const int32_t *__restrict__ nr, int cap,
                                                      int bhShift, int nbins, int32_t *__restrict__ binStart,
@@ -143,14 +147,13 @@ __global__ __launch_bounds__(256) void k_stereo_bins(StereoLevels lv, const orbx
         const int minr = (int)(x & 0xFFF), maxr = (int)((x >> 12) & 0xFFF);
         if (maxr < minr) continue;
         const int b0 = min(minr >> bhShift, nbins - 1), b1 = min(maxr >> bhShift, nbins - 1);
-        atomicAdd(&cnt[b0 + 1], 1);
-        if (b1 != b0) atomicAdd(&cnt[b1 + 1], 1);
+        for (int bb = b0; bb <= b1; bb++) atomicAdd(&cnt[bb + 1], 1);   // <= ST_MAX_SPAN bins (the host chooses bhShift accordingly)
     }
     __syncthreads();
     if (tid == 0) for (int i = 0; i < nbins; i++) cnt[i + 1] += cnt[i];   // <= 512 steps, once per frame
     __syncthreads();
     int32_t *bs = binStart + (size_t)b * (ST_MAX_BINS + 1);
-    uint4 *it = items + (size_t)b * 2 * cap;   // a bin entry is the whole record + the keypoint index: ONE load per candidate
+    uint4 *it = items + (size_t)b * ST_MAX_SPAN * cap;   // a bin entry is the whole record + the keypoint index: ONE load per candidate
     for (int i = tid; i <= nbins; i += 256) bs[i] = cnt[i];
     for (int i = tid; i < Nr; i += 256) {
         const uint2 rec = rcb[i];
@@ -159,8 +162,7 @@ __global__ __launch_bounds__(256) void k_stereo_bins(StereoLevels lv, const orbx
         if (maxr < minr) continue;
         const int b0 = min(minr >> bhShift, nbins - 1), b1 = min(maxr >> bhShift, nbins - 1);
         const uint4 e = make_uint4(rec.x, rec.y, (uint32_t)i, 0u);
-        it[cnt[b0] + atomicAdd(&fill[b0], 1)] = e;
-        if (b1 != b0) it[cnt[b1] + atomicAdd(&fill[b1], 1)] = e;
+        for (int bb = b0; bb <= b1; bb++) it[cnt[bb] + atomicAdd(&fill[bb], 1)] = e;
     }
 }
 // one wave per left keypoint: row-band candidate test (:498-508, :535), level and
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
         int cnt = 0;
         float bestU = 0.f;   // pt.x of this lane's best candidate (the winner's is broadcast after the argmin)
         const int32_t *bs = binStart + (size_t)b * (ST_MAX_BINS + 1);
-        const uint4 *bit = binItems + (size_t)b * 2 * cap;
+        const uint4 *bit = binItems + (size_t)b * ST_MAX_SPAN * cap;
         const int bin = min(row >> bhShift, nbins - 1);
         const int p0 = bs[bin], p1 = bs[bin + 1];
         // two bin chunks per round, their entries requested together and unconditionally from clamped slots (a load under
@@ -416,7 +418,7 @@ static int stereo_scratch_reserve(orbx_extractor *hl, int B, int cap) {
     hl->st_sad = nullptr; hl->st_rc = nullptr; hl->st_binStart = nullptr; hl->st_items = nullptr; hl->st_n = 0; hl->st_nB = 0;
     ORBX_HIP(hipMalloc(&hl->st_sad, sizeof(int32_t) * need));
     ORBX_HIP(hipMalloc(&hl->st_rc, sizeof(uint2) * need));
-    ORBX_HIP(hipMalloc(&hl->st_items, sizeof(uint4) * 2 * need));
+    ORBX_HIP(hipMalloc(&hl->st_items, sizeof(uint4) * ST_MAX_SPAN * need));
     ORBX_HIP(hipMalloc(&hl->st_binStart, sizeof(int32_t) * (ST_MAX_BINS + 1) * (size_t)B));
     hl->st_n = need; hl->st_nB = B;
     return ORBX_OK;
@@ -450,9 +452,12 @@ static int stereo_batch_impl(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, 
     ORBX_HIP(hipSetDevice(hl->device));
     rc = stereo_scratch_reserve(hl, B, cap);
     if (rc) return rc;
-    // bin height: a power of two >= the tallest row band (maxr - minr + 1 <= 2r + 3, r = 2 * scale of the coarsest level)
-    int bhShift = 3;
-    while ((1 << bhShift) < (int)(4.0f * lv.sf[lv.nlevels - 1]) + 4) bhShift++;
+    // bin height: the smallest power of two with which the tallest row band (maxr - minr + 1 <= 2r + 3 rows, r = 2 * scale of the
+    // coarsest level; a band of n rows touches at most ((n - 1) >> shift) + 2 bins) stays within ST_MAX_SPAN bins and the image within
+    // ST_MAX_BINS bins
+    const int maxBand = (int)(4.0f * lv.sf[lv.nlevels - 1]) + 4;
+    int bhShift = 0;
+    while (((maxBand - 1) >> bhShift) + 2 > ST_MAX_SPAN) bhShift++;
     while (((lv.nRows + (1 << bhShift) - 1) >> bhShift) > ST_MAX_BINS) bhShift++;
     const int nbins = std::max(1, (lv.nRows + (1 << bhShift) - 1) >> bhShift);
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream
