@@ -564,6 +564,9 @@ def main():
                     help="no software pipelining across steps (pyramid of the next step / stereo matcher of the previous one on a side "
                          "stream): every step then runs its kernels strictly one after the other")
     ap.add_argument("--no-lag-stereo", action="store_true", help="keep the pyramid built ahead but match each step's frames inside the step")
+    ap.add_argument("--stereo-order", default="late", choices=["late", "early"],
+                    help="order of the side stream behind FAST(i): late = pyramid(i+1) then matcher(i-1) (default, three pyramid buffers), "
+                         "early = matcher(i-1) then pyramid(i+1) (rounds 2-3)")
     ap.add_argument("--overlap-pass", action="store_true",
                     help="after the measurement, an extra pass of K steps alternating over 3 handles on 3 streams; its throughput "
                          "is reported beside the headline value (\"overlapped\").  Off by default so that the kernel launches of "
@@ -655,7 +658,8 @@ def main():
 
     S = max(1, args.streams)
     fe = pipeline.FrontEnd(w, h, nf, stereo, B, device_index=dev_index, nbuf=3, streams=S, world=world, gather=gather,
-                           gather_via_host=(args.backend != "nccl"), prefetch=not args.no_prefetch, lag_stereo=not args.no_lag_stereo, gather_B=gB)
+                           gather_via_host=(args.backend != "nccl"), prefetch=not args.no_prefetch, lag_stereo=not args.no_lag_stereo, gather_B=gB,
+                           stereo_late=(args.stereo_order == "late"))
     fe.upload(left, right)
     m = measure(fe, args.steps, args.warmup, args.ramp_steps, world, dist, dev, torch)
     dt, stage_ms = m["dt"], m["stage_ms"]
