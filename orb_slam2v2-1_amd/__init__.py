@@ -17,7 +17,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liborbx_hip.so")
+# ORBX_LIB: another build of the same library (tools/: lib/liborbx_hip_dev.so, `python orb_slam2v2-1_amd/build.py --developer`)
+LIB_PATH = os.environ.get("ORBX_LIB") or os.path.join(_HERE, "lib", "liborbx_hip.so")
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])

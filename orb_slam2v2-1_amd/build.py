@@ -59,6 +59,22 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_developer(verbose=False):
+    """lib/liborbx_hip_dev.so: the same library with -DORBX_DEVELOPER (orbx_set_option accepts the phase-stop keys 0, 1, 7 that the
+    ablation probes of tools/ use; outputs are incomplete under them).  Never loaded by the tests or bench.py; ORBX_LIB selects it."""
+    out = os.path.join(HERE, "lib", "liborbx_hip_dev.so")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc] + FLAGS + ["-DORBX_DEVELOPER", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
-    print(LIB)
+    if "--developer" in sys.argv:
+        print(build_developer(verbose=True))
+    else:
+        build(force="--force" in sys.argv, verbose=True)
+        print(LIB)

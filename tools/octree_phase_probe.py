@@ -1,7 +1,8 @@
 """Where k_octree_pyr spends its time on ONE image (its duration is the slowest block's critical path):
   rocprofv3 --kernel-trace --stats -- python3 tools/octree_phase_probe.py W H NFEAT STOP
 STOP = developer knob 7 (0 = whole kernel, 1 = after the histogram sweep, 2 = after the count pyramid, 3 = after the
-passes, 4 = after the final sweep)."""
+passes, 4 = after the final sweep).
+The phase-stop options (keys 0, 1, 7) need the developer build: python orb_slam2v2-1_amd/build.py --developer; ORBX_LIB=orb_slam2v2-1_amd/lib/liborbx_hip_dev.so python ..."""
 import sys, os, importlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("orb_slam2v2-1_amd")

@@ -1,4 +1,5 @@
-"""Ad-hoc GPU sanity + timing probe (not a test): python tools/quick_gpu.py [B]"""
+"""Ad-hoc GPU sanity + timing probe (not a test): python tools/quick_gpu.py [B]
+The phase-stop options (keys 0, 1, 7) need the developer build: python orb_slam2v2-1_amd/build.py --developer; ORBX_LIB=orb_slam2v2-1_amd/lib/liborbx_hip_dev.so python ..."""
 import sys, os, time, importlib, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
