@@ -272,35 +272,61 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
                                     (size_t)ORBX_EDGE * lv.pstrideR[levelL] + ORBX_EDGE;
                 const int sL = lv.pstrideL[levelL], sR = lv.pstrideR[levelL];
                 const int cy = (int)scaledvL, cxl = (int)scaleduL, cxr0 = (int)scaleduR0;
-                // this lane's two pixels of the 11x11 window (p = lane, lane + 64 < 121); the window centre is pixel 60, i.e.
-                // the first pixel of lane 60: it is taken from that lane's load, not fetched separately
-                const int p0 = lane, p1 = lane + 64;
-                const bool has1 = p1 < 121;
-                const int ay0 = p0 / 11 - w, ax0 = p0 % 11 - w;
-                const int ay1 = has1 ? p1 / 11 - w : 0, ax1 = has1 ? p1 % 11 - w : 0;
-                const int raw0 = IL[(size_t)(cy + ay0) * sL + cxl + ax0], raw1 = IL[(size_t)(cy + ay1) * sL + cxl + ax1];
+                // The 11 x 11 window against 11 shifts (:577-607).  Round 4: lane = (DPP row g, window row r): the lane loads its row of the
+                // left window once (11 bytes: three dwords from the row's own byte address) and 19 bytes of the right row that cover the
+                // windows of the shifts g, g + 4, g + 8 - a shift of four pixels is the next dword, so the three windows are the same byte
+                // selectors on neighbouring registers.  The reference subtracts the window centres and takes the L1 norm of the difference:
+                // |(a - cL) - (b - cR)|; with + 256 on both sides the terms are u16, a pixel pair is one packed value and
+                // v_sad_u16 sums |x0 - y0| + |x1 - y1| + acc in ONE instruction: 18 instructions per (row, shift) for 11 pixels, the rows
+                // of a shift summed by four DPP additions.  (Rounds 1-3: two window pixels per lane and a wave-wide sum per shift: 242
+                // VALU instructions and 24 byte loads per keypoint; now ~100 and 8 dword loads.)
+                typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+                const int g = lane >> 4, rw = min(lane & 15, 10);
+                const bool rowLane = (lane & 15) < 11;
+                const u32_unaligned *pl = (const u32_unaligned *)(IL + (size_t)(cy + rw - w) * sL + cxl - w);
+                const u32_unaligned *pr = (const u32_unaligned *)(IR + (size_t)(cy + rw - w) * sR + cxr0 - L - w + g);
+                const uint32_t l0 = pl[0], l1 = pl[1], l2 = pl[2];
+                uint32_t q[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) q[k] = pr[k];
+                // window centres: the left one is byte 5 of row 5, the right one of shift g + 4k byte 4k + 5 of row 5 - held by lane 16g + 5
+                const uint32_t cL = ((uint32_t)__builtin_amdgcn_readlane((int)l1, 5) >> 8) & 0xFFu;
+                const int src5 = ((lane & 48) | 5) << 2;
+                uint32_t biasR[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    biasR[k] = (256u - (((uint32_t)__builtin_amdgcn_ds_bpermute(src5, (int)q[k + 1]) >> 8) & 0xFFu)) * 0x00010001u;
+                const uint32_t biasL = (256u - cL) * 0x00010001u;
+                constexpr uint32_t S01 = 0x0c010c00u, S23 = 0x0c030c02u, S2_ = 0x0c0c0c02u;   // bytes (0,1) / (2,3) / (2, none) of a dword as two u16
+                uint32_t Lp[6];
+                Lp[0] = __builtin_amdgcn_perm(0u, l0, S01) + biasL; Lp[1] = __builtin_amdgcn_perm(0u, l0, S23) + biasL;
+                Lp[2] = __builtin_amdgcn_perm(0u, l1, S01) + biasL; Lp[3] = __builtin_amdgcn_perm(0u, l1, S23) + biasL;
+                Lp[4] = __builtin_amdgcn_perm(0u, l2, S01) + biasL; Lp[5] = __builtin_amdgcn_perm(0u, l2, S2_) + (biasL & 0xFFFFu);
+                uint32_t acc[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t bR = biasR[k];
+                    uint32_t a_ = __builtin_amdgcn_sad_u16(Lp[0], __builtin_amdgcn_perm(0u, q[k], S01) + bR, 0u);
+                    a_ = __builtin_amdgcn_sad_u16(Lp[1], __builtin_amdgcn_perm(0u, q[k], S23) + bR, a_);
+                    a_ = __builtin_amdgcn_sad_u16(Lp[2], __builtin_amdgcn_perm(0u, q[k + 1], S01) + bR, a_);
+                    a_ = __builtin_amdgcn_sad_u16(Lp[3], __builtin_amdgcn_perm(0u, q[k + 1], S23) + bR, a_);
+                    a_ = __builtin_amdgcn_sad_u16(Lp[4], __builtin_amdgcn_perm(0u, q[k + 2], S01) + bR, a_);
+                    a_ = __builtin_amdgcn_sad_u16(Lp[5], __builtin_amdgcn_perm(0u, q[k + 2], S2_) + (bR & 0xFFFFu), a_);
+                    a_ = rowLane ? a_ : 0u;
+                    // sum over the window rows = the 16 lanes of the DPP row (lanes 11..15 hold 0): the total ends up in lane 16g + 15
+                    a_ += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_, 0x111, 0xf, 0xf, true);
+                    a_ += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_, 0x112, 0xf, 0xf, true);
+                    a_ += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_, 0x114, 0xf, 0xf, true);
+                    a_ += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_, 0x118, 0xf, 0xf, true);
+                    acc[k] = a_;
+                }
                 float vDists[11];
                 int bestDistS = INT_MAX, bestincR = 0;
-                // the 33 right-image bytes of this lane (2 window pixels + the window centre, 11 shifts each) are all
-                // requested before the first sum: one memory latency instead of eleven
-                int rb0[11], rb1[11];
 #pragma unroll
-                for (int k = 0; k < 11; k++) {
-                    const int cxr = cxr0 + k - L;
-                    rb0[k] = IR[(size_t)(cy + ay0) * sR + cxr + ax0];
-                    rb1[k] = IR[(size_t)(cy + ay1) * sR + cxr + ax1];
-                }
-                const int cL = __builtin_amdgcn_readlane(raw0, 60);
-                const int av0 = raw0 - cL, av1 = raw1 - cL;
-#pragma unroll
-                for (int incR = -L; incR <= L; incR++) {
-                    const int cR = __builtin_amdgcn_readlane(rb0[incR + L], 60);
-                    const int bv0 = rb0[incR + L] - cR;
-                    const int bv1 = rb1[incR + L] - cR;
-                    const int df0 = av0 - bv0, df1 = av1 - bv1;
-                    int s = (df0 < 0 ? -df0 : df0) + (has1 ? (df1 < 0 ? -df1 : df1) : 0);
-                    s = wave_sum_i32(s);
-                    const float dist = (float)s;
+                for (int incR = -L; incR <= L; incR++) {   // shift incR + 5 = g + 4k: DPP row g, accumulator k
+                    const int sft = incR + L;
+                    const int sv = __builtin_amdgcn_readlane((int)acc[sft >> 2], 16 * (sft & 3) + 15);
+                    const float dist = (float)sv;
                     if (dist < (float)bestDistS) { bestDistS = (int)dist; bestincR = incR; }
                     vDists[L + incR] = dist;
                 }
