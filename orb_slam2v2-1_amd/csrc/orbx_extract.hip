@@ -45,7 +45,7 @@ extern "C" int orbx_thread_release_scratch(void) {
 // in a developer build (-DORBX_DEVELOPER).
 extern "C" int orbx_set_option(orbx_extractor_t *h, int key, int value) {
     static const signed char maxv[ORBX_NUM_OPTIONS] = {/*0*/ -1, -1, -2, 64, 3, 3, 3, -1, ORBX_MAX_CHUNKS, 1, 2, 2, 1, 2, 127, ORBX_MAX_LEVELS,
-                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 100, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
+                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
     if (!h || key < 0 || key >= ORBX_NUM_OPTIONS || maxv[key] == -2) { orbx_set_error("orbx_set_option: unknown key %d", key); return ORBX_ERR_ARG; }
 #ifdef ORBX_DEVELOPER
     if (maxv[key] == -1) { if (value < 0) return ORBX_ERR_ARG; h->opt[key] = value; return ORBX_OK; }

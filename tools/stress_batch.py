@@ -1,6 +1,6 @@
 """Randomised parity stress of the BATCHED device entry point: python tools/stress_batch.py [N] [seed] - random sizes, budgets,
 batch sizes 2..12 (both sides of the "fills the GPU" rules), image kinds mixed inside a batch, random alternative paths (split call,
-early quad-tree, k_gather instead of the lists read in place, row pre-test forced, chunks), every call issued twice (the second sees
+early quad-tree, k_gather instead of the lists read in place, the sparse path forced or by density in its three forms, chunks), every call issued THREE times (the second sees
 the first one's per-level verdicts and scratch); every image of every batch against the CPU oracle."""
 import sys, os, importlib, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
 bad = 0
 t0 = time.time()
-KNOBS = [(), ((15, 2),), ((15, 4),), ((19, 2),), ((19, 3),), ((18, 1),), ((16, 2),), ((8, 2),), ((8, 3),), ((6, 3),), ((6, 3), (19, 2)), ((6, 3), (16, 2), (15, 3))]
+KNOBS = [(), ((15, 2),), ((15, 4),), ((19, 2),), ((19, 3),), ((18, 1),), ((16, 2),), ((8, 2),), ((8, 3),), ((6, 3),), ((6, 3), (19, 2)), ((6, 3), (16, 2), (15, 3)),
+         ((6, 3), (20, 1)), ((6, 3), (20, 2)), ((6, 3), (16, 2), (20, 1)), ((6, 3), (16, 2), (20, 2)), ((6, 3), (20, 1), (15, 3)), ((6, 3), (20, 1), (8, 2))]
 for it in range(N):
     w = int(rng.integers(320, 1300)); h = int(rng.integers(240, 720))
     nf = int(rng.choice([50, 300, 800, 1000, 2000]))
@@ -52,7 +53,7 @@ for it in range(N):
     for k, v in knobs:
         pkg.set_default_option(k, v)
     try:
-        for rep in range(2):
+        for rep in range(3):
             ex.extract_batch_device(d_imgs.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, st)
         torch.cuda.synchronize()
     finally:
