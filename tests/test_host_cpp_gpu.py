@@ -25,8 +25,8 @@ def driver(tmp_path_factory):
     return exe
 
 
-def _run(exe, *args):
-    env = dict(os.environ)
+def _run(exe, *args, **extra_env):
+    env = dict(os.environ, **extra_env)
     # one HIP runtime per process: the driver is a plain C++ program, it uses /opt/rocm's
     out = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr + out.stdout
@@ -48,6 +48,28 @@ def test_extractor_class(driver, oracle, synth, pkg, tmp_path):
     np.testing.assert_array_equal(d, od)
     p3 = np.fromfile(str(tmp_path / "o.pyr3"), np.uint8).reshape(ph, pw)
     np.testing.assert_array_equal(p3, orc.pyramid_level(3))
+
+
+@pytest.mark.parametrize("gauss", ["half_up", "sse2"])
+def test_extractor_class_takes_the_flavour_from_the_environment(driver, oracle, synth, pkg, tmp_path, gauss):
+    """The reference's callers construct ORBextractor with five arguments (src/Tracking.cc:119-125); a deployment selects the flavour of
+    cv::GaussianBlur's column rounding with ORBX_GAUSS_ROUNDING.  A four-grey-level image (many exact rounding ties) through the C++
+    class under each setting equals the oracle of that flavour, and the two oracles differ on it."""
+    w, h, nf = 1241, 376, 1500
+    img = ((synth.frame(w, h, 52) >> 6) * 85).astype(np.uint8)
+    img.tofile(tmp_path / "a.raw")
+    n, pw, ph = _run(driver, "extract", tmp_path / "a.raw", w, h, nf, tmp_path / "o", ORBX_GAUSS_ROUNDING=gauss)
+    ok, od = oracle.Extractor(nf, 1.2, 8, 20, 7, gauss=gauss).extract(img)
+    other = oracle.Extractor(nf, 1.2, 8, 20, 7, gauss="sse2" if gauss == "half_up" else "half_up")
+    other.extract(img)
+    k = np.fromfile(str(tmp_path / "o.kps"), pkg.KP_DTYPE)
+    d = np.fromfile(str(tmp_path / "o.desc"), np.uint8).reshape(-1, 32)
+    assert n == len(ok) == len(k)
+    np.testing.assert_array_equal(k[["x", "y", "response", "octave"]], ok[["x", "y", "response", "octave"]])
+    np.testing.assert_array_equal(d, od)
+    ref = oracle.Extractor(nf, 1.2, 8, 20, 7, gauss=gauss)
+    ref.extract(img)
+    assert any((ref.blurred_level(l) != other.blurred_level(l)).any() for l in range(8)), "the test image must hold rounding ties"
 
 
 def test_stereo_through_frame(driver, oracle, synth, tmp_path):
