@@ -211,5 +211,6 @@ def test_bench_launches_its_own_ranks_without_an_outer_launcher():
                         "--batch", "2", "--no-cpu-baseline", "--gen-workers", "1", "--workload", "mono_640x480_1000feat"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert "launch with torch.distributed.run" not in p.stderr
-    assert p.stderr.count("no GPU visible") == 2, p.stderr[-3000:]        # both ranks ran main() up to the GPU check
+    # the ranks ran main() up to the GPU check (the launcher stops the other rank as soon as one has failed: one or two messages)
+    assert 1 <= p.stderr.count("no GPU visible") <= 2, p.stderr[-3000:]
     assert p.returncode != 0 and p.returncode != 2
