@@ -463,6 +463,9 @@ int orbm_set_thread_option(int key, int value);
  * reference's order (column-major over grid cells, insertion order inside a cell) - the order every matcher's "first minimum
  * wins" depends on. */
 int orbx_debug_blur_patches(orbx_extractor_t *h, int enable, uint8_t *out, int n);
+/* Probe hook: out[b * nlevels + l] = 1 iff the quad-tree of level l of image b of the last call was redone by the exact form
+ * (k_octree_pyr's count pyramid too shallow for it; results are the same, the level just took longer).  n <= B * nlevels. */
+int orbx_debug_octree_fallbacks(orbx_extractor_t *h, int32_t *out, int n);
 /* a8, the other form: levels whose keypoint budget makes per-keypoint blurring the more expensive way are blurred as a whole by
  * k_blur_levels and the descriptor kernel only gathers (src/ORBextractor.cc:1083-1090 does exactly this for every level).
  * *mask_out (may be NULL) = levels of the last call that took this form (bit l); dst != NULL fetches level `level` of image b

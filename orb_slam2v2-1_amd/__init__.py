@@ -44,7 +44,7 @@ EXPORTS = [
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
     "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch", "orbx_debug_sincosf",
     "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels", "orbx_extract_batch_device_prefetch", "orbx_stream_wait_fast_stage", "orbx_side_stream", "orbm_stereo_batch_device_prev", "orbx_debug_blur_patches", "orbm_debug_features_in_area",
-    "orbx_debug_blurred_level", "orbx_side_stream_for", "orbx_stereo_frame", "orbx_set_pyramid_buffers",
+    "orbx_debug_blurred_level", "orbx_debug_octree_fallbacks", "orbx_side_stream_for", "orbx_stereo_frame", "orbx_set_pyramid_buffers",
 ]
 
 
@@ -207,6 +207,7 @@ def lib():
     L.orbm_best_in_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, i32, vp, vp, i32]
     L.orbx_debug_sincosf.argtypes = [vp, i32, vp, vp, i32]
     L.orbx_debug_blur_patches.argtypes = [vp, i32, vp, i32]
+    L.orbx_debug_octree_fallbacks.argtypes = [vp, vp, i32]
     L.orbx_debug_blurred_level.argtypes = [vp, i32, i32, vp, i32, vp]
     L.orbm_debug_features_in_area.argtypes = [vp, i32, C.POINTER(GridGeom), f32, f32, f32, i32, i32, vp, C.POINTER(i32), i32]
     L.orbx_last_error.restype = C.c_char_p
@@ -423,6 +424,12 @@ class ORBextractor:
         _check(self._L.orbx_fast_kernels(self._h, int(B), C.byref(st), C.byref(ce), C.byref(ipl)))
         self.fast_images_per_launch = ipl.value
         return [n for n, f in (("k_fast_strips", st.value), ("k_fast_cells", ce.value)) if f]
+
+    def octree_fallbacks(self, B=1):
+        """[B, nlevels] int32: 1 where the last call's quad-tree of that (image, level) was redone by the exact form."""
+        out = np.zeros((B, self.nlevels), np.int32)
+        _check(self._L.orbx_debug_octree_fallbacks(self._h, _p(out), B * self.nlevels))
+        return out
 
     def blurred_mask(self):
         """Levels of the last call that were blurred as a whole by k_blur_levels (bit l)."""

@@ -1381,6 +1381,15 @@ static int ensure_cand(orbx_extractor *h) {
     return ORBX_OK;
 }
 
+// test / probe hook: which (image, level)s of the last call took the exact form of the quad-tree because the count pyramid was too shallow
+extern "C" int orbx_debug_octree_fallbacks(orbx_extractor_t *h, int32_t *out, int n) {
+    if (!h || !out || n < 1 || h->pw == 0 || n > h->pB * h->nlevels) { orbx_set_error("orbx_debug_octree_fallbacks: bad arguments"); return ORBX_ERR_ARG; }
+    ORBX_HIP(hipSetDevice(h->device));
+    if (h->last_valid) ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    ORBX_HIP(hipMemcpy(out, h->d_octFallback, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
 extern "C" int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, int stage, int32_t *out, int cap,
                                        int *n_out) {
     if (!h || !n_out || level < 0 || level >= h->nlevels || h->pw == 0 || b < 0 || b >= h->pB || stage < 0 || stage > 1) {
