@@ -567,6 +567,9 @@ def main():
     ap.add_argument("--stereo-order", default="late", choices=["late", "early"],
                     help="order of the side stream behind FAST(i): late = pyramid(i+1) then matcher(i-1) (default, three pyramid buffers), "
                          "early = matcher(i-1) then pyramid(i+1) (rounds 2-3)")
+    ap.add_argument("--fast-alone", action="store_true",
+                    help="FAST(i+1) waits for the matcher of step i-1 (the arrangement of rounds 2-4: FAST has the GPU to itself; 104.8 k frames/s "
+                         "against 111.8 k without the wait)")
     ap.add_argument("--overlap-pass", action="store_true",
                     help="after the measurement, an extra pass of K steps alternating over 3 handles on 3 streams; its throughput "
                          "is reported beside the headline value (\"overlapped\").  Off by default so that the kernel launches of "
@@ -659,7 +662,7 @@ def main():
     S = max(1, args.streams)
     fe = pipeline.FrontEnd(w, h, nf, stereo, B, device_index=dev_index, nbuf=3, streams=S, world=world, gather=gather,
                            gather_via_host=(args.backend != "nccl"), prefetch=not args.no_prefetch, lag_stereo=not args.no_lag_stereo, gather_B=gB,
-                           stereo_late=(args.stereo_order == "late"))
+                           stereo_late=(args.stereo_order == "late"), fast_alone=args.fast_alone)
     fe.upload(left, right)
     m = measure(fe, args.steps, args.warmup, args.ramp_steps, world, dist, dev, torch)
     dt, stage_ms = m["dt"], m["stage_ms"]
@@ -729,7 +732,9 @@ def main():
                        "ini_th_fast": 20, "min_th_fast": 7, "frames_per_step_per_gpu": B, "clock_ramp_steps": args.ramp_steps,
                        "total_frames_per_step": frames_per_step,
                        "match": "Frame::ComputeStereoMatches" if stereo else "none",
-                       "pipelining": ("behind the FAST stage of step i, on a side stream: stereo matcher of step i-1, then pyramid of step i+1" if fe.lag
+                       "pipelining": (("behind the FAST stage of step i, on a side stream: pyramid of step i+1, then stereo matcher of step i-1" +
+                                       (" (FAST of step i+1 waits for it)" if fe.fast_alone else " (which may run on beside the FAST stage of step i+1)")
+                                       if fe.late else "behind the FAST stage of step i, on a side stream: stereo matcher of step i-1, then pyramid of step i+1") if fe.lag
                                       else "pyramid of the next step built ahead (orbx_extract_batch_device_prefetch)") if fe.prefetch else "none",
                        "parallelism": "frames sharded over %d GPU(s)%s" % (world, ", results all-gathered (%s)" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal") if gather else ""),
                        "world_size_observed": world_seen, "ranks": ranks,
@@ -747,7 +752,7 @@ def main():
                                   "fast_timed_region": round(m["fast_ms"], 4),
                                   "note": "stage breakdown from an untimed pass of %d steps after the timed region, every stage alone on the GPU "
                                           "(in the timed steps %s on a side stream behind the FAST stage of step i, beside its gather / quad-tree / descriptor "
-                                          "kernels, which makes those longer and the step shorter than the sum here); "
+                                          "kernels - and the matcher beside the next FAST stage -, which makes those longer and the step shorter than the sum here); "
                                           "roofline.kernel_ms is the FAST stage (%s) over the %d timed steps" % (
                                               m["nprof"], "the stereo matcher of step i-1 and the pyramid of step i+1 run" if fe.lag else
                                               "the pyramid of step i+1 runs" if fe.prefetch else "nothing runs", roof["kernel"], args.steps)},

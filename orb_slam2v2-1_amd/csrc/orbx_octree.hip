@@ -144,6 +144,73 @@ __device__ __forceinline__ void octree_exact_level(const LevelGeom *geom, int nl
 //         (LDS atomicMax, then one global atomicMax per node it touched); the last workgroup writes the level's keypoints.
 // (struct OctBig: orbx_extract_dev.h - part [B][nBig][K][deepMax] partial histograms, leaf [B][nBig][pyrMax] leaf map,
 // best [B][nBig][capMax] best key per node, state [B][nBig][4]: arrival counters A and B, list length (-1: done by the exact form))
+// Phase-2 visiting order (size descending, later-created first: :689-731 sorts (size, node) pairs and walks them from the back) for
+// lists of up to 64 * R <= 512 nodes, IN REGISTERS: lane holds the keys of list indices lane + 64 r, a key is
+// (2^22 - 1 - size) << 10 | list index (a level whose key capacity reaches 2^22 keeps the 64-bit LDS form of the caller).  A bitonic
+// network whose exchanges with a partner index >= 64 away are register moves inside the lane and the others one ds_bpermute: no LDS
+// storage, no hand-off between stages.  Round 4: the LDS form of the same network (one read-compare-write round trip and a
+// wave_sync per stage) took ~20 us at 256 nodes - most of a four-pass level's pass time (tools/octree_pass_time_probe.py).
+template <int R>
+__device__ __forceinline__ int phase2_order_regs(const uint32_t *cnt, int L, uint16_t *xlist, int lane) {
+    uint32_t key[R];
+    int e = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int k = lane + 64 * r;
+        key[r] = ~0u;
+        if (k < L) {
+            const uint32_t cv = cnt[k];
+            if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) {
+                key[r] = ((0x3FFFFFu - (cv & 0x3FFFFFu)) << 10) | (uint32_t)k;
+                e++;
+            }
+        }
+    }
+    auto lane_stage = [&](int j, bool up, uint32_t &a) {   // exchange with lane ^ j; up: the lower index keeps the smaller key
+        const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ j) << 2, (int)a);
+        a = (((lane & j) == 0) == up) ? min(a, b) : max(a, b);
+    };
+    for (int kk2 = 2; kk2 <= 32; kk2 <<= 1)
+        for (int j = kk2 >> 1; j > 0; j >>= 1) {
+            const bool up = (lane & kk2) == 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) lane_stage(j, up, key[r]);
+        }
+#pragma unroll
+    for (int K = 64; K <= 64 * R; K <<= 1) {
+#pragma unroll
+        for (int j = K >> 1; j >= 64; j >>= 1) {
+            const int jj = j >> 6;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (!(r & jj)) {
+                    const bool up = ((r << 6) & K) == 0;
+                    const uint32_t lo = min(key[r], key[r ^ jj]), hi = max(key[r], key[r ^ jj]);
+                    key[r] = up ? lo : hi;
+                    key[r ^ jj] = up ? hi : lo;
+                }
+        }
+        for (int j = 32; j > 0; j >>= 1) {
+#pragma unroll
+            for (int r = 0; r < R; r++) lane_stage(j, ((r << 6) & K) == 0, key[r]);
+        }
+    }
+    const int E = wave_total_i32(e);
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if (lane + 64 * r < E) xlist[lane + 64 * r] = (uint16_t)(key[r] & 0x3FFu);
+    return E;
+}
+// dispatch on the list length (wave-uniform); false: the caller's LDS network takes the list (longer than 512 nodes - a register budget -, or sizes that need more than 22 bits)
+__device__ __forceinline__ bool phase2_order_in_regs(const uint32_t *cnt, int L, int keyCap, uint16_t *xlist, int lane, int &E) {
+    if (keyCap >= (1 << 22) || L > 512) return false;
+    if (L <= 64) E = phase2_order_regs<1>(cnt, L, xlist, lane);
+    else if (L <= 128) E = phase2_order_regs<2>(cnt, L, xlist, lane);
+    else if (L <= 256) E = phase2_order_regs<4>(cnt, L, xlist, lane);
+    else E = phase2_order_regs<8>(cnt, L, xlist, lane);
+    return true;
+}
+
 template <int MODE>
 __device__ __forceinline__ void octree_pyr_body(
     const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand, size_t keysPerImg,
@@ -154,6 +221,9 @@ __device__ __forceinline__ void octree_pyr_body(
     const int tid = threadIdx.x;
     const LevelGeom g = geom[l];
     const int Dm = g.pyrDepth, nIni = g.nIni, N = g.N;
+#ifdef ORBX_DEVELOPER
+    const unsigned long long dvT0 = wall_clock64();
+#endif
     uint8_t *sp = smem;
     unsigned long long *skey = (unsigned long long *)sp; sp += sizeof(unsigned long long) * pow2cap;
     uint32_t *cntA = (uint32_t *)sp; sp += 4 * 2 * capMax;   // [2][cap] key count, bit31 = fresh
@@ -355,6 +425,9 @@ __device__ __forceinline__ void octree_pyr_body(
     __syncthreads();
     L = sh_L;
     int phase = 1;
+#ifdef ORBX_DEVELOPER
+    const unsigned long long dvT1 = wall_clock64(); int dvPasses = 0; unsigned long long dvSort = 0;
+#endif
 
     // ---- 4. passes: list bookkeeping on node counts only, by wave 0.  (Round 3 tried every step of a pass on the whole workgroup -
     // scans by the block, the phase-2 order by counting instead of the one-wave bitonic sort: identical results, and in a batch the
@@ -399,7 +472,8 @@ __device__ __forceinline__ void octree_pyr_body(
                         const uint32_t cv = cnt[k];
                         if ((cv & 0x80000000u) && (cv & 0x7FFFFFFFu) > 1) xlist[off++] = (uint16_t)k;
                     }
-                } else {            // (size desc, later-created first): bitonic sort of (~size, list index)
+                } else if (phase2_order_in_regs(cnt, L, g.keyCap, xlist, lane, E)) {   // (size desc, later-created first)
+                } else {            // ... longer lists: the same bitonic network of (~size, list index) through LDS
                     int P = 1;
                     while (P < L) P <<= 1;
                     int e = 0;
@@ -550,10 +624,16 @@ __device__ __forceinline__ void octree_pyr_body(
         L = sh_Lnew;
         phase = sh_phase;
         cur ^= 1;
+#ifdef ORBX_DEVELOPER
+        dvPasses++;
+#endif
         if (sh_finish) break;
         __syncthreads();
     }
 
+#ifdef ORBX_DEVELOPER
+    const unsigned long long dvT2 = wall_clock64();
+#endif
     if (dbgStop == 3) return;
     if (CB) {   // ---- 5'. a node of the list is a cell of the pyramid: its best key is already there
         const uint32_t *nid = nidA + cur * capMax;
@@ -573,6 +653,12 @@ __device__ __forceinline__ void octree_pyr_body(
             } else
                 okp[k] = keys[idx];
         }
+#ifdef ORBX_DEVELOPER
+        // developer build: the record holds (passes << 24 | pass loop in 0.1 us << 12 | time since kernel entry in 0.1 us) instead of 0
+        if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; const unsigned long long t = wall_clock64();
+            fallback[b * nlevels + l] = (dvPasses << 24) | ((int)min((dvT2 - dvT1) / 10ull, 4095ull) << 12) | (int)min((t - dvT0) / 10ull, 4095ull); }
+        return;
+#endif
         if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; fallback[b * nlevels + l] = 0; }
         return;
     }
@@ -670,7 +756,15 @@ __device__ __forceinline__ void octree_pyr_body(
     if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; fallback[b * nlevels + l] = 0; }
 }
 
-__global__ __launch_bounds__(OCT_T) void k_octree_pyr(
+// Registers: three 512-thread workgroups per CU is what the LDS allows (~42 KB each at 1241x376 / 1000 features), i.e. 6 waves per SIMD = 80 VGPRs.
+// Left to itself the compiler takes 84 (round 3; with the register sort of the phase-2 order, 115) and only TWO workgroups fit: the 1024
+// workgroups of a 128-image batch then run in two rounds, 58 us instead of the ~43 us the longest workgroup lives.
+#if OCT_T == 512
+#define OCT_PYR_WAVES __attribute__((amdgpu_waves_per_eu(6, 6)))
+#else
+#define OCT_PYR_WAVES
+#endif
+__global__ __launch_bounds__(OCT_T) OCT_PYR_WAVES void k_octree_pyr(
     const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand, size_t keysPerImg,
     const int32_t *__restrict__ candCnt, uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
     const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback, int dbgStop,

@@ -61,7 +61,7 @@ def independent_stream(dev, busy, ncand=8):
 class FrontEnd:
     def __init__(self, w, h, nfeatures, stereo, B, device_index=0, nbuf=3, streams=1, world=1, gather=False,
                  gather_via_host=False, mbf=KITTI_BF, fx=KITTI_FX, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, prefetch=True, lag_stereo=True,
-                 stereo_late=None, gather_B=None, two_side=None):
+                 stereo_late=None, gather_B=None, two_side=None, fast_alone=None):
         if not torch.cuda.is_available():
             raise RuntimeError("orb_slam2v2-1_amd.pipeline.FrontEnd needs a GPU: the HIP path has no CPU fallback")
         self.w, self.h, self.nf, self.stereo, self.B = w, h, nfeatures, stereo, B
@@ -83,7 +83,7 @@ class FrontEnd:
         self.side = torch.cuda.ExternalStream(self._side_raw, device=self.dev) if self.lag else None
         # Order of the two side-stream jobs behind FAST(i).  stereo_late (the default since round 4): pyramid(i+1) first, then matcher(i-1)
         # (three pyramid buffers) - the pyramid starts beside the quad-tree, the matcher runs beside the descriptor kernel, the next FAST
-        # waits for it.  stereo_late = False: matcher(i-1), then pyramid(i+1) - the matcher beside the quad-tree, the pyramid beside the
+        # does NOT wait for it (below).  stereo_late = False: matcher(i-1), then pyramid(i+1) - the matcher beside the quad-tree, the pyramid beside the
         # descriptors (two buffers).  Measured per 64-frame step, round 4 (descriptor kernel 133 us alone): 1000 features 0.613 -> 0.607 ms,
         # round 3 (165 us): 2000 features 76.6 -> 77.6 k frames/s, 1000 features no difference.
         self.late = bool(self.lag and (True if stereo_late is None else stereo_late))
@@ -92,10 +92,18 @@ class FrontEnd:
         # two_side: the matcher of step i-1 on a SECOND side stream, started behind FAST(i) like the pyramid of step i+1 (three pyramid
         # buffers): the matcher beside the quad-tree, the pyramid beside quad-tree + descriptors, neither behind the other
         import os as _os
+        # fast_alone (rounds 2-4 until this change: always): FAST(i+1) waits for matcher(i-1), the last job of the side stream, so that the
+        # issue-bound FAST kernel has the GPU to itself.  It has no data to wait for (the matcher reads buffer set i-1 and the pyramid of
+        # step i-1, FAST(i+1) writes the handle's cell lists and reads the pyramid of step i+1), and the wait left the main stream idle
+        # from the end of the descriptors to the end of the matcher: ~50 us of a 612-us step.  Without it the matcher runs beside FAST
+        # (62 -> 285 us, hidden; FAST 265 -> 277 us) and the step takes 0.573 ms: 104.8 -> 111.8 k frames/s (three runs each, +-0.1).
+        self.fast_alone = bool(int(_os.environ.get("ORBX_FAST_ALONE", "0")) if fast_alone is None else fast_alone)
         self.two_side = bool(self.late and (int(_os.environ.get("ORBX_TWO_SIDE", "0")) if two_side is None else two_side))
+        if self.two_side:
+            self.fast_alone = True     # the pyramid of step i+2 (side) overwrites what matcher(i-1) (side2) reads: ordered through FAST(i+1)'s wait
         self.side2 = independent_stream(self.dev, [main0, self.side]) if self.two_side else None
         self._coll = None              # torch-native stream the all-gather of the pipelined mode is issued from (N > 1)
-        self._ev_late = None           # event behind the last late matcher: the next FAST waits for it (FAST always runs alone)
+        self._ev_late = None           # event behind the last late matcher: with fast_alone the next FAST waits for it
         self._pend = None              # (buffer set, step) whose matcher has not been issued yet
         self._ev_side = {}             # buffer set -> event behind its matcher on the side stream
         self.streams = [torch.cuda.current_stream(self.dev)] + [torch.cuda.Stream(self.dev) for _ in range(self.S - 1)]
@@ -268,7 +276,7 @@ class FrontEnd:
             self._flush() if self.lag else None
         elif j in self._ev_side:
             stream.wait_event(self._ev_side.pop(j))     # the matcher that last wrote buffer set j (nbuf steps ago) is long done
-        if lag and self._ev_late is not None:
+        if lag and self.fast_alone and self._ev_late is not None:
             stream.wait_event(self._ev_late)            # late order: the previous step's matcher is the last job of the side stream
         exi.extract_batch_device(self._imgs(i), self.nimg, w, h, w, w * h, r.kps[j].data_ptr(), r.desc[j].data_ptr(),
                                  r.cnt[j].data_ptr(), cap, st)

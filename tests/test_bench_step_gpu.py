@@ -66,19 +66,23 @@ def test_bench_step_three_handles_three_streams_one_thread():
     _run_stereo(1241, 376, 1000, 16, seed0=200, streams=3, steps=20)
 
 
-@pytest.mark.parametrize("mode", ["pipelined", "pipelined_late", "pipelined_late_two_side", "pyramid_ahead_only", "plain"])
-def test_bench_step_rotating_batches(mode):
+@pytest.mark.parametrize("mode,w,h,nf,B,steps", [(m, 752, 480, 600, 6, 7) for m in ("pipelined", "pipelined_late", "pipelined_late_fast_alone", "pipelined_late_two_side",
+                                                                                  "pyramid_ahead_only", "plain")] +
+                         [("pipelined_late", 1241, 376, 1000, 40, 10)])   # bench-sized kernels: the matcher of step i-1 really runs beside FAST(i+1)
+def test_bench_step_rotating_batches(mode, w, h, nf, B, steps):
     """The software-pipelined step (pyramid of step i+1 and stereo matcher of step i-1 on the side stream beside the tail of step
     i) over THREE different resident batches and the handle's TWO pyramid buffers, seven steps without a host synchronisation:
     a matcher or a FAST stage that read the wrong buffer, or read it too early / too late, would see another batch's pixels.
     Every result still resident at the end (steps 4, 5, 6 = batches 1, 2, 0) must equal the oracle of ITS batch."""
     pl, ref = _pipeline(), _ref()
-    w, h, nf, B, nsets, steps = 752, 480, 600, 6, 3, 7
+    nsets = 3
     # pipelined_late (the default order since round 4): the pyramid of step i+1 is issued BEFORE the matcher of step i-1 on the side
-    # stream (three pyramid buffers); ..._two_side: the matcher on a second side stream, both started behind FAST (measured alternative)
+    # stream (three pyramid buffers) and FAST(i+1) does not wait for that matcher; ..._fast_alone: it does (rounds 2-4); ..._two_side: the
+    # matcher on a second side stream, both started behind FAST (measured alternative; implies fast_alone)
     fe = pl.FrontEnd(w, h, nf, True, B, prefetch=(mode != "plain"), lag_stereo=mode.startswith("pipelined"), stereo_late=mode.startswith("pipelined_late"),
-                     two_side=mode.endswith("two_side"))
+                     two_side=mode.endswith("two_side"), fast_alone=mode.endswith("fast_alone"))
     assert fe.lag == mode.startswith("pipelined") and fe.late == mode.startswith("pipelined_late") and fe.two_side == mode.endswith("two_side")
+    assert fe.fast_alone == (mode.endswith("fast_alone") or mode.endswith("two_side"))
     exps = [ref.run_pool(ref.stereo_frame, [(w, h, nf, 700 + 50 * s + i, fe.mbf, fe.mb) for i in range(B)]) for s in range(nsets)]
     fe.upload(np.stack([e["left"] for e in exps[0]]), np.stack([e["right"] for e in exps[0]]))
     for s in range(1, nsets):

@@ -1,0 +1,23 @@
+"""Developer probe (needs lib/liborbx_hip_dev.so: python orb_slam2v2-1_amd/build.py --developer; run with ORBX_LIB pointing at it):
+per (image, level) workgroup of k_octree_pyr - number of list passes, time in the pass loop, time since kernel entry (0.1 us units,
+from wall_clock64), read through orbx_debug_octree_fallbacks (the developer build stores the stamps in that record)."""
+import sys, importlib, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+pkg = importlib.import_module("orb_slam2v2-1_amd"); synth = importlib.import_module("orb_slam2v2-1_amd.synth")
+for name, gen, w, h, nf in (("dense", synth.frame, 1241, 376, 1000), ("natural", synth.natural, 1241, 376, 1000), ("dense2000", synth.frame, 1241, 376, 2000)):
+    B = 128
+    imgs = np.stack([gen(w, h, 1000 + (i % 16)) for i in range(B)])
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+    ex(imgs[0]); cap = ex.max_keypoints()
+    d = torch.from_numpy(imgs).cuda()
+    k = torch.zeros((B, cap, 7), device="cuda"); de = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"); c = torch.zeros(B, dtype=torch.int32, device="cuda")
+    for rep in range(3):
+        ex.extract_batch_device(d.data_ptr(), B, w, h, w, w * h, k.data_ptr(), de.data_ptr(), c.data_ptr(), cap, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    fb = ex.octree_fallbacks(B).astype(np.int64)
+    passes, loop, total = fb >> 24, ((fb >> 12) & 4095) / 10.0, (fb & 4095) / 10.0
+    print(name)
+    for l in range(8):
+        print("  level %d: passes %s  pass loop us mean %.1f max %.1f   since entry us mean %.1f max %.1f" % (
+            l, sorted(set(passes[:, l].tolist())), loop[:, l].mean(), loop[:, l].max(), total[:, l].mean(), total[:, l].max()))
