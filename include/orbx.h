@@ -428,6 +428,8 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  *                              scored 64 at a time), 2 = the same compaction inside the cell kernel; 1 and 2 measured no faster
  *   ORBX_OPT_DESC_LDS_PAD  21  KB of unused LDS per k_describe workgroup: fewer of them resident per CU, more wave slots for the
  *                              kernels of a neighbouring stream (tuning of the pipelined step; default 0)
+ *   ORBX_OPT_PYR_ROWS      22  output rows per wave of k_pyr_level: 1 = always 8, 2 = always 16 (default: 16 while the level gives
+ *                              every SIMD several waves, else 8)
  * Keys 0, 1 and 7 (stop a kernel after phase n: outputs incomplete) exist only in a library built with -DORBX_DEVELOPER
  * (tools/octree_phase_probe.py); the default build refuses them. */
 #define ORBX_OPT_PYR_TILE 3
@@ -447,6 +449,7 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
 #define ORBX_OPT_EARLY_OCTREE 19
 #define ORBX_OPT_SPARSE_FORM 20
 #define ORBX_OPT_DESC_LDS_PAD 21
+#define ORBX_OPT_PYR_ROWS 22
 #define ORBX_NUM_OPTIONS 32
 int orbx_set_option(orbx_extractor_t *h, int key, int value);
 int orbx_get_option(const orbx_extractor_t *h, int key, int *value);

@@ -45,7 +45,7 @@ extern "C" int orbx_thread_release_scratch(void) {
 // in a developer build (-DORBX_DEVELOPER).
 extern "C" int orbx_set_option(orbx_extractor_t *h, int key, int value) {
     static const signed char maxv[ORBX_NUM_OPTIONS] = {/*0*/ -1, -1, -2, 64, 3, 3, 3, -1, ORBX_MAX_CHUNKS, 1, 2, 2, 1, 2, 127, ORBX_MAX_LEVELS,
-                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
+                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, 2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
     if (!h || key < 0 || key >= ORBX_NUM_OPTIONS || maxv[key] == -2) { orbx_set_error("orbx_set_option: unknown key %d", key); return ORBX_ERR_ARG; }
 #ifdef ORBX_DEVELOPER
     if (maxv[key] == -1) { if (value < 0) return ORBX_ERR_ARG; h->opt[key] = value; return ORBX_OK; }
@@ -640,9 +640,13 @@ static void launch_pyramid(orbx_extractor *h, const uint8_t *d_imgs, uint8_t *py
     hipLaunchKernelGGL(k_pyr_pad<true>, dim3(((g0.pstride >> 4) * g0.prows + 255) / 256, 1, B), dim3(256), 0, st, d_imgs, stride,
                        img_stride, pyr, h->pyrImgBytes, h->d_geom, 0);
     for (int l = 1; l <= lastSingle; l++) {
-        const int nxc = (h->geom[l].w + 1 + 127) / 128, nbands = (h->geom[l].h + PYR_RW - 1) / PYR_RW;
-        hipLaunchKernelGGL(k_pyr_level, dim3((nxc * nbands + 3) / 4, B), dim3(256), 0, st, pyr, h->pyrImgBytes,
-                           h->d_geom, l, h->d_tab, nxc, nbands);
+        // 16 output rows per wave while that still leaves every SIMD several waves (8192 = 8 per SIMD), else 8; same pixels either way
+        const int nxc = (h->geom[l].w + 1 + 127) / 128, nb16 = (h->geom[l].h + 15) / 16, nb8 = (h->geom[l].h + 7) / 8;
+        const bool tall = h->opt[22] == 0 ? (size_t)nxc * nb16 * B >= 8192 && h->scale_factor <= 1.25f : h->opt[22] == 2;
+        if (tall)
+            hipLaunchKernelGGL((k_pyr_level<16, 22>), dim3((nxc * nb16 + 3) / 4, B), dim3(256), 0, st, pyr, h->pyrImgBytes, h->d_geom, l, h->d_tab, nxc, nb16);
+        else
+            hipLaunchKernelGGL((k_pyr_level<8, 12>), dim3((nxc * nb8 + 3) / 4, B), dim3(256), 0, st, pyr, h->pyrImgBytes, h->d_geom, l, h->d_tab, nxc, nb8);
     }
     if (lastSingle < nl - 1)
         hipLaunchKernelGGL(k_pyramid_fused, dim3(h->pyrTilesX * h->pyrTilesY, B), dim3(256), h->pyrLdsBytes, st, d_imgs,

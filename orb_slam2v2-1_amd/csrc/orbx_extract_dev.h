@@ -43,8 +43,6 @@ __device__ __forceinline__ uint32_t udot2_u16_acc(uint32_t a, uint32_t b, uint32
 
 // ---- launch geometry the host side needs
 struct PyrSpan { short o0, o1, c0, c1; };  // owned [o0,o1) and computed [c0,c1) range along one axis
-#define PYR_RW 8   // output rows per wave
-#define PYR_SR 12  // source rows fetched up front: covers PYR_RW rows at scale factors up to ~1.4
 #define FAST_WAVES 4
 #define GATHER_CELLS_PER_BLOCK 16
 #ifndef OCT_T
@@ -81,6 +79,7 @@ __device__ __forceinline__ int level_of_cell(const CellBases &cb, int nlevels, i
 __global__ void k_pyramid_fused(const uint8_t *src, int sstride, size_t simg, uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom,
                                 int nlevels, const int32_t *tab, int xSpanOff, int ySpanOff, int tilesX, int tilesY, int bufBytes,
                                 int maxPar, int l0);                                                             // orbx_pyramid.hip
+template <int RW, int SR>
 __global__ void k_pyr_level(uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int l, const int32_t *tab, int nxc,
                             int nbands);                                                                         // orbx_pyramid.hip
 template <bool FULL>

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_pyramid_fused(
 
 // ------------------------------------------------------------------------------------
 // K1 (level-per-launch form, the default): ComputePyramid as  pad(level 0) -> resize 1..L-1 -> pad(1..L-1).
-//  * k_pyr_level: a wave owns 128 output columns x PYR_RW output rows; a lane owns TWO fixed
+//  * k_pyr_level: a wave owns 128 output columns x RW (8 or 16) output rows; a lane owns TWO fixed
 //    columns (2j-1, 2j: the pair is 2-byte aligned in the padded row), so everything that depends
 //    on the column — source offset, v_perm selector that lifts the two source bytes into a u16
 //    pair, the packed (a0,a1) — is set up once.  Per source row and lane: ONE aligned 8-byte load,
@@ -146,9 +146,15 @@ __global__ __launch_bounds__(256) void k_pyramid_fused(
 // No LDS, no barriers, no dependent chain inside a workgroup (the fused kernel above waits ~45 %
 // of its time on its 8-level chain).
 
+// RW output rows per wave from SR source rows fetched up front (8 from 12: the form for small levels and small batches; 16 from 22 when
+// the level still gives every SIMD several waves: the per-wave set-up - column tables, selectors, row tables - and the source rows two
+// neighbouring bands both fetch are paid half as often, 17 -> 14 VALU instructions per output pixel).
+template <int RW, int SR>
 __global__ __launch_bounds__(256) void k_pyr_level(uint8_t *__restrict__ pyr, size_t pyrImgBytes,
                                                    const LevelGeom *__restrict__ geom, int l,
                                                    const int32_t *__restrict__ tab, int nxc, int nbands) {
+    static_assert((RW == 8 || RW == 16) && SR <= 32, "row table: one lane per output row, a 32-bit mask of source rows");
+    constexpr int RWM = RW - 1;
     int bx, b;
     xcd_block_map(bx, b);
     const int wave = __builtin_amdgcn_readfirstlane(bx * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -170,34 +176,39 @@ __global__ __launch_bounds__(256) void k_pyr_level(uint8_t *__restrict__ pyr, si
     const uint32_t oa = (uint32_t)(ca - A), ob = (uint32_t)(cb - A);
     const uint32_t selA = oa | ((oa + 1) << 16) | 0x0C000C00u, selB = ob | ((ob + 1) << 16) | 0x0C000C00u;
     (void)sw;
-    const int y0 = band * PYR_RW, nrow = min(PYR_RW, G.h - y0);
-    // fast path: the band's source rows rf .. rf+PYR_SR-1 are fetched up front (one memory latency per
-    // wave), then consumed in order.  Lane i < 8 holds the row table of output row y0+i; bit k of
+    const int y0 = band * RW, nrow = min(RW, G.h - y0);
+    // fast path: the band's source rows rf .. rf+SR-1 are fetched up front (one memory latency per
+    // wave), then consumed in order.  Lane i < RW holds the row table of output row y0+i; bit k of
     // `mask` says "the output row whose second source row is rf+k is due after source row k".
-    const int yl = min(y0 + (lane & 7), G.h - 1);
+    const int yl = min(y0 + (lane & RWM), G.h - 1);
     const int vsy = tab[G.yofsOff + yl];
     const uint32_t vbt = (uint32_t)tab[G.ybetaOff + yl];
     const int rf = __builtin_amdgcn_readfirstlane(vsy);
     const int kk = vsy + 1 - rf;
     const int prevsy = __shfl_up(vsy, 1);
-    const bool okl = (lane & 7) >= nrow || (rf >= 0 && vsy + 1 <= sh - 1 && kk < PYR_SR && ((lane & 7) == 0 || vsy > prevsy));
-    const bool regular = (__ballot(okl) & 0xFFull) == 0xFFull;
+    const bool okl = (lane & RWM) >= nrow || (rf >= 0 && vsy + 1 <= sh - 1 && kk < SR && ((lane & RWM) == 0 || vsy > prevsy));
+    constexpr unsigned long long rowLanes = (1ull << RW) - 1ull;
+    const bool regular = (__ballot(okl) & rowLanes) == rowLanes;
     if (regular) {
-        uint32_t m = (lane & 7) < nrow ? 1u << (kk & 31) : 0u;
+        uint32_t m = (lane & RWM) < nrow ? 1u << (kk & 31) : 0u;
         m |= __shfl_xor(m, 1); m |= __shfl_xor(m, 2); m |= __shfl_xor(m, 4);
+        if (RW == 16) m |= __shfl_xor(m, 8);
         const uint32_t mask = __builtin_amdgcn_readfirstlane(m);
-        uint2 q[PYR_SR];
+        const int lastk = 31 - __builtin_clz(mask | 1u);   // source rows past the last output row's second one are neither fetched nor filtered
+        uint2 q[SR];
 #pragma unroll
-        for (int k = 0; k < PYR_SR; k++) {   // scalar row pointer + the lane's 32-bit column offset: no per-lane address arithmetic
+        for (int k = 0; k < SR; k++) {   // scalar row pointer + the lane's 32-bit column offset: no per-lane address arithmetic
             const uint8_t *rowp = srow0 + (size_t)min(rf + k, sh - 1) * sps;
-            q[k] = *(const uint2 *)(rowp + (uint32_t)A);
+            q[k] = make_uint2(0u, 0u);
+            if (k <= lastk) q[k] = *(const uint2 *)(rowp + (uint32_t)A);   // wave-uniform
         }
         uint32_t tpa = 0, tpb = 0;
         int cnt = 0;
         uint8_t *drow = drow0 + (size_t)y0 * G.pstride - 1;   // scalar; the lane's column x0 = xoff - 1 with xoff >= 0
         const uint32_t xoff = (uint32_t)(x0 + 1);
 #pragma unroll
-        for (int k = 0; k < PYR_SR; k++) {
+        for (int k = 0; k < SR; k++) {
+            if (k > lastk) continue;   // wave-uniform
             const uint32_t tca = udot2_u16(__builtin_amdgcn_perm(q[k].y, q[k].x, selA), aa) >> 4;
             const uint32_t tcb = udot2_u16(__builtin_amdgcn_perm(q[k].y, q[k].x, selB), ab) >> 4;
             if (k > 0 && ((mask >> k) & 1u)) {   // wave-uniform
@@ -312,5 +323,7 @@ __global__ __launch_bounds__(256) void k_pyr_pad(const uint8_t *__restrict__ img
     }
 }
 
+template __global__ void k_pyr_level<8, 12>(uint8_t *, size_t, const LevelGeom *, int, const int32_t *, int, int);
+template __global__ void k_pyr_level<16, 22>(uint8_t *, size_t, const LevelGeom *, int, const int32_t *, int, int);
 template __global__ void k_pyr_pad<true>(const uint8_t *, int, size_t, uint8_t *, size_t, const LevelGeom *, int);
 template __global__ void k_pyr_pad<false>(const uint8_t *, int, size_t, uint8_t *, size_t, const LevelGeom *, int);

@@ -328,6 +328,35 @@ def test_pyramid_forms_agree(pkg, oracle, synth, knob):
         pkg.set_default_option(5, 0)
 
 
+@pytest.mark.parametrize("rows", [1, 2])
+def test_pyramid_rows_per_wave_agree(pkg, oracle, synth, rows):
+    """ORBX_OPT_PYR_ROWS: k_pyr_level with 8 (1) or 16 (2) output rows per wave - by default picked per level from the number of
+    waves it leaves the GPU; every level byte for byte, frame included (odd sizes, heights that are no multiple of 16, scale factors
+    at which 16 rows need more source rows than the kernel fetches up front and fall to its row-by-row path), single images and a batch."""
+    pkg.set_default_option(22, rows)
+    try:
+        for (w, h, nl, sf, seed) in ((641, 479, 8, 1.2, 84), (1241, 376, 8, 1.2, 85), (500, 400, 4, 1.3, 86), (1023, 517, 5, 1.5, 89), (770, 431, 9, 1.1, 90),
+                                     (258, 255, 6, 1.2, 91), (1000, 600, 3, 1.7, 92)):
+            img = synth.frame(w, h, seed)
+            ex = pkg.ORBextractor(500, sf, nl, 20, 7)
+            k, d = ex(img)
+            o = oracle.Extractor(500, sf, nl, 20, 7)
+            ok, od = o.extract(img)
+            assert k.tobytes() == ok.tobytes() and d.tobytes() == od.tobytes(), (w, h, nl)
+            for lvl in range(nl):
+                np.testing.assert_array_equal(ex.pyramid_level(lvl, padded=True), o.pyramid_level(lvl, padded=True), err_msg=str((w, h, nl, lvl)))
+            ex.close()
+        imgs = np.stack([synth.frame(752, 480, 300 + i) for i in range(5)])
+        ex = pkg.ORBextractor(800, 1.2, 8, 20, 7)
+        o = oracle.Extractor(800, 1.2, 8, 20, 7)
+        for b, (k, d) in enumerate(ex.extract_batch(imgs)):
+            ok, od = o.extract(imgs[b])
+            assert k.tobytes() == ok.tobytes() and d.tobytes() == od.tobytes(), b
+        ex.close()
+    finally:
+        pkg.set_default_option(22, 0)
+
+
 def test_small_budget_many_roots(pkg, oracle, synth):
     """The coarsest level of a 1229x497 image at scale 1.5 has 4 quad-tree roots and a budget of 5: the first pass splits all
     roots (16 nodes) before N is looked at (src/ORBextractor.cc:606-672)."""
