@@ -149,6 +149,11 @@ __global__ __launch_bounds__(256) void k_pyramid_fused(
 // RW output rows per wave from SR source rows fetched up front (8 from 12: the form for small levels and small batches; 16 from 22 when
 // the level still gives every SIMD several waves: the per-wave set-up - column tables, selectors, row tables - and the source rows two
 // neighbouring bands both fetch are paid half as often, 17 -> 14 VALU instructions per output pixel).
+// VResizeLinear's (beta * (S >> 4)) >> 16 as ONE 24-bit multiply: the horizontal sum keeps its scale with the low four bits cleared
+// (S & ~15 = (S >> 4) << 4, below 2^19), beta (<= 2048) is shifted up by 12 (below 2^24), and the high half of the 48-bit product
+// (b << 12) * ((S >> 4) << 4) is (b * (S >> 4)) >> 16 exactly.  v_mul_hi_u32_u24 is a full-rate instruction; the multiply + shift it
+// replaces were two.
+__device__ __forceinline__ uint32_t vmulhi24(uint32_t a, uint32_t b) { return __umulhi(a & 0xFFFFFFu, b & 0xFFFFFFu); }   // (the masks are known no-ops: they let the compiler pick the 24-bit form)
 template <int RW, int SR>
 __global__ __launch_bounds__(256) void k_pyr_level(uint8_t *__restrict__ pyr, size_t pyrImgBytes,
                                                    const LevelGeom *__restrict__ geom, int l,
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(256) void k_pyr_level(uint8_t *__restrict__ pyr, si
         uint2 q[SR];
 #pragma unroll
         for (int k = 0; k < SR; k++) {   // scalar row pointer + the lane's 32-bit column offset: no per-lane address arithmetic
-            const uint8_t *rowp = srow0 + (size_t)min(rf + k, sh - 1) * sps;
+            const uint8_t *rowp = srow0 + (uint32_t)(min(rf + k, sh - 1) * sps);   // 32-bit scalar product (a padded level is far smaller than 4 GiB)
             q[k] = make_uint2(0u, 0u);
             if (k <= lastk) q[k] = *(const uint2 *)(rowp + (uint32_t)A);   // wave-uniform
         }
@@ -209,13 +214,13 @@ __global__ __launch_bounds__(256) void k_pyr_level(uint8_t *__restrict__ pyr, si
 #pragma unroll
         for (int k = 0; k < SR; k++) {
             if (k > lastk) continue;   // wave-uniform
-            const uint32_t tca = udot2_u16(__builtin_amdgcn_perm(q[k].y, q[k].x, selA), aa) >> 4;
-            const uint32_t tcb = udot2_u16(__builtin_amdgcn_perm(q[k].y, q[k].x, selB), ab) >> 4;
+            const uint32_t tca = udot2_u16(__builtin_amdgcn_perm(q[k].y, q[k].x, selA), aa) & 0x7FFF0u;
+            const uint32_t tcb = udot2_u16(__builtin_amdgcn_perm(q[k].y, q[k].x, selB), ab) & 0x7FFF0u;
             if (k > 0 && ((mask >> k) & 1u)) {   // wave-uniform
                 const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)vbt, cnt);
-                const uint32_t b0 = bb & 0xFFFFu, b1 = bb >> 16;
-                const uint32_t pa = (((b0 * tpa) >> 16) + ((b1 * tca) >> 16) + 2) >> 2;
-                const uint32_t pb = (((b0 * tpb) >> 16) + ((b1 * tcb) >> 16) + 2) >> 2;
+                const uint32_t b0 = (bb & 0xFFFu) << 12, b1 = ((bb >> 16) & 0xFFFu) << 12;   // scalar; beta <= 2048
+                const uint32_t pa = (vmulhi24(b0, tpa) + vmulhi24(b1, tca) + 2) >> 2;
+                const uint32_t pb = (vmulhi24(b0, tpb) + vmulhi24(b1, tcb) + 2) >> 2;
                 if (vst) *(uint16_t *)(drow + xoff) = (uint16_t)(pa | (pb << 8));
                 drow += G.pstride;
                 cnt++;
@@ -234,22 +239,22 @@ __global__ __launch_bounds__(256) void k_pyr_level(uint8_t *__restrict__ pyr, si
         if (r0 == cr1) { t0a = t1a; t0b = t1b; cr0 = cr1; }
         else if (r0 != cr0) {
             const uint2 q = *(const uint2 *)(srow0 + (size_t)r0 * sps + A);
-            t0a = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selA), aa) >> 4;
-            t0b = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selB), ab) >> 4;
+            t0a = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selA), aa) & 0x7FFF0u;
+            t0b = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selB), ab) & 0x7FFF0u;
             cr0 = r0;
         }
         if (r1 != cr1) {
             if (r1 == cr0) { t1a = t0a; t1b = t0b; }
             else {
                 const uint2 q = *(const uint2 *)(srow0 + (size_t)r1 * sps + A);
-                t1a = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selA), aa) >> 4;
-                t1b = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selB), ab) >> 4;
+                t1a = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selA), aa) & 0x7FFF0u;
+                t1b = udot2_u16(__builtin_amdgcn_perm(q.y, q.x, selB), ab) & 0x7FFF0u;
             }
             cr1 = r1;
         }
-        const uint32_t b0 = bb & 0xFFFFu, b1 = bb >> 16;
-        const uint32_t pa = (((b0 * t0a) >> 16) + ((b1 * t1a) >> 16) + 2) >> 2;
-        const uint32_t pb = (((b0 * t0b) >> 16) + ((b1 * t1b) >> 16) + 2) >> 2;
+        const uint32_t b0 = (bb & 0xFFFu) << 12, b1 = ((bb >> 16) & 0xFFFu) << 12;
+        const uint32_t pa = (vmulhi24(b0, t0a) + vmulhi24(b1, t1a) + 2) >> 2;
+        const uint32_t pb = (vmulhi24(b0, t0b) + vmulhi24(b1, t1b) + 2) >> 2;
         if (vst) *(uint16_t *)(drow0 + (size_t)y * G.pstride + x0) = (uint16_t)(pa | (pb << 8));
     }
 }
