@@ -14,7 +14,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
 bad = 0
 t0 = time.time()
 KNOBS = [(), ((15, 2),), ((15, 4),), ((19, 2),), ((19, 3),), ((18, 1),), ((16, 2),), ((8, 2),), ((8, 3),), ((6, 3),), ((6, 3), (19, 2)), ((6, 3), (16, 2), (15, 3)),
-         ((6, 3), (20, 1)), ((6, 3), (20, 2)), ((6, 3), (16, 2), (20, 1)), ((6, 3), (16, 2), (20, 2)), ((6, 3), (20, 1), (15, 3)), ((6, 3), (20, 1), (8, 2))]
+         ((6, 3), (20, 1)), ((6, 3), (20, 2)), ((6, 3), (16, 2), (20, 1)), ((6, 3), (16, 2), (20, 2)), ((6, 3), (20, 1), (15, 3)), ((6, 3), (20, 1), (8, 2)),
+         ((22, 1),), ((22, 2),), ((6, 3), (22, 2))]
 for it in range(N):
     w = int(rng.integers(320, 1300)); h = int(rng.integers(240, 720))
     nf = int(rng.choice([50, 300, 800, 1000, 2000]))

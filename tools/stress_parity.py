@@ -2,7 +2,8 @@
 random sizes / budgets / thresholds / image statistics (not part of the pytest suite).  Every configuration runs three times:
 the default kernel choice of a single image (k_fast_cells, one-workgroup quad-tree), the strip FAST kernel forced (option 6 = 3),
 strips + the multi-workgroup quad-tree on every level (option 4 = 2), strips with the sparse path forced on every level (option
-16 = 2) in its three forms (row skip, strip compaction, cell compaction: option 20), k_gather + compacted keys, and - against the
+16 = 2) in its three forms (row skip, strip compaction, cell compaction: option 20), k_gather + compacted keys, k_pyr_level with 16 rows
+per wave on every level (option 22 = 2), and - against the
 oracle of that flavour - a handle of the SSE2 flavour of the Gaussian's column rounding."""
 import sys, os, importlib, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -63,7 +64,7 @@ for it in range(N):
     for variant, knobs in (("default", ()), ("strips", ((6, 3),)), ("strips+multi-wg quad-tree", ((6, 3), (4, 2))),
                            ("strips+row skip pre-test", ((6, 3), (16, 2))), ("strips+strip compaction pre-test", ((6, 3), (16, 2), (20, 1))),
                            ("strips+cell compaction pre-test", ((6, 3), (16, 2), (20, 2))), ("k_gather + compacted keys", ((18, 1),)),
-                           ("sse2 flavour", ())):
+                           ("pyramid 16 rows per wave", ((22, 2),)), ("sse2 flavour", ())):
         e, wk, wd = (ex2, ok2, od2) if variant.startswith("sse2") else (ex, ok, od)
         for k, v in knobs:
             e.set_option(k, v)
