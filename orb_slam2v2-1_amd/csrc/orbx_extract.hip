@@ -708,7 +708,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     // Fused: k_octree_pyr reads the FAST stage's cell lists in place (no k_gather launch, no compacted key array: -35 us per
     // 128 images 1241x376, -200 us per 64 images 1920x1080 in the pipelined step).  Not for the multi-workgroup form, the exact
     // form alone and the phase-stop knobs, which sweep the compacted array (developer knob 18 = 1: never fused).
-    const bool fused = usePyr && !multiWg && h->opt[7] == 0 && h->opt[1] == 0 && h->opt[18] != 1;
+    const bool fused = usePyr && !multiWg && (h->opt[7] == 0 || h->opt[7] == 8) && h->opt[1] == 0 && h->opt[18] != 1;   // (7 = 8, developer build: time stamps, no stop)
     const int sparsePerCell = h->opt[16] == 2 ? 1 << 20 : ORBX_SPARSE_PER_CELL;
     OctSrc osrc = {};
     if (fused) {

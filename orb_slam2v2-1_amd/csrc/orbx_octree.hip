@@ -223,6 +223,7 @@ __device__ __forceinline__ void octree_pyr_body(
     const int Dm = g.pyrDepth, nIni = g.nIni, N = g.N;
 #ifdef ORBX_DEVELOPER
     const unsigned long long dvT0 = wall_clock64();
+    unsigned long long dvTA = dvT0, dvTB = dvT0;
 #endif
     uint8_t *sp = smem;
     unsigned long long *skey = (unsigned long long *)sp; sp += sizeof(unsigned long long) * pow2cap;
@@ -301,6 +302,9 @@ __device__ __forceinline__ void octree_pyr_body(
         __syncthreads();
         // one sweep over the cell lists: 16 lanes per cell, a lane owns four CONSECUTIVE entries (one 16-byte load; a cell's slot block
         // is capc = 1 KB apart), so the run merging below works as on the compacted array; the next round's entries are in flight
+#ifdef ORBX_DEVELOPER
+        dvTA = wall_clock64();
+#endif
         constexpr int CPR = OCT_T / 16;
         const int sub = tid & 15, cgrp = tid >> 4, capc = g.capc;
         auto fetch = [&](int cell, uint4 &e, uint32_t &rw) {
@@ -371,6 +375,9 @@ __device__ __forceinline__ void octree_pyr_body(
     }
     }   // !fused
     __syncthreads();
+#ifdef ORBX_DEVELOPER
+    dvTB = wall_clock64();
+#endif
     if (MODE == 1) {   // partial histogram -> global; the last workgroup to arrive carries on with the sum of all K
         const int deepWords = ((nIni << (2 * Dm)) + 1) >> 1;
         uint32_t *gp = big.part + (bigSlot * big.K + slice) * big.deepMax;
@@ -656,7 +663,12 @@ __device__ __forceinline__ void octree_pyr_body(
 #ifdef ORBX_DEVELOPER
         // developer build: the record holds (passes << 24 | pass loop in 0.1 us << 12 | time since kernel entry in 0.1 us) instead of 0
         if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; const unsigned long long t = wall_clock64();
-            fallback[b * nlevels + l] = (dvPasses << 24) | ((int)min((dvT2 - dvT1) / 10ull, 4095ull) << 12) | (int)min((t - dvT0) / 10ull, 4095ull); }
+            // dbgStop == 8: the finer split instead - four 8-bit fields in 0.25-us units: entry -> sweep start -> sweep end -> first pass -> last pass
+            if (dbgStop == 8)
+                fallback[b * nlevels + l] = ((int)min((dvTA - dvT0) / 25ull, 255ull) << 24) | ((int)min((dvTB - dvTA) / 25ull, 255ull) << 16) |
+                                            ((int)min((dvT1 - dvTB) / 25ull, 255ull) << 8) | (int)min((dvT2 - dvT1) / 25ull, 255ull);
+            else
+                fallback[b * nlevels + l] = (dvPasses << 24) | ((int)min((dvT2 - dvT1) / 10ull, 4095ull) << 12) | (int)min((t - dvT0) / 10ull, 4095ull); }
         return;
 #endif
         if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; fallback[b * nlevels + l] = 0; }

@@ -21,3 +21,13 @@ for name, gen, w, h, nf in (("dense", synth.frame, 1241, 376, 1000), ("natural",
     for l in range(8):
         print("  level %d: passes %s  pass loop us mean %.1f max %.1f   since entry us mean %.1f max %.1f" % (
             l, sorted(set(passes[:, l].tolist())), loop[:, l].mean(), loop[:, l].max(), total[:, l].mean(), total[:, l].max()))
+    ex.set_option(7, 8)     # the finer split: entry -> sweep start -> sweep end -> first pass -> last pass (0.25-us units)
+    for rep in range(2):
+        ex.extract_batch_device(d.data_ptr(), B, w, h, w, w * h, k.data_ptr(), de.data_ptr(), c.data_ptr(), cap, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    fb = ex.octree_fallbacks(B).astype(np.int64)
+    f = [((fb >> s) & 255) / 4.0 for s in (24, 16, 8, 0)]
+    for l in range(8):
+        print("  level %d: set-up %.1f us, key sweep %.1f, count pyramid + roots %.1f, passes %.1f (means over %d images)" % (
+            l, f[0][:, l].mean(), f[1][:, l].mean(), f[2][:, l].mean(), f[3][:, l].mean(), B))
+    ex.set_option(7, 0)
