@@ -314,6 +314,41 @@ def measure(fe, steps, warmup, ramp, world, dist, dev, torch):
             "nprof": nprof, "gathered": gath, "long_run": long_run}
 
 
+def measure_gather_leg(fe, torch, n=200):
+    """Cost of the communication leg of ONE step, alone on the GPU (--force-gather): the pack kernel (B frame records of fixed capacity)
+    and the all-gather of them, issued exactly as the pipelined step issues them (pack on the side stream, collective from the
+    front end's collective stream, async work handle waited for when the buffer set comes round again), n times back to back."""
+    r = fe.ring
+    fe.drain()
+    side = fe.side if fe.side is not None else torch.cuda.current_stream(fe.dev)
+    def leg(k):
+        for i in range(k):
+            j = r.acquire(i)
+            if fe.lag:
+                fe._publish_side(j, None, side)
+            else:
+                r.publish(j, None)
+        r.drain()
+        torch.cuda.synchronize(fe.dev)
+    leg(20)
+    t0 = time.perf_counter()
+    leg(n)
+    dt = (time.perf_counter() - t0) / n
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(side):
+        e0.record(side)
+        for i in range(n):
+            r.pack_set(i % r.nbuf)
+        e1.record(side)
+    torch.cuda.synchronize(fe.dev)
+    rb = r.pack[0].shape[1]
+    return {"ms_per_step_alone": round(dt * 1e3, 4), "pack_kernel_ms": round(e0.elapsed_time(e1) / n, 4), "record_bytes_per_frame": int(rb),
+            "bytes_per_step_per_rank": int(rb * r.gB), "ranks": r.world,
+            "note": "pack + all_gather_into_tensor(async_op=True) + work.wait(), %d times back to back with nothing else on the GPU: the upper "
+                    "bound of what the leg adds to a step (in the timed steps it runs beside the next step's kernels); a ONE-rank communicator "
+                    "moves the records inside one GPU - no xGMI traffic, no scaling figure" % n}
+
+
 def measure_end_to_end(fe, left, right, steps, warmup, torch):
     """The same step fed from PINNED HOST memory and delivering to pinned host memory (FrontEnd.enable_host_streaming): uploads of
     batch i + 2 and downloads of batch i - 1 on their own streams beside the kernels of batches i, i + 1.  Times K steps from the
@@ -549,6 +584,10 @@ def main():
                          "scaling; BASELINE config 4 = --workload mono_1920x1080_4000feat --total-frames 512 --gpus 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the result all-gather when N > 1")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="N = 1: run the pack + all-gather leg of the N > 1 step anyway, in a ONE-rank communicator of --backend (nccl = RCCL): "
+                         "communicator set-up, the collective's stream, the async work handle and the hand-off from the handle's side stream all "
+                         "execute on the one GPU of a test box; the line then also carries `gather_leg` (its cost per step)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short untimed-by-the-driver runs of the other north-star sizes (other_workloads block)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step")
@@ -652,12 +691,22 @@ def main():
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    force_gather = bool(args.force_gather and world == 1 and not args.no_gather)
+    if force_gather:      # a one-rank job has no launcher that sets the rendezvous: this process is rank 0 of 1 on the loopback address
+        import socket
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+        s_.close()
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_gather:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
-    gather = world > 1 and not args.no_gather
+    gather = (world > 1 or force_gather) and not args.no_gather
     # the all-gather is a fixed-shape collective: every rank contributes as many record rows as the LARGEST block holds (a batch that
     # does not divide by the rank count leaves blocks that differ by one frame; the short blocks' last row stays empty)
     gB = max(b - a for a, b in (batching.shard_range(args.total_frames, r, world) for r in range(world))) if strong else B
@@ -665,9 +714,10 @@ def main():
     S = max(1, args.streams)
     fe = pipeline.FrontEnd(w, h, nf, stereo, B, device_index=dev_index, nbuf=3, streams=S, world=world, gather=gather,
                            gather_via_host=(args.backend != "nccl"), prefetch=not args.no_prefetch, lag_stereo=not args.no_lag_stereo, gather_B=gB,
-                           stereo_late=(args.stereo_order == "late"), fast_alone=args.fast_alone)
+                           stereo_late=(args.stereo_order == "late"), fast_alone=args.fast_alone, force_gather=force_gather)
     fe.upload(left, right)
     m = measure(fe, args.steps, args.warmup, args.ramp_steps, world, dist, dev, torch)
+    gather_leg = measure_gather_leg(fe, torch) if force_gather else None
     dt, stage_ms = m["dt"], m["stage_ms"]
 
     # Extra pass (--overlap-pass, 1 GPU): the same K steps alternating over THREE extractor handles on three streams.
@@ -739,7 +789,8 @@ def main():
                                        (" (FAST of step i+1 waits for it)" if fe.fast_alone else " (which may run on beside the FAST stage of step i+1)")
                                        if fe.late else "behind the FAST stage of step i, on a side stream: stereo matcher of step i-1, then pyramid of step i+1") if fe.lag
                                       else "pyramid of the next step built ahead (orbx_extract_batch_device_prefetch)") if fe.prefetch else "none",
-                       "parallelism": "frames sharded over %d GPU(s)%s" % (world, ", results all-gathered (%s)" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal") if gather else ""),
+                       "parallelism": "frames sharded over %d GPU(s)%s" % (world, ", results all-gathered (%s%s)" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal",
+                                                                                  ", one-rank communicator (--force-gather)" if force_gather else "") if gather else ""),
                        "world_size_observed": world_seen, "ranks": ranks,
                        "avg_keypoints_per_image": round(navg, 1), "gauss_flavour": args.gauss_flavour,
                        "handle_options": handle_options},
@@ -816,12 +867,14 @@ def main():
                         "value_without_row_pretest": round(ob * osteps / om2["dt"], 2)})
                 del ofe
             out["other_workloads"] = ow_out
+        if gather_leg is not None:
+            out["gather_leg"] = gather_leg
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if overlapped is not None:
             out["overlapped"] = overlapped
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_gather:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -453,10 +453,12 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
 #define ORBX_NUM_OPTIONS 32
 int orbx_set_option(orbx_extractor_t *h, int key, int value);
 int orbx_get_option(const orbx_extractor_t *h, int key, int *value);
-/* The guided-search matchers keep their scratch per host thread, and so their one option: ORBM_OPT_EXACT_KERNELS = 1 makes the
- * calling thread's matcher calls take the exact one-workgroup kernels instead of candidate search + speculative resolution
- * (identical results; the tests run both).  Thread-local. */
+/* The guided-search matchers keep their scratch per host thread, and so their options: ORBM_OPT_EXACT_KERNELS = 1 makes the
+ * calling thread's matcher calls take the exact one-workgroup kernels instead of candidate search + resolution; ORBM_OPT_RESOLVER
+ * = 1 makes the resolution the single-wave speculative walk of rounds 1-4 instead of the whole-workgroup fixed-point iteration
+ * (k_resolve_par, the default since round 5).  Identical results whatever the setting; the tests run all three.  Thread-local. */
 #define ORBM_OPT_EXACT_KERNELS 2
+#define ORBM_OPT_RESOLVER 3
 int orbm_set_thread_option(int key, int value);
 /* Test hooks for two rows of the scope table that have no output of their own.
  * orbx_debug_blur_patches (a8, cv::GaussianBlur 7x7 sigma 2 - fused into the descriptor kernel, never stored): enable = 1, then

@@ -89,9 +89,11 @@ class ResultRing:
         ring.drain()             # wait for every outstanding all-gather
     Frames are the first B images of a set (a stereo pair's right image sits at slot B + b and is not exchanged)."""
 
-    def __init__(self, nbuf, B, nimg, cap, device, world=1, gather=False, blocking_via_host=False, gather_B=None):
+    def __init__(self, nbuf, B, nimg, cap, device, world=1, gather=False, blocking_via_host=False, gather_B=None, force_gather=False):
         self.nbuf, self.B, self.nimg, self.cap, self.world = nbuf, B, nimg, cap, world
-        self.gather = gather and world > 1
+        # force_gather: pack + all-gather even in a one-rank communicator (valid for RCCL): the collective leg - communicator, its
+        # stream, the async work handle, the hand-off from the handle's side stream - then runs on a box with ONE GPU
+        self.gather = gather and (world > 1 or force_gather)
         # rows every rank contributes to the fixed-shape collective: the LARGEST block of any rank when a batch does not divide
         # evenly (shard_range: sizes differ by at most one); a smaller block leaves its last row zero (count 0)
         self.gB = B if gather_B is None else int(gather_B)

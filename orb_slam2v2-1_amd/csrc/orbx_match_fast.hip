@@ -509,6 +509,154 @@ __global__ __launch_bounds__(64) void k_resolve_windows(const u64 *__restrict__ 
     if (lane == 0) { out[0] = nm; out[1] = ov ? 1 : 0; }
 }
 
+// ---- B'. the resolution as a FIXED POINT, by one workgroup of RP_T threads instead of one wave (round 5).
+// The reference's loop is sequential because a committed match may BLOCK its keypoint for the queries behind it (mvpMapPoints[idx]
+// set to a point with Observations() > 0, :87-89 / :1405-1407).  Write claim(q) for the keypoint query q commits to (none: -1) and
+// T[j] = min { q : claim(q) = j and q blocks } for the first query that blocks keypoint j.  Query q sees exactly the keypoints
+// with T[j] < q as blocked, so the reference's result is the unique assignment with claim(q) = decide(q, { j : T[j] < q }) for
+// every q.  Iteration: start from decide(q, {}) for all q at once, rebuild T from the claims, re-decide every q, until no claim
+// changes.  After round r the claims of the queries 0 .. r are final (query q's decision only depends on claims of queries
+// below q), so it ends after at most m + 1 rounds - in practice two to four, each a few hundred nanoseconds of LDS traffic for
+// the whole workgroup - and a fixed point IS the sequential result (induction over q).  The single-wave speculative resolver
+// above took 47 us for 2000 queries (k_resolve_frame) and 19 us (k_resolve_mp) of a 100-us call; this one ~5.
+// Afterwards: holder[j] = the LARGEST committed q with claim j (the loop overwrites), the orientation histogram over all
+// commits (:1435-1469: an entry in a losing bin clears its keypoint even when a later query overwrote the holder), counts.
+// MODE 0: SearchByProjection(F, MPs) (best + second, ratio test); 1: SearchByProjection(cur, last); 2: projected windows.
+#define RP_T 1024
+#define RP_Q 4          // queries per thread: m <= RP_T * RP_Q, larger calls keep the single-wave resolver
+template <int MODE>
+__global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ keys, const int32_t *__restrict__ ncand,
+                                                      const void *__restrict__ meta, const orbx_keypoint_t *__restrict__ kun,
+                                                      int m, int n, const int32_t *holder_in, int32_t *holder_out,
+                                                      int32_t *holder_host, float nnratio, int max_dist, int check_ori,
+                                                      int32_t *__restrict__ out, int32_t *__restrict__ out_host) {
+    extern __shared__ uint32_t rp_lds[];
+    uint32_t *bt = rp_lds;                       // [n] T[j] during the rounds, then the largest committed query + 1
+    uint32_t *dead = rp_lds + n;                 // [(n + 31) / 32] bit j: an orientation loser claimed keypoint j
+    __shared__ int hn[HISTO_LENGTH];
+    __shared__ int ind[3];
+    __shared__ int sh_nm, sh_ov;
+    const int tid = threadIdx.x;
+    uint32_t c[RP_Q][QK];       // candidates of my queries, best first: dist << 20 | index << 4 | octave (~0: none)
+    int nc[RP_Q], blk[RP_Q], claim[RP_Q];
+    float ang[RP_Q];
+    bool overflow = false;
+#pragma unroll
+    for (int r = 0; r < RP_Q; r++) {
+        const int qi = tid + r * RP_T;
+        nc[r] = 0; blk[r] = 0; ang[r] = 0.0f; claim[r] = -1;
+#pragma unroll
+        for (int k = 0; k < QK; k++) c[r][k] = ~0u;
+        if (qi < m) {
+            nc[r] = ncand[qi];
+            if (MODE == 0) blk[r] = ((const orbm_mappoint_t *)meta)[qi].observations > 0;
+            else if (MODE == 1) { blk[r] = ((const orbm_lastpoint_t *)meta)[qi].observations > 0; ang[r] = ((const orbm_lastpoint_t *)meta)[qi].angle; }
+            else { blk[r] = ((const orbm_window_query_t *)meta)[qi].blocks != 0; ang[r] = ((const orbm_window_query_t *)meta)[qi].angle; }
+            if (nc[r] > 0) {
+#pragma unroll
+                for (int k = 0; k < QK; k++) {
+                    const u64 key = keys[(size_t)qi * QK + k];
+                    if (key != ~0ull) c[r][k] = ((uint32_t)KEY_DIST(key) << 20) | ((uint32_t)KEY_IDX(key) << 4) | (uint32_t)KEY_OCT(key);
+                }
+            }
+            if (nc[r] > CAND_CAP) overflow = true;   // k_cand dropped candidates: its top-QK is not trustworthy
+        }
+    }
+    if (tid < HISTO_LENGTH) hn[tid] = 0;
+    if (tid == 0) { sh_nm = 0; sh_ov = 0; }
+    bool ranout[RP_Q];
+    // the decision of query r of this thread given the blocking times in bt (useBt = false: nothing is blocked)
+    auto decide = [&](int r, bool useBt) -> int {
+        const uint32_t qi = (uint32_t)(tid + r * RP_T);
+        int best = -1, bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, found = 0;
+#pragma unroll
+        for (int k = 0; k < QK; k++) {
+            const uint32_t e = c[r][k];
+            if (found < (MODE == 0 ? 2 : 1) && e != ~0u) {
+                const int idx = (int)((e >> 4) & 0xFFFFu);
+                if (!(useBt && bt[idx] < qi)) {
+                    if (found == 0) { best = idx; bestDist = (int)(e >> 20); bestLevel = (int)(e & 15u); }
+                    else { bestDist2 = (int)(e >> 20); bestLevel2 = (int)(e & 15u); }
+                    found++;
+                }
+            }
+        }
+        ranout[r] = (MODE == 0 ? found < 2 : best < 0) && nc[r] > QK;   // more candidates existed than were kept
+        bool accept;
+        if (MODE == 0) accept = best >= 0 && bestDist <= TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2);
+        else accept = best >= 0 && bestDist <= (MODE == 1 ? TH_HIGH : max_dist);
+        return accept ? best : -1;
+    };
+#pragma unroll
+    for (int r = 0; r < RP_Q; r++) { ranout[r] = false; if (nc[r] > 0) claim[r] = decide(r, false); }
+    for (int round = 0; round <= m + 1; round++) {
+        for (int j = tid; j < n; j += RP_T) bt[j] = 0xFFFFFFFFu;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RP_Q; r++)
+            if (claim[r] >= 0 && blk[r]) atomicMin(&bt[claim[r]], (uint32_t)(tid + r * RP_T));
+        __syncthreads();
+        int changed = 0;
+#pragma unroll
+        for (int r = 0; r < RP_Q; r++)
+            if (nc[r] > 0) {
+                const int nw = decide(r, true);
+                changed |= nw != claim[r];
+                claim[r] = nw;
+            }
+        if (!__syncthreads_or(changed)) break;     // (also the barrier between this round's reads of bt and the next round's reset)
+    }
+    // holders, orientation histogram, counts
+    for (int j = tid; j < n; j += RP_T) bt[j] = 0;
+    for (int j = tid; j < (n + 31) / 32; j += RP_T) dead[j] = 0;
+    __syncthreads();
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nm = 0, bin[RP_Q];
+#pragma unroll
+    for (int r = 0; r < RP_Q; r++) {
+        bin[r] = -1;
+        if (ranout[r]) overflow = true;
+        if (claim[r] >= 0) {
+            atomicMax(&bt[claim[r]], (uint32_t)(tid + r * RP_T) + 1u);
+            nm++;
+            if (MODE != 0 && check_ori) {
+                float rot = ang[r] - kun[claim[r]].angle;
+                if (rot < 0.0f) rot += 360.0f;
+                int bn = (int)roundf(rot * factor);
+                if (bn == HISTO_LENGTH) bn = 0;
+                bin[r] = bn;
+                atomicAdd(&hn[bn], 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (MODE != 0 && check_ori) {
+        if (tid == 0) three_maxima(hn, HISTO_LENGTH, ind[0], ind[1], ind[2]);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RP_Q; r++)
+            if (bin[r] >= 0 && bin[r] != ind[0] && bin[r] != ind[1] && bin[r] != ind[2]) {   // :1463-1464
+                atomicOr(&dead[claim[r] >> 5], 1u << (claim[r] & 31));
+                nm--;
+            }
+        __syncthreads();
+    }
+    for (int j = tid; j < n; j += RP_T) {
+        const uint32_t wq = bt[j];
+        const int32_t v = ((dead[j >> 5] >> (j & 31)) & 1u) ? -1 : wq ? (int32_t)wq - 1 : holder_in[j];
+        holder_out[j] = v;
+        if (holder_host) holder_host[j] = v;
+    }
+    nm = wave_sum_i32(nm);
+    if ((tid & 63) == 0 && nm) atomicAdd(&sh_nm, nm);
+    if (__ballot(overflow) && (tid & 63) == 0) sh_ov = 1;
+    __syncthreads();
+    if (tid == 0) {
+        out[0] = sh_nm; out[1] = sh_ov;
+        if (out_host) { out_host[0] = sh_nm; out_host[1] = sh_ov; }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_queries_windows(const orbm_window_query_t *__restrict__ w, int m,
                                                          GQuery *__restrict__ q, const int32_t *__restrict__ holder,
                                                          const int32_t *__restrict__ ext_blocks, int n,
@@ -677,7 +825,7 @@ static void frustum_pose(const float *T, FrustumPose &P) {   // mRcw, mtcw, mOw 
 // hipMemcpyAsync (UP ... FLUSH_UP); results come down into the mirror in one or two copies and ONE stream
 // synchronisation (DOWN ... after the sync, copy out).  A call used to issue 8-10 pageable copies and 2 syncs.
 struct Arena {
-    uint8_t *base = nullptr, *hbase = nullptr; size_t cap = 0, off = 0, up_lo = 0, up_hi = 0; int device = -1; hipStream_t st = nullptr;
+    uint8_t *base = nullptr, *hbase = nullptr, *hdev = nullptr; size_t cap = 0, off = 0, up_lo = 0, up_hi = 0; int device = -1; hipStream_t st = nullptr;
 };
 static thread_local Arena g_ar;
 static int arena_begin(int device, size_t need) {
@@ -693,6 +841,7 @@ static int arena_begin(int device, size_t need) {
         const size_t cap = std::max(need * 2, (size_t)4 << 20);
         ORBX_HIP(hipMalloc(&g_ar.base, cap));
         ORBX_HIP(hipHostMalloc((void **)&g_ar.hbase, cap, hipHostMallocDefault));
+        ORBX_HIP(hipHostGetDevicePointer((void **)&g_ar.hdev, g_ar.hbase, 0));   // the mirror as the kernels see it (small inputs are read, results written, in place)
         g_ar.cap = cap; g_ar.device = device;
     }
     g_ar.off = 0;
@@ -705,7 +854,7 @@ void orbx_internal_release_arena() {
     if (g_ar.st) { hipStreamSynchronize(g_ar.st); hipStreamDestroy(g_ar.st); g_ar.st = nullptr; }
     if (g_ar.base) hipFree(g_ar.base);
     if (g_ar.hbase) hipHostFree(g_ar.hbase);
-    g_ar.base = nullptr; g_ar.hbase = nullptr; g_ar.cap = 0; g_ar.device = -1;
+    g_ar.base = nullptr; g_ar.hbase = nullptr; g_ar.hdev = nullptr; g_ar.cap = 0; g_ar.device = -1;
 }
 template <typename T> static T *arena_get(size_t count) {
     const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
@@ -732,7 +881,19 @@ static inline void arena_stage(void *dst, const void *src, size_t bytes) {
 // device -> pinned mirror (same offset); valid after the stream is synchronised
 template <typename T> static const T *arena_host(const T *dev) { return (const T *)(g_ar.hbase + ((const uint8_t *)dev - g_ar.base)); }
 #define DOWN(dev, count) ORBX_HIP(hipMemcpyAsync((void *)arena_host(dev), (dev), sizeof(*(dev)) * (size_t)(count), hipMemcpyDeviceToHost, st))
+// the pinned mirror of a device allocation as a kernel addresses it: results a kernel stores there are on the host when the stream
+// is synchronised (no copy command, no copy kernel: a call's download used to be two blit kernels of ~5 us each behind the resolver)
+template <typename T> static T *arena_hostdev(T *dev) { return (T *)(g_ar.hdev + ((uint8_t *)dev - g_ar.base)); }
 #define ORBX_FAST_FALLBACK 1  // positive: not an error, the caller runs the exact legacy kernel
+extern thread_local int t_matchResolver;   // ORBM_OPT_RESOLVER (orbx_match.hip)
+static inline bool use_resolve_par(int m, int n) { return t_matchResolver == 0 && m <= RP_T * RP_Q && n <= 30000; }
+static inline size_t resolve_par_lds(int n) { return sizeof(uint32_t) * ((size_t)n + (size_t)(n + 31) / 32); }
+#define RESOLVE_PAR_LAUNCH(MODE, ...)                                                                                     \
+    do {                                                                                                                  \
+        const size_t lds_ = resolve_par_lds(n);                                                                           \
+        if (lds_ > 48 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_resolve_par<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+        hipLaunchKernelGGL(k_resolve_par<MODE>, dim3(1), dim3(RP_T), lds_, st, __VA_ARGS__);                              \
+    } while (0)
 
 // Returns ORBX_OK (results written), ORBX_FAST_FALLBACK, or a negative error.
 int fast_search_for_initialization(const orbx_keypoint_t *k1, const uint8_t *d1, int n1, const orbx_keypoint_t *k2,
@@ -840,9 +1001,14 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
     hipLaunchKernelGGL(k_queries_mp, dim3((mx + 255) / 256), dim3(256), 0, st, dmp, m, dsf, th, dq, dfm,
                        ext_obs ? deo : (const int32_t *)nullptr, n, dsb);
     hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dmd, m, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
-    hipLaunchKernelGGL(k_resolve_mp, dim3(1), dim3(64), 2 * (size_t)((n + 15) & ~15), st, dkeys, dnc, dmp, m, n, dfm, nnratio, dout);
-    ORBX_HIP(hipGetLastError());
-    DOWN(dout, 2); DOWN(dfm, n);
+    if (use_resolve_par(m, n)) {   // results land in the pinned mirror straight from the kernel
+        RESOLVE_PAR_LAUNCH(0, dkeys, dnc, (const void *)dmp, dk, m, n, dfm, dfm, arena_hostdev(dfm), nnratio, 0, 0, dout, arena_hostdev(dout));
+        ORBX_HIP(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_resolve_mp, dim3(1), dim3(64), 2 * (size_t)((n + 15) & ~15), st, dkeys, dnc, dmp, m, n, dfm, nnratio, dout);
+        ORBX_HIP(hipGetLastError());
+        DOWN(dout, 2); DOWN(dfm, n);
+    }
     ORBX_HIP(hipStreamSynchronize(st));
     if (world && proj_out) memcpy(proj_out, arena_host(dmp), sizeof(orbm_mappoint_t) * (size_t)m);
     const int32_t *out = arena_host(dout);
@@ -884,10 +1050,15 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
     hipLaunchKernelGGL(k_queries_frame, dim3((mx + 255) / 256), dim3(256), 0, st, dl, nlast, dsf, *cam, *g, dT, dT + 16, th,
                        mono, dq, dcm, ext_obs ? deo : (const int32_t *)nullptr, n, dsb);
     hipLaunchKernelGGL(k_cand<false>, dim3((nlast + 3) / 4), dim3(256), 0, st, dq, dld, nlast, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
-    hipLaunchKernelGGL(k_resolve_frame, dim3(1), dim3(64), 2 * (size_t)((n + 15) & ~15), st, dkeys, dnc, dl, dk, nlast, n, dcm,
-                       dhi, dhb, check_ori, dout);
-    ORBX_HIP(hipGetLastError());
-    DOWN(dout, 2); DOWN(dcm, n);
+    if (use_resolve_par(nlast, n)) {
+        RESOLVE_PAR_LAUNCH(1, dkeys, dnc, (const void *)dl, dk, nlast, n, dcm, dcm, arena_hostdev(dcm), 0.0f, 0, check_ori, dout, arena_hostdev(dout));
+        ORBX_HIP(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_resolve_frame, dim3(1), dim3(64), 2 * (size_t)((n + 15) & ~15), st, dkeys, dnc, dl, dk, nlast, n, dcm,
+                           dhi, dhb, check_ori, dout);
+        ORBX_HIP(hipGetLastError());
+        DOWN(dout, 2); DOWN(dcm, n);
+    }
     ORBX_HIP(hipStreamSynchronize(st));
     const int32_t *out = arena_host(dout);
     if (out[1]) return ORBX_FAST_FALLBACK;
@@ -928,10 +1099,15 @@ int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const fl
     hipLaunchKernelGGL(k_queries_windows, dim3((mx + 255) / 256), dim3(256), 0, st, dw, m, dq, dh,
                        ext_blocks ? deb : (const int32_t *)nullptr, n, dsb);
     hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dqd, m, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
-    hipLaunchKernelGGL(k_resolve_windows, dim3(1), dim3(64), 2 * (size_t)((n + 15) & ~15), st, dkeys, dnc, dw, dk, m, n, dh, dhi,
-                       dhb, max_dist, check_ori, dout);
-    ORBX_HIP(hipGetLastError());
-    DOWN(dout, 2); DOWN(dh, n);
+    if (use_resolve_par(m, n)) {
+        RESOLVE_PAR_LAUNCH(2, dkeys, dnc, (const void *)dw, dk, m, n, dh, dh, arena_hostdev(dh), 0.0f, max_dist, check_ori, dout, arena_hostdev(dout));
+        ORBX_HIP(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_resolve_windows, dim3(1), dim3(64), 2 * (size_t)((n + 15) & ~15), st, dkeys, dnc, dw, dk, m, n, dh, dhi,
+                           dhb, max_dist, check_ori, dout);
+        ORBX_HIP(hipGetLastError());
+        DOWN(dout, 2); DOWN(dh, n);
+    }
     ORBX_HIP(hipStreamSynchronize(st));
     const int32_t *out = arena_host(dout);
     if (out[1]) return ORBX_FAST_FALLBACK;

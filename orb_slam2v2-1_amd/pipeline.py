@@ -61,7 +61,7 @@ def independent_stream(dev, busy, ncand=8):
 class FrontEnd:
     def __init__(self, w, h, nfeatures, stereo, B, device_index=0, nbuf=3, streams=1, world=1, gather=False,
                  gather_via_host=False, mbf=KITTI_BF, fx=KITTI_FX, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, prefetch=True, lag_stereo=True,
-                 stereo_late=None, gather_B=None, two_side=None, fast_alone=None):
+                 stereo_late=None, gather_B=None, two_side=None, fast_alone=None, force_gather=False):
         if not torch.cuda.is_available():
             raise RuntimeError("orb_slam2v2-1_amd.pipeline.FrontEnd needs a GPU: the HIP path has no CPU fallback")
         self.w, self.h, self.nf, self.stereo, self.B = w, h, nfeatures, stereo, B
@@ -110,7 +110,7 @@ class FrontEnd:
         self.d_imgs = None
         self.cap = None
         self.ring = None
-        self._ring_args = (max(nbuf, self.S), world, gather, gather_via_host, gather_B)
+        self._ring_args = (max(nbuf, self.S), world, gather, gather_via_host, gather_B, force_gather)
         self._hs = None                # host-streaming state (enable_host_streaming)
 
     def upload(self, left, right=None):
@@ -122,9 +122,9 @@ class FrontEnd:
         self.cap = self.ex.max_keypoints()
         self.d_imgs = torch.from_numpy(np.ascontiguousarray(imgs)).to(self.dev)
         self.d_sets = [self.d_imgs]
-        nbuf, world, gather, via_host, gB = self._ring_args
+        nbuf, world, gather, via_host, gB, force = self._ring_args
         self.ring = ResultRing(nbuf, self.B, self.nimg, self.cap, self.dev, world=world, gather=gather,
-                               blocking_via_host=via_host, gather_B=gB)
+                               blocking_via_host=via_host, gather_B=gB, force_gather=force)
         return self
 
     def upload_more(self, left, right=None):
@@ -151,6 +151,8 @@ class FrontEnd:
         self._pend = None
         main = self.streams[0]
         self.side.wait_stream(main)
+        if self.two_side:
+            self.side.wait_stream(self.side2)     # the matcher of the step before ran there and uses the same stereo scratch of the handle
         self._match(self.ex, j, self.side.cuda_stream)
         self._publish_side(j, step)
         main.wait_stream(self.side)
@@ -190,6 +192,9 @@ class FrontEnd:
         self.drain()
         self.late = False
         self._ev_late = None
+        # (the second side stream only exists in the late order: with it on and `late` off, nothing would order the pyramid built
+        # ahead on `side` behind the matcher on `side2` that still reads the buffer it overwrites)
+        self.two_side = False
         hs = type("HostStream", (), {})()
         hs.n = nimgbuf
         hs.d = [torch.empty((self.nimg, self.h, self.w), dtype=torch.uint8, device=self.dev) for _ in range(nimgbuf)]

@@ -76,13 +76,16 @@ def test_stereo_edge_cases(pkg, oracle, synth):
     assert n == 0 and (ur == -1).all() and (dp == -1).all()
 
 
-@pytest.fixture(params=["fast", "exact"])
+@pytest.fixture(params=["fast", "fast_wave", "exact"])
 def matcher_path(request, pkg):
-    """Both implementations of the guided searches: parallel candidates + speculative
-    resolution (default) and the exact one-workgroup kernels it falls back to."""
+    """The implementations of the guided searches: parallel candidates + the whole-workgroup fixed-point resolution (default,
+    round 5), parallel candidates + the single-wave speculative resolution (rounds 1-4), and the exact one-workgroup kernels
+    both fall back to."""
     pkg.lib().orbm_set_thread_option(2, 1 if request.param == "exact" else 0)
+    pkg.lib().orbm_set_thread_option(3, 1 if request.param == "fast_wave" else 0)
     yield request.param
     pkg.lib().orbm_set_thread_option(2, 0)
+    pkg.lib().orbm_set_thread_option(3, 0)
 
 
 def test_search_for_initialization(pkg, oracle, synth, matcher_path):
@@ -291,7 +294,7 @@ def test_match_windows_generic_paths_agree(pkg, oracle, synth, matcher_path):
     holder = np.full(n, -1, np.int32)
     pkg.lib().orbm_set_thread_option(2, 1)
     en, eh = pkg.match_windows(k, d, uright, pkg.grid_geom(w, h), q, qd, holder, None, 100, True)
-    pkg.lib().orbm_set_thread_option(2, 0 if matcher_path == "fast" else 1)
+    pkg.lib().orbm_set_thread_option(2, 1 if matcher_path == "exact" else 0)
     gn, gh = pkg.match_windows(k, d, uright, pkg.grid_geom(w, h), q, qd, holder, None, 100, True)
     assert gn == en > 100
     np.testing.assert_array_equal(gh, eh)
