@@ -152,12 +152,9 @@ int orbx_pyramid_host(orbx_extractor_t *h, int b, int level, int padded, uint8_t
 int orbx_pyramid_device(orbx_extractor_t *h, int b, int level, const uint8_t **d_ptr, int *w, int *hgt,
                         int *stride);
 
-/* Stage introspection for parity tests (not part of the reference API):
- * stage 0 = FAST candidates before the quad-tree (vToDistributeKeys order),
- * stage 1 = keypoints kept by DistributeOctTree (list order).
- * out: triples (x, y, score) int32, coordinates relative to minBorder (16,16). */
-int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, int stage, int32_t *out_xys, int cap,
-                            int *n_out);
+/* FAST candidates kept per level (what vToDistributeKeys holds, src/ORBextractor.cc:789-829) and keypoints DistributeOctTree returned
+ * per level for image slot b of the last call: candidates[nlevels], keypoints[nlevels] (either may be NULL).  Read-only statistics. */
+int orbx_level_counts(orbx_extractor_t *h, int b, int32_t *candidates, int32_t *keypoints);
 
 /* Per-stage GPU time in ms, measured with HIP events recorded on the launch stream around
  * each stage of every batch call while profiling is enabled (a ring of event sets, so no
@@ -231,6 +228,31 @@ int orbm_stereo_batch_device_prev(orbx_extractor_t *hl, orbx_extractor_t *hr, in
 int orbx_stereo_frame(orbx_extractor_t *h, const uint8_t *left, const uint8_t *right, int w, int hgt, int stride,
                       float mbf, float mb, int cap, orbx_keypoint_t *kl, uint8_t *dl, int *nl, orbx_keypoint_t *kr,
                       uint8_t *dr, int *nr, float *uright, float *depth, int *nmatch);
+
+/* The LATENCY form of the same call (round 5) - the shape the reference runs this path in: ONE stereo frame at a time, the next
+ * frame needing this one's pose (src/Tracking.cc:275 -> Frame::Frame, src/Frame.cc:61-120).  Nothing is copied by a copy command:
+ *  - left / right may be PINNED host memory (orbx_host_alloc, hipHostMalloc, hipHostRegister: the first kernel reads the pixels
+ *    over the bus itself), device memory, or ordinary pageable memory (then the call stages them through a pinned buffer of the
+ *    handle with one memcpy each - the price of a pageable cv::Mat; allocate capture buffers with orbx_host_alloc to avoid it);
+ *  - the results are one fixed-layout record per frame that the LAST kernel writes to pinned host memory of the handle; *view
+ *    points into it (host) and into the same record in HBM (d_*: what the device-resident matchers orbm_*_device take).
+ * The handle keeps TWO records and alternates: the view of a call stays valid until the call after the next one on the same
+ * handle (the previous frame's descriptors are what SearchByProjection(cur, last) reads, src/ORBmatcher.cc:1330-1472).
+ * Results are those of orbx_stereo_frame bit for bit.  Empty image: ORBX_OK, zero counts, pointers NULL.  Synchronous. */
+typedef struct {
+    int32_t nl, nr, nmatch, cap;              /* keypoints left / right, stereo matches, rows allocated per array */
+    const orbx_keypoint_t *kl, *kr;           /* host (pinned, owned by the handle) */
+    const uint8_t *dl, *dr;                   /* 32 B per keypoint */
+    const float *uright, *depth;              /* mvuRight, mvDepth of the left keypoints */
+    const orbx_keypoint_t *d_kl, *d_kr;       /* the same arrays in HBM */
+    const uint8_t *d_dl, *d_dr;
+    const float *d_uright, *d_depth;
+} orbx_stereo_view_t;
+int orbx_stereo_frame_view(orbx_extractor_t *h, const uint8_t *left, const uint8_t *right, int w, int hgt, int stride,
+                           float mbf, float mb, orbx_stereo_view_t *view);
+/* Pinned host memory for image / capture buffers (cv::Mat can wrap it: cv::Mat(rows, cols, CV_8UC1, ptr)); NULL on failure. */
+void *orbx_host_alloc(size_t bytes);
+void orbx_host_free(void *p);
 
 /* Host-buffer convenience for one frame (synchronous); pyramids come from hl / hr, which
  * must have just extracted the left / right image (image slot 0). */
@@ -429,7 +451,11 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  *   ORBX_OPT_DESC_LDS_PAD  21  KB of unused LDS per k_describe workgroup: fewer of them resident per CU, more wave slots for the
  *                              kernels of a neighbouring stream (tuning of the pipelined step; default 0)
  *   ORBX_OPT_PYR_ROWS      22  output rows per wave of k_pyr_level: 1 = always 8, 2 = always 16 (default: 16 while the level gives
- *                              every SIMD several waves, else 8)
+ *                              every SIMD several waves, else 8).  2 only pays up to scale factor 1.25: beyond it 16 output rows
+ *                              need more than the 22 source rows the form fetches and every band takes the row-by-row path
+ *                              (correct, much slower than the 8-row form)
+ *   ORBX_OPT_OCT_HIST      23  quad-tree input of batches of up to four images: 0 = the FAST stage histograms its emissions at the L2
+ *                              and k_octree_pyr loads the histogram (no key sweep on one CU: the latency form, default), 1 = never
  * Keys 0, 1 and 7 (stop a kernel after phase n: outputs incomplete) exist only in a library built with -DORBX_DEVELOPER
  * (tools/octree_phase_probe.py); the default build refuses them. */
 #define ORBX_OPT_PYR_TILE 3
@@ -450,6 +476,7 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
 #define ORBX_OPT_SPARSE_FORM 20
 #define ORBX_OPT_DESC_LDS_PAD 21
 #define ORBX_OPT_PYR_ROWS 22
+#define ORBX_OPT_OCT_HIST 23
 #define ORBX_NUM_OPTIONS 32
 int orbx_set_option(orbx_extractor_t *h, int key, int value);
 int orbx_get_option(const orbx_extractor_t *h, int key, int *value);
@@ -460,29 +487,8 @@ int orbx_get_option(const orbx_extractor_t *h, int key, int *value);
 #define ORBM_OPT_EXACT_KERNELS 2
 #define ORBM_OPT_RESOLVER 3
 int orbm_set_thread_option(int key, int value);
-/* Test hooks for two rows of the scope table that have no output of their own.
- * orbx_debug_blur_patches (a8, cv::GaussianBlur 7x7 sigma 2 - fused into the descriptor kernel, never stored): enable = 1, then
- * orbx_extract of ONE image with cap <= the handle's keypoint bound, then out != NULL fetches the 37x37 blurred block around each
- * of the first n keypoints (n * 1369 bytes, keypoint order); enable = 0 releases the buffer.
- * orbm_debug_features_in_area (a12, Frame::GetFeaturesInArea src/Frame.cc:342-395): the indices the query returns, in the
- * reference's order (column-major over grid cells, insertion order inside a cell) - the order every matcher's "first minimum
- * wins" depends on. */
-int orbx_debug_blur_patches(orbx_extractor_t *h, int enable, uint8_t *out, int n);
-/* Probe hook: out[b * nlevels + l] = 1 iff the quad-tree of level l of image b of the last call was redone by the exact form
- * (k_octree_pyr's count pyramid too shallow for it; results are the same, the level just took longer).  n <= B * nlevels. */
-int orbx_debug_octree_fallbacks(orbx_extractor_t *h, int32_t *out, int n);
-/* a8, the other form: levels whose keypoint budget makes per-keypoint blurring the more expensive way are blurred as a whole by
- * k_blur_levels and the descriptor kernel only gathers (src/ORBextractor.cc:1083-1090 does exactly this for every level).
- * *mask_out (may be NULL) = levels of the last call that took this form (bit l); dst != NULL fetches level `level` of image b
- * (inner ROI, dst_stride bytes per row) - ORBX_ERR_ARG when that level is not in the mask.  ORBX_OPT_BLUR_FORM (orbx_set_option):
- * 1 = no level, 2 = every level; ORBX_OPT_BLUR_THRESHOLD = the rule's threshold in percent (level-wide iff nfeatures_l * 37^2 * 100 >=
- * thr * w_l * h_l).  Results never depend on the form. */
-int orbx_debug_blurred_level(orbx_extractor_t *h, int b, int level, uint8_t *dst, int dst_stride, unsigned *mask_out);
-int orbm_debug_features_in_area(const orbx_keypoint_t *kun, int n, const orbm_grid_geom_t *g, float x, float y, float r,
-                                int min_level, int max_level, int32_t *out_idx, int *n_out, int device);
-/* Test hook: the device's restatement of libm cosf / sinf (the float overloads src/ORBextractor.cc:113 resolves to) on n
- * host angles in [0, 2 pi]; the descriptor kernel uses exactly this routine. */
-int orbx_debug_sincosf(const float *angles, int n, float *sin_out, float *cos_out, int device);
+/* The read-only stage hooks the staged parity tests look through (orbx_debug_* / orbm_debug_*) are NOT part of this library: they
+ * exist in the developer build only (liborbx_hip_dev.so, -DORBX_DEVELOPER) and are declared in include/orbx_dev.h. */
 
 /* ---- misc ---------------------------------------------------------------------------- */
 /* ---- DBoW2 vocabulary descent and the BoW-guided matchers.

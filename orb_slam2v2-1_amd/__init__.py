@@ -17,8 +17,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ORBX_LIB: another build of the same library (tools/: lib/liborbx_hip_dev.so, `python orb_slam2v2-1_amd/build.py --developer`)
+# The PRODUCT library (no test hooks), and the DEVELOPER build of the same sources (-DORBX_DEVELOPER: + the read-only stage hooks of
+# include/orbx_dev.h, + the phase-stop / time-stamp option keys of the probes in tools/).  ORBX_LIB names another file for the first.
 LIB_PATH = os.environ.get("ORBX_LIB") or os.path.join(_HERE, "lib", "liborbx_hip.so")
+DEV_LIB_PATH = os.path.join(_HERE, "lib", "liborbx_hip_dev.so")
+# extractors created while this is True come from the developer build (tests that look at intermediate stages: `hooks` fixture)
+default_developer = False
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
@@ -36,22 +40,34 @@ NUM_STAGES = 5
 EXPORTS = [
     "orbx_create", "orbx_destroy", "orbx_get_levels", "orbx_get_scale_factor", "orbx_get_tables",
     "orbx_max_keypoints", "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_device",
-    "orbx_pyramid_host", "orbx_pyramid_device", "orbx_debug_level_points", "orbx_set_profiling",
+    "orbx_pyramid_host", "orbx_pyramid_device", "orbx_level_counts", "orbx_set_profiling",
     "orbx_get_stage_ms", "orbx_create_flavoured", "orbx_get_flavour", "orbx_set_option", "orbx_get_option", "orbm_set_thread_option", "orbm_hamming", "orbm_hamming_matrix_device", "orbm_stereo_batch_device",
     "orbm_stereo", "orbm_search_for_initialization", "orbm_search_by_projection_mp",
     "orbm_search_by_projection_frame", "orbm_match_windows", "orbm_best_in_windows", "orbm_distinctive_descriptors", "orbm_predict_scale_thresholds", "orbm_is_in_frustum",
     "orbm_search_local_points", "orbv_create", "orbv_load_text", "orbv_destroy", "orbv_info", "orbv_transform",
     "orbm_search_by_bow", "orbm_search_for_triangulation", "orbx_last_error", "orbx_version", "orbx_device_count",
-    "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch", "orbx_debug_sincosf",
-    "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels", "orbx_extract_batch_device_prefetch", "orbx_stream_wait_fast_stage", "orbx_side_stream", "orbm_stereo_batch_device_prev", "orbx_debug_blur_patches", "orbm_debug_features_in_area",
-    "orbx_debug_blurred_level", "orbx_debug_octree_fallbacks", "orbx_side_stream_for", "orbx_stereo_frame", "orbx_set_pyramid_buffers",
+    "orbx_record_bytes", "orbx_pack_records_device", "orbx_thread_release_scratch",
+    "orbm_search_by_projection_frame_device", "orbm_search_local_points_device", "orbx_fast_kernels", "orbx_extract_batch_device_prefetch", "orbx_stream_wait_fast_stage", "orbx_side_stream", "orbm_stereo_batch_device_prev",
+    "orbx_side_stream_for", "orbx_stereo_frame", "orbx_set_pyramid_buffers",
+    "orbx_stereo_frame_view", "orbx_host_alloc", "orbx_host_free",
 ]
+# what include/orbx_dev.h declares on top: exported by the developer build only
+DEV_EXPORTS = ["orbx_debug_level_points", "orbx_debug_sincosf", "orbx_debug_blur_patches", "orbm_debug_features_in_area",
+               "orbx_debug_blurred_level", "orbx_debug_octree_fallbacks"]
 
 
 class OrbxError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__("orbx status %d: %s" % (status, msg))
         self.status = status
+
+
+class StereoView(C.Structure):
+    """orbx_stereo_view_t (orbx_stereo_frame_view)."""
+    _fields_ = [("nl", C.c_int32), ("nr", C.c_int32), ("nmatch", C.c_int32), ("cap", C.c_int32),
+                ("kl", C.c_void_p), ("kr", C.c_void_p), ("dl", C.c_void_p), ("dr", C.c_void_p), ("uright", C.c_void_p), ("depth", C.c_void_p),
+                ("d_kl", C.c_void_p), ("d_kr", C.c_void_p), ("d_dl", C.c_void_p), ("d_dr", C.c_void_p), ("d_uright", C.c_void_p),
+                ("d_depth", C.c_void_p)]
 
 
 class GridGeom(C.Structure):
@@ -102,6 +118,7 @@ def set_default_option(key, value):
 
 
 _lib = None
+_dev_lib = None
 
 
 def build(force=False):
@@ -132,16 +149,24 @@ def _preload_shared_hip_runtime():
                 pass
 
 
-def lib():
-    """Load the HIP library; fails loudly when it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def lib(developer=False):
+    """Load the HIP library (developer = True: the developer build with the stage hooks); fails loudly when it has not been built."""
+    global _lib, _dev_lib
+    if developer:
+        if _dev_lib is None:
+            _dev_lib = _load(DEV_LIB_PATH, True)
+        return _dev_lib
+    if _lib is None:
+        _lib = _load(LIB_PATH, os.path.basename(LIB_PATH) == "liborbx_hip_dev.so")
+    return _lib
+
+
+def _load(path, dev):
+    if not os.path.exists(path):
         raise OrbxError(ORBX_ERR_NO_DEVICE, "HIP library %s is missing: run `python __graft_entry__.py` "
-                                            "(build()) first; there is no CPU fallback" % LIB_PATH)
+                                            "(build()) first; there is no CPU fallback" % path)
     _preload_shared_hip_runtime()
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     L.orbx_create.restype = i32
     L.orbx_create.argtypes = [i32, f32, i32, i32, i32, i32, C.POINTER(vp)]
@@ -165,12 +190,17 @@ def lib():
     L.orbx_side_stream.restype = vp
     L.orbx_stereo_frame.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, C.POINTER(i32), vp, vp, C.POINTER(i32), vp, vp,
                                     C.POINTER(i32)]
+    L.orbx_stereo_frame_view.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, vp]
+    L.orbx_host_alloc.argtypes = [sz]
+    L.orbx_host_alloc.restype = vp
+    L.orbx_host_free.argtypes = [vp]
+    L.orbx_host_free.restype = None
     L.orbx_set_pyramid_buffers.argtypes = [vp, i32]
     L.orbx_side_stream_for.argtypes = [vp, vp]
     L.orbx_side_stream_for.restype = vp
     L.orbx_pyramid_host.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.orbx_pyramid_device.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
-    L.orbx_debug_level_points.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
+    L.orbx_level_counts.argtypes = [vp, i32, vp, vp]
     L.orbx_set_profiling.argtypes = [vp, i32]
     L.orbx_fast_kernels.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.orbx_record_bytes.argtypes = [i32]
@@ -205,23 +235,22 @@ def lib():
                                            vp, vp, vp, f32, f32, i32, C.POINTER(i32), vp]
     L.orbm_search_local_points_device.argtypes = L.orbm_search_local_points.argtypes + [vp]
     L.orbm_best_in_windows.argtypes = [vp, vp, vp, i32, C.POINTER(GridGeom), C.POINTER(GridGeom), vp, vp, i32, vp, i32, vp, vp, i32]
-    L.orbx_debug_sincosf.argtypes = [vp, i32, vp, vp, i32]
-    L.orbx_debug_blur_patches.argtypes = [vp, i32, vp, i32]
-    L.orbx_debug_octree_fallbacks.argtypes = [vp, vp, i32]
-    L.orbx_debug_blurred_level.argtypes = [vp, i32, i32, vp, i32, vp]
-    L.orbm_debug_features_in_area.argtypes = [vp, i32, C.POINTER(GridGeom), f32, f32, f32, i32, i32, vp, C.POINTER(i32), i32]
+    if dev:
+        L.orbx_debug_level_points.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
+        L.orbx_debug_sincosf.argtypes = [vp, i32, vp, vp, i32]
+        L.orbx_debug_blur_patches.argtypes = [vp, i32, vp, i32]
+        L.orbx_debug_octree_fallbacks.argtypes = [vp, vp, i32]
+        L.orbx_debug_blurred_level.argtypes = [vp, i32, i32, vp, i32, vp]
+        L.orbm_debug_features_in_area.argtypes = [vp, i32, C.POINTER(GridGeom), f32, f32, f32, i32, i32, vp, C.POINTER(i32), i32]
     L.orbx_last_error.restype = C.c_char_p
     L.orbx_version.restype = C.c_char_p
-    for name in EXPORTS:
-        if getattr(L, name).restype is C.c_int:
-            pass
-    _lib = L
+    L._orbx_developer = bool(dev)
     return L
 
 
-def _check(rc):
+def _check(rc, L=None):
     if rc != 0:
-        raise OrbxError(rc, lib().orbx_last_error().decode())
+        raise OrbxError(rc, (L or lib()).orbx_last_error().decode())
 
 
 def _p(a):
@@ -249,15 +278,16 @@ class ORBextractor:
     argument of the reference is ignored there (src/ORBextractor.cc:1043) and absent here.
     """
 
-    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device=0, gauss=None):
-        """gauss: "half_up" / "sse2" = orbx_flavour_t.gauss_rounding (include/orbx.h); None = default_gauss_flavour."""
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device=0, gauss=None, developer=None):
+        """gauss: "half_up" / "sse2" = orbx_flavour_t.gauss_rounding (include/orbx.h); None = default_gauss_flavour.
+        developer: True = this handle lives in the developer build of the library (stage hooks debug_*); None = default_developer."""
         global _live
-        self._L = lib()
+        self._L = lib(default_developer if developer is None else developer)
         h = C.c_void_p()
         self.gauss = default_gauss_flavour if gauss is None else gauss
         fl = Flavour()
         fl.gauss_rounding = GAUSS_FLAVOURS[self.gauss]
-        _check(self._L.orbx_create_flavoured(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST),
+        self._ck(self._L.orbx_create_flavoured(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST),
                                              int(minThFAST), int(device), C.byref(fl), C.byref(h)))
         self._h = h
         self.nfeatures, self.nlevels, self.device = int(nfeatures), int(nlevels), int(device)
@@ -269,18 +299,31 @@ class ORBextractor:
         for k, v in _default_options.items():
             self.set_option(k, v)
 
+    def _ck(self, rc):
+        _check(rc, self._L)
+
+    def _hooks(self):
+        if not self._L._orbx_developer:
+            raise OrbxError(ORBX_ERR_ARG, "stage hooks (debug_*) exist in the developer build only: ORBextractor(..., developer=True)")
+
+    def level_counts(self, b=0):
+        """(FAST candidates per level, keypoints kept per level) of image slot b of the last call (orbx_level_counts)."""
+        c, k = np.zeros(self.nlevels, np.int32), np.zeros(self.nlevels, np.int32)
+        self._ck(self._L.orbx_level_counts(self._h, int(b), _p(c), _p(k)))
+        return c, k
+
     def set_option(self, key, value):
         """orbx_set_option: per-handle choice among kernels / arrangements with identical results (ORBX_OPT_* of include/orbx.h)."""
-        _check(self._L.orbx_set_option(self._h, int(key), int(value)))
+        self._ck(self._L.orbx_set_option(self._h, int(key), int(value)))
 
     def get_option(self, key):
         v = C.c_int(0)
-        _check(self._L.orbx_get_option(self._h, int(key), C.byref(v)))
+        self._ck(self._L.orbx_get_option(self._h, int(key), C.byref(v)))
         return v.value
 
     def flavour(self):
         fl = Flavour()
-        _check(self._L.orbx_get_flavour(self._h, C.byref(fl)))
+        self._ck(self._L.orbx_get_flavour(self._h, C.byref(fl)))
         return {v: k for k, v in GAUSS_FLAVOURS.items()}[fl.gauss_rounding]
 
     def close(self):
@@ -304,7 +347,7 @@ class ORBextractor:
     def _tables(self):
         n = self.nlevels
         t = [np.zeros(n, np.float32) for _ in range(4)] + [np.zeros(n, np.int32), np.zeros(16, np.int32)]
-        _check(self._L.orbx_get_tables(self._h, *[_p(a) for a in t]))
+        self._ck(self._L.orbx_get_tables(self._h, *[_p(a) for a in t]))
         return t
 
     def GetScaleFactors(self): return self._tables()[0]
@@ -332,7 +375,7 @@ class ORBextractor:
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int(0)
-        _check(self._L.orbx_extract(self._h, _p(image), w, h, image.strides[0], _p(kps), _p(desc), cap, C.byref(n)))
+        self._ck(self._L.orbx_extract(self._h, _p(image), w, h, image.strides[0], _p(kps), _p(desc), cap, C.byref(n)))
         self._shape = (h, w)
         return kps[:n.value].copy(), desc[:n.value].copy()
 
@@ -345,19 +388,19 @@ class ORBextractor:
         desc = np.zeros((B, cap, 32), np.uint8)
         n = np.zeros(B, np.int32)
         ptrs = (C.c_void_p * B)(*[images[b].ctypes.data for b in range(B)])
-        _check(self._L.orbx_extract_batch(self._h, C.cast(ptrs, C.c_void_p), B, w, h, w, _p(kps), _p(desc), cap, _p(n)))
+        self._ck(self._L.orbx_extract_batch(self._h, C.cast(ptrs, C.c_void_p), B, w, h, w, _p(kps), _p(desc), cap, _p(n)))
         self._shape = (h, w)
         return [(kps[b, :n[b]].copy(), desc[b, :n[b]].copy()) for b in range(B)]
 
     def extract_batch_device(self, d_imgs, B, w, h, stride, image_stride, d_kps, d_desc, d_counts, cap, stream=0):
         """Device-resident batched mode; all d_* are raw device pointers (ints)."""
-        _check(self._L.orbx_extract_batch_device(self._h, d_imgs, B, w, h, stride, image_stride, d_kps, d_desc,
+        self._ck(self._L.orbx_extract_batch_device(self._h, d_imgs, B, w, h, stride, image_stride, d_kps, d_desc,
                                                  d_counts, cap, stream))
         self._shape = (h, w)
 
     def prefetch_batch_device(self, d_imgs, B, w, h, stride, image_stride, side_stream=0):
         """Start the pyramid of the NEXT batch now (orbx_extract_batch_device_prefetch): the images must be complete in HBM."""
-        _check(self._L.orbx_extract_batch_device_prefetch(self._h, d_imgs, B, w, h, stride, image_stride, side_stream))
+        self._ck(self._L.orbx_extract_batch_device_prefetch(self._h, d_imgs, B, w, h, stride, image_stride, side_stream))
 
     def side_stream(self):
         """hipStream_t of the handle's own side stream (orbx_side_stream)."""
@@ -373,16 +416,40 @@ class ORBextractor:
         dl, dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
         ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
         nl, nr, nm = C.c_int(), C.c_int(), C.c_int()
-        _check(self._L.orbx_stereo_frame(self._h, _p(left), _p(right), w, hgt, w, float(mbf), float(mb), cap, _p(kl), _p(dl), C.byref(nl),
+        self._ck(self._L.orbx_stereo_frame(self._h, _p(left), _p(right), w, hgt, w, float(mbf), float(mb), cap, _p(kl), _p(dl), C.byref(nl),
                                          _p(kr), _p(dr), C.byref(nr), _p(ur), _p(dp), C.byref(nm)))
         self._shape = (hgt, w)
         a, b = nl.value, nr.value
         return {"kl": kl[:a].copy(), "dl": dl[:a].copy(), "kr": kr[:b].copy(), "dr": dr[:b].copy(), "uright": ur[:a].copy(),
                 "depth": dp[:a].copy(), "nmatch": nm.value}
 
+    def stereo_frame_view(self, left, right, mbf, mb, shape=None):
+        """The latency form of stereo_frame (orbx_stereo_frame_view): no copy commands, results in the handle's pinned record.
+        left / right: uint8 numpy arrays [h, w] (pageable: staged by the call), or objects with data_ptr() (torch tensors - pinned
+        host or device memory), or raw addresses (then shape = (h, w)).  Returns dict(kl, dl, kr, dr, uright, depth, nmatch, view):
+        numpy VIEWS of the pinned record (valid until the call after the next one on this handle) and the StereoView with the
+        device pointers (d_kl, d_dl, d_uright, ...)."""
+        def addr(a):
+            if isinstance(a, int):
+                return a, None
+            if hasattr(a, "data_ptr"):
+                return a.data_ptr(), tuple(a.shape)
+            a = np.ascontiguousarray(a, np.uint8)
+            return a.ctypes.data, a.shape, a
+        la, ra = addr(left), addr(right)
+        hgt, w = shape if shape is not None else la[1]
+        v = StereoView()
+        self._ck(self._L.orbx_stereo_frame_view(self._h, la[0], ra[0], w, hgt, w, float(mbf), float(mb), C.byref(v)))
+        self._shape = (hgt, w)
+        a, b = v.nl, v.nr
+        view = lambda p, n, dt: np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(p), dt) if n > 0 else np.zeros(0, dt)
+        return {"kl": view(v.kl, a, KP_DTYPE), "dl": view(v.dl, a * 32, np.uint8).reshape(a, 32), "kr": view(v.kr, b, KP_DTYPE),
+                "dr": view(v.dr, b * 32, np.uint8).reshape(b, 32), "uright": view(v.uright, a, np.float32),
+                "depth": view(v.depth, a, np.float32), "nmatch": v.nmatch, "view": v}
+
     def set_pyramid_buffers(self, n):
         """2 (default) or 3 pyramid buffers (orbx_set_pyramid_buffers)."""
-        _check(self._L.orbx_set_pyramid_buffers(self._h, int(n)))
+        self._ck(self._L.orbx_set_pyramid_buffers(self._h, int(n)))
 
     def side_stream_for(self, main_stream):
         """The side stream, probed (and replaced if need be) so that it does not share a hardware queue with main_stream."""
@@ -390,14 +457,14 @@ class ORBextractor:
 
     def stream_wait_fast_stage(self, stream):
         """Order `stream` behind the FAST stage of the last extraction call (orbx_stream_wait_fast_stage)."""
-        _check(self._L.orbx_stream_wait_fast_stage(self._h, stream))
+        self._ck(self._L.orbx_stream_wait_fast_stage(self._h, stream))
 
     # -- mvImagePyramid (include/ORBextractor.h:85)
     def pyramid_level(self, level, b=0, padded=False):
         w, h = C.c_int(), C.c_int()
-        _check(self._L.orbx_pyramid_host(self._h, b, level, int(padded), None, 0, C.byref(w), C.byref(h)))
+        self._ck(self._L.orbx_pyramid_host(self._h, b, level, int(padded), None, 0, C.byref(w), C.byref(h)))
         out = np.zeros((h.value, w.value), np.uint8)
-        _check(self._L.orbx_pyramid_host(self._h, b, level, int(padded), _p(out), w.value, C.byref(w), C.byref(h)))
+        self._ck(self._L.orbx_pyramid_host(self._h, b, level, int(padded), _p(out), w.value, C.byref(w), C.byref(h)))
         return out
 
     @property
@@ -406,66 +473,70 @@ class ORBextractor:
 
     def pyramid_device(self, level, b=0):
         ptr, w, h, s = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
-        _check(self._L.orbx_pyramid_device(self._h, b, level, C.byref(ptr), C.byref(w), C.byref(h), C.byref(s)))
+        self._ck(self._L.orbx_pyramid_device(self._h, b, level, C.byref(ptr), C.byref(w), C.byref(h), C.byref(s)))
         return ptr.value, w.value, h.value, s.value
 
     # -- test / profiling hooks
     def debug_level_points(self, level, stage, b=0):
+        self._hooks()
         n = C.c_int()
-        _check(self._L.orbx_debug_level_points(self._h, b, level, stage, None, 0, C.byref(n)))
+        self._ck(self._L.orbx_debug_level_points(self._h, b, level, stage, None, 0, C.byref(n)))
         out = np.zeros((max(n.value, 1), 3), np.int32)
         if n.value:
-            _check(self._L.orbx_debug_level_points(self._h, b, level, stage, _p(out), n.value, C.byref(n)))
+            self._ck(self._L.orbx_debug_level_points(self._h, b, level, stage, _p(out), n.value, C.byref(n)))
         return out[:n.value]
 
     def fast_kernels(self, B):
         """names of the FAST kernel(s) a batch of B images of the planned size runs"""
         st, ce, ipl = C.c_int(0), C.c_int(0), C.c_int(0)
-        _check(self._L.orbx_fast_kernels(self._h, int(B), C.byref(st), C.byref(ce), C.byref(ipl)))
+        self._ck(self._L.orbx_fast_kernels(self._h, int(B), C.byref(st), C.byref(ce), C.byref(ipl)))
         self.fast_images_per_launch = ipl.value
         return [n for n, f in (("k_fast_strips", st.value), ("k_fast_cells", ce.value)) if f]
 
     def octree_fallbacks(self, B=1):
         """[B, nlevels] int32: 1 where the last call's quad-tree of that (image, level) was redone by the exact form."""
+        self._hooks()
         out = np.zeros((B, self.nlevels), np.int32)
-        _check(self._L.orbx_debug_octree_fallbacks(self._h, _p(out), B * self.nlevels))
+        self._ck(self._L.orbx_debug_octree_fallbacks(self._h, _p(out), B * self.nlevels))
         return out
 
     def blurred_mask(self):
         """Levels of the last call that were blurred as a whole by k_blur_levels (bit l)."""
         m = C.c_uint()
-        _check(self._L.orbx_debug_blurred_level(self._h, 0, 0, None, 0, C.byref(m)))
+        self._ck(self._L.orbx_debug_blurred_level(self._h, 0, 0, None, 0, C.byref(m)))
         return m.value
 
     def blurred_level(self, level, b=0):
         """Level `level` of image b after GaussianBlur(7x7, sigma 2) as k_blur_levels wrote it (levels in blurred_mask())."""
+        self._hooks()
         w, h = C.c_int(), C.c_int()
-        _check(self._L.orbx_pyramid_host(self._h, b, level, 0, None, 0, C.byref(w), C.byref(h)))
+        self._ck(self._L.orbx_pyramid_host(self._h, b, level, 0, None, 0, C.byref(w), C.byref(h)))
         out = np.zeros((h.value, w.value), np.uint8)
-        _check(self._L.orbx_debug_blurred_level(self._h, b, level, _p(out), w.value, None))
+        self._ck(self._L.orbx_debug_blurred_level(self._h, b, level, _p(out), w.value, None))
         return out
 
     def debug_blur_patches(self, image):
         """Test hook: extract one image and also return the 37x37 blurred block around every keypoint [N,37,37]."""
-        _check(self._L.orbx_debug_blur_patches(self._h, 1, None, 0))
+        self._hooks()
+        self._ck(self._L.orbx_debug_blur_patches(self._h, 1, None, 0))
         try:
             k, d = self(image)
             out = np.zeros((max(len(k), 1), 37, 37), np.uint8)
             if len(k):
-                _check(self._L.orbx_debug_blur_patches(self._h, 1, _p(out), len(k)))
+                self._ck(self._L.orbx_debug_blur_patches(self._h, 1, _p(out), len(k)))
         finally:
             self._L.orbx_debug_blur_patches(self._h, 0, None, 0)
         return k, d, out[:len(k)]
 
     def set_profiling(self, mode=1):
         """0/False off, 1/True events at every stage boundary, 2 only around k_fast_cells (see orbx.h)."""
-        _check(self._L.orbx_set_profiling(self._h, int(mode)))
+        self._ck(self._L.orbx_set_profiling(self._h, int(mode)))
 
     def stage_ms(self):
         """(average ms per call [pyramid, FAST, quad-tree, describe, total], calls averaged)"""
         ms = np.zeros(NUM_STAGES, np.float32)
         n = C.c_int(0)
-        _check(self._L.orbx_get_stage_ms(self._h, _p(ms), C.byref(n)))
+        self._ck(self._L.orbx_get_stage_ms(self._h, _p(ms), C.byref(n)))
         return ms, n.value
 
 
@@ -474,8 +545,8 @@ def debug_features_in_area(kun, geom, x, y, r, min_level=-1, max_level=-1, devic
     kun = np.ascontiguousarray(kun, KP_DTYPE)
     out = np.zeros(max(len(kun), 1), np.int32)
     n = C.c_int(0)
-    _check(lib().orbm_debug_features_in_area(_p(kun), len(kun), C.byref(geom), float(x), float(y), float(r), int(min_level),
-                                             int(max_level), _p(out), C.byref(n), int(device)))
+    _check(lib(True).orbm_debug_features_in_area(_p(kun), len(kun), C.byref(geom), float(x), float(y), float(r), int(min_level),
+                                             int(max_level), _p(out), C.byref(n), int(device)), lib(True))
     return out[:n.value].copy()
 
 
@@ -483,7 +554,7 @@ def debug_sincosf(angles, device=0):
     """Test hook: the device's cosf / sinf restatement -> (sin, cos) float32 arrays."""
     a = np.ascontiguousarray(angles, np.float32)
     s, c = np.zeros_like(a), np.zeros_like(a)
-    _check(lib().orbx_debug_sincosf(_p(a), len(a), _p(s), _p(c), int(device)))
+    _check(lib(True).orbx_debug_sincosf(_p(a), len(a), _p(s), _p(c), int(device)), lib(True))
     return s, c
 
 
@@ -694,11 +765,11 @@ class Vocabulary:
         self._L = lib()
         h = C.c_void_p()
         if path is not None:
-            _check(self._L.orbv_load_text(str(path).encode(), int(device), C.byref(h)))
+            self._ck(self._L.orbv_load_text(str(path).encode(), int(device), C.byref(h)))
         else:
             parent = np.ascontiguousarray(parent, np.int32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
             desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); weight = np.ascontiguousarray(weight, np.float64)
-            _check(self._L.orbv_create(int(k), int(L), int(scoring), int(weighting), len(parent), _p(parent), _p(is_leaf), _p(desc),
+            self._ck(self._L.orbv_create(int(k), int(L), int(scoring), int(weighting), len(parent), _p(parent), _p(is_leaf), _p(desc),
                                        _p(weight), int(device), C.byref(h)))
         self._h = h
 
@@ -709,7 +780,7 @@ class Vocabulary:
 
     def info(self):
         v = [C.c_int(0) for _ in range(6)]
-        _check(self._L.orbv_info(self._h, *[C.byref(x) for x in v]))
+        self._ck(self._L.orbv_info(self._h, *[C.byref(x) for x in v]))
         return dict(zip(("k", "L", "scoring", "weighting", "nnodes", "nwords"), [x.value for x in v]))
 
     def transform(self, desc, levelsup=4):
@@ -717,7 +788,7 @@ class Vocabulary:
         d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
         n = len(d)
         w = np.zeros(n, np.int32); nid = np.zeros(n, np.int32); wt = np.zeros(n, np.float64)
-        _check(self._L.orbv_transform(self._h, _p(d), n, int(levelsup), _p(w), _p(nid), _p(wt)))
+        self._ck(self._L.orbv_transform(self._h, _p(d), n, int(levelsup), _p(w), _p(nid), _p(wt)))
         return w, nid, wt
 
 

@@ -658,6 +658,8 @@ ORBX_DESC_INSTANCE(ORBX_GAUSS_ROUND_HALF_UP, true)
 ORBX_DESC_INSTANCE(ORBX_GAUSS_ROUND_SSE2, false)
 ORBX_DESC_INSTANCE(ORBX_GAUSS_ROUND_SSE2, true)
 
+#ifdef ORBX_DEVELOPER
+#include "orbx_dev.h"
 // ---- test hook: the device's cosf / sinf restatement on an array of angles (tests compare it with the oracle's and with
 // the host libm over the whole angle domain; a descriptor only ever exercises the angles its keypoints happen to have)
 __global__ __launch_bounds__(256) void k_debug_sincosf(const float *__restrict__ a, int n, float *__restrict__ s, float *__restrict__ c) {
@@ -684,3 +686,4 @@ extern "C" int orbx_debug_sincosf(const float *angles, int n, float *sin_out, fl
     ORBX_HIP(e);
     return ORBX_OK;
 }
+#endif   // ORBX_DEVELOPER

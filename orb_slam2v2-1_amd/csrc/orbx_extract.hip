@@ -9,6 +9,9 @@
 // Integer / bitwise work: no MFMA.  Build with -ffp-contract=off (the float expressions of
 // the reference are evaluated operation by operation).
 #include "orbx_extract_dev.h"
+#ifdef ORBX_DEVELOPER
+#include "orbx_dev.h"
+#endif
 #include <math.h>
 #include <float.h>
 #include <stdarg.h>
@@ -45,7 +48,7 @@ extern "C" int orbx_thread_release_scratch(void) {
 // in a developer build (-DORBX_DEVELOPER).
 extern "C" int orbx_set_option(orbx_extractor_t *h, int key, int value) {
     static const signed char maxv[ORBX_NUM_OPTIONS] = {/*0*/ -1, -1, -2, 64, 3, 3, 3, -1, ORBX_MAX_CHUNKS, 1, 2, 2, 1, 2, 127, ORBX_MAX_LEVELS,
-                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, 2, -2, -2, -2, -2, -2, -2, -2, -2, -2};
+                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, 2, 1, -2, -2, -2, -2, -2, -2, -2, -2};
     if (!h || key < 0 || key >= ORBX_NUM_OPTIONS || maxv[key] == -2) { orbx_set_error("orbx_set_option: unknown key %d", key); return ORBX_ERR_ARG; }
 #ifdef ORBX_DEVELOPER
     if (maxv[key] == -1) { if (value < 0) return ORBX_ERR_ARG; h->opt[key] = value; return ORBX_OK; }
@@ -142,7 +145,7 @@ extern "C" int orbx_create_flavoured(int nfeatures, float scale_factor, int nlev
     ORBX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     // host-mapped word the quad-tree kernels store a call's sequence number into when they flag a corner-sparse level (launch_chunk)
     ORBX_HIP(hipHostMalloc((void **)&h->h_sparseSeen, sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
-    *h->h_sparseSeen = -(1 << 30);
+    *h->h_sparseSeen = (int32_t)0xC0000000u;   // far behind call 0 in unsigned distance
     ORBX_HIP(hipHostGetDevicePointer((void **)&h->d_sparseSeen, h->h_sparseSeen, 0));
     for (int i = 0; i < ORBX_SIDE_STREAMS; i++) {
         ORBX_HIP(hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
@@ -174,6 +177,7 @@ static void free_plan(orbx_extractor *h) {
     hipFree(h->d_geom); hipFree(h->d_tab); hipFree(h->d_pyr); hipFree(h->d_cellCnt); hipFree(h->d_slots);
     hipFree(h->d_cand); hipFree(h->d_lvlKp); hipFree(h->d_nodeOf); hipFree(h->d_candCnt); hipFree(h->d_lvlCnt);
     hipFree(h->d_sparse); h->d_sparse = nullptr;
+    hipFree(h->d_histCnt); hipFree(h->d_histBest); h->d_histCnt = h->d_histBest = nullptr;
     h->d_geom = nullptr; h->d_tab = nullptr; h->d_pyr = nullptr; h->d_cellCnt = nullptr; h->d_slots = nullptr;
     h->d_cand = nullptr; h->d_lvlKp = nullptr; h->d_nodeOf = nullptr; h->d_candCnt = nullptr; h->d_lvlCnt = nullptr;
     h->pw = h->ph = h->pB = 0;
@@ -189,6 +193,8 @@ extern "C" int orbx_destroy(orbx_extractor_t *h) {
     free_plan(h);
     hipFree(h->d_in); hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_counts); hipFree(h->d_dbgBlur);
     hipFree(h->d_sfr); if (h->h_sfr) hipHostFree(h->h_sfr);
+    for (int i = 0; i < 2; i++) { hipFree(h->fv_d[i]); if (h->fv_h[i]) hipHostFree(h->fv_h[i]); }
+    if (h->fv_stage) hipHostFree(h->fv_stage);
     if (h->h_sparseSeen) hipHostFree(h->h_sparseSeen);
     if (h->h_kps) { hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); }
     for (int r = 0; r < ORBX_EV_RING; r++)
@@ -517,6 +523,16 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
     ORBX_HIP(hipMalloc(&h->d_lvlKp, sizeof(uint32_t) * (size_t)h->lvlKpCap * Bz));
     ORBX_HIP(hipMalloc(&h->d_octFallback, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
     ORBX_HIP(hipMemset(h->d_octFallback, 0, sizeof(int32_t) * ORBX_MAX_LEVELS * Bz));
+    {   // small batches: the quad-tree's deepest-depth histogram, filled by the FAST stage (FastHist) - 4 image slots
+        int maxDeep = 0;
+        for (int l = 0; l < h->nlevels; l++) maxDeep = std::max(maxDeep, h->geom[l].nIni << (2 * h->geom[l].pyrDepth));
+        h->histStride = (maxDeep + 3) & ~3;
+        const size_t words = (size_t)ORBX_HIST_IMAGES * h->nlevels * h->histStride;
+        ORBX_HIP(hipMalloc(&h->d_histCnt, sizeof(uint32_t) * words));
+        ORBX_HIP(hipMalloc(&h->d_histBest, sizeof(uint32_t) * words));
+        ORBX_HIP(hipMemset(h->d_histCnt, 0, sizeof(uint32_t) * words));
+        ORBX_HIP(hipMemset(h->d_histBest, 0, sizeof(uint32_t) * words));
+    }
     h->octBigMask = bigMask; h->octDeepMax = maxDeepWords;
     {
         const size_t slots = Bz * h->nlevels;
@@ -642,7 +658,7 @@ static void launch_pyramid(orbx_extractor *h, const uint8_t *d_imgs, uint8_t *py
     for (int l = 1; l <= lastSingle; l++) {
         // 16 output rows per wave while that still leaves every SIMD several waves (8192 = 8 per SIMD), else 8; same pixels either way
         const int nxc = (h->geom[l].w + 1 + 127) / 128, nb16 = (h->geom[l].h + 15) / 16, nb8 = (h->geom[l].h + 7) / 8;
-        const bool tall = h->opt[22] == 0 ? (size_t)nxc * nb16 * B >= 8192 && h->scale_factor <= 1.25f : h->opt[22] == 2;
+        const bool tall = h->scale_factor <= 1.25f && (h->opt[22] == 0 ? (size_t)nxc * nb16 * B >= 8192 : h->opt[22] == 2);   // (beyond 1.25 the 16-row form cannot cover a band from 22 source rows)
         if (tall)
             hipLaunchKernelGGL((k_pyr_level<16, 22>), dim3((nxc * nb16 + 3) / 4, B), dim3(256), 0, st, pyr, h->pyrImgBytes, h->d_geom, l, h->d_tab, nxc, nb16);
         else
@@ -708,7 +724,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     // Fused: k_octree_pyr reads the FAST stage's cell lists in place (no k_gather launch, no compacted key array: -35 us per
     // 128 images 1241x376, -200 us per 64 images 1920x1080 in the pipelined step).  Not for the multi-workgroup form, the exact
     // form alone and the phase-stop knobs, which sweep the compacted array (developer knob 18 = 1: never fused).
-    const bool fused = usePyr && !multiWg && (h->opt[7] == 0 || h->opt[7] == 8) && h->opt[1] == 0 && h->opt[18] != 1;   // (7 = 8, developer build: time stamps, no stop)
+    const bool fused = usePyr && !multiWg && (h->opt[7] == 0 || h->opt[7] == 8 || h->opt[7] == 9) && h->opt[1] == 0 && h->opt[18] != 1;   // (7 = 8 / 9, developer build: time stamps, no stop)
     const int sparsePerCell = h->opt[16] == 2 ? 1 << 20 : ORBX_SPARSE_PER_CELL;
     OctSrc osrc = {};
     if (fused) {
@@ -717,6 +733,15 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
         osrc.sparseFlag = v.sparse; osrc.sparsePerCell = sparsePerCell; osrc.candOut = v.cand;
         osrc.sparseSeen = h->opt[20] != 0 ? h->d_sparseSeen : nullptr; osrc.callSeq = h->callSeq;   // (the hint only serves the compaction forms)
         h->candStale = std::max(h->candStale, v.b0 + B);
+    }
+    // ORBX_OPT_OCT_HIST (0 = by batch size, 1 = never): with at most ORBX_HIST_IMAGES images and every level done by k_fast_cells, the FAST
+    // stage histograms its emissions for the quad-tree (FastHist) and k_octree_pyr loads the histogram instead of sweeping the keys
+    const bool stripsWanted = h->totalStrips > 0 && (h->opt[6] == 0 ? (size_t)h->totalStrips * B >= 4096 : h->opt[6] == 3);
+    const bool histOct = fused && h->opt[23] == 0 && B <= ORBX_HIST_IMAGES && h->lastChunks == 1 && !stripsWanted && h->opt[0] == 0;
+    FastHist fhist = {};
+    if (histOct) {
+        fhist.cnt = h->d_histCnt; fhist.best = h->d_histBest; fhist.stride = h->histStride; fhist.tab = h->d_tab;
+        osrc.histCnt = h->d_histCnt; osrc.histBest = h->d_histBest; osrc.histStride = h->histStride;
     }
     int pow2 = 1;
     while (pow2 < h->maxNodeCap) pow2 <<= 1;
@@ -744,7 +769,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             // into a host-mapped word when it flags one (a hint that lags by the calls in flight; a wrong hint costs speed only,
             // because both kernels take the SAME device flags).
             compact = spf != nullptr && h->opt[20] != 0 &&
-                      (h->opt[16] == 2 || (h->h_sparseSeen && h->callSeq - *(volatile int32_t *)h->h_sparseSeen <= 16));
+                      (h->opt[16] == 2 || (h->h_sparseSeen && (uint32_t)h->callSeq - (uint32_t)*(volatile int32_t *)h->h_sparseSeen <= 16u));   // (sequence numbers wrap: unsigned distance)
             // Early quad-tree (developer knob 19: a >= 2 = levels [0, a); default 0 = off): the quad-tree of the large levels is ONE
             // workgroup per level walking a serial chain - the critical path behind FAST.  Their strips go first, in a launch of their
             // own, and their quad-tree starts on a second stream as soon as that launch is done, beside the FAST of the remaining
@@ -787,7 +812,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     hipLaunchKernelGGL((k_fast_cells<EST, SP>), grid, dim3(64 * FAST_WAVES), (size_t)(LDSW) * FAST_WAVES, st,              \
                        v.pyr, h->pyrImgBytes, h->d_geom, nl, h->totalCells, v.cellCnt, v.cellRaw, v.slots, \
                        h->slotsPerImg, h->ini_th, h->min_th, h->fastTileStride, h->fastScoreStride, h->fastTileRows, \
-                       (LDSW), h->opt[0], cb, stripLevels, v.sparse)
+                       (LDSW), h->opt[0], cb, stripLevels, v.sparse, (SP) ? FastHist{} : fhist)
         if (compact && h->opt[20] == 1) {   // the flagged (image, level)s: the strip kernel's compaction twin
             StripBases sb;
             for (int l = 0; l <= ORBX_MAX_LEVELS; l++) sb.v[l] = h->stripBase[l];
@@ -978,7 +1003,7 @@ static int launch_pipeline(orbx_extractor *h, const uint8_t *d_imgs, int B, int 
     const int nch = chunk_count(h, B, prof, skipPyr);
     h->lastChunks = nch;
     h->candStale = 0;
-    h->callSeq++;
+    h->callSeq = (int)((unsigned)h->callSeq + 1u);   // wraps (compared by unsigned distance)
     h->prevPyrValid = skipPyr ? 1 : 0;   // d_pyr is overwritten unless this call took a pyramid built ahead (then d_pyrAlt keeps the previous one)
     h->framesStale = (!pyramid_fused_all(h) && h->nlevels > 1) ? B : 0;   // frames of levels >= 1: written on demand (ensure_frames)
     int b0 = 0;
@@ -1294,6 +1319,85 @@ extern "C" int orbx_stereo_frame(orbx_extractor_t *h, const uint8_t *left, const
     return status;
 }
 
+// ---- the latency form: one stereo frame, no copy commands (include/orbx.h: orbx_stereo_frame_view)
+extern "C" void *orbx_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void orbx_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+// the address a kernel reads the image at, or NULL when the memory is ordinary pageable host memory
+static const uint8_t *device_visible(const uint8_t *p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // (older runtimes: an error for unregistered memory)
+    if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeHost || a.type == hipMemoryTypeManaged) return (const uint8_t *)a.devicePointer;
+    return nullptr;
+}
+
+extern "C" int orbx_stereo_frame_view(orbx_extractor_t *h, const uint8_t *left, const uint8_t *right, int w, int hgt, int stride,
+                                      float mbf, float mb, orbx_stereo_view_t *view) {
+    if (!h || !view) { orbx_set_error("orbx_stereo_frame_view: bad arguments"); return ORBX_ERR_ARG; }
+    memset(view, 0, sizeof(*view));
+    if (!left || !right || w <= 0 || hgt <= 0) return ORBX_OK;   // empty image (:1046-1047)
+    if (stride < w) { orbx_set_error("stride < width"); return ORBX_ERR_ARG; }
+    ORBX_HIP(hipSetDevice(h->device));
+    int rc = ensure_plan(h, w, hgt, 2);
+    if (rc) return rc;
+    const int cap = (h->max_kp + 3) & ~3;   // the record's blocks are 16-byte aligned for any multiple of 4
+    const size_t recBytes = (size_t)128 * cap + 16;
+    if (h->fv_cap < cap) {
+        ORBX_HIP(hipStreamSynchronize(h->stream));
+        for (int i = 0; i < 2; i++) {
+            hipFree(h->fv_d[i]); h->fv_d[i] = nullptr;
+            if (h->fv_h[i]) { hipHostFree(h->fv_h[i]); h->fv_h[i] = nullptr; }
+        }
+        h->fv_cap = 0;
+        for (int i = 0; i < 2; i++) {
+            ORBX_HIP(hipMalloc(&h->fv_d[i], recBytes));
+            ORBX_HIP(hipMemset(h->fv_d[i], 0, recBytes));
+            ORBX_HIP(hipHostMalloc((void **)&h->fv_h[i], recBytes, hipHostMallocDefault));
+            ORBX_HIP(hipHostGetDevicePointer((void **)&h->fv_hdev[i], h->fv_h[i], 0));
+        }
+        h->fv_cap = cap;
+    }
+    const size_t span = (size_t)stride * (hgt - 1) + w, img_bytes = (span + 255) & ~(size_t)255;
+    const uint8_t *dl = device_visible(left), *dr = device_visible(right);
+    if (!dl || !dr) {   // pageable memory: one memcpy per image into the handle's pinned staging buffer, read from there
+        if (h->fv_stage_bytes < 2 * img_bytes) {
+            ORBX_HIP(hipStreamSynchronize(h->stream));
+            if (h->fv_stage) { hipHostFree(h->fv_stage); h->fv_stage = nullptr; h->fv_stage_bytes = 0; }
+            ORBX_HIP(hipHostMalloc((void **)&h->fv_stage, 2 * img_bytes, hipHostMallocDefault));
+            ORBX_HIP(hipHostGetDevicePointer((void **)&h->fv_stage_dev, h->fv_stage, 0));
+            h->fv_stage_bytes = 2 * img_bytes;
+        }
+        if (!dl) { memcpy(h->fv_stage, left, span); dl = h->fv_stage_dev; }
+        if (!dr) { memcpy(h->fv_stage + img_bytes, right, span); dr = h->fv_stage_dev + img_bytes; }
+    }
+    const int i = h->fv_next;
+    h->fv_next ^= 1;
+    uint8_t *rec = h->fv_d[i];
+    const size_t c = (size_t)cap;
+    hipStream_t st = h->stream;
+    // image b of the batch of two sits at dl + b * (dr - dl): the kernels add the (unsigned, possibly wrapped) difference once
+    rc = launch_pipeline(h, dl, 2, w, hgt, stride, (size_t)((uintptr_t)dr - (uintptr_t)dl), (orbx_keypoint_t *)rec, rec + 56 * c, (int32_t *)(rec + 128 * c), cap, st);
+    if (rc) return rc;
+    rc = orbx_internal_stereo_frame_record(h, rec, h->fv_hdev[i], cap, mbf, mb, st);
+    if (rc) return rc;
+    ORBX_HIP(hipStreamSynchronize(st));
+    const uint8_t *hr = h->fv_h[i];
+    const int32_t *tail = (const int32_t *)(hr + 128 * c);
+    view->nl = std::min(tail[0], cap); view->nr = std::min(tail[1], cap); view->nmatch = tail[2]; view->cap = cap;
+    view->kl = (const orbx_keypoint_t *)hr; view->kr = (const orbx_keypoint_t *)(hr + 28 * c);
+    view->dl = hr + 56 * c; view->dr = hr + 88 * c;
+    view->uright = (const float *)(hr + 120 * c); view->depth = (const float *)(hr + 124 * c);
+    view->d_kl = (const orbx_keypoint_t *)rec; view->d_kr = (const orbx_keypoint_t *)(rec + 28 * c);
+    view->d_dl = rec + 56 * c; view->d_dr = rec + 88 * c;
+    view->d_uright = (const float *)(rec + 120 * c); view->d_depth = (const float *)(rec + 124 * c);
+    return ORBX_OK;
+}
+
 extern "C" int orbx_extract(orbx_extractor_t *h, const uint8_t *img, int w, int hgt, int stride,
                             orbx_keypoint_t *kps, uint8_t *desc, int cap, int *n_out) {
     if (!h || !n_out) { orbx_set_error("orbx_extract: bad arguments"); return ORBX_ERR_ARG; }
@@ -1385,6 +1489,16 @@ static int ensure_cand(orbx_extractor *h) {
     return ORBX_OK;
 }
 
+extern "C" int orbx_level_counts(orbx_extractor_t *h, int b, int32_t *candidates, int32_t *keypoints) {
+    if (!h || h->pw == 0 || b < 0 || b >= h->pB || !h->last_valid) { orbx_set_error("orbx_level_counts: bad arguments or no frame extracted yet"); return ORBX_ERR_ARG; }
+    ORBX_HIP(hipSetDevice(h->device));
+    ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    if (candidates) ORBX_HIP(hipMemcpy(candidates, h->d_candCnt + (size_t)b * h->nlevels, sizeof(int32_t) * h->nlevels, hipMemcpyDeviceToHost));
+    if (keypoints) ORBX_HIP(hipMemcpy(keypoints, h->d_lvlCnt + (size_t)b * h->nlevels, sizeof(int32_t) * h->nlevels, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+#ifdef ORBX_DEVELOPER   // ---- read-only stage hooks: developer build only (include/orbx_dev.h)
 // test / probe hook: which (image, level)s of the last call took the exact form of the quad-tree because the count pyramid was too shallow
 extern "C" int orbx_debug_octree_fallbacks(orbx_extractor_t *h, int32_t *out, int n) {
     if (!h || !out || n < 1 || h->pw == 0 || n > h->pB * h->nlevels) { orbx_set_error("orbx_debug_octree_fallbacks: bad arguments"); return ORBX_ERR_ARG; }
@@ -1422,6 +1536,8 @@ extern "C" int orbx_debug_level_points(orbx_extractor_t *h, int b, int level, in
     return n > cap ? ORBX_ERR_CAPACITY : ORBX_OK;
 }
 
+#endif   // ORBX_DEVELOPER
+
 // Which FAST kernel(s) a batch of B images of the planned size runs (the rule of launch_pipeline): for benchmarks that name the
 // kernel they time.  *strips = 1 if k_fast_strips takes part, *cells = 1 if k_fast_cells does.
 extern "C" int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, int *cells, int *images_per_launch) {
@@ -1437,6 +1553,7 @@ extern "C" int orbx_fast_kernels(const orbx_extractor_t *h, int B, int *strips, 
     return ORBX_OK;
 }
 
+#ifdef ORBX_DEVELOPER
 // Test hook for SURVEY section 8 row a8 (cv::GaussianBlur 7x7, sigma 2, fused into k_describe and never stored): the next
 // single-image orbx_extract calls also write, for keypoint i, the 37x37 blurred block centred on it (the only blurred
 // pixels the descriptor can read) to a device buffer, fetched here.  enable = 0 frees the buffer.
@@ -1478,6 +1595,8 @@ extern "C" int orbx_debug_blurred_level(orbx_extractor_t *h, int b, int level, u
     for (int r = 0; r < g.h; r++) memcpy(dst + (size_t)r * dst_stride, tmp.data() + (size_t)r * g.pstride, g.w);
     return ORBX_OK;
 }
+
+#endif   // ORBX_DEVELOPER
 
 extern "C" int orbx_set_profiling(orbx_extractor_t *h, int enabled) {
     if (!h) return ORBX_ERR_ARG;

@@ -92,11 +92,16 @@ __global__ void k_fast_strips(const uint8_t *pyr, size_t pyrImgBytes, const Leve
 __global__ void k_fast_strips_sparse(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalStrips, int totalCells,
                                      uint32_t *cellCnt, uint32_t *cellRaw, uint32_t *slots, size_t slotsPerImg, int iniTh, int minTh,
                                      StripBases sb, const int32_t *sparseFlag);                                                               // orbx_fast.hip
+// Small batches (B <= 4, round 5): the FAST stage also histograms what it emits - per (image, level), count and best key of every
+// cell of the quad-tree's count pyramid at its deepest depth - with atomics at the L2, spread over every CU that runs FAST cells;
+// k_octree_pyr then LOADS that histogram instead of sweeping the level's keys through the LDS atomics of its one CU (a 1241x376
+// level 0 at 2000 features: 15.5 us of a 39-us workgroup), and zeroes it again for the next call.  cnt == NULL: off.
+struct FastHist { uint32_t *cnt, *best; int stride; const int32_t *tab; };
 template <int ES_T, bool SPARSE>   // SPARSE: the compaction form for the flagged (image, level)s of the strip levels
 __global__ void k_fast_cells(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalCells,
                              uint32_t *cellCnt, uint32_t *cellRaw, uint32_t *slots, size_t slotsPerImg, int iniTh, int minTh, int ESrt,
                              int SSrt, int tileRows, int ldsPerWave, int phaseLimit, CellBases cb, unsigned stripLevels,
-                             const int32_t *sparseFlag);  // orbx_fast.hip
+                             const int32_t *sparseFlag, FastHist fh);  // orbx_fast.hip
 __global__ void k_gather(const LevelGeom *geom, int nlevels, int totalCells, const uint32_t *cellCnt, const uint32_t *cellRaw,
                          const uint32_t *slots, size_t slotsPerImg, uint32_t *cand, size_t keysPerImg, int32_t *candCnt, int iniTh,
                          int minTh, CellBases cb, int32_t *sparseFlag, int sparsePerCell, int32_t *sparseSeen, int callSeq);                                                               // orbx_fast.hip
@@ -118,6 +123,7 @@ struct OctSrc {
     int32_t *sparseSeen;     // host-mapped word: the sequence number of the last call that found a corner-sparse level (may be NULL)
     int callSeq;
     uint32_t *candOut;       // compacted keys, written only by a level that falls back to the exact form
+    uint32_t *histCnt, *histBest; int histStride;   // != NULL: the deepest-depth histogram of every (image, level) as the FAST stage left it (FastHist)
 };
 __global__ void k_octree_pyr(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
                              uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,

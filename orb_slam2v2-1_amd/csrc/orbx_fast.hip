@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
     const uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom, int nlevels,
     int totalCells, uint32_t *__restrict__ cellCnt, uint32_t *__restrict__ cellRaw, uint32_t *__restrict__ slots, size_t slotsPerImg,
     int iniTh, int minTh, int ESrt, int SSrt, int tileRows, int ldsPerWave, int phaseLimit, CellBases cb, unsigned stripLevels,
-    const int32_t *__restrict__ sparseFlag) {
+    const int32_t *__restrict__ sparseFlag, FastHist fh) {
     const int ES = ES_T ? ES_T : ESrt, SS = ES_T ? ES_T - 8 : SSrt;
     extern __shared__ __align__(16) uint8_t smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -357,9 +357,17 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
         const unsigned long long m = __ballot(emit);
         if (emit) {
             const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < g.capc)
-                out[pos] = (uint32_t)((e & 0xFF) + 3 + cj * g.wCell) | ((uint32_t)(((e >> 8) & 0xFF) + 3 + ci * g.hCell) << 12) |
-                           ((e >> 16) << 24);
+            if (pos < g.capc) {
+                const uint32_t kx = (e & 0xFF) + 3 + cj * g.wCell, ky = ((e >> 8) & 0xFF) + 3 + ci * g.hCell;
+                out[pos] = kx | (ky << 12) | ((e >> 16) << 24);
+                if (fh.cnt) {   // (wave-uniform) quad-tree histogram at the L2: deepest cell of the key's path, count + best key (response, then
+                                // the EARLIEST position in vToDistributeKeys order = smallest slot index: :744-760 keeps the first maximum)
+                    const uint32_t cc = (uint32_t)fh.tab[g.xPathOff + kx] | (uint32_t)fh.tab[g.yPathOff + ky];
+                    const size_t ho = ((size_t)b * nlevels + l) * fh.stride + cc;
+                    atomicAdd(fh.cnt + ho, 1u);
+                    atomicMax(fh.best + ho, ((e >> 16) << 24) | (0xFFFFFFu - (uint32_t)(c * g.capc + pos)));
+                }
+            }
         }
         total += __popcll(m);
     }
@@ -873,7 +881,7 @@ __global__ __launch_bounds__(256) void k_gather(const LevelGeom *__restrict__ ge
 // the tile strides of the usual 30-px cell grids + the run-time-stride instance, each in the dense and the compaction form
 #define ORBX_FAST_INSTANCE(EST, SP)                                                                                              \
     template __global__ void k_fast_cells<EST, SP>(const uint8_t *, size_t, const LevelGeom *, int, int, uint32_t *, uint32_t *, \
-                                                   uint32_t *, size_t, int, int, int, int, int, int, int, CellBases, unsigned, const int32_t *)
+                                                   uint32_t *, size_t, int, int, int, int, int, int, int, CellBases, unsigned, const int32_t *, FastHist)
 ORBX_FAST_INSTANCE(0, false);
 ORBX_FAST_INSTANCE(44, false);
 ORBX_FAST_INSTANCE(48, false);

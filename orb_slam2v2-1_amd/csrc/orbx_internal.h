@@ -16,6 +16,7 @@
 #define ORBX_EV_RING 32
 #define ORBX_MAX_CHUNKS 4      // chunks a batch may be cut into (launch_pipeline)
 #define ORBX_SIDE_STREAMS 2    // handle-owned streams for the chunks behind the first
+#define ORBX_HIST_IMAGES 4     // batches up to this size: the FAST stage histograms its emissions for the quad-tree (FastHist)
 
 void orbx_set_error(const char *fmt, ...);
 
@@ -93,12 +94,16 @@ struct orbx_extractor {
     int candStale;       // > 0: the compacted key arrays (d_cand / d_candCnt of every level) of that many images were not written by the last call
                          // (k_octree_pyr read the cell lists in place); k_gather materialises them on demand (test hooks)
     int32_t *h_sparseSeen, *d_sparseSeen; int callSeq;   // host-mapped word: sequence number of the last call that flagged a corner-sparse level
+    uint32_t *d_histCnt, *d_histBest; int histStride;   // [ORBX_HIST_IMAGES][nlevels][histStride] deepest-depth histogram of small batches (FastHist)
     int32_t *d_sparse;   // [B][nlevels] verdict of the last call: level with few FAST candidates (k_gather writes, k_fast_strips of the next call reads)
     // staging for the host API
     uint8_t *d_in; size_t d_in_bytes;
     orbx_keypoint_t *d_kps; uint8_t *d_desc; int32_t *d_counts; int out_cap, out_B;
     orbx_keypoint_t *h_kps; uint8_t *h_desc; int32_t *h_counts;   // pinned mirrors of the three above
     float *d_sfr; float *h_sfr; int sfr_cap;   // orbx_stereo_frame: mvuRight | mvDepth | nmatch of one frame (device + pinned mirror)
+    // orbx_stereo_frame_view: two alternating frame records (HBM + pinned host twin, and the twin as kernels address it), pinned staging for pageable images
+    uint8_t *fv_d[2], *fv_h[2], *fv_hdev[2]; int fv_cap, fv_next;
+    uint8_t *fv_stage, *fv_stage_dev; size_t fv_stage_bytes;
     uint8_t *d_dbgBlur; int dbgBlurCap;   // test hook: blurred 37x37 blocks of a single-image call (orbx_debug_blur_patches)
     hipStream_t stream;      // own stream
     hipStream_t side[ORBX_SIDE_STREAMS]; hipEvent_t evPyr[ORBX_MAX_CHUNKS], evJoin[ORBX_SIDE_STREAMS]; int lastChunks;   // chunk overlap (launch_pipeline)
@@ -129,6 +134,8 @@ struct orbx_extractor {
 
 // extractor internals used by the matcher side
 void orbx_internal_free_stereo_scratch(orbx_extractor *h);   // orbx_match.hip
+// ComputeStereoMatches of the frame in image slots 0 / 1 of h with the record layout of orbx_stereo_frame_view (orbx_match.hip)
+int orbx_internal_stereo_frame_record(orbx_extractor *h, uint8_t *d_rec, uint8_t *rec_hostdev, int cap, float mbf, float mb, hipStream_t st);
 void orbx_internal_release_match_scratch();                  // orbx_match.hip      (thread-local staging pair)
 void orbx_internal_release_arena();                          // orbx_match_fast.hip (thread-local arena)
 void orbx_internal_release_bow_scratch();                    // orbx_bow.hip        (thread-local scratch)

@@ -130,7 +130,8 @@ __device__ __forceinline__ uint2 stereo_right_record(const StereoLevels &lv, con
 // ~35 / ~65 entries: one round (k_stereo_match 44 -> see DESIGN.md section 6).
 #define ST_MAX_BINS 512
 #define ST_MAX_SPAN 6     // bin entries per right keypoint at most (the item array holds ST_MAX_SPAN * cap entries per frame)
-__global__ __launch_bounds__(256) void k_stereo_bins(StereoLevels lv, const orbx_keypoint_t *__restrict__ kr,
+#define SB_T 1024   // (round 5: 256 threads walked a frame's ~2000 right keypoints in eight dependent rounds of global loads - 11 us for one frame)
+__global__ __launch_bounds__(SB_T) void k_stereo_bins(StereoLevels lv, const orbx_keypoint_t *__restrict__ kr,
                                                      uint2 *__restrict__ rc, const int32_t *__restrict__ nr, int cap,
                                                      int bhShift, int nbins, int32_t *__restrict__ binStart,
                                                      uint4 *__restrict__ items) {
@@ -138,10 +139,10 @@ __global__ __launch_bounds__(256) void k_stereo_bins(StereoLevels lv, const orbx
     const int b = blockIdx.x, tid = threadIdx.x;
     const int Nr = min(nr[b], cap);
     uint2 *rcb = rc + (size_t)b * cap;
-    for (int i = tid; i <= nbins; i += 256) cnt[i] = 0;
-    for (int i = tid; i < nbins; i += 256) fill[i] = 0;
+    for (int i = tid; i <= nbins; i += SB_T) cnt[i] = 0;
+    for (int i = tid; i < nbins; i += SB_T) fill[i] = 0;
     __syncthreads();
-    for (int i = tid; i < Nr; i += 256) {   // the compact records are made here (each thread re-reads only its own below)
+    for (int i = tid; i < Nr; i += SB_T) {   // the compact records are made here (each thread re-reads only its own below)
         const uint2 rec = stereo_right_record(lv, kr[(size_t)b * cap + i]);
         rcb[i] = rec;
         const uint32_t x = rec.x;
@@ -151,12 +152,21 @@ __global__ __launch_bounds__(256) void k_stereo_bins(StereoLevels lv, const orbx
         for (int bb = b0; bb <= b1; bb++) atomicAdd(&cnt[bb + 1], 1);   // <= ST_MAX_SPAN bins (the host chooses bhShift accordingly)
     }
     __syncthreads();
-    if (tid == 0) for (int i = 0; i < nbins; i++) cnt[i + 1] += cnt[i];   // <= 512 steps, once per frame
+    // inclusive scan of the bin counts by ONE wave, eight bins per lane (round 5: thread 0 walking the <= 512 bins alone was a chain
+    // of dependent LDS round trips - ~10 of this kernel's 12 us for one frame)
+    if (tid < 64) {
+        int v[8], s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int i = 8 * tid + k; v[k] = i < nbins ? cnt[i + 1] : 0; s += v[k]; }
+        int run = wave_incl_scan_dpp(s) - s;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int i = 8 * tid + k; run += v[k]; if (i < nbins) cnt[i + 1] = run; }
+    }
     __syncthreads();
     int32_t *bs = binStart + (size_t)b * (ST_MAX_BINS + 1);
     uint4 *it = items + (size_t)b * ST_MAX_SPAN * cap;   // a bin entry is the whole record + the keypoint index: ONE load per candidate
-    for (int i = tid; i <= nbins; i += 256) bs[i] = cnt[i];
-    for (int i = tid; i < Nr; i += 256) {
+    for (int i = tid; i <= nbins; i += SB_T) bs[i] = cnt[i];
+    for (int i = tid; i < Nr; i += SB_T) {
         const uint2 rec = rcb[i];
         const uint32_t x = rec.x;
         const int minr = (int)(x & 0xFFF), maxr = (int)((x >> 12) & 0xFFF);
@@ -354,55 +364,63 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
     if (lane == 0) { uright[o] = out_u; depth[o] = out_d; sad[o] = out_s; }
 }
 
-// one workgroup per frame: median of the SAD distances of the accepted matches
-// (sort + vDistIdx[size/2], :641-642) by a two-level radix select, then drop
-// every match with dist >= 1.5*1.4*median (:643-654).
-#define SM_T 256
-__global__ __launch_bounds__(SM_T) void k_stereo_median(const int32_t *__restrict__ nl, int cap,
-                                                        float *__restrict__ uright, float *__restrict__ depth,
-                                                        const int32_t *__restrict__ sad,
-                                                        int32_t *__restrict__ nmatch, int useLds) {
-    extern __shared__ int32_t sd_lds[];  // [cap] sad (or -1) when useLds; larger frames re-read the global array
-    __shared__ int sh_nd, sh_keep;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int N = min(nl[b], cap);
-    const size_t o = (size_t)b * cap;
-    if (tid == 0) { sh_nd = 0; sh_keep = 0; }
+// median of the SAD distances of the accepted matches (sort + vDistIdx[size/2], :641-642) by a two-level radix select -> the
+// threshold 1.5 * 1.4 * median of :643.  Block-wide (SM_T threads, every one calls it); returns the number of accepted matches
+// (0: no threshold).  sd_lds: [N] when useLds (filled here), else the global array is re-read.
+#define SM_T 1024   // (round 5: 256 -> 1024 threads, a frame's SAD values in two rounds of loads instead of eight)
+__device__ __forceinline__ int stereo_sad_threshold(const int32_t *__restrict__ sadg, int N, int32_t *sd_lds, int useLds, float *thDist) {
+    __shared__ int sh_nd, hist[256], sh_hi, sh_rank, sh_lo, sh_rest;
+    const int tid = threadIdx.x;
+    if (tid == 0) sh_nd = 0;
     __syncthreads();
-    const int32_t *sd = useLds ? sd_lds : sad + o;
+    const int32_t *sd = useLds ? sd_lds : sadg;
     int c = 0;
     for (int i = tid; i < N; i += SM_T) {
-        const int s = sad[o + i];
+        const int s = sadg[i];
         if (useLds) sd_lds[i] = s;
         c += s >= 0;
     }
     if (c) atomicAdd(&sh_nd, c);
     __syncthreads();
     const int nd = sh_nd;
-    if (nd == 0) {  // reference: UB on the empty vector (:642); defined here as "no matches"
-        if (nmatch && tid == 0) nmatch[b] = 0;
-        return;
-    }
-    // median = element of rank nd/2 of the sorted SAD distances (values < 2^16: 121*510 max):
-    // two-level radix select on (high byte, low byte) histograms
-    __shared__ int hist[256];
-    __shared__ int sh_hi, sh_rank, sh_lo, sh_rest;
+    if (nd == 0) return 0;   // reference: UB on the empty vector (:642); defined here as "no matches"
+    // element of rank nd/2 of the sorted values (< 2^16: 121*510 max): (high byte, low byte) histograms
     const int target = nd / 2;
-    hist[tid] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
     for (int i = tid; i < N; i += SM_T) { const int s = sd[i]; if (s >= 0) atomicAdd(&hist[(s >> 8) & 0xFF], 1); }
     __syncthreads();
     if (tid < 64) hist256_select(hist, target, tid, &sh_hi, &sh_rank);   // (a serial 256-step scan by one thread cost 5 us)
     __syncthreads();
     const int hi8 = sh_hi;
-    hist[tid] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
     for (int i = tid; i < N; i += SM_T) { const int s = sd[i]; if (s >= 0 && ((s >> 8) & 0xFF) == hi8) atomicAdd(&hist[s & 0xFF], 1); }
     __syncthreads();
     if (tid < 64) hist256_select(hist, sh_rank, tid, &sh_lo, &sh_rest);
     __syncthreads();
     const float median = (float)((hi8 << 8) | sh_lo);
-    const float thDist = 1.5f * 1.4f * median;
+    *thDist = 1.5f * 1.4f * median;
+    return nd;
+}
+// one workgroup per frame: drop every match with dist >= 1.5*1.4*median (:643-654)
+__global__ __launch_bounds__(SM_T) void k_stereo_median(const int32_t *__restrict__ nl, int cap,
+                                                        float *__restrict__ uright, float *__restrict__ depth,
+                                                        const int32_t *__restrict__ sad,
+                                                        int32_t *__restrict__ nmatch, int useLds) {
+    extern __shared__ int32_t sd_lds[];  // [cap] sad (or -1) when useLds; larger frames re-read the global array
+    __shared__ int sh_keep;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = min(nl[b], cap);
+    const size_t o = (size_t)b * cap;
+    if (tid == 0) sh_keep = 0;
+    float thDist = 0.0f;
+    const int nd = stereo_sad_threshold(sad + o, N, sd_lds, useLds, &thDist);
+    if (nd == 0) {
+        if (nmatch && tid == 0) nmatch[b] = 0;
+        return;
+    }
+    const int32_t *sd = useLds ? sd_lds : sad + o;
     int keep = 0;
     for (int i = tid; i < N; i += SM_T) {
         const int s = sd[i];
@@ -413,6 +431,59 @@ __global__ __launch_bounds__(SM_T) void k_stereo_median(const int32_t *__restric
     if (keep) atomicAdd(&sh_keep, keep);
     __syncthreads();
     if (nmatch && tid == 0) nmatch[b] = sh_keep;
+}
+
+// ONE stereo frame, last launch of the latency path (orbx_stereo_frame_view): the median step above AND the frame's whole result
+// record - keypoints and descriptors of both images, mvuRight, mvDepth, counts - written to PINNED HOST memory by the kernel
+// itself.  Every workgroup finds the threshold for itself (2000 values: a few hundred nanoseconds; no hand-off between
+// workgroups), then moves its slice of the record, 16 bytes per lane, applying the :643-654 rule to the mvuRight / mvDepth words on
+// the way; workgroup 0 also applies it to the device arrays (the guided searches that follow read mvuRight in HBM) and writes the
+// match count.  Replaces k_stereo_median + k_pack_records + a device-to-host copy command and the ~10-us hand-over between the
+// compute queue and the copy engine (one frame of the tracking chain: 10.5 + 4.2 + 10 + 7 us).
+// Record (bytes; cap a multiple of 4): kps L @0 | kps R @28 cap | desc L @56 cap | desc R @88 cap | mvuRight @120 cap | mvDepth @124 cap
+// | @128 cap: int32 nl, nr, nmatch, 0.
+__global__ __launch_bounds__(SM_T) void k_stereo_finish(uint4 *rec, uint4 *__restrict__ rec_host, int cap,
+                                                        const int32_t *__restrict__ sad, int useLds) {
+    extern __shared__ int32_t sd_lds[];
+    __shared__ int sh_keep;
+    const int tid = threadIdx.x;
+    int32_t *tail = (int32_t *)((uint8_t *)rec + (size_t)128 * cap);
+    const int N = min(tail[0], cap);
+    float *uright = (float *)((uint8_t *)rec + (size_t)120 * cap), *depth = uright + cap;
+    if (tid == 0) sh_keep = 0;
+    float thDist = 0.0f;
+    const int nd = stereo_sad_threshold(sad, N, sd_lds, useLds, &thDist);
+    const int32_t *sd = useLds ? sd_lds : sad;
+    {   // the match count (every workgroup: the one that copies the record's tail needs it) and, by workgroup 0, the rule on the device arrays
+        int keep = 0;
+        if (nd > 0)
+            for (int i = tid; i < N; i += SM_T) {
+                const int s = sd[i];
+                if (s < 0) continue;
+                if ((float)s < thDist) keep++;
+                else if (blockIdx.x == 0) { uright[i] = -1; depth[i] = -1; }
+            }
+        if (keep) atomicAdd(&sh_keep, keep);
+        __syncthreads();
+        if (blockIdx.x == 0 && tid == 0) tail[2] = sh_keep;
+    }
+    // copy-out: 16-byte units [0, 8 cap + 1); units of the mvuRight / mvDepth block get the rule applied (the device words may or may
+    // not have been rewritten by workgroup 0 yet: the rule gives the same word either way)
+    const int total = 8 * cap + 1, ur0 = (120 * cap) >> 4, ur1 = (128 * cap) >> 4;
+    for (int u = blockIdx.x * SM_T + tid; u < total; u += gridDim.x * SM_T) {
+        uint4 v = rec[u];
+        if (u >= ur0 && u < ur1) {
+            const int i0 = ((u - ur0) * 4) % cap;     // keypoint of the unit's first word (mvuRight and mvDepth blocks: cap words each)
+            uint32_t *w = (uint32_t *)&v;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = i0 + k;
+                if (nd > 0 && i < N) { const int s = sd[i]; if (s >= 0 && !((float)s < thDist)) w[k] = 0xBF800000u; }   // -1.0f
+            }
+        } else if (u == total - 1)
+            v.z = (uint32_t)sh_keep;
+        rec_host[u] = v;
+    }
 }
 
 static int fill_stereo_levels(orbx_extractor *hl, orbx_extractor *hr, StereoLevels *lv) {
@@ -460,7 +531,7 @@ static int stereo_batch_impl(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, 
                              int right_slot0, const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
                              const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
                              int cap, float mbf, float mb, float *d_uright, float *d_depth,
-                             int32_t *d_nmatch, void *stream, bool prev) {
+                             int32_t *d_nmatch, void *stream, bool prev, uint8_t *finish_rec = nullptr, uint8_t *finish_host = nullptr) {
     if (!hl || !hr || !d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_uright || !d_depth || B < 1 ||
         cap < 1 || left_slot0 < 0 || right_slot0 < 0 || left_slot0 + B > hl->pB || right_slot0 + B > hr->pB) {
         orbx_set_error("orbm_stereo_batch_device: bad arguments");
@@ -490,13 +561,17 @@ static int stereo_batch_impl(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, 
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream
     dim3 grid((cap + ST_WAVES - 1) / ST_WAVES, B);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_stereo_bins, dim3(B), dim3(256), 0, st, lv, d_kr, hl->st_rc, d_nr, cap, bhShift, nbins, hl->st_binStart, hl->st_items);
+    hipLaunchKernelGGL(k_stereo_bins, dim3(B), dim3(SB_T), 0, st, lv, d_kr, hl->st_rc, d_nr, cap, bhShift, nbins, hl->st_binStart, hl->st_items);
     hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * ST_WAVES), 0, st, lv, pyrL + (size_t)left_slot0 * hl->pyrImgBytes, hl->pyrImgBytes,
                        pyrR + (size_t)right_slot0 * hr->pyrImgBytes, hr->pyrImgBytes, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
                        hl->st_sad, hl->st_rc, hl->st_binStart, hl->st_items, bhShift, nbins);
     const int useLds = cap <= SM_LDS_CAP;
-    hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(SM_T), useLds ? sizeof(int32_t) * cap : 0, st, d_nl, cap, d_uright,
-                       d_depth, hl->st_sad, d_nmatch, useLds);
+    if (finish_rec)   // one frame, latency path: median step + the whole record to pinned host memory, one launch
+        hipLaunchKernelGGL(k_stereo_finish, dim3((8 * cap + 1 + SM_T - 1) / SM_T), dim3(SM_T), useLds ? sizeof(int32_t) * cap : 0, st,
+                           (uint4 *)finish_rec, (uint4 *)finish_host, cap, hl->st_sad, useLds);
+    else
+        hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(SM_T), useLds ? sizeof(int32_t) * cap : 0, st, d_nl, cap, d_uright,
+                           d_depth, hl->st_sad, d_nmatch, useLds);
     ORBX_HIP(hipGetLastError());
     hl->st_stream = st;
     return ORBX_OK;
@@ -509,6 +584,15 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
                                         int32_t *d_nmatch, void *stream) {
     return stereo_batch_impl(hl, hr, B, left_slot0, right_slot0, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, cap, mbf, mb, d_uright, d_depth,
                              d_nmatch, stream, false);
+}
+
+int orbx_internal_stereo_frame_record(orbx_extractor *h, uint8_t *d_rec, uint8_t *rec_hostdev, int cap, float mbf, float mb, hipStream_t st) {
+    const size_t c = (size_t)cap;
+    orbx_keypoint_t *kl = (orbx_keypoint_t *)d_rec, *kr = (orbx_keypoint_t *)(d_rec + 28 * c);
+    uint8_t *dl = d_rec + 56 * c, *dr = d_rec + 88 * c;
+    float *ur = (float *)(d_rec + 120 * c), *dp = (float *)(d_rec + 124 * c);
+    int32_t *tail = (int32_t *)(d_rec + 128 * c);
+    return stereo_batch_impl(h, h, 1, 0, 1, kl, dl, tail, kr, dr, tail + 1, cap, mbf, mb, ur, dp, tail + 2, (void *)st, false, d_rec, rec_hostdev);
 }
 
 // The same on the pyramids of the extraction call BEFORE the last one (software pipelining: the matcher of batch i-1 issued
@@ -641,6 +725,8 @@ __device__ Top2 block_top2(Top2 t, u64 *sh) {
     return r;
 }
 
+#ifdef ORBX_DEVELOPER
+#include "orbx_dev.h"
 // ---- test hook: Frame::GetFeaturesInArea (src/Frame.cc:342-395) as the matchers see it - the predicate in_area() and the
 // scan-order key (column-major over cells, index order inside a cell).  Every matcher takes "the first minimum in this
 // order"; here the order itself comes out: key (cellx, celly, j) of every keypoint the query returns, ~0 for the others,
@@ -680,6 +766,7 @@ extern "C" int orbm_debug_features_in_area(const orbx_keypoint_t *kun, int n, co
     *n_out = (int)v.size();
     return ORBX_OK;
 }
+#endif   // ORBX_DEVELOPER
 
 // ---- SearchForInitialization: one workgroup, F1 keypoints in order (the steal / gate on
 // vMatchedDistance makes iteration i1 depend on all earlier ones)

@@ -550,7 +550,7 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
         if (qi < m) {
             nc[r] = ncand[qi];
             if (MODE == 0) blk[r] = ((const orbm_mappoint_t *)meta)[qi].observations > 0;
-            else if (MODE == 1) { blk[r] = ((const orbm_lastpoint_t *)meta)[qi].observations > 0; ang[r] = ((const orbm_lastpoint_t *)meta)[qi].angle; }
+            else if (MODE == 1) { const float2 qm = ((const float2 *)meta)[qi]; blk[r] = qm.x != 0.0f; ang[r] = qm.y; }   // (blocks, angle): k_queries_frame's compact copy
             else { blk[r] = ((const orbm_window_query_t *)meta)[qi].blocks != 0; ang[r] = ((const orbm_window_query_t *)meta)[qi].angle; }
             if (nc[r] > 0) {
 #pragma unroll
@@ -660,9 +660,11 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
 __global__ __launch_bounds__(256) void k_queries_windows(const orbm_window_query_t *__restrict__ w, int m,
                                                          GQuery *__restrict__ q, const int32_t *__restrict__ holder,
                                                          const int32_t *__restrict__ ext_blocks, int n,
-                                                         uint8_t *__restrict__ sblocked) {
+                                                         uint8_t *__restrict__ sblocked, const orbx_keypoint_t *__restrict__ kp,
+                                                         orbm_grid_geom_t gcode, uint16_t *__restrict__ code) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
+        code[i] = (uint16_t)cell_code(gcode, kp[i]);   // (was a launch of its own, k_cell_codes)
         const int hm = holder[i];
         sblocked[i] = hm == -1 ? 0 : hm == -2 ? (ext_blocks ? (ext_blocks[i] != 0) : 1) : (w[hm].blocks != 0);
     }
@@ -691,9 +693,11 @@ __global__ __launch_bounds__(256) void k_queries_init(const orbx_keypoint_t *__r
 __global__ __launch_bounds__(256) void k_queries_mp(const orbm_mappoint_t *__restrict__ mps, int m,
                                                     const float *__restrict__ sf, float th, GQuery *__restrict__ q,
                                                     const int32_t *__restrict__ frame_mp, const int32_t *__restrict__ ext_obs,
-                                                    int n, uint8_t *__restrict__ sblocked) {
+                                                    int n, uint8_t *__restrict__ sblocked, const orbx_keypoint_t *__restrict__ kp,
+                                                    orbm_grid_geom_t gcode, uint16_t *__restrict__ code) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {  // holders present before the call (:87-89)
+        code[i] = (uint16_t)cell_code(gcode, kp[i]);
         const int hm = frame_mp[i];
         sblocked[i] = hm == -1 ? 0 : hm == -2 ? (ext_obs && ext_obs[i] > 0) : (mps[hm].observations > 0);
     }
@@ -716,9 +720,11 @@ __global__ __launch_bounds__(256) void k_queries_frame(const orbm_lastpoint_t *_
                                                        const float *__restrict__ Tl, float th, int mono,
                                                        GQuery *__restrict__ q, const int32_t *__restrict__ cur_mp,
                                                        const int32_t *__restrict__ ext_obs, int n,
-                                                       uint8_t *__restrict__ sblocked) {
+                                                       uint8_t *__restrict__ sblocked, const orbx_keypoint_t *__restrict__ kp,
+                                                       uint16_t *__restrict__ code, float2 *__restrict__ qmeta) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
+        code[i] = (uint16_t)cell_code(g, kp[i]);
         const int hm = cur_mp[i];
         sblocked[i] = hm == -1 ? 0 : hm == -2 ? (ext_obs && ext_obs[i] > 0) : (last[hm].observations > 0);
     }
@@ -737,6 +743,7 @@ __global__ __launch_bounds__(256) void k_queries_frame(const orbm_lastpoint_t *_
     }
     const bool bForward = tlc2 > cam.mb && !mono, bBackward = -tlc2 > cam.mb && !mono;
     const orbm_lastpoint_t p = last[i];
+    qmeta[i] = make_float2(p.observations > 0 ? 1.0f : 0.0f, p.angle);   // what the resolver needs of the record (`last` may sit in host memory)
     GQuery Q;
     Q.valid = 0; Q.x = Q.y = Q.r = 0; Q.minLevel = Q.maxLevel = -1; Q.ur_c = 0; Q.ur_tol = -1.0f;
     if (p.has_mp) {
@@ -772,7 +779,7 @@ struct FrustumPose { float R[9], t[3], Ow[3]; };
 __global__ __launch_bounds__(256) void k_frustum(const orbm_worldpoint_t *__restrict__ pts, int m, FrustumPose P,
                                                  orbm_camera_t cam, orbm_grid_geom_t g, float viewCosLimit,
                                                  const float *__restrict__ thr, int nlevels,
-                                                 orbm_mappoint_t *__restrict__ out) {
+                                                 orbm_mappoint_t *__restrict__ out, orbm_mappoint_t *__restrict__ out_host) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
     const orbm_worldpoint_t p = pts[i];
@@ -810,6 +817,7 @@ __global__ __launch_bounds__(256) void k_frustum(const orbm_worldpoint_t *__rest
         }
     }
     out[i] = o;
+    if (out_host) out_host[i] = o;   // the caller's copy, written in place of a download
 }
 static void frustum_pose(const float *T, FrustumPose &P) {   // mRcw, mtcw, mOw = -mRcw.t()*mtcw (src/Frame.cc:272-279)
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) P.R[r * 3 + c] = T[r * 4 + c]; P.t[r] = T[r * 4 + 3]; }
@@ -869,6 +877,14 @@ static inline void arena_stage(void *dst, const void *src, size_t bytes) {
     g_ar.up_hi = std::max(g_ar.up_hi, o + bytes);
 }
 #define UP(dst, src, count) arena_stage((dst), (src), sizeof(*(dst)) * (size_t)(count))
+// A SMALL input that one kernel reads once: written into the pinned mirror and read there by the kernel (its device-visible address
+// is returned) - no copy command in front of the first kernel (a call's upload was one ~10-us copy plus ~9 us until the kernel
+// behind it started: the copy engine and the compute queue hand over through a signal)
+template <typename T> static T *arena_zc(T *dev, const void *src, size_t count) {
+    memcpy(g_ar.hbase + ((uint8_t *)dev - g_ar.base), src, sizeof(T) * count);
+    return (T *)(g_ar.hdev + ((uint8_t *)dev - g_ar.base));
+}
+#define ZC(dst, src, count) arena_zc((dst), (src), (size_t)(count))
 // everything staged since the last flush goes up in one copy (call before the first kernel that reads it)
 #define FLUSH_UP()                                                                                                        \
     do {                                                                                                                  \
@@ -944,9 +960,8 @@ int fast_is_in_frustum(const orbm_worldpoint_t *pts, int m, const float *Tcw16, 
     FrustumPose P;
     frustum_pose(Tcw16, P);
     FLUSH_UP();
-    hipLaunchKernelGGL(k_frustum, dim3((m + 255) / 256), dim3(256), 0, st, dw, m, P, *cam, *g, viewCosLimit, dthr, nlevels, dmp);
+    hipLaunchKernelGGL(k_frustum, dim3((m + 255) / 256), dim3(256), 0, st, dw, m, P, *cam, *g, viewCosLimit, dthr, nlevels, dmp, arena_hostdev(dmp));
     ORBX_HIP(hipGetLastError());
-    DOWN(dmp, m);
     ORBX_HIP(hipStreamSynchronize(st));
     memcpy(out, arena_host(dmp), sizeof(orbm_mappoint_t) * (size_t)m);
     return ORBX_OK;
@@ -976,20 +991,21 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
     GQuery *dq = arena_get<GQuery>(m);
     u64 *dkeys = arena_get<u64>((size_t)m * QK);
     if (!dev) { UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(du, uright, n); }
-    UP(dsf, sf, nlevels);
-    UP(dmd, mp_desc, (size_t)32 * m); UP(dfm, frame_mp, n);
-    if (ext_obs) UP(deo, ext_obs, n);
+    // small inputs are read by the kernels in the pinned mirror (zero copy); with a device-resident frame nothing is copied up at all
+    const float *zsf = ZC(dsf, sf, nlevels);
+    const uint8_t *zmd = ZC(dmd, mp_desc, (size_t)32 * m);
+    int32_t *zfm = ZC(dfm, frame_mp, n);
+    const int32_t *zeo = ext_obs ? ZC(deo, ext_obs, n) : (const int32_t *)nullptr;
     if (world) {
         orbm_worldpoint_t *dw = arena_get<orbm_worldpoint_t>(m);
         float *dthr = arena_get<float>(nlevels);
-        UP(dw, world->pts, m);
-        if (nlevels > 1) UP(dthr, world->thr, nlevels - 1);
+        const orbm_worldpoint_t *zw = ZC(dw, world->pts, m);
+        const float *zthr = nlevels > 1 ? ZC(dthr, world->thr, nlevels - 1) : dthr;
         FrustumPose P;
         frustum_pose(world->Tcw16, P);
         FLUSH_UP();
-        hipLaunchKernelGGL(k_frustum, dim3((m + 255) / 256), dim3(256), 0, st, dw, m, P, *world->cam, *g, world->viewCosLimit, dthr,
-                           nlevels, dmp);
-        if (proj_out) DOWN(dmp, m);
+        hipLaunchKernelGGL(k_frustum, dim3((m + 255) / 256), dim3(256), 0, st, zw, m, P, *world->cam, *g, world->viewCosLimit, zthr,
+                           nlevels, dmp, proj_out ? arena_hostdev(dmp) : (orbm_mappoint_t *)nullptr);
         if (n > 30000) {
             ORBX_HIP(hipStreamSynchronize(st));
             if (proj_out) memcpy(proj_out, arena_host(dmp), sizeof(orbm_mappoint_t) * (size_t)m);
@@ -997,14 +1013,13 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
         }
     } else { UP(dmp, mps, m); FLUSH_UP(); }
     const int mx = std::max(n, m);
-    hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *g, dcode);
-    hipLaunchKernelGGL(k_queries_mp, dim3((mx + 255) / 256), dim3(256), 0, st, dmp, m, dsf, th, dq, dfm,
-                       ext_obs ? deo : (const int32_t *)nullptr, n, dsb);
-    hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dmd, m, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
+    hipLaunchKernelGGL(k_queries_mp, dim3((mx + 255) / 256), dim3(256), 0, st, dmp, m, zsf, th, dq, zfm, zeo, n, dsb, dk, *g, dcode);
+    hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, zmd, m, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
     if (use_resolve_par(m, n)) {   // results land in the pinned mirror straight from the kernel
-        RESOLVE_PAR_LAUNCH(0, dkeys, dnc, (const void *)dmp, dk, m, n, dfm, dfm, arena_hostdev(dfm), nnratio, 0, 0, dout, arena_hostdev(dout));
+        RESOLVE_PAR_LAUNCH(0, dkeys, dnc, (const void *)dmp, dk, m, n, zfm, zfm, (int32_t *)nullptr, nnratio, 0, 0, dout, arena_hostdev(dout));
         ORBX_HIP(hipGetLastError());
     } else {
+        ORBX_HIP(hipMemcpyAsync(dfm, arena_host(dfm), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));   // this resolver works on the device copy
         hipLaunchKernelGGL(k_resolve_mp, dim3(1), dim3(64), 2 * (size_t)((n + 15) & ~15), st, dkeys, dnc, dmp, m, n, dfm, nnratio, dout);
         ORBX_HIP(hipGetLastError());
         DOWN(dout, 2); DOWN(dfm, n);
@@ -1024,7 +1039,7 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
                                     const uint8_t *last_desc, int nlast, int32_t *cur_mp, const int32_t *ext_obs,
                                     float th, int mono, int check_ori, int device, int *nmatches, const DevFrame *dev) {
     if (n > 30000) return ORBX_FAST_FALLBACK;
-    const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)nlast * (28 + 32 + QK * 8 + 64) + 65536;
+    const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)nlast * (28 + 32 + QK * 8 + 64 + 8) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
     hipStream_t st = dev ? dev->stream : g_ar.st;   // dev: kun / desc / uright / last_desc are device arrays (see fast_search_by_projection_mp)
@@ -1041,19 +1056,23 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
     float T2[32];
     memcpy(T2, Tc16, 64); memcpy(T2 + 16, Tl16, 64);
     if (!dev) { UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(du, uright, n); UP(dld, last_desc, (size_t)32 * nlast); }
-    UP(dsf, sf, nlevels); UP(dl, last, nlast);
-    UP(dcm, cur_mp, n); UP(dT, T2, 32);
-    if (ext_obs) UP(deo, ext_obs, n);
+    // small inputs: read by the kernels in the pinned mirror (see ZC)
+    const float *zsf = ZC(dsf, sf, nlevels), *zT = ZC(dT, T2, 32);
+    const orbm_lastpoint_t *zl = ZC(dl, last, nlast);
+    int32_t *zcm = ZC(dcm, cur_mp, n);
+    const int32_t *zeo = ext_obs ? ZC(deo, ext_obs, n) : (const int32_t *)nullptr;
     FLUSH_UP();
     const int mx = std::max(n, nlast);
-    hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *g, dcode);
-    hipLaunchKernelGGL(k_queries_frame, dim3((mx + 255) / 256), dim3(256), 0, st, dl, nlast, dsf, *cam, *g, dT, dT + 16, th,
-                       mono, dq, dcm, ext_obs ? deo : (const int32_t *)nullptr, n, dsb);
+    float2 *dqm = arena_get<float2>(nlast);
+    hipLaunchKernelGGL(k_queries_frame, dim3((mx + 255) / 256), dim3(256), 0, st, zl, nlast, zsf, *cam, *g, zT, zT + 16, th,
+                       mono, dq, zcm, zeo, n, dsb, dk, dcode, dqm);
     hipLaunchKernelGGL(k_cand<false>, dim3((nlast + 3) / 4), dim3(256), 0, st, dq, dld, nlast, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
     if (use_resolve_par(nlast, n)) {
-        RESOLVE_PAR_LAUNCH(1, dkeys, dnc, (const void *)dl, dk, nlast, n, dcm, dcm, arena_hostdev(dcm), 0.0f, 0, check_ori, dout, arena_hostdev(dout));
+        RESOLVE_PAR_LAUNCH(1, dkeys, dnc, (const void *)dqm, dk, nlast, n, zcm, zcm, (int32_t *)nullptr, 0.0f, 0, check_ori, dout, arena_hostdev(dout));
         ORBX_HIP(hipGetLastError());
     } else {
+        ORBX_HIP(hipMemcpyAsync(dcm, arena_host(dcm), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+        ORBX_HIP(hipMemcpyAsync(dl, arena_host(dl), sizeof(orbm_lastpoint_t) * (size_t)nlast, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_resolve_frame, dim3(1), dim3(64), 2 * (size_t)((n + 15) & ~15), st, dkeys, dnc, dl, dk, nlast, n, dcm,
                            dhi, dhb, check_ori, dout);
         ORBX_HIP(hipGetLastError());
@@ -1095,9 +1114,8 @@ int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const fl
     if (ext_blocks) UP(deb, ext_blocks, n);
     FLUSH_UP();
     const int mx = std::max(n, m);
-    hipLaunchKernelGGL(k_cell_codes, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, *ga, dcode);
     hipLaunchKernelGGL(k_queries_windows, dim3((mx + 255) / 256), dim3(256), 0, st, dw, m, dq, dh,
-                       ext_blocks ? deb : (const int32_t *)nullptr, n, dsb);
+                       ext_blocks ? deb : (const int32_t *)nullptr, n, dsb, dk, *ga, dcode);
     hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dqd, m, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
     if (use_resolve_par(m, n)) {
         RESOLVE_PAR_LAUNCH(2, dkeys, dnc, (const void *)dw, dk, m, n, dh, dh, arena_hostdev(dh), 0.0f, max_dist, check_ori, dout, arena_hostdev(dout));

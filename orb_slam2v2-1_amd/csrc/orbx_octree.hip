@@ -276,7 +276,22 @@ __device__ __forceinline__ void octree_pyr_body(
     if (CB) for (int i = tid; i < (nIni << (2 * Dm)); i += OCT_T) bestP[offDeep + i] = 0;
     if (tid == 0) sh_abort = 0;
     __syncthreads();
-    if (fused) {
+    // HIST (small batches): the FAST stage histogrammed its emissions at the L2 (FastHist, orbx_extract_dev.h): deepest-depth counts
+    // and best keys (the tie-break index is the key's SLOT index cell * capc + position: the same order as vToDistributeKeys) are
+    // loaded - two 16-bit counters per LDS word - and the global arrays zeroed for the next call.  No sweep, no raw-index scan.
+    const bool fromHist = fused && src.histCnt != nullptr;   // uniform
+    if (fromHist) {
+        uint32_t *hc = src.histCnt + ((size_t)b * nlevels + l) * src.histStride, *hb = src.histBest + ((size_t)b * nlevels + l) * src.histStride;
+        const int nDeep4 = (nIni << (2 * Dm)) >> 2;    // (a multiple of four cells: Dm >= 1)
+        for (int i = tid; i < nDeep4; i += OCT_T) {
+            const uint4 cv = ((const uint4 *)hc)[i], bv = ((const uint4 *)hb)[i];
+            pyr[offDeep + 2 * i] = cv.x | (cv.y << 16);
+            pyr[offDeep + 2 * i + 1] = cv.z | (cv.w << 16);
+            bestP[offDeep + 4 * i] = bv.x; bestP[offDeep + 4 * i + 1] = bv.y; bestP[offDeep + 4 * i + 2] = bv.z; bestP[offDeep + 4 * i + 3] = bv.w;
+            ((uint4 *)hc)[i] = make_uint4(0u, 0u, 0u, 0u);
+            ((uint4 *)hb)[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    } else if (fused) {
         // raw list lengths -> first raw index of every cell (the tie-break index of a key is its position in the concatenated RAW
         // lists: same relative order as in vToDistributeKeys, which only drops entries); kept keys of the level for the records
         if (tid == 0) sh_kept = 0;
@@ -422,18 +437,27 @@ __device__ __forceinline__ void octree_pyr_body(
     if (dbgStop == 2) return;
     // ---- 3. root nodes (:543-592)
     if (tid == 0) {
-        int L0 = 0;
+        int L0 = 0, kept = 0;
         for (int r = 0; r < nIni; r++) {
             const uint32_t c = pyr[r];
+            kept += (int)c;
             if (c > 0) { cntA[L0] = c | 0x80000000u; nidA[L0] = (uint32_t)r; L0++; }
         }
         sh_L = L0;
+        if (fromHist) {   // the records the sweep form writes before its sweep: kept keys of the level, verdict for the next call's FAST
+            src.candCntOut[b * nlevels + l] = kept;
+            if (src.sparseFlag) {
+                const int sparse = kept < src.sparsePerCell * g.ncells ? 1 : 0;
+                src.sparseFlag[b * nlevels + l] = sparse;
+                if (sparse && b == 0 && src.sparseSeen) __hip_atomic_store(src.sparseSeen, src.callSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
     __syncthreads();
     L = sh_L;
     int phase = 1;
 #ifdef ORBX_DEVELOPER
-    const unsigned long long dvT1 = wall_clock64(); int dvPasses = 0; unsigned long long dvSort = 0;
+    const unsigned long long dvT1 = wall_clock64(); int dvPasses = 0;
 #endif
 
     // ---- 4. passes: list bookkeeping on node counts only, by wave 0.  (Round 3 tried every step of a pass on the whole workgroup -
@@ -650,7 +674,8 @@ __device__ __forceinline__ void octree_pyr_body(
             const int d = (int)(nid[k] >> 28);
             const uint32_t v = bestP[(uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u) + (nid[k] & 0x0FFFFFFFu)];
             const int idx = (int)(0xFFFFFFu - (v & 0xFFFFFFu));
-            if (fused) {   // raw index -> (cell, position): the last cell whose first raw index is <= idx
+            if (fromHist) okp[k] = fSlots[idx];   // the index IS the slot
+            else if (fused) {   // raw index -> (cell, position): the last cell whose first raw index is <= idx
                 int lo = 0, hi = g.ncells;
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
@@ -661,15 +686,18 @@ __device__ __forceinline__ void octree_pyr_body(
                 okp[k] = keys[idx];
         }
 #ifdef ORBX_DEVELOPER
-        // developer build: the record holds (passes << 24 | pass loop in 0.1 us << 12 | time since kernel entry in 0.1 us) instead of 0
-        if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; const unsigned long long t = wall_clock64();
-            // dbgStop == 8: the finer split instead - four 8-bit fields in 0.25-us units: entry -> sweep start -> sweep end -> first pass -> last pass
-            if (dbgStop == 8)
-                fallback[b * nlevels + l] = ((int)min((dvTA - dvT0) / 25ull, 255ull) << 24) | ((int)min((dvTB - dvTA) / 25ull, 255ull) << 16) |
-                                            ((int)min((dvT1 - dvTB) / 25ull, 255ull) << 8) | (int)min((dvT2 - dvT1) / 25ull, 255ull);
-            else
-                fallback[b * nlevels + l] = (dvPasses << 24) | ((int)min((dvT2 - dvT1) / 10ull, 4095ull) << 12) | (int)min((t - dvT0) / 10ull, 4095ull); }
-        return;
+        // developer build, option 7 = 9: the record holds (passes << 24 | pass loop in 0.1 us << 12 | time since kernel entry in 0.1 us) instead
+        // of the 0 / 1 flag; 7 = 8: the finer split - four 8-bit fields in 0.25-us units: entry -> sweep start -> sweep end -> first pass ->
+        // last pass.  With the option at 0 the record is the product build's (orbx_debug_octree_fallbacks reads 0 / 1).
+        if (dbgStop == 8 || dbgStop == 9) {
+            if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; const unsigned long long t = wall_clock64();
+                if (dbgStop == 8)
+                    fallback[b * nlevels + l] = ((int)min((dvTA - dvT0) / 25ull, 255ull) << 24) | ((int)min((dvTB - dvTA) / 25ull, 255ull) << 16) |
+                                                ((int)min((dvT1 - dvTB) / 25ull, 255ull) << 8) | (int)min((dvT2 - dvT1) / 25ull, 255ull);
+                else
+                    fallback[b * nlevels + l] = (dvPasses << 24) | ((int)min((dvT2 - dvT1) / 10ull, 4095ull) << 12) | (int)min((t - dvT0) / 10ull, 4095ull); }
+            return;
+        }
 #endif
         if (tid == 0) { lvlCnt[b * nlevels + l] = Lout; fallback[b * nlevels + l] = 0; }
         return;

@@ -30,3 +30,14 @@ def oracle():
     import oracle as o
     o.build()
     return o
+
+
+@pytest.fixture
+def hooks(pkg):
+    """The test looks at intermediate stages (FAST candidates, quad-tree lists, blurred blocks ...): extractors it creates live in the
+    DEVELOPER build of the library (liborbx_hip_dev.so: the same sources + the read-only hooks of include/orbx_dev.h).  Everything
+    end-to-end or timed uses the product library, which exports no hook."""
+    old = pkg.default_developer
+    pkg.default_developer = True
+    yield
+    pkg.default_developer = old

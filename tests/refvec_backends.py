@@ -16,7 +16,7 @@ def hip_vectors(case, gauss=None):
     left, right = refvec.case_images(case)
     p = name + "/"
     out = {}
-    ex = pkg.ORBextractor(nf, refvec.SCALE, refvec.NLEVELS, refvec.INI_TH, refvec.MIN_TH, gauss=gauss)
+    ex = pkg.ORBextractor(nf, refvec.SCALE, refvec.NLEVELS, refvec.INI_TH, refvec.MIN_TH, gauss=gauss, developer=True)   # (stage hooks)
     # the blurred level is never stored by the default path (the Gaussian is fused into the descriptor kernel): one extra extraction
     # with every level blurred as a whole (k_blur_levels, ORBX_OPT_BLUR_FORM = 2) materialises it for the checksum
     ex.set_option(13, 2)

@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    txt = open(os.path.join(ROOT, "include", "orbx.h")).read()
+def _declared(header="orbx.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(orb[xmv]_[a-z0-9_]+)\s*\(", txt)))
 
@@ -25,6 +25,16 @@ def test_library_exports_every_declared_symbol(pkg):
     for n in names:
         assert hasattr(L, n), "missing export %s" % n
     assert sorted(pkg.EXPORTS) == names, "EXPORTS list and include/orbx.h disagree"
+    # the test hooks are NOT product surface: no *_debug_* symbol in the product library (nm -D), all of them - and everything else - in
+    # the developer build, declared in include/orbx_dev.h
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert "debug" not in nm, [l for l in nm.splitlines() if "debug" in l]
+    D = pkg.lib(developer=True)
+    dev = sorted(set(_declared("orbx_dev.h")) - set(names))
+    assert dev == sorted(pkg.DEV_EXPORTS) and len(dev) == 6
+    for n in names + dev:
+        assert hasattr(D, n), "developer build: missing export %s" % n
 
 
 def test_keypoint_struct_is_28_bytes(pkg):

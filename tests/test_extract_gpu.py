@@ -7,6 +7,14 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _staged_tests_use_the_developer_build(hooks):
+    """Every test of this module compares stage by stage (orbx_debug_level_points ...): its extractors come from the developer
+    build.  test_product_library_end_to_end below runs the same images through the product library."""
+    yield
+
+
 SIZES = [(640, 480, 1000), (1241, 376, 1000), (1241, 376, 2000), (752, 480, 1000), (320, 240, 500)]
 
 
@@ -78,9 +86,9 @@ def _compare(pkg, oracle, img, nf, sf=1.2, nl=8, ini=20, mn=7):
 _KNOB6 = [0]   # tests that set knob 6 themselves (test_fast_cell_kernel_instances) say so here
 
 
-def _check_against(ex, orc, ok, od, img, nl):
+def _check_against(ex, orc, ok, od, img, nl, staged=True):
     gk, gd = ex(img)
-    for l in range(nl):
+    for l in range(nl if staged else 0):
         np.testing.assert_array_equal(ex.debug_level_points(l, 0), _cands(orc.level_candidates(l)),
                                       err_msg="FAST candidates level %d" % l)
         np.testing.assert_array_equal(ex.debug_level_points(l, 1), _cands(orc.level_keypoints(l)),
@@ -817,3 +825,25 @@ def _cands_of(oracle, img, nf, l):
     o = oracle.Extractor(nf, 1.2, 8, 20, 7)
     o.extract(img)
     return _cands(o.level_candidates(l))
+
+
+def test_product_library_end_to_end(pkg, oracle, synth):
+    """The PRODUCT library (no hooks: what bench.py, the pipeline and the host classes load) on the sizes of test_staged_parity:
+    final keypoints and descriptors against the oracle, single images (the small-batch kernels) and one batch of eight (the
+    batched ones), and the hooks really are absent from it."""
+    assert not any(hasattr(pkg.lib(), n) for n in pkg.DEV_EXPORTS)
+    for w, h, nf in SIZES:
+        ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, developer=False)
+        with pytest.raises(pkg.OrbxError):
+            ex.debug_level_points(0, 0)
+        orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+        imgs = [synth.frame(w, h, 900 + i) for i in range(8)]
+        exp = [orc.extract(im) for im in imgs]
+        _check_against(ex, orc, exp[0][0], exp[0][1], imgs[0], 8, staged=False)
+        for (gk, gd), (ok, od) in zip(ex.extract_batch(np.stack(imgs)), exp):
+            assert len(gk) == len(ok)
+            for f in ("x", "y", "size", "response", "octave"):
+                np.testing.assert_array_equal(gk[f], ok[f], err_msg=f)
+            np.testing.assert_array_equal(gd, od)
+        cand, kept = ex.level_counts(7)
+        assert kept.sum() == len(exp[7][0]) and (cand >= kept).all()

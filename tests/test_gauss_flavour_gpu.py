@@ -15,6 +15,11 @@ pytestmark = pytest.mark.gpu
 FLAVOURS = ["half_up", "sse2"]
 
 
+@pytest.fixture(autouse=True)
+def _staged_tests_use_the_developer_build(hooks):
+    yield
+
+
 def _check(gk, gd, ok, od):
     assert len(gk) == len(ok)
     for f in ("x", "y", "size", "response", "octave", "class_id"):

@@ -1,6 +1,7 @@
 """Chained multi-frame parity: 30 frames of a synthetic stereo sequence through the tracking front-end of
 tests/tracking_chain.py - the state (map points, holders, observation counts, temporal points) carried from frame to
-frame - by the CPU oracle and by the HIP library (host-array entry points, and the device-resident *_device entry points).
+frame - by the CPU oracle and by the HIP library (host-array entry points, the device-resident *_device entry points, and the latency path
+orbx_stereo_frame_view + device-resident matchers).
 Every frame's keypoints, descriptors, mvuRight, mvDepth, SearchByProjection holders, isInFrustum records, SearchLocalPoints
 holders and the map-point assignment must be identical: a single differing bit anywhere diverges the chains for good."""
 import importlib
@@ -22,7 +23,7 @@ def test_chained_tracking_front_end(oracle, w, h, nf, T):
     step = 0.04
     frames, _ = synth.stereo_sequence(w, h, T, k=11, step=step)
     Ts = tc.poses(T, step)
-    chains = [tc.Chain(B(w, h, nf), w, h, nf) for B in (tc.OracleBackend, tc.GpuHostBackend, tc.GpuStereoFrameBackend, tc.GpuDeviceBackend)]
+    chains = [tc.Chain(B(w, h, nf), w, h, nf) for B in (tc.OracleBackend, tc.GpuHostBackend, tc.GpuStereoFrameBackend, tc.GpuDeviceBackend, tc.GpuViewBackend)]
     for t in range(T):
         snaps = [c.step(frames[t][0], frames[t][1], Ts[t]) for c in chains]
         for c in chains[1:]:

@@ -334,6 +334,37 @@ class GpuDeviceBackend(GpuHostBackend):
                                                    wp, mp_desc, Tcw, self.cam, 0.5, self.thr, frame_mp, ext_obs, th, nnratio, 0, self.stream)
 
 
+class GpuViewBackend(GpuHostBackend):
+    """The latency path (round 5): one orbx_stereo_frame_view call per frame - the first kernel reads the images in pinned host
+    memory, the last one writes the frame's record to pinned host memory, no copy command in between - and the guided searches on
+    the record the call left in HBM.  The arrays handed to the host bookkeeping are VIEWS of the handle's pinned record (two
+    records alternate: the last frame's stay valid while the current one is written)."""
+    name = "gpu-view"
+
+    def __init__(self, w, h, nf):
+        super().__init__(w, h, nf)
+        import torch
+        self.torch = torch
+        self.ex = self.exl
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def frame(self, left, right, mbf, mb):
+        f = self.ex.stereo_frame_view(left, right, mbf, mb)
+        return {"k": f["kl"], "d": f["dl"], "uright": f["uright"], "depth": f["depth"], "view": f["view"], "n": len(f["kl"])}
+
+    def search_frame(self, f, flast, Tc, Tl, lp, cur_mp, th):
+        v, vl = f["view"], flast["view"]
+        return self.pkg.search_by_projection_frame_device(v.d_kl, v.d_dl, v.d_uright, f["n"], self.geom, self.sf, self.cam, Tc, Tl, lp,
+                                                          vl.d_dl, cur_mp, None, th, False, True, 0, self.stream)
+
+    def search_local(self, f, wp, mp_desc, Tcw, frame_mp, ext_obs, th, nnratio, log_sf):
+        if self.thr is None:
+            self.thr = self.pkg.predict_scale_thresholds(log_sf, NLEVELS)
+        v = f["view"]
+        return self.pkg.search_local_points_device(v.d_kl, v.d_dl, v.d_uright, f["n"], self.geom, self.sf, wp, mp_desc, Tcw, self.cam,
+                                                   0.5, self.thr, frame_mp, ext_obs, th, nnratio, 0, self.stream)
+
+
 def poses(nframes, step):
     """True poses of synth.stereo_sequence: the camera advances step * baseline per frame along +X (Tcw = [I | -C])."""
     b = float(np.float32(BF) / np.float32(FX))

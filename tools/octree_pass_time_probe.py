@@ -10,6 +10,7 @@ for name, gen, w, h, nf in (("dense", synth.frame, 1241, 376, 1000), ("natural",
     imgs = np.stack([gen(w, h, 1000 + (i % 16)) for i in range(B)])
     ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
     ex(imgs[0]); cap = ex.max_keypoints()
+    ex.set_option(7, 9)     # time stamps in place of the fall-back flags (developer build)
     d = torch.from_numpy(imgs).cuda()
     k = torch.zeros((B, cap, 7), device="cuda"); de = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"); c = torch.zeros(B, dtype=torch.int32, device="cuda")
     for rep in range(3):

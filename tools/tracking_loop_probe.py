@@ -20,10 +20,11 @@ synth = importlib.import_module(tc.PKG + ".synth")
 frames, _ = synth.stereo_sequence(w, h, T, k=11, step=step)
 Ts = tc.poses(T, step)
 res = {}
-for B in ((tc.GpuDeviceBackend,) if ONLY == "device" else (tc.GpuHostBackend, tc.GpuStereoFrameBackend, tc.GpuDeviceBackend)):
+for B in ((tc.GpuDeviceBackend,) if ONLY == "device" else (tc.GpuViewBackend,) if ONLY == "view" else
+          (tc.GpuHostBackend, tc.GpuStereoFrameBackend, tc.GpuDeviceBackend, tc.GpuViewBackend)):
     c = tc.Chain(B(w, h, nf), w, h, nf)
     src = frames
-    if B is tc.GpuDeviceBackend:      # the device-resident chain takes its frames from pinned host memory (a capture buffer)
+    if B in (tc.GpuDeviceBackend, tc.GpuViewBackend):      # the device-resident chain takes its frames from pinned host memory (a capture buffer)
         import torch
         src = [(torch.from_numpy(l).pin_memory(), torch.from_numpy(r).pin_memory()) for l, r in frames]
     for t in range(T):
@@ -37,5 +38,4 @@ for B in ((tc.GpuDeviceBackend,) if ONLY == "device" else (tc.GpuHostBackend, tc
              1e3 / (ms("t_frame") + ms("t_proj") + ms("t_local")), int(np.median([s["proj_n"] for s in log])),
              int(np.median([s["local_n"] for s in log]))))
 if not ONLY:
-    print("chains identical:", tc.first_difference(res["gpu-host"], res["gpu-device"]) is None and
-          tc.first_difference(res["gpu-host"], res["gpu-host-1call"]) is None)
+    print("chains identical:", all(tc.first_difference(res["gpu-host"], res[k]) is None for k in ("gpu-device", "gpu-host-1call", "gpu-view")))
