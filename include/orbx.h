@@ -456,6 +456,12 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  *                              (correct, much slower than the 8-row form)
  *   ORBX_OPT_OCT_HIST      23  quad-tree input of batches of up to four images: 0 = the FAST stage histograms its emissions at the L2
  *                              and k_octree_pyr loads the histogram (no key sweep on one CU: the latency form, default), 1 = never
+ *   ORBX_OPT_PAD_FORM      24  level 0 (copy of the input + copyMakeBorder): 0 = source rows staged in LDS for batches of up to four
+ *                              images (each input byte read once, aligned: the input of a latency call sits in pinned host memory),
+ *                              1 = never (k_pyr_pad: unaligned 16-byte chunks), 2 = always
+ *   ORBX_OPT_PYR_CHAINS    25  levels >= 1 of batches of up to four images: 0 = in chains of up to four levels per launch (k_pyr_chain:
+ *                              a tile's intermediate levels stay in LDS - per-level launches of one or two images are latency-bound),
+ *                              1 = one launch per level as in a large batch.  ORBX_OPT_PYRAMID_FORM = 4 forces the chains at any batch size
  * Keys 0, 1 and 7 (stop a kernel after phase n: outputs incomplete) exist only in a library built with -DORBX_DEVELOPER
  * (tools/octree_phase_probe.py); the default build refuses them. */
 #define ORBX_OPT_PYR_TILE 3
@@ -477,6 +483,8 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
 #define ORBX_OPT_DESC_LDS_PAD 21
 #define ORBX_OPT_PYR_ROWS 22
 #define ORBX_OPT_OCT_HIST 23
+#define ORBX_OPT_PAD_FORM 24
+#define ORBX_OPT_PYR_CHAINS 25
 #define ORBX_NUM_OPTIONS 32
 int orbx_set_option(orbx_extractor_t *h, int key, int value);
 int orbx_get_option(const orbx_extractor_t *h, int key, int *value);

@@ -47,8 +47,8 @@ extern "C" int orbx_thread_release_scratch(void) {
 // There is no process-global switch.  Keys 0, 1, 7 stop a kernel after phase n (ablation timing; outputs incomplete) and exist only
 // in a developer build (-DORBX_DEVELOPER).
 extern "C" int orbx_set_option(orbx_extractor_t *h, int key, int value) {
-    static const signed char maxv[ORBX_NUM_OPTIONS] = {/*0*/ -1, -1, -2, 64, 3, 3, 3, -1, ORBX_MAX_CHUNKS, 1, 2, 2, 1, 2, 127, ORBX_MAX_LEVELS,
-                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, 2, 1, -2, -2, -2, -2, -2, -2, -2, -2};
+    static const signed char maxv[ORBX_NUM_OPTIONS] = {/*0*/ -1, -1, -2, 64, 3, 4, 3, -1, ORBX_MAX_CHUNKS, 1, 2, 2, 1, 2, 127, ORBX_MAX_LEVELS,
+                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, 2, 1, 2, 1, -2, -2, -2, -2, -2, -2};
     if (!h || key < 0 || key >= ORBX_NUM_OPTIONS || maxv[key] == -2) { orbx_set_error("orbx_set_option: unknown key %d", key); return ORBX_ERR_ARG; }
 #ifdef ORBX_DEVELOPER
     if (maxv[key] == -1) { if (value < 0) return ORBX_ERR_ARG; h->opt[key] = value; return ORBX_OK; }
@@ -466,6 +466,71 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
         h->pyrLdsBytes = 2 * (size_t)h->pyrBufBytes + (size_t)h->pyrMaxPar * 16 + 16;
         if (h->pyrLdsBytes > 150 * 1024) { orbx_set_error("pyramid tile needs %zu B of LDS", h->pyrLdsBytes); return ORBX_ERR_UNSUPPORTED; }
     }
+    {   // level chains of small batches (ChainPlan, orbx_extract_dev.h): levels 1 .. nlevels-1 in groups of up to PC_MAXL, the first group the short one
+        h->nChains = 0;
+        const int nbTotal = h->nlevels - 1;
+        if (nbTotal >= 1 && h->scale_factor <= 2.0) {
+            const int nch = (nbTotal + PC_MAXL - 1) / PC_MAXL;
+            int la = 0;
+            bool ok = true;
+            for (int c = 0; c < nch && ok; c++) {
+                const int nb = c == 0 ? nbTotal - PC_MAXL * (nch - 1) : PC_MAXL, lb = la + nb;
+                ChainPlan cp;
+                memset(&cp, 0, sizeof(cp));
+                cp.la = la; cp.lb = lb;
+                const int TY = 8;
+                bool fits = false;
+                for (int TX = 96; TX >= 16 && !fits; TX -= 4) {
+                    const size_t mark = tab.size();
+                    int maxW = 0, maxRows = 0;
+                    std::vector<int> cwv((size_t)(nb + 1), 0), chv((size_t)(nb + 1), 0);
+                    for (int axis = 0; axis < 2; axis++) {
+                        auto dim = [&](int l) { return axis == 0 ? h->geom[l].w : h->geom[l].h; };
+                        const int T = axis == 0 ? TX : TY, dc = dim(lb), nt = (dc + T - 1) / T;
+                        if (axis == 0) cp.tilesX = nt; else cp.tilesY = nt;
+                        const size_t off = tab.size();
+                        tab.resize(off + (size_t)2 * (nb + 1) * nt);   // PyrSpan = 4 shorts = 2 int32
+                        if (axis == 0) cp.xSpanOff = (int)off; else cp.ySpanOff = (int)off;
+                        for (int t = 0; t < nt; t++) {
+                            int c0 = 0, c1 = 0;
+                            for (int l = lb; l >= la; l--) {
+                                const int d = dim(l);
+                                const int b0 = std::min(t * T, dc), b1 = std::min((t + 1) * T, dc);
+                                const int o0 = (int)((long long)b0 * d / dc), o1 = (t == nt - 1) ? d : (int)((long long)b1 * d / dc);
+                                if (l == lb) { c0 = o0; c1 = o1; }
+                                else {   // rows / cols of level l read by comp_{l+1} = [c0, c1)
+                                    const LevelGeom &gn = h->geom[l + 1];
+                                    const int ofsOff = axis == 0 ? gn.xofsOff : gn.yofsOff;
+                                    int n0 = tab[ofsOff + c0], n1 = tab[ofsOff + c1 - 1] + 1;
+                                    n0 = std::min(std::max(n0, 0), d - 1);
+                                    n1 = std::min(std::max(n1, 0), d - 1);
+                                    c0 = std::min(n0, o0);
+                                    c1 = std::max(n1 + 1, o1);
+                                }
+                                short *e = (short *)&tab[off] + 4 * ((size_t)(l - la) * nt + t);
+                                e[0] = (short)o0; e[1] = (short)o1; e[2] = (short)c0; e[3] = (short)c1;
+                                int &mx = axis == 0 ? cwv[(size_t)(l - la)] : chv[(size_t)(l - la)];
+                                mx = std::max(mx, c1 - c0);
+                            }
+                        }
+                    }
+                    int buf = 0;
+                    for (int k = 0; k <= nb; k++) {
+                        if (k > 0) { maxW = std::max(maxW, cwv[(size_t)k]); maxRows = std::max(maxRows, chv[(size_t)k]); }
+                        buf = std::max(buf, (((cwv[(size_t)k] + 8 + 3) & ~3)) * chv[(size_t)k]);
+                    }
+                    cp.bufBytes = (buf + 15) & ~15;
+                    cp.maxRows = maxRows;
+                    fits = maxW <= 128 && 2 * (size_t)cp.bufBytes + (size_t)nb * maxRows * 8 <= 60 * 1024;
+                    if (!fits) tab.resize(mark);
+                }
+                ok = fits;
+                if (ok) h->chains[h->nChains++] = cp;
+                la = lb;
+            }
+            if (!ok) h->nChains = 0;
+        }
+    }
     if (maxTw > 65 || maxTh > 65) { orbx_set_error("cell window %dx%d exceeds 65", maxTw, maxTh); return ORBX_ERR_UNSUPPORTED; }
     {   // k_fast_strips takes the levels whose cells are at most 32 px wide (16 pixel pairs = one DPP row), k_fast_cells the rest
         int nstrips = 0;
@@ -653,8 +718,24 @@ static void launch_pyramid(orbx_extractor *h, const uint8_t *d_imgs, uint8_t *py
     const bool hybrid = h->opt[5] == 3;
     const int lastSingle = hybrid ? std::min(2, nl - 1) : nl - 1;
     const LevelGeom &g0 = h->geom[0];
-    hipLaunchKernelGGL(k_pyr_pad<true>, dim3(((g0.pstride >> 4) * g0.prows + 255) / 256, 1, B), dim3(256), 0, st, d_imgs, stride,
-                       img_stride, pyr, h->pyrImgBytes, h->d_geom, 0);
+    // level 0 of a small batch: source rows staged in LDS (ORBX_OPT_PAD_FORM: 0 = by batch size, 1 = never, 2 = always) - the image of a latency
+    // call is read in pinned host memory, where each byte should cross the bus once, in aligned transactions
+    const size_t padLds = (size_t)PAD_ROWS_PER_BLOCK * stride + 32;
+    if ((h->opt[24] == 2 || (h->opt[24] == 0 && B <= ORBX_HIST_IMAGES)) && padLds <= 60 * 1024)
+        hipLaunchKernelGGL(k_pyr_pad_rows, dim3((g0.h + PAD_ROWS_PER_BLOCK - 1) / PAD_ROWS_PER_BLOCK, B), dim3(256), padLds, st, d_imgs, stride, img_stride, pyr,
+                           h->pyrImgBytes, h->d_geom);
+    else
+        hipLaunchKernelGGL(k_pyr_pad<true>, dim3(((g0.pstride >> 4) * g0.prows + 255) / 256, 1, B), dim3(256), 0, st, d_imgs, stride,
+                           img_stride, pyr, h->pyrImgBytes, h->d_geom, 0);
+    // ORBX_OPT_PYRAMID_FORM = 4 (and small batches by default, ORBX_OPT_PYR_CHAINS): the levels in chains, one launch per chain
+    if (h->nChains > 0 && !hybrid && (h->opt[5] == 4 || (h->opt[5] == 0 && h->opt[25] != 1 && B <= ORBX_HIST_IMAGES))) {
+        for (int c = 0; c < h->nChains; c++) {
+            const ChainPlan &cp = h->chains[c];
+            const size_t lds = 2 * (size_t)cp.bufBytes + (size_t)(cp.lb - cp.la) * cp.maxRows * 8;
+            hipLaunchKernelGGL(k_pyr_chain, dim3(cp.tilesX * cp.tilesY, B), dim3(256), lds, st, pyr, h->pyrImgBytes, h->d_geom, h->d_tab, cp);
+        }
+        return;
+    }
     for (int l = 1; l <= lastSingle; l++) {
         // 16 output rows per wave while that still leaves every SIMD several waves (8192 = 8 per SIMD), else 8; same pixels either way
         const int nxc = (h->geom[l].w + 1 + 127) / 128, nb16 = (h->geom[l].h + 15) / 16, nb8 = (h->geom[l].h + 7) / 8;
@@ -1474,6 +1555,16 @@ extern "C" int orbx_pyramid_host(orbx_extractor_t *h, int b, int level, int padd
     return ORBX_OK;
 }
 
+extern "C" int orbx_level_counts(orbx_extractor_t *h, int b, int32_t *candidates, int32_t *keypoints) {
+    if (!h || h->pw == 0 || b < 0 || b >= h->pB || !h->last_valid) { orbx_set_error("orbx_level_counts: bad arguments or no frame extracted yet"); return ORBX_ERR_ARG; }
+    ORBX_HIP(hipSetDevice(h->device));
+    ORBX_HIP(hipStreamSynchronize(h->last_stream));
+    if (candidates) ORBX_HIP(hipMemcpy(candidates, h->d_candCnt + (size_t)b * h->nlevels, sizeof(int32_t) * h->nlevels, hipMemcpyDeviceToHost));
+    if (keypoints) ORBX_HIP(hipMemcpy(keypoints, h->d_lvlCnt + (size_t)b * h->nlevels, sizeof(int32_t) * h->nlevels, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+#ifdef ORBX_DEVELOPER   // ---- read-only stage hooks: developer build only (include/orbx_dev.h)
 // the compacted key arrays of the last call, when k_octree_pyr read the cell lists in place: gathered now, for the test hooks
 static int ensure_cand(orbx_extractor *h) {
     if (h->candStale <= 0) return ORBX_OK;
@@ -1489,16 +1580,6 @@ static int ensure_cand(orbx_extractor *h) {
     return ORBX_OK;
 }
 
-extern "C" int orbx_level_counts(orbx_extractor_t *h, int b, int32_t *candidates, int32_t *keypoints) {
-    if (!h || h->pw == 0 || b < 0 || b >= h->pB || !h->last_valid) { orbx_set_error("orbx_level_counts: bad arguments or no frame extracted yet"); return ORBX_ERR_ARG; }
-    ORBX_HIP(hipSetDevice(h->device));
-    ORBX_HIP(hipStreamSynchronize(h->last_stream));
-    if (candidates) ORBX_HIP(hipMemcpy(candidates, h->d_candCnt + (size_t)b * h->nlevels, sizeof(int32_t) * h->nlevels, hipMemcpyDeviceToHost));
-    if (keypoints) ORBX_HIP(hipMemcpy(keypoints, h->d_lvlCnt + (size_t)b * h->nlevels, sizeof(int32_t) * h->nlevels, hipMemcpyDeviceToHost));
-    return ORBX_OK;
-}
-
-#ifdef ORBX_DEVELOPER   // ---- read-only stage hooks: developer build only (include/orbx_dev.h)
 // test / probe hook: which (image, level)s of the last call took the exact form of the quad-tree because the count pyramid was too shallow
 extern "C" int orbx_debug_octree_fallbacks(orbx_extractor_t *h, int32_t *out, int n) {
     if (!h || !out || n < 1 || h->pw == 0 || n > h->pB * h->nlevels) { orbx_set_error("orbx_debug_octree_fallbacks: bad arguments"); return ORBX_ERR_ARG; }

@@ -85,6 +85,17 @@ __global__ void k_pyr_level(uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *g
 template <bool FULL>
 __global__ void k_pyr_pad(const uint8_t *img, int sstride, size_t simg, uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom,
                           int l0);                                                                               // orbx_pyramid.hip
+// ---- level CHAINS (small batches, round 5): up to PC_MAXL consecutive levels built by ONE launch from the level in front of them.
+// Per-level launches of a batch of one or two images are latency-bound (a level kernel lasts ~4.8 us however little it resizes: seven
+// of them are 34 us of a stereo frame); a chain keeps the intermediate levels of a tile in LDS, so the only trips to memory are the
+// source rectangle at the start and each level's own rectangle on the way out.  A workgroup owns a tile of the chain's LAST level and,
+// through the resize source offsets, the matching rectangles of the levels before it (own_l partitions level l; comp_l = own_l +
+// what comp_{l+1} reads: 1-2 px of halo per level, recomputed by the neighbours, written by the owner only) - the span tables of
+// k_pyramid_fused, built per chain.  Arithmetic per pixel pair is k_pyr_level's.
+// (struct ChainPlan, PC_MAXL: orbx_internal.h)
+__global__ void k_pyr_chain(uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, const int32_t *tab, ChainPlan cp);   // orbx_pyramid.hip
+__global__ void k_pyr_pad_rows(const uint8_t *img, int sstride, size_t simg, uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom);   // orbx_pyramid.hip
+#define PAD_ROWS_PER_BLOCK 8
 struct StripBases { int v[ORBX_MAX_LEVELS + 1]; };   // first strip of every level (levels with cells wider than 32 px own none)
 __global__ void k_fast_strips(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalStrips, int totalCells,
                               uint32_t *cellCnt, uint32_t *cellRaw, uint32_t *slots, size_t slotsPerImg, int iniTh, int minTh,

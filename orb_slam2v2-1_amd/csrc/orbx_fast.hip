@@ -391,6 +391,12 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(
 //   * survivors with score >= min(iniTh, minTh) go straight to the cell's slot list in row-major order (ballot prefix inside the
 //     cell's 16 lanes); the per-cell threshold fallback (:809-816) is decided at the end of the strip from per-lane counters
 //     (nA: survivors >= iniTh, nB: >= minTh) and applied by k_gather while it compacts: count = nA ? nA : nB.
+// tools/phase_count.py: assembler comments at the phase boundaries of k_fast_strips (-DORBX_PHASE_MARKERS only: a volatile asm is a scheduling barrier)
+#ifdef ORBX_PHASE_MARKERS
+#define FPHASE(name) asm volatile("; ORBX_PHASE " name)
+#else
+#define FPHASE(name)
+#endif
 #define STRIP_ES 144      // dwords per tile row: 4 x 32 px + 6 px of window + alignment shift (<= 3) + the last pair's partner, 16-B rows
 #define STRIP_SLOTS 8     // ring of 8 window rows (the loop is unrolled by 8 rows, so every ring slot is a compile-time offset)
 __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
@@ -489,6 +495,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
     // slot (R + k) & 7, an immediate offset from ONE base register - no mirror of the ring's first rows, no per-row address
     auto rowstep = [&](const int R, int y, uint32_t &kpOut, uint32_t &sOut) {
         uint32_t S = 0;
+        FPHASE("ring_reads");
         if (y < chS) {   // wave-uniform
             const uint32_t *q = q0;
 #define SLOT(k) (((R + (k)) & 7) * STRIP_ES)
@@ -496,6 +503,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
             uint32_t rr[16];
             rr[0] = q[SLOT(6)];  rr[4] = q[SLOT(3) + 3];  rr[8] = q[SLOT(0)];  rr[12] = q[SLOT(3) - 3];
             bool go = true;
+            FPHASE("row_pretest");
             if (pretest) {   // wave-uniform
                 // Every nine-arc of the ring holds r[0] or r[8] and r[4] or r[12].  So bright = (max over arcs of the arc's minimum) - v
                 // <= min(max(r0, r8), max(r4, r12)) - v and dark = v - (min over arcs of the arc's maximum) <= v - max(min(r0, r8),
@@ -510,11 +518,13 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
                 const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_maximum(ub, ud), tl2) - tl2) & vmask;
                 go = __ballot(u != 0) != 0;   // U - tlo > 0 for some pixel of the evaluated area (exact on these values: max(U, tlo) - tlo >= 0)
             }
+            FPHASE("ring_reads");
             if (go) {
                 rr[1] = q[SLOT(6) + 1];   rr[2] = q[SLOT(5) + 2];   rr[3] = q[SLOT(4) + 3];
                 rr[5] = q[SLOT(2) + 3];   rr[6] = q[SLOT(1) + 2];   rr[7] = q[SLOT(0) + 1];
                 rr[9] = q[SLOT(0) - 1];   rr[10] = q[SLOT(1) - 2];  rr[11] = q[SLOT(2) - 3];
                 rr[13] = q[SLOT(4) - 3];  rr[14] = q[SLOT(5) - 2];  rr[15] = q[SLOT(6) - 1];
+                FPHASE("score");
                 const half2v best = fast_ring_score(vv, rr);
                 // score + 1, clamped at 0, pixels outside the cell's evaluated area = 0
                 S = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(best, (half2v){(_Float16)0, (_Float16)0})) & vmask;
@@ -522,6 +532,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
 #undef SLOT
         }
         // row y: (left neighbour's second pixel, my first) and (my second, right neighbour's first); zero beyond the cell
+        FPHASE("suppression");
         const uint32_t Lp = __builtin_amdgcn_perm(S, dpp_row_shr1(S), 0x05040302u);   // bytes: shr.hi | S.lo << 16
         const uint32_t Rp = __builtin_amdgcn_perm(dpp_row_shl1(S), S, 0x05040302u);   // bytes: S.hi | shl.lo << 16
         const half2v Lh = __builtin_bit_cast(half2v, Lp), Rh = __builtin_bit_cast(half2v, Rp), Sh = __builtin_bit_cast(half2v, S);
@@ -535,6 +546,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
         sOut = S1;
         S1 = S; H2 = H1; H1 = H0; LR1 = LR0;
         // stream: window row y+7 (loaded during this iteration) replaces row y-1 in the ring; row y+8 goes in flight
+        FPHASE("row_stream");
         if (y + 7 < thS) write_row((R + 7) & 7, pre);   // wave-uniform
         pre = load_row(y + 8);
         wave_sync();
@@ -546,6 +558,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
         uint32_t kpA, sA, kpB, sB;
         rowstep(R, y, kpA, sA);          // verdict for row y-1
         rowstep(R + 1, y + 1, kpB, sB);  // verdict for row y   (y + 1 > chS: an all-zero row, nothing survives)
+        FPHASE("emission");
         const short2v fa = __builtin_bit_cast(short2v, kpA), fb = __builtin_bit_cast(short2v, kpB);
         const bool inA = fa.x > 0 || fa.y > 0, inB = fb.x > 0 || fb.y > 0;
         const unsigned long long mA = __ballot(inA), mB = __ballot(inB);
@@ -563,14 +576,17 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_strips(
             nRaw += __popc(aA) + __popc(aB);
         }
     };
+    FPHASE("loop");
     for (int yv = 0; yv <= chS; yv += 8) {
         const int y = __builtin_amdgcn_readfirstlane(yv);   // everything derived from the row number stays on the scalar unit
+        FPHASE("loop");
         rowpair(0, y);
         if (y + 2 <= chS) rowpair(2, y + 2);   // wave-uniform
         if (y + 4 <= chS) rowpair(4, y + 4);
         if (y + 6 <= chS) rowpair(6, y + 6);
     }
     // per-cell totals: the 16 lanes of a cell
+    FPHASE("epilogue");
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) nHi += __shfl_xor(nHi, o);
     if (j == 0 && exists) {

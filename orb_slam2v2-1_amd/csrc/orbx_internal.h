@@ -58,6 +58,15 @@ struct LevelGeom {
     float size;                      // (float)(int)(31*scale)                            (:837,846)
 };
 
+// One launch of k_pyr_chain (orbx_extract_dev.h): up to PC_MAXL consecutive pyramid levels built from the level in front of them
+#define PC_MAXL 4
+struct ChainPlan {
+    int la, lb;                  // source level, last level built (lb - la <= PC_MAXL)
+    int tilesX, tilesY;
+    int xSpanOff, ySpanOff;      // int32 offsets into tab: PyrSpan [lb - la + 1][tiles] per axis (level la first)
+    int bufBytes, maxRows;       // one LDS level buffer, rows of the ypar table per level
+};
+
 struct orbx_extractor {
     int nfeatures, nlevels, ini_th, min_th, device;
     double scale_factor;
@@ -84,6 +93,7 @@ struct orbx_extractor {
     uint32_t *d_octPart, *d_octLeaf, *d_octBest; int32_t *d_octState;
     int pyrTilesX, pyrTilesY, pyrXSpanOff, pyrYSpanOff, pyrBufBytes, pyrMaxDim, pyrMaxPar;
     size_t pyrLdsBytes;
+    ChainPlan chains[4]; int nChains;   // level chains of small batches (k_pyr_chain)
     // device buffers
     LevelGeom *d_geom;
     int32_t *d_tab;

@@ -448,10 +448,16 @@ __global__ __launch_bounds__(SM_T) void k_stereo_finish(uint4 *rec, uint4 *__res
     __shared__ int sh_keep;
     const int tid = threadIdx.x;
     int32_t *tail = (int32_t *)((uint8_t *)rec + (size_t)128 * cap);
-    const int N = min(tail[0], cap);
     float *uright = (float *)((uint8_t *)rec + (size_t)120 * cap), *depth = uright + cap;
+    // my unit of the record is requested first: nothing below depends on it until the copy-out (k_stereo_match wrote sad = -1 for
+    // every slot behind the last keypoint, so the median step walks all cap slots and needs no count either: no dependent load chain)
+    const int total = 8 * cap + 1, ur0 = (120 * cap) >> 4, ur1 = (128 * cap) >> 4;
+    const int u0 = blockIdx.x * SM_T + tid;
+    uint4 v0 = make_uint4(0u, 0u, 0u, 0u);
+    if (u0 < total) v0 = rec[u0];
     if (tid == 0) sh_keep = 0;
     float thDist = 0.0f;
+    const int N = cap;
     const int nd = stereo_sad_threshold(sad, N, sd_lds, useLds, &thDist);
     const int32_t *sd = useLds ? sd_lds : sad;
     {   // the match count (every workgroup: the one that copies the record's tail needs it) and, by workgroup 0, the rule on the device arrays
@@ -469,9 +475,8 @@ __global__ __launch_bounds__(SM_T) void k_stereo_finish(uint4 *rec, uint4 *__res
     }
     // copy-out: 16-byte units [0, 8 cap + 1); units of the mvuRight / mvDepth block get the rule applied (the device words may or may
     // not have been rewritten by workgroup 0 yet: the rule gives the same word either way)
-    const int total = 8 * cap + 1, ur0 = (120 * cap) >> 4, ur1 = (128 * cap) >> 4;
-    for (int u = blockIdx.x * SM_T + tid; u < total; u += gridDim.x * SM_T) {
-        uint4 v = rec[u];
+    for (int u = u0; u < total; u += gridDim.x * SM_T) {
+        uint4 v = u == u0 ? v0 : rec[u];
         if (u >= ur0 && u < ur1) {
             const int i0 = ((u - ur0) * 4) % cap;     // keypoint of the unit's first word (mvuRight and mvDepth blocks: cap words each)
             uint32_t *w = (uint32_t *)&v;

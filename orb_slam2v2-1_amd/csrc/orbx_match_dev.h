@@ -132,6 +132,17 @@ __device__ __forceinline__ bool in_area(const AreaQuery &q, unsigned code, const
     const float distx = kp.x - q.x, disty = kp.y - q.y;
     return fabsf(distx) < q.r && fabsf(disty) < q.r;
 }
+__device__ __forceinline__ bool in_area_xy(const AreaQuery &q, unsigned code, float kx, float ky, int octave) {   // in_area on unpacked fields
+    if (code == 0xFFFFu) return false;
+    const int cx = (int)(code >> 8), cy = (int)(code & 0xFF);
+    if (cx < q.x0 || cx > q.x1 || cy < q.y0 || cy > q.y1) return false;
+    if (q.checkLevels) {
+        if (octave < q.minLevel) return false;
+        if (q.maxLevel >= 0 && octave > q.maxLevel) return false;
+    }
+    const float distx = kx - q.x, disty = ky - q.y;
+    return fabsf(distx) < q.r && fabsf(disty) < q.r;
+}
 __device__ __forceinline__ u64 scan_key(int dist, unsigned code, int j) {
     return ((u64)dist << 28) | ((u64)(code >> 8) << 22) | ((u64)(code & 0xFF) << 16) | (u64)j;
 }

@@ -42,13 +42,23 @@ __global__ __launch_bounds__(256) void k_cell_codes(const orbx_keypoint_t *__res
     if (j < n) code[j] = (uint16_t)cell_code(g, kp[j]);
 }
 
+// A keypoint as the candidate scan reads it: ONE coalesced 16-byte load per lane and round instead of a 2-byte code, three fields of a
+// 28-byte record, a flag byte and (stereo gate) a float from four arrays (round 5: k_cand is bound by exactly these loads - 2000
+// waves x 2000 keypoints).  x, y: float bits; z: cell code | octave << 16 | blocked-before-the-call << 24; w: mvuRight bits.
+__device__ __forceinline__ uint4 compact_kp(const orbm_grid_geom_t &g, const orbx_keypoint_t &kp, bool blocked, float ur) {
+    return make_uint4(__float_as_uint(kp.x), __float_as_uint(kp.y), cell_code(g, kp) | ((uint32_t)(kp.octave & 0xFF) << 16) | (blocked ? 1u << 24 : 0u),
+                      __float_as_uint(ur));
+}
+__global__ __launch_bounds__(256) void k_compact_kps(const orbx_keypoint_t *__restrict__ kp, int n, orbm_grid_geom_t g, uint4 *__restrict__ ckp) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) ckp[j] = compact_kp(g, kp[j], false, 0.0f);
+}
+
 // ---- A. one wave per query: all candidates -> LDS; out: the QK smallest keys (sorted), or with
 // FULL the whole sorted list (stride CAND_CAP) for searches whose runner-up can be deep in the list
 template <bool FULL>
 __global__ __launch_bounds__(256) void k_cand(const GQuery *__restrict__ qs, const uint8_t *__restrict__ qdesc, int m,
-                                              const orbx_keypoint_t *__restrict__ kps, const uint8_t *__restrict__ desc,
-                                              const float *__restrict__ uright, const uint8_t *__restrict__ sblocked,
-                                              const uint16_t *__restrict__ code, int n, orbm_grid_geom_t g,
+                                              const uint4 *__restrict__ ckp, const uint8_t *__restrict__ desc, int n, orbm_grid_geom_t g,
                                               u64 *__restrict__ keys, int32_t *__restrict__ ncand) {
     __shared__ u64 cl[4][CAND_CAP];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -61,19 +71,22 @@ __global__ __launch_bounds__(256) void k_cand(const GQuery *__restrict__ qs, con
         const AreaQuery aq = make_query(g, Q.x, Q.y, Q.r, Q.minLevel, Q.maxLevel);
         if (!aq.empty) {
             const Desc256 da = load_desc(qdesc + (size_t)qi * 32);
+            uint4 rn = ckp[min(lane, n - 1)];   // the next round's records are in flight while this round is tested
             for (int j0 = 0; j0 < n; j0 += 64) {
                 const int j = j0 + lane;
+                const uint4 r = rn;
+                rn = ckp[min(j + 64, n - 1)];
                 bool ok = false;
                 u64 key = ~0ull;
                 if (j < n) {
-                    const unsigned c = code[j];
-                    const orbx_keypoint_t kp = kps[j];
-                    ok = in_area(aq, c, kp) && !(sblocked && sblocked[j]);
+                    const unsigned c = r.z & 0xFFFFu;
+                    const int oct = (int)((r.z >> 16) & 0xFFu);
+                    ok = in_area_xy(aq, c, __uint_as_float(r.x), __uint_as_float(r.y), oct) && !((r.z >> 24) & 1u);
                     if (ok && Q.ur_tol >= 0.0f) {
-                        const float u = uright[j];
+                        const float u = __uint_as_float(r.w);
                         if (u > 0 && fabsf(Q.ur_c - u) > Q.ur_tol) ok = false;
                     }
-                    if (ok) key = fast_key(ham(da, load_desc(desc + (size_t)j * 32)), c, j, kp.octave);
+                    if (ok) key = fast_key(ham(da, load_desc(desc + (size_t)j * 32)), c, j, oct);
                 }
                 const u64 mk = __ballot(ok);
                 if (ok) {
@@ -568,17 +581,20 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
     // the decision of query r of this thread given the blocking times in bt (useBt = false: nothing is blocked)
     auto decide = [&](int r, bool useBt) -> int {
         const uint32_t qi = (uint32_t)(tid + r * RP_T);
+        // the blocking times of all QK candidates are requested at once (independent LDS reads: one latency per decision, not one per
+        // candidate - a round of the iteration is a handful of such latencies and the iteration takes as many rounds as the longest
+        // chain of displaced queries)
+        uint32_t tb[QK];
+#pragma unroll
+        for (int k = 0; k < QK; k++) tb[k] = useBt ? bt[c[r][k] == ~0u ? 0u : (c[r][k] >> 4) & 0xFFFFu] : 0xFFFFFFFFu;   // (an empty slot looks at entry 0 and ignores it)
         int best = -1, bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, found = 0;
 #pragma unroll
         for (int k = 0; k < QK; k++) {
             const uint32_t e = c[r][k];
-            if (found < (MODE == 0 ? 2 : 1) && e != ~0u) {
-                const int idx = (int)((e >> 4) & 0xFFFFu);
-                if (!(useBt && bt[idx] < qi)) {
-                    if (found == 0) { best = idx; bestDist = (int)(e >> 20); bestLevel = (int)(e & 15u); }
-                    else { bestDist2 = (int)(e >> 20); bestLevel2 = (int)(e & 15u); }
-                    found++;
-                }
+            if (found < (MODE == 0 ? 2 : 1) && e != ~0u && !(tb[k] < qi)) {
+                if (found == 0) { best = (int)((e >> 4) & 0xFFFFu); bestDist = (int)(e >> 20); bestLevel = (int)(e & 15u); }
+                else { bestDist2 = (int)(e >> 20); bestLevel2 = (int)(e & 15u); }
+                found++;
             }
         }
         ranout[r] = (MODE == 0 ? found < 2 : best < 0) && nc[r] > QK;   // more candidates existed than were kept
@@ -589,7 +605,9 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
     };
 #pragma unroll
     for (int r = 0; r < RP_Q; r++) { ranout[r] = false; if (nc[r] > 0) claim[r] = decide(r, false); }
+    int rounds = 0;
     for (int round = 0; round <= m + 1; round++) {
+        rounds++;
         for (int j = tid; j < n; j += RP_T) bt[j] = 0xFFFFFFFFu;
         __syncthreads();
 #pragma unroll
@@ -652,21 +670,20 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
     if (__ballot(overflow) && (tid & 63) == 0) sh_ov = 1;
     __syncthreads();
     if (tid == 0) {
-        out[0] = sh_nm; out[1] = sh_ov;
-        if (out_host) { out_host[0] = sh_nm; out_host[1] = sh_ov; }
+        out[0] = sh_nm; out[1] = sh_ov; out[2] = rounds;     // [2]: rounds the iteration took (diagnostics)
+        if (out_host) { out_host[0] = sh_nm; out_host[1] = sh_ov; out_host[2] = rounds; }
     }
 }
 
 __global__ __launch_bounds__(256) void k_queries_windows(const orbm_window_query_t *__restrict__ w, int m,
                                                          GQuery *__restrict__ q, const int32_t *__restrict__ holder,
                                                          const int32_t *__restrict__ ext_blocks, int n,
-                                                         uint8_t *__restrict__ sblocked, const orbx_keypoint_t *__restrict__ kp,
-                                                         orbm_grid_geom_t gcode, uint16_t *__restrict__ code) {
+                                                         const orbx_keypoint_t *__restrict__ kp, const float *__restrict__ uright,
+                                                         orbm_grid_geom_t gcode, uint4 *__restrict__ ckp) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
-        code[i] = (uint16_t)cell_code(gcode, kp[i]);   // (was a launch of its own, k_cell_codes)
+    if (i < n) {   // the frame's keypoints as the candidate scan reads them (cell codes were a launch of their own, k_cell_codes)
         const int hm = holder[i];
-        sblocked[i] = hm == -1 ? 0 : hm == -2 ? (ext_blocks ? (ext_blocks[i] != 0) : 1) : (w[hm].blocks != 0);
+        ckp[i] = compact_kp(gcode, kp[i], hm == -1 ? false : hm == -2 ? (ext_blocks ? (ext_blocks[i] != 0) : true) : (w[hm].blocks != 0), uright[i]);
     }
     if (i >= m) return;
     GQuery Q;
@@ -693,13 +710,12 @@ __global__ __launch_bounds__(256) void k_queries_init(const orbx_keypoint_t *__r
 __global__ __launch_bounds__(256) void k_queries_mp(const orbm_mappoint_t *__restrict__ mps, int m,
                                                     const float *__restrict__ sf, float th, GQuery *__restrict__ q,
                                                     const int32_t *__restrict__ frame_mp, const int32_t *__restrict__ ext_obs,
-                                                    int n, uint8_t *__restrict__ sblocked, const orbx_keypoint_t *__restrict__ kp,
-                                                    orbm_grid_geom_t gcode, uint16_t *__restrict__ code) {
+                                                    int n, const orbx_keypoint_t *__restrict__ kp, const float *__restrict__ uright,
+                                                    orbm_grid_geom_t gcode, uint4 *__restrict__ ckp) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {  // holders present before the call (:87-89)
-        code[i] = (uint16_t)cell_code(gcode, kp[i]);
         const int hm = frame_mp[i];
-        sblocked[i] = hm == -1 ? 0 : hm == -2 ? (ext_obs && ext_obs[i] > 0) : (mps[hm].observations > 0);
+        ckp[i] = compact_kp(gcode, kp[i], hm == -1 ? false : hm == -2 ? (ext_obs && ext_obs[i] > 0) : (mps[hm].observations > 0), uright[i]);
     }
     if (i >= m) return;
     const orbm_mappoint_t p = mps[i];
@@ -720,13 +736,12 @@ __global__ __launch_bounds__(256) void k_queries_frame(const orbm_lastpoint_t *_
                                                        const float *__restrict__ Tl, float th, int mono,
                                                        GQuery *__restrict__ q, const int32_t *__restrict__ cur_mp,
                                                        const int32_t *__restrict__ ext_obs, int n,
-                                                       uint8_t *__restrict__ sblocked, const orbx_keypoint_t *__restrict__ kp,
-                                                       uint16_t *__restrict__ code, float2 *__restrict__ qmeta) {
+                                                       const orbx_keypoint_t *__restrict__ kp, const float *__restrict__ uright,
+                                                       uint4 *__restrict__ ckp, float2 *__restrict__ qmeta) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
-        code[i] = (uint16_t)cell_code(g, kp[i]);
         const int hm = cur_mp[i];
-        sblocked[i] = hm == -1 ? 0 : hm == -2 ? (ext_obs && ext_obs[i] > 0) : (last[hm].observations > 0);
+        ckp[i] = compact_kp(g, kp[i], hm == -1 ? false : hm == -2 ? (ext_obs && ext_obs[i] > 0) : (last[hm].observations > 0), uright[i]);
     }
     if (i >= nlast) return;
     // twc = -Rcw^T tcw; tlc = Rlw twc + tlw (:1343-1351): cv::gemm on CV_32F accumulates in double
@@ -916,7 +931,7 @@ int fast_search_for_initialization(const orbx_keypoint_t *k1, const uint8_t *d1,
                                    const uint8_t *d2, int n2, const orbm_grid_geom_t *g2, float *prev, int32_t *m12,
                                    int window, float nnratio, int check_ori, int device, int *nmatches) {
     if (n2 > 7000 || n1 > 65535) return ORBX_FAST_FALLBACK;  // LDS plan of k_resolve_init (9 B per F2 keypoint, 64 KB)
-    const size_t need = (size_t)(n1 + n2) * (28 + 32 + 64) + (size_t)n1 * (CAND_CAP * 8 + 64) + 65536;
+    const size_t need = (size_t)(n1 + n2) * (28 + 32 + 64 + 16) + (size_t)n1 * (CAND_CAP * 8 + 64) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
     hipStream_t st = g_ar.st;
@@ -924,15 +939,14 @@ int fast_search_for_initialization(const orbx_keypoint_t *k1, const uint8_t *d1,
     uint8_t *dd1 = arena_get<uint8_t>((size_t)32 * n1), *dd2 = arena_get<uint8_t>((size_t)32 * n2);
     float *dprev = arena_get<float>(2 * (size_t)n1);
     int32_t *dm12 = arena_get<int32_t>(n1), *dbin = arena_get<int32_t>(n1), *dnc = arena_get<int32_t>(n1), *dout = arena_get<int32_t>(4);
-    uint16_t *dcode = arena_get<uint16_t>(n2);
+    uint4 *dckp = arena_get<uint4>(n2);
     GQuery *dq = arena_get<GQuery>(n1);
     u64 *dkeys = arena_get<u64>((size_t)n1 * CAND_CAP);
     UP(dk1, k1, n1); UP(dk2, k2, n2); UP(dd1, d1, (size_t)32 * n1); UP(dd2, d2, (size_t)32 * n2); UP(dprev, prev, 2 * (size_t)n1);
     FLUSH_UP();
-    hipLaunchKernelGGL(k_cell_codes, dim3((n2 + 255) / 256), dim3(256), 0, st, dk2, n2, *g2, dcode);
+    hipLaunchKernelGGL(k_compact_kps, dim3((n2 + 255) / 256), dim3(256), 0, st, dk2, n2, *g2, dckp);
     hipLaunchKernelGGL(k_queries_init, dim3((n1 + 255) / 256), dim3(256), 0, st, dk1, dprev, n1, window, dq);
-    hipLaunchKernelGGL(k_cand<true>, dim3((n1 + 3) / 4), dim3(256), 0, st, dq, dd1, n1, dk2, dd2, (const float *)nullptr,
-                       (const uint8_t *)nullptr, dcode, n2, *g2, dkeys, dnc);
+    hipLaunchKernelGGL(k_cand<true>, dim3((n1 + 3) / 4), dim3(256), 0, st, dq, dd1, n1, dckp, dd2, n2, *g2, dkeys, dnc);
     hipLaunchKernelGGL(k_resolve_init, dim3(1), dim3(64), sizeof(int32_t) * 2 * (size_t)n2 + (size_t)((n2 + 15) & ~15), st, dkeys, dnc, dk1, dk2, n1, n2,
                        dprev, dm12, dbin, nnratio, check_ori, dout);
     ORBX_HIP(hipGetLastError());
@@ -975,7 +989,7 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
                                  float nnratio, int device, int *nmatches, const FrustumArgs *world, orbm_mappoint_t *proj_out,
                                  const DevFrame *dev) {
     if (n > 30000 && !world) return ORBX_FAST_FALLBACK;
-    const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)m * (28 + 32 + QK * 8 + 64 + sizeof(orbm_worldpoint_t)) + 65536;
+    const size_t need = (size_t)n * (28 + 32 + 32 + 16) + (size_t)m * (28 + 32 + QK * 8 + 64 + sizeof(orbm_worldpoint_t)) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
     // dev: the frame's keypoints / descriptors / mvuRight are already in HBM (outputs of orbx_extract_batch_device and
@@ -983,11 +997,10 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
     hipStream_t st = dev ? dev->stream : g_ar.st;
     orbx_keypoint_t *dk = dev ? const_cast<orbx_keypoint_t *>(kun) : arena_get<orbx_keypoint_t>(n);
     uint8_t *dd = dev ? const_cast<uint8_t *>(desc) : arena_get<uint8_t>((size_t)32 * n);
-    uint8_t *dmd = arena_get<uint8_t>((size_t)32 * m), *dsb = arena_get<uint8_t>(n);
+    uint8_t *dmd = arena_get<uint8_t>((size_t)32 * m);
     float *du = dev ? const_cast<float *>(uright) : arena_get<float>(n), *dsf = arena_get<float>(nlevels);
     orbm_mappoint_t *dmp = arena_get<orbm_mappoint_t>(m);
     int32_t *dfm = arena_get<int32_t>(n), *deo = arena_get<int32_t>(n), *dnc = arena_get<int32_t>(m), *dout = arena_get<int32_t>(4);
-    uint16_t *dcode = arena_get<uint16_t>(n);
     GQuery *dq = arena_get<GQuery>(m);
     u64 *dkeys = arena_get<u64>((size_t)m * QK);
     if (!dev) { UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(du, uright, n); }
@@ -1013,8 +1026,9 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
         }
     } else { UP(dmp, mps, m); FLUSH_UP(); }
     const int mx = std::max(n, m);
-    hipLaunchKernelGGL(k_queries_mp, dim3((mx + 255) / 256), dim3(256), 0, st, dmp, m, zsf, th, dq, zfm, zeo, n, dsb, dk, *g, dcode);
-    hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, zmd, m, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
+    uint4 *dckp = arena_get<uint4>(n);
+    hipLaunchKernelGGL(k_queries_mp, dim3((mx + 255) / 256), dim3(256), 0, st, dmp, m, zsf, th, dq, zfm, zeo, n, dk, du, *g, dckp);
+    hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, zmd, m, dckp, dd, n, *g, dkeys, dnc);
     if (use_resolve_par(m, n)) {   // results land in the pinned mirror straight from the kernel
         RESOLVE_PAR_LAUNCH(0, dkeys, dnc, (const void *)dmp, dk, m, n, zfm, zfm, (int32_t *)nullptr, nnratio, 0, 0, dout, arena_hostdev(dout));
         ORBX_HIP(hipGetLastError());
@@ -1039,18 +1053,17 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
                                     const uint8_t *last_desc, int nlast, int32_t *cur_mp, const int32_t *ext_obs,
                                     float th, int mono, int check_ori, int device, int *nmatches, const DevFrame *dev) {
     if (n > 30000) return ORBX_FAST_FALLBACK;
-    const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)nlast * (28 + 32 + QK * 8 + 64 + 8) + 65536;
+    const size_t need = (size_t)n * (28 + 32 + 32 + 16) + (size_t)nlast * (28 + 32 + QK * 8 + 64 + 8) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
     hipStream_t st = dev ? dev->stream : g_ar.st;   // dev: kun / desc / uright / last_desc are device arrays (see fast_search_by_projection_mp)
     orbx_keypoint_t *dk = dev ? const_cast<orbx_keypoint_t *>(kun) : arena_get<orbx_keypoint_t>(n);
     uint8_t *dd = dev ? const_cast<uint8_t *>(desc) : arena_get<uint8_t>((size_t)32 * n);
-    uint8_t *dld = dev ? const_cast<uint8_t *>(last_desc) : arena_get<uint8_t>((size_t)32 * nlast), *dsb = arena_get<uint8_t>(n);
+    uint8_t *dld = dev ? const_cast<uint8_t *>(last_desc) : arena_get<uint8_t>((size_t)32 * nlast);
     float *du = dev ? const_cast<float *>(uright) : arena_get<float>(n), *dsf = arena_get<float>(nlevels), *dT = arena_get<float>(32);
     orbm_lastpoint_t *dl = arena_get<orbm_lastpoint_t>(nlast);
     int32_t *dcm = arena_get<int32_t>(n), *deo = arena_get<int32_t>(n), *dnc = arena_get<int32_t>(nlast), *dout = arena_get<int32_t>(4);
     int32_t *dhi = arena_get<int32_t>(nlast), *dhb = arena_get<int32_t>(nlast);
-    uint16_t *dcode = arena_get<uint16_t>(n);
     GQuery *dq = arena_get<GQuery>(nlast);
     u64 *dkeys = arena_get<u64>((size_t)nlast * QK);
     float T2[32];
@@ -1064,9 +1077,10 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
     FLUSH_UP();
     const int mx = std::max(n, nlast);
     float2 *dqm = arena_get<float2>(nlast);
+    uint4 *dckp = arena_get<uint4>(n);
     hipLaunchKernelGGL(k_queries_frame, dim3((mx + 255) / 256), dim3(256), 0, st, zl, nlast, zsf, *cam, *g, zT, zT + 16, th,
-                       mono, dq, zcm, zeo, n, dsb, dk, dcode, dqm);
-    hipLaunchKernelGGL(k_cand<false>, dim3((nlast + 3) / 4), dim3(256), 0, st, dq, dld, nlast, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
+                       mono, dq, zcm, zeo, n, dk, du, dckp, dqm);
+    hipLaunchKernelGGL(k_cand<false>, dim3((nlast + 3) / 4), dim3(256), 0, st, dq, dld, nlast, dckp, dd, n, *g, dkeys, dnc);
     if (use_resolve_par(nlast, n)) {
         RESOLVE_PAR_LAUNCH(1, dkeys, dnc, (const void *)dqm, dk, nlast, n, zcm, zcm, (int32_t *)nullptr, 0.0f, 0, check_ori, dout, arena_hostdev(dout));
         ORBX_HIP(hipGetLastError());
@@ -1091,17 +1105,16 @@ int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const fl
                        const uint8_t *qdesc, int m,
                        int32_t *holder, const int32_t *ext_blocks, int max_dist, int check_ori, int device, int *nmatches) {
     if (n > 30000) return ORBX_FAST_FALLBACK;
-    const size_t need = (size_t)n * (28 + 32 + 32) + (size_t)m * (40 + 32 + QK * 8 + 96) + 65536;
+    const size_t need = (size_t)n * (28 + 32 + 32 + 16) + (size_t)m * (40 + 32 + QK * 8 + 96) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
     hipStream_t st = g_ar.st;
     orbx_keypoint_t *dk = arena_get<orbx_keypoint_t>(n);
-    uint8_t *dd = arena_get<uint8_t>((size_t)32 * n), *dqd = arena_get<uint8_t>((size_t)32 * m), *dsb = arena_get<uint8_t>(n);
+    uint8_t *dd = arena_get<uint8_t>((size_t)32 * n), *dqd = arena_get<uint8_t>((size_t)32 * m);
     float *du = arena_get<float>(n);
     orbm_window_query_t *dw = arena_get<orbm_window_query_t>(m);
     int32_t *dh = arena_get<int32_t>(n), *deb = arena_get<int32_t>(n), *dnc = arena_get<int32_t>(m), *dout = arena_get<int32_t>(4);
     int32_t *dhi = arena_get<int32_t>(m), *dhb = arena_get<int32_t>(m);
-    uint16_t *dcode = arena_get<uint16_t>(n);
     GQuery *dq = arena_get<GQuery>(m);
     u64 *dkeys = arena_get<u64>((size_t)m * QK);
     UP(dk, kun, n); UP(dd, desc, (size_t)32 * n); UP(dw, q, m); UP(dqd, qdesc, (size_t)32 * m); UP(dh, holder, n);
@@ -1114,9 +1127,10 @@ int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const fl
     if (ext_blocks) UP(deb, ext_blocks, n);
     FLUSH_UP();
     const int mx = std::max(n, m);
+    uint4 *dckp = arena_get<uint4>(n);
     hipLaunchKernelGGL(k_queries_windows, dim3((mx + 255) / 256), dim3(256), 0, st, dw, m, dq, dh,
-                       ext_blocks ? deb : (const int32_t *)nullptr, n, dsb, dk, *ga, dcode);
-    hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dqd, m, dk, dd, du, dsb, dcode, n, *g, dkeys, dnc);
+                       ext_blocks ? deb : (const int32_t *)nullptr, n, dk, du, *ga, dckp);
+    hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dqd, m, dckp, dd, n, *g, dkeys, dnc);
     if (use_resolve_par(m, n)) {
         RESOLVE_PAR_LAUNCH(2, dkeys, dnc, (const void *)dw, dk, m, n, dh, dh, arena_hostdev(dh), 0.0f, max_dist, check_ori, dout, arena_hostdev(dout));
         ORBX_HIP(hipGetLastError());

@@ -328,6 +328,159 @@ __global__ __launch_bounds__(256) void k_pyr_pad(const uint8_t *__restrict__ img
     }
 }
 
+// Level 0 of a SMALL batch (round 5): the same padded level as k_pyr_pad<true>, built from source rows staged in LDS.  The image of a
+// latency call sits in pinned HOST memory and is read over the bus by this kernel (no copy command): there every load is a bus
+// transaction, so each source byte is fetched exactly once, by ALIGNED 16-byte loads over one contiguous span per workgroup (PAD_ROWS
+// whole source rows; an aligned 16-byte load that holds one valid byte never leaves that byte's page).  k_pyr_pad<true> reads
+// unaligned 16-byte chunks (split into several transactions) and gathers the frame bytes one by one: 28.8 us for two 1241x376
+// images against ~19 at the bus rate.  The padded rows - the rows themselves and their BORDER_REFLECT_101 mirror images above /
+// below the image - are then assembled from LDS.  Dynamic LDS: PAD_ROWS * sstride + 32 bytes.
+#define PAD_ROWS 8
+__global__ __launch_bounds__(256) void k_pyr_pad_rows(const uint8_t *__restrict__ img, int sstride, size_t simg, uint8_t *__restrict__ pyr,
+                                                      size_t pyrImgBytes, const LevelGeom *__restrict__ geom) {
+    extern __shared__ __align__(16) uint8_t rows_lds[];
+    const LevelGeom G = geom[0];
+    const int tid = threadIdx.x, r0 = blockIdx.x * PAD_ROWS, nr = min(PAD_ROWS, G.h - r0);
+    const uint8_t *src = img + (size_t)blockIdx.y * simg;
+    uint8_t *lvl = pyr + (size_t)blockIdx.y * pyrImgBytes + G.poff;
+    // ---- 1. the span of the nr source rows, aligned outwards to 16 bytes
+    const uintptr_t p0 = (uintptr_t)(src + (size_t)r0 * sstride), p1 = p0 + (size_t)(nr - 1) * sstride + G.w;
+    const uintptr_t a0 = p0 & ~(uintptr_t)15;
+    const int nch = (int)(((p1 + 15) & ~(uintptr_t)15) - a0) >> 4, lead = (int)(p0 - a0);   // LDS byte of source byte (r, x): lead + (r - r0) * sstride + x
+    for (int i = tid; i < nch; i += 256) ((uint4 *)rows_lds)[i] = ((const uint4 *)a0)[i];
+    __syncthreads();
+    // ---- 2. padded rows: 16-byte chunks of the row itself (target 0) and of its mirror images (targets 1, 2)
+    const int pc = G.pstride >> 4;
+    for (int t = 0; t < 3; t++) {
+        for (int i = tid; i < nr * pc; i += 256) {
+            const int sr = i / pc, c = i - sr * pc, r = r0 + sr;
+            int py;
+            if (t == 0) py = r + ORBX_EDGE;
+            else if (t == 1) { if (r < 1 || r > ORBX_EDGE) continue; py = ORBX_EDGE - r; }                                  // rows above the image
+            else { if (r < G.h - 1 - ORBX_EDGE || r > G.h - 2) continue; py = 2 * (G.h - 1) - r + ORBX_EDGE; }            // rows below
+            const uint8_t *row = rows_lds + lead + sr * sstride;
+            const int px = c * 16 - ORBX_EDGE;
+            uint4 v;
+            if (px >= 0 && px + 15 < G.w) {   // inside the row: 16 contiguous bytes at any LDS alignment = five aligned dwords, byte-aligned
+                const uint32_t off = (uint32_t)(row - rows_lds) + (uint32_t)px, sh = off & 3u;
+                const uint32_t *d = (const uint32_t *)(rows_lds + (off & ~3u));
+                const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
+                v = make_uint4(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                               __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh));
+            } else {
+                uint32_t w4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    w4[u] = (uint32_t)row[reflect101c(px + 4 * u, G.w)] | ((uint32_t)row[reflect101c(px + 4 * u + 1, G.w)] << 8) |
+                            ((uint32_t)row[reflect101c(px + 4 * u + 2, G.w)] << 16) | ((uint32_t)row[reflect101c(px + 4 * u + 3, G.w)] << 24);
+                v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+            *(uint4 *)(lvl + (size_t)py * G.pstride + c * 16) = v;
+        }
+    }
+}
+
+// Level chain (see ChainPlan, orbx_extract_dev.h).  256 threads; a lane owns TWO adjacent columns of the tile's rectangle at every level
+// (a rectangle is at most 128 columns wide: the host sizes the tiles accordingly), the four waves take the rows round-robin.
+// LDS: two level buffers (ping-pong, row pitch a multiple of 4 with >= 8 bytes of slack, so every source access is two ALIGNED dwords)
+// and the row parameters of every level (source rows relative to the buffer, clamped, + the packed betas).
+__global__ __launch_bounds__(256) void k_pyr_chain(uint8_t *__restrict__ pyr, size_t pyrImgBytes, const LevelGeom *__restrict__ geom,
+                                                   const int32_t *__restrict__ tab, ChainPlan cp) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ PyrSpan sX[PC_MAXL + 1], sY[PC_MAXL + 1];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tx = blockIdx.x % cp.tilesX, ty = blockIdx.x / cp.tilesX, b = blockIdx.y;
+    const int nb = cp.lb - cp.la;     // levels built
+    const int ntX = cp.tilesX, ntY = cp.tilesY;
+    if (tid <= nb) sX[tid] = ((const PyrSpan *)(tab + cp.xSpanOff))[tid * ntX + tx];
+    else if (tid >= 32 && tid <= 32 + nb) sY[tid - 32] = ((const PyrSpan *)(tab + cp.ySpanOff))[(tid - 32) * ntY + ty];
+    __syncthreads();
+    uint8_t *buf[2] = {smem, smem + cp.bufBytes};
+    uint2 *ypar = (uint2 *)(smem + 2 * cp.bufBytes);      // [nb][maxRows]
+    uint8_t *base = pyr + (size_t)b * pyrImgBytes;
+    // ---- column parameters of my two columns at every built level (registers) and the row parameters (LDS): one round of loads,
+    // issued together with the source rectangle
+    int ia[PC_MAXL], ob[PC_MAXL]; uint32_t aa[PC_MAXL], ab[PC_MAXL];
+#pragma unroll
+    for (int k = 0; k < PC_MAXL; k++) {
+        ia[k] = 0; ob[k] = 0; aa[k] = 0; ab[k] = 0;
+        if (k < nb) {
+            const LevelGeom *g = geom + cp.la + 1 + k;
+            const PyrSpan X = sX[k + 1], Xp = sX[k];
+            const int xa = min(X.c0 + 2 * lane, g->w - 1), xb = min(xa + 1, g->w - 1);
+            const int sa = tab[g->xofsOff + xa], sb2 = tab[g->xofsOff + xb];
+            aa[k] = (uint32_t)tab[g->xalphaOff + xa]; ab[k] = (uint32_t)tab[g->xalphaOff + xb];
+            ia[k] = sa - Xp.c0;                 // column of the first source byte in the previous level's buffer (>= 0 inside my rectangle)
+            ob[k] = sb2 - sa;                   // 0, 1 or 2 (scale factor <= 3)
+            const PyrSpan Y = sY[k + 1], Yp = sY[k];
+            const int sh = g[-1].h, ch = Y.c1 - Y.c0;
+            for (int y = tid; y < ch; y += 256) {
+                const int sy = tab[g->yofsOff + Y.c0 + y];
+                uint2 q;
+                q.x = (uint32_t)(min(max(sy, 0), sh - 1) - Yp.c0) | ((uint32_t)(min(max(sy + 1, 0), sh - 1) - Yp.c0) << 16);
+                q.y = (uint32_t)tab[g->ybetaOff + Y.c0 + y];
+                ypar[k * cp.maxRows + y] = q;
+            }
+        }
+    }
+    {   // source rectangle: rows of level la (inner pixels of the padded buffer), aligned dword pairs -> LDS dwords
+        const LevelGeom *g = geom + cp.la;
+        const PyrSpan X = sX[0], Y = sY[0];
+        const int cw = X.c1 - X.c0, ch = Y.c1 - Y.c0, pitch = (cw + 8 + 3) & ~3, nd = pitch >> 2;
+        const uint8_t *s0 = base + g->poff + (size_t)(ORBX_EDGE + Y.c0) * g->pstride + ORBX_EDGE + X.c0;
+        const uint32_t shf = (uint32_t)((uintptr_t)s0 & 3);   // pstride % 4 == 0: the same misalignment in every row
+        const uint8_t *s0a = s0 - shf;
+        const unsigned M = ((1u << 20) + nd - 1) / nd;
+        for (int i = tid; i < nd * ch; i += 256) {
+            const int r = (int)(((unsigned)i * M) >> 20), k = i - r * nd;
+            const uint32_t *p = (const uint32_t *)(s0a + (size_t)r * g->pstride) + k;     // (reads up to 7 bytes past the rectangle: still inside the padded row)
+            ((uint32_t *)(buf[0] + r * pitch))[k] = __builtin_amdgcn_alignbyte(p[1], p[0], shf);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PC_MAXL; k++) {
+        if (k >= nb) break;
+        const LevelGeom *g = geom + cp.la + 1 + k;
+        const PyrSpan X = sX[k + 1], Y = sY[k + 1];
+        const int cw = X.c1 - X.c0, ch = Y.c1 - Y.c0;
+        const int ppitch = (sX[k].c1 - sX[k].c0 + 8 + 3) & ~3, pitch = (cw + 8 + 3) & ~3;
+        const uint8_t *prev = buf[k & 1];
+        uint8_t *cur = buf[(k & 1) ^ 1];
+        const int A = ia[k] & ~3;
+        const uint32_t oa = (uint32_t)(ia[k] - A), obb = oa + (uint32_t)ob[k];
+        const uint32_t selA = oa | ((oa + 1) << 16) | 0x0C000C00u, selB = obb | ((obb + 1) << 16) | 0x0C000C00u;
+        const bool act = 2 * lane < cw;
+        const int xa = X.c0 + 2 * lane;
+        const bool ownA = xa >= X.o0 && xa < X.o1, ownB = xa + 1 >= X.o0 && xa + 1 < X.o1 && 2 * lane + 1 < cw;
+        uint8_t *drow0 = base + g->poff + (size_t)ORBX_EDGE * g->pstride + ORBX_EDGE + xa;
+        const uint2 *yp = ypar + k * cp.maxRows;
+        for (int y = wave; y < ch; y += 4) {       // wave-uniform row
+            const uint2 q = yp[y];
+            const uint32_t r0 = q.x & 0xFFFFu, r1 = q.x >> 16;
+            const uint32_t b0 = (q.y & 0xFFFu) << 12, b1 = ((q.y >> 16) & 0xFFFu) << 12;
+            if (act) {
+                const uint32_t *p0 = (const uint32_t *)(prev + r0 * ppitch + A), *p1 = (const uint32_t *)(prev + r1 * ppitch + A);
+                const uint32_t d00 = p0[0], d01 = p0[1], d10 = p1[0], d11 = p1[1];
+                const uint32_t t0a = udot2_u16(__builtin_amdgcn_perm(d01, d00, selA), aa[k]) & 0x7FFF0u;
+                const uint32_t t0b = udot2_u16(__builtin_amdgcn_perm(d01, d00, selB), ab[k]) & 0x7FFF0u;
+                const uint32_t t1a = udot2_u16(__builtin_amdgcn_perm(d11, d10, selA), aa[k]) & 0x7FFF0u;
+                const uint32_t t1b = udot2_u16(__builtin_amdgcn_perm(d11, d10, selB), ab[k]) & 0x7FFF0u;
+                const uint32_t pa = (vmulhi24(b0, t0a) + vmulhi24(b1, t1a) + 2) >> 2;
+                const uint32_t pb = (vmulhi24(b0, t0b) + vmulhi24(b1, t1b) + 2) >> 2;
+                *(uint16_t *)(cur + y * pitch + 2 * lane) = (uint16_t)(pa | (pb << 8));
+                const int yy = Y.c0 + y;
+                if (yy >= Y.o0 && yy < Y.o1) {     // wave-uniform: the owner writes the level
+                    uint8_t *d = drow0 + (size_t)yy * g->pstride;
+                    if (ownA) d[0] = (uint8_t)pa;
+                    if (ownB) d[1] = (uint8_t)pb;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template __global__ void k_pyr_level<8, 12>(uint8_t *, size_t, const LevelGeom *, int, const int32_t *, int, int);
 template __global__ void k_pyr_level<16, 22>(uint8_t *, size_t, const LevelGeom *, int, const int32_t *, int, int);
 template __global__ void k_pyr_pad<true>(const uint8_t *, int, size_t, uint8_t *, size_t, const LevelGeom *, int);

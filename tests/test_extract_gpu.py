@@ -314,11 +314,12 @@ def test_fused_pyramid_kernel(pkg, oracle, synth):
         pkg.set_default_option(5, 0)
 
 
-@pytest.mark.parametrize("knob", [2, 3])
+@pytest.mark.parametrize("knob", [2, 3, 4])
 def test_pyramid_forms_agree(pkg, oracle, synth, knob):
-    """ORBX_OPT_PYRAMID_FORM: 2 = one launch per level (the default), 3 = the hybrid (levels 1, 2 per launch, levels 3.. chained
-    through LDS in ONE launch; measured slower, kept as a tested alternative): every level byte for byte, frame included,
-    for odd sizes, a 3-, 4- and a 10-level pyramid, scale factors 1.1 to 1.7, and the key points behind them."""
+    """ORBX_OPT_PYRAMID_FORM: 2 = one launch per level (the default of large batches), 3 = the hybrid (levels 1, 2 per launch, levels
+    3.. chained through LDS in ONE launch; measured slower, kept as a tested alternative), 4 = level chains (k_pyr_chain, round 5: the
+    default of batches of up to four images): every level byte for byte, frame included, for odd sizes, a 3-, 4- and a 10-level
+    pyramid, scale factors 1.1 to 1.7, and the key points behind them."""
     pkg.set_default_option(5, knob)
     try:
         for (w, h, nl, sf, seed) in ((641, 479, 8, 1.2, 84), (1241, 376, 8, 1.2, 85), (500, 400, 4, 1.3, 86), (900, 700, 10, 1.2, 87), (320, 240, 3, 1.2, 88),
@@ -847,3 +848,64 @@ def test_product_library_end_to_end(pkg, oracle, synth):
             np.testing.assert_array_equal(gd, od)
         cand, kept = ex.level_counts(7)
         assert kept.sum() == len(exp[7][0]) and (cand >= kept).all()
+
+
+def test_small_batch_forms_agree(pkg, oracle, synth):
+    """The kernels a batch of up to four images takes by default (round 5: level 0 from source rows staged in LDS, levels in chains,
+    the quad-tree fed by the histogram the FAST stage fills at the L2) against the large-batch forms of the same stages switched in
+    one by one (ORBX_OPT_PAD_FORM / _PYR_CHAINS / _OCT_HIST = 1) and against the oracle: batches of 1, 2, 3 and 4 images, sizes whose
+    byte count is and is not a multiple of the page size, every padded level and every stage list."""
+    for (w, h, nf, seed) in ((1241, 376, 2000, 11), (640, 480, 1000, 12), (333, 257, 300, 13), (1920, 1080, 4000, 14)):
+        for B in ((1, 2, 3, 4) if w < 1900 else (1, 2)):
+            imgs = np.stack([synth.frame(w, h, seed * 10 + i) for i in range(B)])
+            orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+            exp = [orc.extract(im) for im in imgs]
+            for opts in ((), ((24, 1),), ((25, 1),), ((23, 1),), ((24, 1), (25, 1), (23, 1)), ((24, 2), (5, 4))):
+                ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+                for k_, v_ in opts:
+                    ex.set_option(k_, v_)
+                got = ex.extract_batch(imgs)
+                for b in range(B):
+                    assert got[b][0].tobytes() == exp[b][0].tobytes() and got[b][1].tobytes() == exp[b][1].tobytes(), (w, h, B, b, opts)
+                orc.extract(imgs[B - 1])
+                for l in range(8):
+                    np.testing.assert_array_equal(ex.pyramid_level(l, b=B - 1, padded=True), orc.pyramid_level(l, padded=True), err_msg=str((w, h, B, l, opts)))
+                    np.testing.assert_array_equal(ex.debug_level_points(l, 1, b=B - 1), _cands(orc.level_keypoints(l)), err_msg=str((w, h, B, l, opts)))
+                ex.close()
+
+
+def test_stereo_frame_view_equals_stereo_frame(pkg, oracle, synth):
+    """orbx_stereo_frame_view (the latency path: images read where they lie, record written to pinned host memory by the last kernel,
+    two alternating records) == orbx_stereo_frame == the oracle, for pageable, pinned-host and device-resident images; the view of
+    the previous call stays intact while the next one is produced."""
+    import torch
+    w, h, nf = 752, 480, 1000
+    mbf, mb = 386.1448, float(np.float32(386.1448) / np.float32(718.856))
+    frames, _ = synth.stereo_sequence(w, h, 3, k=21, step=0.04)
+    ex, ex2 = pkg.ORBextractor(nf, 1.2, 8, 20, 7, developer=False), pkg.ORBextractor(nf, 1.2, 8, 20, 7, developer=False)
+    prev = None
+    for t, (l, r) in enumerate(frames):
+        ref = ex2.stereo_frame(l, r, mbf, mb)
+        if t == 0:
+            args = (l, r)                                                                    # pageable numpy arrays
+        elif t == 1:
+            args = (torch.from_numpy(l).pin_memory(), torch.from_numpy(r).pin_memory())      # pinned host memory
+        else:
+            args = (torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda())                  # device memory
+        f = ex.stereo_frame_view(*args, mbf, mb, shape=(h, w))
+        for key in ("kl", "dl", "kr", "dr", "uright", "depth"):
+            assert f[key].tobytes() == ref[key].tobytes(), (t, key)
+        assert f["nmatch"] == ref["nmatch"] > 50
+        v = f["view"]
+        nl = len(f["kl"])
+        dk = torch.zeros(nl * 7, dtype=torch.float32, device="cuda")     # the same record in HBM
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(C.c_void_p(dk.data_ptr()), C.c_void_p(v.d_kl), C.c_size_t(nl * 28), C.c_int(3)) == 0
+        assert dk.cpu().numpy().tobytes() == f["kl"].tobytes()
+        if prev is not None:
+            for key in ("kl", "dl", "uright", "depth"):
+                assert prev[0][key].tobytes() == prev[1][key], "the previous frame's view changed under the next call"
+        prev = (f, {key: f[key].tobytes() for key in ("kl", "dl", "uright", "depth")})
+    ok, od = oracle.Extractor(nf, 1.2, 8, 20, 7).extract(frames[2][0])
+    assert f["kl"].tobytes() == ok.tobytes() and f["dl"].tobytes() == od.tobytes()

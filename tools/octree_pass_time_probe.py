@@ -5,8 +5,11 @@ import sys, importlib, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 pkg = importlib.import_module("orb_slam2v2-1_amd"); synth = importlib.import_module("orb_slam2v2-1_amd.synth")
-for name, gen, w, h, nf in (("dense", synth.frame, 1241, 376, 1000), ("natural", synth.natural, 1241, 376, 1000), ("dense2000", synth.frame, 1241, 376, 2000)):
-    B = 128
+SETS = (("dense", synth.frame, 1241, 376, 1000, 128), ("natural", synth.natural, 1241, 376, 1000, 128), ("dense2000", synth.frame, 1241, 376, 2000, 128),
+        ("fullhd4000", synth.frame, 1920, 1080, 4000, 32))
+if len(sys.argv) > 1:
+    SETS = tuple(s for s in SETS if s[0] in sys.argv[1:])
+for name, gen, w, h, nf, B in SETS:
     imgs = np.stack([gen(w, h, 1000 + (i % 16)) for i in range(B)])
     ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
     ex(imgs[0]); cap = ex.max_keypoints()

@@ -15,7 +15,7 @@ for r in csv.DictReader(open(k)):
 for r in csv.DictReader(open(m)):
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "?").replace("MEMORY_COPY_", "") + " %s B" % r.get("Size", r.get("Bytes", "?"))))
 ev.sort()
-pads = [i for i, e in enumerate(ev) if "k_pyr_pad<true>" in e[2]]
+pads = [i for i, e in enumerate(ev) if "k_pyr_pad<true>" in e[2] or "k_pyr_pad_rows" in e[2]]
 i0, i1 = pads[-3], pads[-2]
 while i0 > 0 and ev[i0 - 1][2].startswith("COPY") and ev[i0][0] - ev[i0 - 1][1] < 200000: i0 -= 1
 while i1 > 0 and ev[i1 - 1][2].startswith("COPY") and ev[i1][0] - ev[i1 - 1][1] < 200000: i1 -= 1
