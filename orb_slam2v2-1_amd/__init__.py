@@ -760,6 +760,9 @@ def search_local_points(kun, desc, uright, geom, sf, pts, mp_desc, Tcw, cam, vie
 class Vocabulary:
     """DBoW2 vocabulary on the GPU (orbv_*): from per-node arrays in file order, or from an ORBvoc.txt file."""
 
+    def _ck(self, rc):
+        _check(rc, self._L)
+
     def __init__(self, k=None, L=None, scoring=0, weighting=0, parent=None, is_leaf=None, desc=None, weight=None, path=None,
                  device=0):
         self._L = lib()

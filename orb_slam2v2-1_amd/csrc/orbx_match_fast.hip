@@ -17,6 +17,7 @@
 // the call falls back to the exact one-workgroup kernels of orbx_match.hip (same results).
 #include "orbx_match_dev.h"
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 
 #define QK 8
@@ -1041,6 +1042,7 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
     ORBX_HIP(hipStreamSynchronize(st));
     if (world && proj_out) memcpy(proj_out, arena_host(dmp), sizeof(orbm_mappoint_t) * (size_t)m);
     const int32_t *out = arena_host(dout);
+    if (getenv("ORBX_TRACE_RESOLVE")) fprintf(stderr, "k_resolve_par<mp>: %d queries, %d keypoints, %d rounds\n", m, n, out[2]);
     if (out[1]) return ORBX_FAST_FALLBACK;
     memcpy(frame_mp, arena_host(dfm), sizeof(int32_t) * (size_t)n);
     *nmatches = out[0];
@@ -1094,6 +1096,7 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
     }
     ORBX_HIP(hipStreamSynchronize(st));
     const int32_t *out = arena_host(dout);
+    if (getenv("ORBX_TRACE_RESOLVE")) fprintf(stderr, "k_resolve_par<frame>: %d queries, %d keypoints, %d rounds\n", nlast, n, out[2]);
     if (out[1]) return ORBX_FAST_FALLBACK;
     memcpy(cur_mp, arena_host(dcm), sizeof(int32_t) * (size_t)n);
     *nmatches = out[0];
