@@ -636,6 +636,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu
     PHASE("store");
     const size_t oi = (size_t)b * cap + (o - obefore);   // a launch that starts behind level 0 fills the scratch arrays from their start
     if (lane < 4) ((unsigned long long *)(desc + oi * 32))[lane] = bits[lane];
+    if (grp.hostDelta && lane < 4) ((unsigned long long *)(desc + oi * 32 + grp.hostDelta))[lane] = bits[lane];   // (wave-uniform condition)
     if (lane == 0) {
         orbx_keypoint_t kp;
         kp.x = (float)cx;
@@ -647,6 +648,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu
         kp.octave = l;
         kp.class_id = -1;
         kps[oi] = kp;
+        if (grp.hostDelta) *(orbx_keypoint_t *)((uint8_t *)(kps + oi) + grp.hostDelta) = kp;
     }
 }
 

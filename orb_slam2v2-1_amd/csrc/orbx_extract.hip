@@ -48,7 +48,7 @@ extern "C" int orbx_thread_release_scratch(void) {
 // in a developer build (-DORBX_DEVELOPER).
 extern "C" int orbx_set_option(orbx_extractor_t *h, int key, int value) {
     static const signed char maxv[ORBX_NUM_OPTIONS] = {/*0*/ -1, -1, -2, 64, 3, 4, 3, -1, ORBX_MAX_CHUNKS, 1, 2, 2, 1, 2, 127, ORBX_MAX_LEVELS,
-                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, 2, 1, 2, 1, -2, -2, -2, -2, -2, -2};
+                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, 2, 1, 2, 1, 1, -2, -2, -2, -2, -2};
     if (!h || key < 0 || key >= ORBX_NUM_OPTIONS || maxv[key] == -2) { orbx_set_error("orbx_set_option: unknown key %d", key); return ORBX_ERR_ARG; }
 #ifdef ORBX_DEVELOPER
     if (maxv[key] == -1) { if (value < 0) return ORBX_ERR_ARG; h->opt[key] = value; return ORBX_OK; }
@@ -178,6 +178,7 @@ static void free_plan(orbx_extractor *h) {
     hipFree(h->d_cand); hipFree(h->d_lvlKp); hipFree(h->d_nodeOf); hipFree(h->d_candCnt); hipFree(h->d_lvlCnt);
     hipFree(h->d_sparse); h->d_sparse = nullptr;
     hipFree(h->d_histCnt); hipFree(h->d_histBest); h->d_histCnt = h->d_histBest = nullptr;
+    hipFree(h->d_octPartBest); hipFree(h->d_octPartCnt); hipFree(h->d_octSliceState); h->d_octPartBest = h->d_octPartCnt = nullptr; h->d_octSliceState = nullptr;
     h->d_geom = nullptr; h->d_tab = nullptr; h->d_pyr = nullptr; h->d_cellCnt = nullptr; h->d_slots = nullptr;
     h->d_cand = nullptr; h->d_lvlKp = nullptr; h->d_nodeOf = nullptr; h->d_candCnt = nullptr; h->d_lvlCnt = nullptr;
     h->pw = h->ph = h->pB = 0;
@@ -606,6 +607,15 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
         ORBX_HIP(hipMalloc(&h->d_octBest, sizeof(uint32_t) * slots * (size_t)maxNodeCap));
         ORBX_HIP(hipMalloc(&h->d_octState, sizeof(int32_t) * slots * 4));
         ORBX_HIP(hipMemset(h->d_octState, 0, sizeof(int32_t) * slots * 4));
+        // shared sweeps of large levels in a batch (OctSrc::nslice): best-key partials beside the count partials of d_octPart, arrival counters
+        h->octSliceStride = 0;
+        for (int l = 0; l < h->nlevels; l++) if (h->geom[l].ncells >= 600) h->octSliceStride = std::max(h->octSliceStride, (h->geom[l].nIni << (2 * h->geom[l].pyrDepth)));
+        if (h->octSliceStride > 0) {
+            ORBX_HIP(hipMalloc(&h->d_octPartBest, sizeof(uint32_t) * slots * OCT_MAX_SLICES * (size_t)h->octSliceStride));
+            ORBX_HIP(hipMalloc(&h->d_octPartCnt, sizeof(uint32_t) * slots * OCT_MAX_SLICES * (size_t)h->octSliceStride));
+            ORBX_HIP(hipMalloc(&h->d_octSliceState, sizeof(int32_t) * slots));
+            ORBX_HIP(hipMemset(h->d_octSliceState, 0, sizeof(int32_t) * slots));
+        }
     }
     ORBX_HIP(hipMemcpy(h->d_geom, h->geom, sizeof(LevelGeom) * ORBX_MAX_LEVELS, hipMemcpyHostToDevice));
     if (!tab.empty()) ORBX_HIP(hipMemcpy(h->d_tab, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice));
@@ -1003,9 +1013,24 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
                                 h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
                                 pow2, h->octPyrWords, v.octFallback, 0, v.nodeOf, scratch, 0, 0u, aSplit, osrc);
             } else {   // no large level (or a phase-stop knob is set): one workgroup per level, one launch
-                ORBX_OCT_LAUNCH(k_octree_pyr, k_octree_pyr_wide, dim3(B, nl), lds, h->d_geom, nl, v.cand,
+                // ... except that in a BATCH the sweep of a large level (>= 600 FAST cells) is shared by two or four workgroups
+                // (ORBX_OPT_OCT_SLICES: 0 = by level size, 1 = never): the level-0 workgroup of a 1920x1080 image is otherwise the critical path
+                OctSrc os = osrc;
+                int kmax = 1;
+                if (fused && !histOct && h->opt[26] == 0 && h->d_octPartBest && h->opt[7] == 0 && h->opt[1] == 0) {
+                    for (int l = 0; l < nl; l++) {
+                        const int k = h->geom[l].ncells >= 1600 ? 4 : h->geom[l].ncells >= 600 ? 2 : 1;
+                        os.nslice[l] = (unsigned char)k;
+                        kmax = std::max(kmax, k);
+                    }
+                    os.partCnt = h->d_octPartCnt + v.octSlot0 * OCT_MAX_SLICES * (size_t)h->octSliceStride;
+                    os.partBest = h->d_octPartBest + v.octSlot0 * OCT_MAX_SLICES * (size_t)h->octSliceStride;
+                    os.sliceState = h->d_octSliceState + v.octSlot0;
+                    os.maxSlices = OCT_MAX_SLICES; os.partStride = h->octSliceStride;
+                }
+                ORBX_OCT_LAUNCH(k_octree_pyr, k_octree_pyr_wide, dim3(B, nl, kmax), lds, h->d_geom, nl, v.cand,
                                 h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
-                                pow2, h->octPyrWords, v.octFallback, h->opt[7], v.nodeOf, scratch, h->opt[1], 0u, 0, osrc);
+                                pow2, h->octPyrWords, v.octFallback, h->opt[7], v.nodeOf, scratch, h->opt[1], 0u, 0, os);
             }
         } else {        // developer knob 4 = 1: the exact form alone
             const bool wide = h->opt[11] == 0 ? h->octBigMask != 0 : h->opt[11] == 2;
@@ -1044,7 +1069,8 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
         } else {
             const int maxo = std::min(cap, h->max_kp);
             dim3 grid((maxo + DESC_WAVES - 1) / DESC_WAVES, B);
-            const DescGroup gAll = {0, nl, 1, (int)grid.x, nullptr, nullptr};
+            DescGroup gAll = {0, nl, 1, (int)grid.x, nullptr, nullptr};
+            gAll.hostDelta = h->descHostDelta;   // latency form: records also stored into their pinned host twin
             hipLaunchKernelGGL(kDesc, grid, dim3(64 * DESC_WAVES), descPad, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
                                v.lvlKp, h->lvlKpCap, v.lvlCnt, d_kps, d_desc, d_counts, cap, h->d_dbgBlur, blurp, h->blurMaskLast, gAll);
         }
@@ -1462,9 +1488,13 @@ extern "C" int orbx_stereo_frame_view(orbx_extractor_t *h, const uint8_t *left, 
     const size_t c = (size_t)cap;
     hipStream_t st = h->stream;
     // image b of the batch of two sits at dl + b * (dr - dl): the kernels add the (unsigned, possibly wrapped) difference once
+    // the descriptor kernel stores every record twice - HBM and the pinned twin - unless an option took the split-call path (its scratch records move later)
+    h->descHostDelta = h->opt[15] >= 2 ? 0 : (long long)((intptr_t)h->fv_hdev[i] - (intptr_t)rec);
+    const long long twin = h->descHostDelta;
     rc = launch_pipeline(h, dl, 2, w, hgt, stride, (size_t)((uintptr_t)dr - (uintptr_t)dl), (orbx_keypoint_t *)rec, rec + 56 * c, (int32_t *)(rec + 128 * c), cap, st);
+    h->descHostDelta = 0;
     if (rc) return rc;
-    rc = orbx_internal_stereo_frame_record(h, rec, h->fv_hdev[i], cap, mbf, mb, st);
+    rc = orbx_internal_stereo_frame_record(h, rec, h->fv_hdev[i], cap, mbf, mb, st, twin != 0);
     if (rc) return rc;
     ORBX_HIP(hipStreamSynchronize(st));
     const uint8_t *hr = h->fv_h[i];

@@ -60,6 +60,8 @@ struct DescGroup {
     int copyBlock0;                      // first copy block (grid.x when there is nothing to move)
     const orbx_keypoint_t *kpsScratch;   // records of the levels [lvEnd, nlevels) to move
     const uint8_t *descScratch;
+    long long hostDelta;                 // != 0 (latency form): every keypoint / descriptor / count store is repeated at address + hostDelta - the
+                                         // frame record's twin in pinned host memory - so that the last kernel only has mvuRight / mvDepth left to move
 };
 #define DESC_COPY_PER_BLOCK 16
 #define BLUR_R 16                // output rows per wave of k_blur_levels
@@ -95,7 +97,7 @@ __global__ void k_pyr_pad(const uint8_t *img, int sstride, size_t simg, uint8_t 
 // (struct ChainPlan, PC_MAXL: orbx_internal.h)
 __global__ void k_pyr_chain(uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, const int32_t *tab, ChainPlan cp);   // orbx_pyramid.hip
 __global__ void k_pyr_pad_rows(const uint8_t *img, int sstride, size_t simg, uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom);   // orbx_pyramid.hip
-#define PAD_ROWS_PER_BLOCK 8
+#define PAD_ROWS_PER_BLOCK 4
 struct StripBases { int v[ORBX_MAX_LEVELS + 1]; };   // first strip of every level (levels with cells wider than 32 px own none)
 __global__ void k_fast_strips(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalStrips, int totalCells,
                               uint32_t *cellCnt, uint32_t *cellRaw, uint32_t *slots, size_t slotsPerImg, int iniTh, int minTh,
@@ -135,7 +137,12 @@ struct OctSrc {
     int callSeq;
     uint32_t *candOut;       // compacted keys, written only by a level that falls back to the exact form
     uint32_t *histCnt, *histBest; int histStride;   // != NULL: the deepest-depth histogram of every (image, level) as the FAST stage left it (FastHist)
+    // large levels of a batch: the sweep of level l is shared by nslice[l] workgroups (blockIdx.z); their partial histograms (counts: two 16-bit
+    // counters per word, best keys: one word per cell) and the arrival counter of every (image, level)
+    unsigned char nslice[ORBX_MAX_LEVELS];
+    uint32_t *partCnt, *partBest; int32_t *sliceState; int maxSlices, partStride;
 };
+#define OCT_MAX_SLICES 4
 __global__ void k_octree_pyr(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,
                              uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax, int pow2cap,
                              int pyrWords, int32_t *fallback, int dbgStop, uint16_t *nodeOf, int scratchInts, int dbgStopExact,

@@ -104,6 +104,7 @@ struct orbx_extractor {
     int candStale;       // > 0: the compacted key arrays (d_cand / d_candCnt of every level) of that many images were not written by the last call
                          // (k_octree_pyr read the cell lists in place); k_gather materialises them on demand (test hooks)
     int32_t *h_sparseSeen, *d_sparseSeen; int callSeq;   // host-mapped word: sequence number of the last call that flagged a corner-sparse level
+    uint32_t *d_octPartBest, *d_octPartCnt; int32_t *d_octSliceState; int octSliceStride;   // shared sweeps of large levels in a batch (OctSrc::nslice)
     uint32_t *d_histCnt, *d_histBest; int histStride;   // [ORBX_HIST_IMAGES][nlevels][histStride] deepest-depth histogram of small batches (FastHist)
     int32_t *d_sparse;   // [B][nlevels] verdict of the last call: level with few FAST candidates (k_gather writes, k_fast_strips of the next call reads)
     // staging for the host API
@@ -114,6 +115,7 @@ struct orbx_extractor {
     // orbx_stereo_frame_view: two alternating frame records (HBM + pinned host twin, and the twin as kernels address it), pinned staging for pageable images
     uint8_t *fv_d[2], *fv_h[2], *fv_hdev[2]; int fv_cap, fv_next;
     uint8_t *fv_stage, *fv_stage_dev; size_t fv_stage_bytes;
+    long long descHostDelta;   // != 0 while a latency call is being issued: k_describe repeats its stores at address + delta (the record's pinned twin)
     uint8_t *d_dbgBlur; int dbgBlurCap;   // test hook: blurred 37x37 blocks of a single-image call (orbx_debug_blur_patches)
     hipStream_t stream;      // own stream
     hipStream_t side[ORBX_SIDE_STREAMS]; hipEvent_t evPyr[ORBX_MAX_CHUNKS], evJoin[ORBX_SIDE_STREAMS]; int lastChunks;   // chunk overlap (launch_pipeline)
@@ -145,7 +147,7 @@ struct orbx_extractor {
 // extractor internals used by the matcher side
 void orbx_internal_free_stereo_scratch(orbx_extractor *h);   // orbx_match.hip
 // ComputeStereoMatches of the frame in image slots 0 / 1 of h with the record layout of orbx_stereo_frame_view (orbx_match.hip)
-int orbx_internal_stereo_frame_record(orbx_extractor *h, uint8_t *d_rec, uint8_t *rec_hostdev, int cap, float mbf, float mb, hipStream_t st);
+int orbx_internal_stereo_frame_record(orbx_extractor *h, uint8_t *d_rec, uint8_t *rec_hostdev, int cap, float mbf, float mb, hipStream_t st, bool recordsOnHost);
 void orbx_internal_release_match_scratch();                  // orbx_match.hip      (thread-local staging pair)
 void orbx_internal_release_arena();                          // orbx_match_fast.hip (thread-local arena)
 void orbx_internal_release_bow_scratch();                    // orbx_bow.hip        (thread-local scratch)

@@ -367,7 +367,9 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_stereo_match(
 // median of the SAD distances of the accepted matches (sort + vDistIdx[size/2], :641-642) by a two-level radix select -> the
 // threshold 1.5 * 1.4 * median of :643.  Block-wide (SM_T threads, every one calls it); returns the number of accepted matches
 // (0: no threshold).  sd_lds: [N] when useLds (filled here), else the global array is re-read.
-#define SM_T 1024   // (round 5: 256 -> 1024 threads, a frame's SAD values in two rounds of loads instead of eight)
+#define SM_T 1024   // k_stereo_median (round 5: 256 -> 1024 threads, a frame's SAD values in two rounds of loads instead of eight)
+#define SF_T 1024   // k_stereo_finish (256-thread workgroups measured slower: 13.9 against 11.4 us)
+template <int T>
 __device__ __forceinline__ int stereo_sad_threshold(const int32_t *__restrict__ sadg, int N, int32_t *sd_lds, int useLds, float *thDist) {
     __shared__ int sh_nd, hist[256], sh_hi, sh_rank, sh_lo, sh_rest;
     const int tid = threadIdx.x;
@@ -375,7 +377,7 @@ __device__ __forceinline__ int stereo_sad_threshold(const int32_t *__restrict__ 
     __syncthreads();
     const int32_t *sd = useLds ? sd_lds : sadg;
     int c = 0;
-    for (int i = tid; i < N; i += SM_T) {
+    for (int i = tid; i < N; i += T) {
         const int s = sadg[i];
         if (useLds) sd_lds[i] = s;
         c += s >= 0;
@@ -388,14 +390,14 @@ __device__ __forceinline__ int stereo_sad_threshold(const int32_t *__restrict__ 
     const int target = nd / 2;
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < N; i += SM_T) { const int s = sd[i]; if (s >= 0) atomicAdd(&hist[(s >> 8) & 0xFF], 1); }
+    for (int i = tid; i < N; i += T) { const int s = sd[i]; if (s >= 0) atomicAdd(&hist[(s >> 8) & 0xFF], 1); }
     __syncthreads();
     if (tid < 64) hist256_select(hist, target, tid, &sh_hi, &sh_rank);   // (a serial 256-step scan by one thread cost 5 us)
     __syncthreads();
     const int hi8 = sh_hi;
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < N; i += SM_T) { const int s = sd[i]; if (s >= 0 && ((s >> 8) & 0xFF) == hi8) atomicAdd(&hist[s & 0xFF], 1); }
+    for (int i = tid; i < N; i += T) { const int s = sd[i]; if (s >= 0 && ((s >> 8) & 0xFF) == hi8) atomicAdd(&hist[s & 0xFF], 1); }
     __syncthreads();
     if (tid < 64) hist256_select(hist, sh_rank, tid, &sh_lo, &sh_rest);
     __syncthreads();
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(SM_T) void k_stereo_median(const int32_t *__restric
     const size_t o = (size_t)b * cap;
     if (tid == 0) sh_keep = 0;
     float thDist = 0.0f;
-    const int nd = stereo_sad_threshold(sad + o, N, sd_lds, useLds, &thDist);
+    const int nd = stereo_sad_threshold<SM_T>(sad + o, N, sd_lds, useLds, &thDist);
     if (nd == 0) {
         if (nmatch && tid == 0) nmatch[b] = 0;
         return;
@@ -442,8 +444,8 @@ __global__ __launch_bounds__(SM_T) void k_stereo_median(const int32_t *__restric
 // compute queue and the copy engine (one frame of the tracking chain: 10.5 + 4.2 + 10 + 7 us).
 // Record (bytes; cap a multiple of 4): kps L @0 | kps R @28 cap | desc L @56 cap | desc R @88 cap | mvuRight @120 cap | mvDepth @124 cap
 // | @128 cap: int32 nl, nr, nmatch, 0.
-__global__ __launch_bounds__(SM_T) void k_stereo_finish(uint4 *rec, uint4 *__restrict__ rec_host, int cap,
-                                                        const int32_t *__restrict__ sad, int useLds) {
+__global__ __launch_bounds__(SF_T) void k_stereo_finish(uint4 *rec, uint4 *__restrict__ rec_host, int cap,
+                                                        const int32_t *__restrict__ sad, int useLds, int uBegin) {
     extern __shared__ int32_t sd_lds[];
     __shared__ int sh_keep;
     const int tid = threadIdx.x;
@@ -452,18 +454,18 @@ __global__ __launch_bounds__(SM_T) void k_stereo_finish(uint4 *rec, uint4 *__res
     // my unit of the record is requested first: nothing below depends on it until the copy-out (k_stereo_match wrote sad = -1 for
     // every slot behind the last keypoint, so the median step walks all cap slots and needs no count either: no dependent load chain)
     const int total = 8 * cap + 1, ur0 = (120 * cap) >> 4, ur1 = (128 * cap) >> 4;
-    const int u0 = blockIdx.x * SM_T + tid;
+    const int u0 = uBegin + blockIdx.x * SF_T + tid;   // uBegin = first unit this launch moves (k_describe may have stored the keypoint / descriptor blocks already)
     uint4 v0 = make_uint4(0u, 0u, 0u, 0u);
     if (u0 < total) v0 = rec[u0];
     if (tid == 0) sh_keep = 0;
     float thDist = 0.0f;
     const int N = cap;
-    const int nd = stereo_sad_threshold(sad, N, sd_lds, useLds, &thDist);
+    const int nd = stereo_sad_threshold<SF_T>(sad, N, sd_lds, useLds, &thDist);
     const int32_t *sd = useLds ? sd_lds : sad;
     {   // the match count (every workgroup: the one that copies the record's tail needs it) and, by workgroup 0, the rule on the device arrays
         int keep = 0;
         if (nd > 0)
-            for (int i = tid; i < N; i += SM_T) {
+            for (int i = tid; i < N; i += SF_T) {
                 const int s = sd[i];
                 if (s < 0) continue;
                 if ((float)s < thDist) keep++;
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(SM_T) void k_stereo_finish(uint4 *rec, uint4 *__res
     }
     // copy-out: 16-byte units [0, 8 cap + 1); units of the mvuRight / mvDepth block get the rule applied (the device words may or may
     // not have been rewritten by workgroup 0 yet: the rule gives the same word either way)
-    for (int u = u0; u < total; u += gridDim.x * SM_T) {
+    for (int u = u0; u < total; u += gridDim.x * SF_T) {
         uint4 v = u == u0 ? v0 : rec[u];
         if (u >= ur0 && u < ur1) {
             const int i0 = ((u - ur0) * 4) % cap;     // keypoint of the unit's first word (mvuRight and mvDepth blocks: cap words each)
@@ -536,7 +538,7 @@ static int stereo_batch_impl(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, 
                              int right_slot0, const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
                              const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
                              int cap, float mbf, float mb, float *d_uright, float *d_depth,
-                             int32_t *d_nmatch, void *stream, bool prev, uint8_t *finish_rec = nullptr, uint8_t *finish_host = nullptr) {
+                             int32_t *d_nmatch, void *stream, bool prev, uint8_t *finish_rec = nullptr, uint8_t *finish_host = nullptr, bool finish_tail_only = false) {
     if (!hl || !hr || !d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_uright || !d_depth || B < 1 ||
         cap < 1 || left_slot0 < 0 || right_slot0 < 0 || left_slot0 + B > hl->pB || right_slot0 + B > hr->pB) {
         orbx_set_error("orbm_stereo_batch_device: bad arguments");
@@ -572,8 +574,11 @@ static int stereo_batch_impl(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, 
                        hl->st_sad, hl->st_rc, hl->st_binStart, hl->st_items, bhShift, nbins);
     const int useLds = cap <= SM_LDS_CAP;
     if (finish_rec)   // one frame, latency path: median step + the whole record to pinned host memory, one launch
-        hipLaunchKernelGGL(k_stereo_finish, dim3((8 * cap + 1 + SM_T - 1) / SM_T), dim3(SM_T), useLds ? sizeof(int32_t) * cap : 0, st,
-                           (uint4 *)finish_rec, (uint4 *)finish_host, cap, hl->st_sad, useLds);
+    {
+        const int uBegin = finish_tail_only ? (120 * cap) >> 4 : 0;
+        hipLaunchKernelGGL(k_stereo_finish, dim3((8 * cap + 1 - uBegin + SF_T - 1) / SF_T), dim3(SF_T), useLds ? sizeof(int32_t) * cap : 0, st,
+                           (uint4 *)finish_rec, (uint4 *)finish_host, cap, hl->st_sad, useLds, uBegin);
+    }
     else
         hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(SM_T), useLds ? sizeof(int32_t) * cap : 0, st, d_nl, cap, d_uright,
                            d_depth, hl->st_sad, d_nmatch, useLds);
@@ -591,13 +596,13 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
                              d_nmatch, stream, false);
 }
 
-int orbx_internal_stereo_frame_record(orbx_extractor *h, uint8_t *d_rec, uint8_t *rec_hostdev, int cap, float mbf, float mb, hipStream_t st) {
+int orbx_internal_stereo_frame_record(orbx_extractor *h, uint8_t *d_rec, uint8_t *rec_hostdev, int cap, float mbf, float mb, hipStream_t st, bool recordsOnHost) {
     const size_t c = (size_t)cap;
     orbx_keypoint_t *kl = (orbx_keypoint_t *)d_rec, *kr = (orbx_keypoint_t *)(d_rec + 28 * c);
     uint8_t *dl = d_rec + 56 * c, *dr = d_rec + 88 * c;
     float *ur = (float *)(d_rec + 120 * c), *dp = (float *)(d_rec + 124 * c);
     int32_t *tail = (int32_t *)(d_rec + 128 * c);
-    return stereo_batch_impl(h, h, 1, 0, 1, kl, dl, tail, kr, dr, tail + 1, cap, mbf, mb, ur, dp, tail + 2, (void *)st, false, d_rec, rec_hostdev);
+    return stereo_batch_impl(h, h, 1, 0, 1, kl, dl, tail, kr, dr, tail + 1, cap, mbf, mb, ur, dp, tail + 2, (void *)st, false, d_rec, rec_hostdev, recordsOnHost);
 }
 
 // The same on the pyramids of the extraction call BEFORE the last one (software pipelining: the matcher of batch i-1 issued

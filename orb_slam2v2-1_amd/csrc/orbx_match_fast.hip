@@ -544,14 +544,15 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
                                                       int m, int n, const int32_t *holder_in, int32_t *holder_out,
                                                       int32_t *holder_host, float nnratio, int max_dist, int check_ori,
                                                       int32_t *__restrict__ out, int32_t *__restrict__ out_host) {
-    extern __shared__ uint32_t rp_lds[];
-    uint32_t *bt = rp_lds;                       // [n] T[j] during the rounds, then the largest committed query + 1
-    uint32_t *dead = rp_lds + n;                 // [(n + 31) / 32] bit j: an orientation loser claimed keypoint j
+    extern __shared__ __align__(16) uint32_t rp_lds[];
+    uint32_t *cq = rp_lds;                                   // [m][QK] candidates of every query, best first: dist << 20 | index << 4 | octave (~0: none)
+    uint32_t *bt = rp_lds + (size_t)QK * m;                  // [n] T[j] during the rounds, then the largest committed query + 1
+    uint32_t *dead = bt + n;                                 // [(n + 31) / 32] bit j: an orientation loser claimed keypoint j
     __shared__ int hn[HISTO_LENGTH];
     __shared__ int ind[3];
     __shared__ int sh_nm, sh_ov;
     const int tid = threadIdx.x;
-    uint32_t c[RP_Q][QK];       // candidates of my queries, best first: dist << 20 | index << 4 | octave (~0: none)
+    // (the candidates live in LDS, not in registers: 4 queries x 8 candidates per thread beside the decision's own state spilled)
     int nc[RP_Q], blk[RP_Q], claim[RP_Q];
     float ang[RP_Q];
     bool overflow = false;
@@ -559,25 +560,31 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
     for (int r = 0; r < RP_Q; r++) {
         const int qi = tid + r * RP_T;
         nc[r] = 0; blk[r] = 0; ang[r] = 0.0f; claim[r] = -1;
-#pragma unroll
-        for (int k = 0; k < QK; k++) c[r][k] = ~0u;
         if (qi < m) {
             nc[r] = ncand[qi];
             if (MODE == 0) blk[r] = ((const orbm_mappoint_t *)meta)[qi].observations > 0;
             else if (MODE == 1) { const float2 qm = ((const float2 *)meta)[qi]; blk[r] = qm.x != 0.0f; ang[r] = qm.y; }   // (blocks, angle): k_queries_frame's compact copy
             else { blk[r] = ((const orbm_window_query_t *)meta)[qi].blocks != 0; ang[r] = ((const orbm_window_query_t *)meta)[qi].angle; }
-            if (nc[r] > 0) {
+            uint32_t e[QK];
 #pragma unroll
-                for (int k = 0; k < QK; k++) {
+            for (int k = 0; k < QK; k++) {
+                e[k] = ~0u;
+                if (nc[r] > 0) {
                     const u64 key = keys[(size_t)qi * QK + k];
-                    if (key != ~0ull) c[r][k] = ((uint32_t)KEY_DIST(key) << 20) | ((uint32_t)KEY_IDX(key) << 4) | (uint32_t)KEY_OCT(key);
+                    if (key != ~0ull) e[k] = ((uint32_t)KEY_DIST(key) << 20) | ((uint32_t)KEY_IDX(key) << 4) | (uint32_t)KEY_OCT(key);
                 }
             }
+            ((uint4 *)(cq + (size_t)QK * qi))[0] = make_uint4(e[0], e[1], e[2], e[3]);
+            ((uint4 *)(cq + (size_t)QK * qi))[1] = make_uint4(e[4], e[5], e[6], e[7]);
             if (nc[r] > CAND_CAP) overflow = true;   // k_cand dropped candidates: its top-QK is not trustworthy
         }
     }
     if (tid < HISTO_LENGTH) hn[tid] = 0;
     if (tid == 0) { sh_nm = 0; sh_ov = 0; }
+    // the holders before the call (they may sit in the pinned mirror: a bus round trip) are requested now, for the write-back at the end
+    int32_t hin[RP_Q];
+#pragma unroll
+    for (int r = 0; r < RP_Q; r++) { const int j = tid + r * RP_T; hin[r] = j < n ? holder_in[j] : -1; }
     bool ranout[RP_Q];
     // the decision of query r of this thread given the blocking times in bt (useBt = false: nothing is blocked)
     auto decide = [&](int r, bool useBt) -> int {
@@ -585,13 +592,15 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
         // the blocking times of all QK candidates are requested at once (independent LDS reads: one latency per decision, not one per
         // candidate - a round of the iteration is a handful of such latencies and the iteration takes as many rounds as the longest
         // chain of displaced queries)
+        const uint4 c0 = ((const uint4 *)(cq + (size_t)QK * qi))[0], c1 = ((const uint4 *)(cq + (size_t)QK * qi))[1];
+        const uint32_t e8[QK] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
         uint32_t tb[QK];
 #pragma unroll
-        for (int k = 0; k < QK; k++) tb[k] = useBt ? bt[c[r][k] == ~0u ? 0u : (c[r][k] >> 4) & 0xFFFFu] : 0xFFFFFFFFu;   // (an empty slot looks at entry 0 and ignores it)
+        for (int k = 0; k < QK; k++) tb[k] = useBt ? bt[e8[k] == ~0u ? 0u : (e8[k] >> 4) & 0xFFFFu] : 0xFFFFFFFFu;   // (an empty slot looks at entry 0 and ignores it)
         int best = -1, bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, found = 0;
 #pragma unroll
         for (int k = 0; k < QK; k++) {
-            const uint32_t e = c[r][k];
+            const uint32_t e = e8[k];
             if (found < (MODE == 0 ? 2 : 1) && e != ~0u && !(tb[k] < qi)) {
                 if (found == 0) { best = (int)((e >> 4) & 0xFFFFu); bestDist = (int)(e >> 20); bestLevel = (int)(e & 15u); }
                 else { bestDist2 = (int)(e >> 20); bestLevel2 = (int)(e & 15u); }
@@ -660,7 +669,17 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
             }
         __syncthreads();
     }
-    for (int j = tid; j < n; j += RP_T) {
+#pragma unroll
+    for (int r = 0; r < RP_Q; r++) {
+        const int j = tid + r * RP_T;
+        if (j < n) {
+            const uint32_t wq = bt[j];
+            const int32_t v = ((dead[j >> 5] >> (j & 31)) & 1u) ? -1 : wq ? (int32_t)wq - 1 : hin[r];
+            holder_out[j] = v;
+            if (holder_host) holder_host[j] = v;
+        }
+    }
+    for (int j = tid + RP_Q * RP_T; j < n; j += RP_T) {
         const uint32_t wq = bt[j];
         const int32_t v = ((dead[j >> 5] >> (j & 31)) & 1u) ? -1 : wq ? (int32_t)wq - 1 : holder_in[j];
         holder_out[j] = v;
@@ -918,11 +937,11 @@ template <typename T> static const T *arena_host(const T *dev) { return (const T
 template <typename T> static T *arena_hostdev(T *dev) { return (T *)(g_ar.hdev + ((uint8_t *)dev - g_ar.base)); }
 #define ORBX_FAST_FALLBACK 1  // positive: not an error, the caller runs the exact legacy kernel
 extern thread_local int t_matchResolver;   // ORBM_OPT_RESOLVER (orbx_match.hip)
-static inline bool use_resolve_par(int m, int n) { return t_matchResolver == 0 && m <= RP_T * RP_Q && n <= 30000; }
-static inline size_t resolve_par_lds(int n) { return sizeof(uint32_t) * ((size_t)n + (size_t)(n + 31) / 32); }
-#define RESOLVE_PAR_LAUNCH(MODE, ...)                                                                                     \
+static inline size_t resolve_par_lds(int m, int n) { return sizeof(uint32_t) * ((size_t)QK * m + (size_t)n + (size_t)(n + 31) / 32); }
+static inline bool use_resolve_par(int m, int n) { return t_matchResolver == 0 && m <= RP_T * RP_Q && n <= 30000 && resolve_par_lds(m, n) <= 158 * 1024; }
+#define RESOLVE_PAR_LAUNCH(MODE, M_, ...)                                                                                   \
     do {                                                                                                                  \
-        const size_t lds_ = resolve_par_lds(n);                                                                           \
+        const size_t lds_ = resolve_par_lds((M_), n);                                                                   \
         if (lds_ > 48 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_resolve_par<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
         hipLaunchKernelGGL(k_resolve_par<MODE>, dim3(1), dim3(RP_T), lds_, st, __VA_ARGS__);                              \
     } while (0)
@@ -1031,7 +1050,7 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
     hipLaunchKernelGGL(k_queries_mp, dim3((mx + 255) / 256), dim3(256), 0, st, dmp, m, zsf, th, dq, zfm, zeo, n, dk, du, *g, dckp);
     hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, zmd, m, dckp, dd, n, *g, dkeys, dnc);
     if (use_resolve_par(m, n)) {   // results land in the pinned mirror straight from the kernel
-        RESOLVE_PAR_LAUNCH(0, dkeys, dnc, (const void *)dmp, dk, m, n, zfm, zfm, (int32_t *)nullptr, nnratio, 0, 0, dout, arena_hostdev(dout));
+        RESOLVE_PAR_LAUNCH(0, m, dkeys, dnc, (const void *)dmp, dk, m, n, zfm, zfm, (int32_t *)nullptr, nnratio, 0, 0, dout, arena_hostdev(dout));
         ORBX_HIP(hipGetLastError());
     } else {
         ORBX_HIP(hipMemcpyAsync(dfm, arena_host(dfm), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));   // this resolver works on the device copy
@@ -1084,7 +1103,7 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
                        mono, dq, zcm, zeo, n, dk, du, dckp, dqm);
     hipLaunchKernelGGL(k_cand<false>, dim3((nlast + 3) / 4), dim3(256), 0, st, dq, dld, nlast, dckp, dd, n, *g, dkeys, dnc);
     if (use_resolve_par(nlast, n)) {
-        RESOLVE_PAR_LAUNCH(1, dkeys, dnc, (const void *)dqm, dk, nlast, n, zcm, zcm, (int32_t *)nullptr, 0.0f, 0, check_ori, dout, arena_hostdev(dout));
+        RESOLVE_PAR_LAUNCH(1, nlast, dkeys, dnc, (const void *)dqm, dk, nlast, n, zcm, zcm, (int32_t *)nullptr, 0.0f, 0, check_ori, dout, arena_hostdev(dout));
         ORBX_HIP(hipGetLastError());
     } else {
         ORBX_HIP(hipMemcpyAsync(dcm, arena_host(dcm), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
@@ -1135,7 +1154,7 @@ int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const fl
                        ext_blocks ? deb : (const int32_t *)nullptr, n, dk, du, *ga, dckp);
     hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dqd, m, dckp, dd, n, *g, dkeys, dnc);
     if (use_resolve_par(m, n)) {
-        RESOLVE_PAR_LAUNCH(2, dkeys, dnc, (const void *)dw, dk, m, n, dh, dh, arena_hostdev(dh), 0.0f, max_dist, check_ori, dout, arena_hostdev(dout));
+        RESOLVE_PAR_LAUNCH(2, m, dkeys, dnc, (const void *)dw, dk, m, n, dh, dh, arena_hostdev(dh), 0.0f, max_dist, check_ori, dout, arena_hostdev(dout));
         ORBX_HIP(hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_resolve_windows, dim3(1), dim3(64), 2 * (size_t)((n + 15) & ~15), st, dkeys, dnc, dw, dk, m, n, dh, dhi,

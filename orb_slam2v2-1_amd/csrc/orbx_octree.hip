@@ -258,7 +258,7 @@ __device__ __forceinline__ void octree_pyr_body(
     constexpr bool CB = MODE == 0;
     uint32_t *bestP = (uint32_t *)(pathL + ((nPath + 1) & ~1));   // [nIni * (4^(Dm+1) - 1) / 3], depth d at nIni * (4^d - 1) / 3 like the counts
     int *cellOff = (int *)(bestP + (uint32_t)nIni * (((1u << (2 * (Dm + 1))) - 1u) / 3u));   // fused: [ncells + 1] first raw index of every FAST cell
-    __shared__ int sh_kept, wsumF[OCT_T / 64 + 1];
+    __shared__ int wsumF[OCT_T / 64 + 1];
     const uint32_t *fCnt = fused ? src.cellCnt + (size_t)b * src.totalCells + g.cellBase : nullptr;
     const uint32_t *fRaw = fused ? src.cellRaw + (size_t)b * src.totalCells + g.cellBase : nullptr;
     const uint32_t *fSlots = fused ? src.slots + (size_t)b * src.slotsPerImg + g.slotOff : nullptr;
@@ -292,31 +292,15 @@ __device__ __forceinline__ void octree_pyr_body(
             ((uint4 *)hb)[i] = make_uint4(0u, 0u, 0u, 0u);
         }
     } else if (fused) {
-        // raw list lengths -> first raw index of every cell (the tie-break index of a key is its position in the concatenated RAW
-        // lists: same relative order as in vToDistributeKeys, which only drops entries); kept keys of the level for the records
-        if (tid == 0) sh_kept = 0;
-        __syncthreads();
-        int kept = 0;
-        for (int i = tid; i < g.ncells; i += OCT_T) { cellOff[i] = (int)(fRaw[i] & 0x7FFFFFFFu); kept += (int)fCnt[i]; }
-        kept = wave_total_i32(kept);
-        if ((tid & 63) == 0 && kept) atomicAdd(&sh_kept, kept);
-        __syncthreads();
-        const int rawTotal = array_scan_excl(cellOff, g.ncells, wsumF);
-        if (tid == 0) {
-            cellOff[g.ncells] = rawTotal;
-            src.candCntOut[b * nlevels + l] = sh_kept;
-            if (src.sparseFlag) {   // verdict for the next call's FAST
-                const int sparse = sh_kept < src.sparsePerCell * g.ncells ? 1 : 0;
-                src.sparseFlag[b * nlevels + l] = sparse;
-                // the host learns (late, never needed for correctness) that calls on this handle meet corner-sparse levels: it then adds
-                // the compaction kernel's launch to the FAST stage.  Image slot 0 speaks for the batch: a store to host memory from every
-                // (image, level) workgroup made this kernel 3x slower (200 instead of 72 us per 128 corner-sparse images)
-                if (sparse && b == 0 && src.sparseSeen) __hip_atomic_store(src.sparseSeen, src.callSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        __syncthreads();
-        // one sweep over the cell lists: 16 lanes per cell, a lane owns four CONSECUTIVE entries (one 16-byte load; a cell's slot block
-        // is capc = 1 KB apart), so the run merging below works as on the compacted array; the next round's entries are in flight
+        // One sweep over the FAST stage's cell lists, read in place.  The tie-break index of a key is its SLOT index cell * capc + position
+        // in the cell's raw list: the same order as vToDistributeKeys (which only drops entries), and the winner's slot is the index
+        // itself (rounds 3-4 used the position in the concatenated raw lists: a scan over the cells in front of the sweep and a binary
+        // search behind it).  Round 5: a LARGE level's sweep is shared by K workgroups (src.nslice, slice = blockIdx.z): each sweeps its
+        // K-th of the cells into its own LDS histogram, leaves it in global memory, and the one that arrives last adds the others' to
+        // its own and carries on - in a batch of 1920x1080 images the level-0 workgroup swept ~70 k keys through the LDS atomics of
+        // one CU for 64 of its 109 us while the CUs of the small levels had long finished.
+        const int K = MODE == 0 && src.nslice[l] > 1 ? (int)src.nslice[l] : 1;
+        const int cBeg = (int)((long long)g.ncells * slice / K), cEnd = (int)((long long)g.ncells * (slice + 1) / K);
 #ifdef ORBX_DEVELOPER
         dvTA = wall_clock64();
 #endif
@@ -328,14 +312,14 @@ __device__ __forceinline__ void octree_pyr_body(
             e = *(const uint4 *)(fSlots + (size_t)cc * capc + 4 * sub);
         };
         uint4 en; uint32_t rwn;
-        fetch(cgrp, en, rwn);
-        for (int c0 = 0; c0 < g.ncells; c0 += CPR) {
+        fetch(cBeg + cgrp, en, rwn);
+        for (int c0 = cBeg; c0 < cEnd; c0 += CPR) {
             const int cell = c0 + cgrp;
             uint4 e = en; const uint32_t rw = rwn;
             fetch(c0 + CPR + cgrp, en, rwn);
-            const int nraw = cell < g.ncells ? (int)(rw & 0x7FFFFFFFu) : 0;
+            const int nraw = cell < cEnd ? (int)(rw & 0x7FFFFFFFu) : 0;
             const uint32_t thr = (rw >> 31) ? (uint32_t)src.iniTh : (uint32_t)src.minTh;
-            const int base = cellOff[min(cell, g.ncells)];
+            const int base = cell * capc;
             for (int j0 = 0; j0 < nraw; j0 += 64) {   // (wave-divergent trip count only for cells with more than 64 raw entries)
                 if (j0 > 0) e = *(const uint4 *)(fSlots + (size_t)cell * capc + j0 + 4 * sub);
                 const uint32_t key[4] = {e.x, e.y, e.z, e.w};
@@ -359,6 +343,30 @@ __device__ __forceinline__ void octree_pyr_body(
                         atomicMax(&bestP[offDeep + c[u]], bv[u]);
                     }
             }
+        }
+        if (K > 1) {   // my partial histogram -> global; the last of the K to arrive adds the others' to its own (hand-off as in MODE 1 below)
+            __syncthreads();
+            const int nDeep = nIni << (2 * Dm), deepWords = (nDeep + 1) >> 1;
+            const size_t slot = (size_t)b * nlevels + l;
+            uint32_t *pcnt = src.partCnt + (slot * src.maxSlices + slice) * (size_t)src.partStride;
+            uint32_t *pbst = src.partBest + (slot * src.maxSlices + slice) * (size_t)src.partStride;
+            for (int i = tid; i < deepWords; i += OCT_T) pcnt[i] = pyr[offDeep + i];
+            for (int i = tid; i < nDeep; i += OCT_T) pbst[i] = bestP[offDeep + i];
+            __syncthreads();
+            if (tid == 0) {
+                sh_last = __hip_atomic_fetch_add(&src.sliceState[slot], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == K - 1;
+                if (sh_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // only the last arrival pays the invalidation
+            }
+            __syncthreads();
+            if (!sh_last) return;
+            for (int k = 0; k < K; k++) {
+                if (k == slice) continue;
+                const uint32_t *qc = src.partCnt + (slot * src.maxSlices + k) * (size_t)src.partStride;
+                const uint32_t *qb = src.partBest + (slot * src.maxSlices + k) * (size_t)src.partStride;
+                for (int i = tid; i < deepWords; i += OCT_T) pyr[offDeep + i] += qc[i];     // two 16-bit counters per word, no carry between them
+                for (int i = tid; i < nDeep; i += OCT_T) bestP[offDeep + i] = max(bestP[offDeep + i], qb[i]);
+            }
+            if (tid == 0) src.sliceState[slot] = 0;   // ready for the next call
         }
     } else {
     uint32_t nkey[4];
@@ -444,7 +452,7 @@ __device__ __forceinline__ void octree_pyr_body(
             if (c > 0) { cntA[L0] = c | 0x80000000u; nidA[L0] = (uint32_t)r; L0++; }
         }
         sh_L = L0;
-        if (fromHist) {   // the records the sweep form writes before its sweep: kept keys of the level, verdict for the next call's FAST
+        if (fused) {   // kept keys of the level (= the sum of the root counts), verdict for the next call's FAST
             src.candCntOut[b * nlevels + l] = kept;
             if (src.sparseFlag) {
                 const int sparse = kept < src.sparsePerCell * g.ncells ? 1 : 0;
@@ -674,15 +682,8 @@ __device__ __forceinline__ void octree_pyr_body(
             const int d = (int)(nid[k] >> 28);
             const uint32_t v = bestP[(uint32_t)nIni * (((1u << (2 * d)) - 1u) / 3u) + (nid[k] & 0x0FFFFFFFu)];
             const int idx = (int)(0xFFFFFFu - (v & 0xFFFFFFu));
-            if (fromHist) okp[k] = fSlots[idx];   // the index IS the slot
-            else if (fused) {   // raw index -> (cell, position): the last cell whose first raw index is <= idx
-                int lo = 0, hi = g.ncells;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (cellOff[mid] <= idx) lo = mid; else hi = mid;
-                }
-                okp[k] = fSlots[(size_t)lo * g.capc + (idx - cellOff[lo])];
-            } else
+            if (fused) okp[k] = fSlots[idx];   // the index IS the slot (cell * capc + position)
+            else
                 okp[k] = keys[idx];
         }
 #ifdef ORBX_DEVELOPER
@@ -811,12 +812,14 @@ __global__ __launch_bounds__(OCT_T) OCT_PYR_WAVES void k_octree_pyr(
     uint16_t *__restrict__ nodeOf, int scratchInts, int dbgStopExact, unsigned bigMask, int l0, OctSrc src) {
     const int l = l0 + (int)blockIdx.y, b = blockIdx.x;  // level-major: large levels start first (l0: first level of a group launch)
     if ((bigMask >> l) & 1u) return;             // shared by several workgroups: k_octree_big
+    const int slice = blockIdx.z;                // > 0: one of the extra workgroups of a level whose sweep is shared (OctSrc::nslice)
+    if (slice >= max(1, (int)src.nslice[l])) return;
     // A level is ONE workgroup walking a serial chain: when other kernels share its CU (the pyramid built ahead, the stereo
     // matcher of the previous batch), its waves take the issue slots first - the chain is the critical path, the others are not.
     __builtin_amdgcn_s_setprio(3);
     OctBig none = {};
     octree_pyr_body<0>(geom, nlevels, cand, keysPerImg, candCnt, lvlKp, lvlKpCap, lvlCnt, tab, capMax, pow2cap, pyrWords, fallback, dbgStop,
-                       nodeOf, scratchInts, dbgStopExact, l, b, 0, 0, none, src);
+                       nodeOf, scratchInts, dbgStopExact, l, b, slice, 0, none, src);
 }
 template <int MODE>
 __global__ __launch_bounds__(OCT_T) void k_octree_big(

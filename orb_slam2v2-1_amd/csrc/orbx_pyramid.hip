@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void k_pyr_pad(const uint8_t *__restrict__ img
 // unaligned 16-byte chunks (split into several transactions) and gathers the frame bytes one by one: 28.8 us for two 1241x376
 // images against ~19 at the bus rate.  The padded rows - the rows themselves and their BORDER_REFLECT_101 mirror images above /
 // below the image - are then assembled from LDS.  Dynamic LDS: PAD_ROWS * sstride + 32 bytes.
-#define PAD_ROWS 8
+#define PAD_ROWS PAD_ROWS_PER_BLOCK   // (orbx_extract_dev.h: the launch sizes its LDS with it)
 __global__ __launch_bounds__(256) void k_pyr_pad_rows(const uint8_t *__restrict__ img, int sstride, size_t simg, uint8_t *__restrict__ pyr,
                                                       size_t pyrImgBytes, const LevelGeom *__restrict__ geom) {
     extern __shared__ __align__(16) uint8_t rows_lds[];
@@ -347,7 +347,13 @@ __global__ __launch_bounds__(256) void k_pyr_pad_rows(const uint8_t *__restrict_
     const uintptr_t p0 = (uintptr_t)(src + (size_t)r0 * sstride), p1 = p0 + (size_t)(nr - 1) * sstride + G.w;
     const uintptr_t a0 = p0 & ~(uintptr_t)15;
     const int nch = (int)(((p1 + 15) & ~(uintptr_t)15) - a0) >> 4, lead = (int)(p0 - a0);   // LDS byte of source byte (r, x): lead + (r - r0) * sstride + x
-    for (int i = tid; i < nch; i += 256) ((uint4 *)rows_lds)[i] = ((const uint4 *)a0)[i];
+    for (int i0 = 0; i0 < nch; i0 += 4 * 256) {   // a thread's (up to) four chunks are all requested before the first is stored: one bus round trip, not four
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int i = i0 + tid + 256 * k; v[k] = ((const uint4 *)a0)[min(i, nch - 1)]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int i = i0 + tid + 256 * k; if (i < nch) ((uint4 *)rows_lds)[i] = v[k]; }
+    }
     __syncthreads();
     // ---- 2. padded rows: 16-byte chunks of the row itself (target 0) and of its mirror images (targets 1, 2)
     const int pc = G.pstride >> 4;

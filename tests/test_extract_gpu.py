@@ -909,3 +909,26 @@ def test_stereo_frame_view_equals_stereo_frame(pkg, oracle, synth):
         prev = (f, {key: f[key].tobytes() for key in ("kl", "dl", "uright", "depth")})
     ok, od = oracle.Extractor(nf, 1.2, 8, 20, 7).extract(frames[2][0])
     assert f["kl"].tobytes() == ok.tobytes() and f["dl"].tobytes() == od.tobytes()
+
+
+def test_quadtree_shared_sweep_in_a_batch(pkg, oracle, synth):
+    """ORBX_OPT_OCT_SLICES: in a batch the key sweep of a level with >= 600 FAST cells is shared by two workgroups, >= 1600 by four
+    (1920x1080: levels 0-3), each leaving a partial histogram + best keys in global memory for the last one to arrive.  Six images
+    of 1920x1080 / 4000 features (more than the four of the small-batch forms) with and without the sharing, 512- and 1024-thread
+    builds, three calls each (the arrival counters must be left at zero): keypoints and descriptors of every image == oracle."""
+    w, h, nf, B = 1920, 1080, 4000, 6
+    imgs = np.stack([synth.frame(w, h, 4100 + i) for i in range(B)])
+    orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    exp = [orc.extract(im) for im in imgs]
+    for opts in ((), ((26, 1),), ((11, 1),), ((11, 1), (26, 1))):
+        ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
+        for k_, v_ in opts:
+            ex.set_option(k_, v_)
+        for rep in range(3):
+            got = ex.extract_batch(imgs)
+            for b in range(B):
+                assert got[b][0].tobytes() == exp[b][0].tobytes() and got[b][1].tobytes() == exp[b][1].tobytes(), (opts, rep, b)
+        orc.extract(imgs[B - 1])
+        for l in range(8):
+            np.testing.assert_array_equal(ex.debug_level_points(l, 1, b=B - 1), _cands(orc.level_keypoints(l)), err_msg=str((opts, l)))
+        ex.close()
