@@ -1028,7 +1028,14 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
                     os.sliceState = h->d_octSliceState + v.octSlot0;
                     os.maxSlices = OCT_MAX_SLICES; os.partStride = h->octSliceStride;
                 }
-                ORBX_OCT_LAUNCH(k_octree_pyr, k_octree_pyr_wide, dim3(B, nl, kmax), lds, h->d_geom, nl, v.cand,
+                dim3 ogrid(B, nl);
+                if (kmax > 1) {   // linear grid: every slice of the large levels in front of the small levels
+                    os.linear = 1; os.nImages = B;
+                    int tot = 0;
+                    for (int l = 0; l <= ORBX_MAX_LEVELS; l++) { os.blkPrefix[l] = tot; if (l < nl) tot += B * std::max(1, (int)os.nslice[l]); }
+                    ogrid = dim3(tot);
+                }
+                ORBX_OCT_LAUNCH(k_octree_pyr, k_octree_pyr_wide, ogrid, lds, h->d_geom, nl, v.cand,
                                 h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
                                 pow2, h->octPyrWords, v.octFallback, h->opt[7], v.nodeOf, scratch, h->opt[1], 0u, 0, os);
             }

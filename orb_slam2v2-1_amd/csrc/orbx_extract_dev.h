@@ -141,6 +141,10 @@ struct OctSrc {
     // counters per word, best keys: one word per cell) and the arrival counter of every (image, level)
     unsigned char nslice[ORBX_MAX_LEVELS];
     uint32_t *partCnt, *partBest; int32_t *sliceState; int maxSlices, partStride;
+    // with shared sweeps the grid is LINEAR: workgroups [blkPrefix[l], blkPrefix[l + 1]) are level l's, slice-major inside (slice * B + image), so that every
+    // slice of the large levels is dispatched before the small levels (in a (B, levels, slices) grid the extra slices queued behind ALL first slices and
+    // started when the small levels were done: nothing gained)
+    int linear, nImages, blkPrefix[ORBX_MAX_LEVELS + 1];
 };
 #define OCT_MAX_SLICES 4
 __global__ void k_octree_pyr(const LevelGeom *geom, int nlevels, const uint32_t *cand, size_t keysPerImg, const int32_t *candCnt,

@@ -536,8 +536,8 @@ __global__ __launch_bounds__(64) void k_resolve_windows(const u64 *__restrict__ 
 // Afterwards: holder[j] = the LARGEST committed q with claim j (the loop overwrites), the orientation histogram over all
 // commits (:1435-1469: an entry in a losing bin clears its keypoint even when a later query overwrote the holder), counts.
 // MODE 0: SearchByProjection(F, MPs) (best + second, ratio test); 1: SearchByProjection(cur, last); 2: projected windows.
-#define RP_T 1024
-#define RP_Q 4          // queries per thread: m <= RP_T * RP_Q, larger calls keep the single-wave resolver
+#define RP_T 512        // (1024 threads measured ~1 us per barrier: 16 waves; a round is two barriers)
+#define RP_Q 8          // queries per thread: m <= RP_T * RP_Q, larger calls keep the single-wave resolver
 template <int MODE>
 __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ keys, const int32_t *__restrict__ ncand,
                                                       const void *__restrict__ meta, const orbx_keypoint_t *__restrict__ kun,
@@ -548,6 +548,8 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
     uint32_t *cq = rp_lds;                                   // [m][QK] candidates of every query, best first: dist << 20 | index << 4 | octave (~0: none)
     uint32_t *bt = rp_lds + (size_t)QK * m;                  // [n] T[j] during the rounds, then the largest committed query + 1
     uint32_t *dead = bt + n;                                 // [(n + 31) / 32] bit j: an orientation loser claimed keypoint j
+    uint32_t *bt2 = dead + (n + 31) / 32;                    // [n] the blocking times of the NEXT round (double buffer: one barrier less per round)
+    __shared__ int sh_flag[3];
     __shared__ int hn[HISTO_LENGTH];
     __shared__ int ind[3];
     __shared__ int sh_nm, sh_ov;
@@ -587,7 +589,8 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
     for (int r = 0; r < RP_Q; r++) { const int j = tid + r * RP_T; hin[r] = j < n ? holder_in[j] : -1; }
     bool ranout[RP_Q];
     // the decision of query r of this thread given the blocking times in bt (useBt = false: nothing is blocked)
-    auto decide = [&](int r, bool useBt) -> int {
+    auto decide = [&](int r, const uint32_t *btp) -> int {   // btp: blocking times to decide against (NULL: nothing is blocked)
+        const bool useBt = btp != nullptr;
         const uint32_t qi = (uint32_t)(tid + r * RP_T);
         // the blocking times of all QK candidates are requested at once (independent LDS reads: one latency per decision, not one per
         // candidate - a round of the iteration is a handful of such latencies and the iteration takes as many rounds as the longest
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
         const uint32_t e8[QK] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
         uint32_t tb[QK];
 #pragma unroll
-        for (int k = 0; k < QK; k++) tb[k] = useBt ? bt[e8[k] == ~0u ? 0u : (e8[k] >> 4) & 0xFFFFu] : 0xFFFFFFFFu;   // (an empty slot looks at entry 0 and ignores it)
+        for (int k = 0; k < QK; k++) tb[k] = useBt ? btp[e8[k] == ~0u ? 0u : (e8[k] >> 4) & 0xFFFFu] : 0xFFFFFFFFu;   // (an empty slot looks at entry 0 and ignores it)
         int best = -1, bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, found = 0;
 #pragma unroll
         for (int k = 0; k < QK; k++) {
@@ -614,25 +617,31 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
         return accept ? best : -1;
     };
 #pragma unroll
-    for (int r = 0; r < RP_Q; r++) { ranout[r] = false; if (nc[r] > 0) claim[r] = decide(r, false); }
+    for (int r = 0; r < RP_Q; r++) { ranout[r] = false; if (nc[r] > 0) claim[r] = decide(r, nullptr); }
+    for (int j = tid; j < n; j += RP_T) { bt[j] = 0xFFFFFFFFu; bt2[j] = 0xFFFFFFFFu; }
+    if (tid < 3) sh_flag[tid] = 0;
+    __syncthreads();
     int rounds = 0;
-    for (int round = 0; round <= m + 1; round++) {
+    for (int round = 0; round <= m + 1; round++) {   // two barriers per round: T of this round in one array while the other is reset for the next
         rounds++;
-        for (int j = tid; j < n; j += RP_T) bt[j] = 0xFFFFFFFFu;
-        __syncthreads();
+        uint32_t *A = (round & 1) ? bt2 : bt, *Bn = (round & 1) ? bt : bt2;
+        if (tid == 0) sh_flag[(round + 1) % 3] = 0;
 #pragma unroll
         for (int r = 0; r < RP_Q; r++)
-            if (claim[r] >= 0 && blk[r]) atomicMin(&bt[claim[r]], (uint32_t)(tid + r * RP_T));
+            if (claim[r] >= 0 && blk[r]) atomicMin(&A[claim[r]], (uint32_t)(tid + r * RP_T));
         __syncthreads();
-        int changed = 0;
+        bool changed = false;
 #pragma unroll
         for (int r = 0; r < RP_Q; r++)
             if (nc[r] > 0) {
-                const int nw = decide(r, true);
+                const int nw = decide(r, A);
                 changed |= nw != claim[r];
                 claim[r] = nw;
             }
-        if (!__syncthreads_or(changed)) break;     // (also the barrier between this round's reads of bt and the next round's reset)
+        for (int j = tid; j < n; j += RP_T) Bn[j] = 0xFFFFFFFFu;     // (last read in the round before this one, behind two barriers)
+        if (__ballot(changed) && (tid & 63) == 0) sh_flag[round % 3] = 1;
+        __syncthreads();
+        if (!sh_flag[round % 3]) break;
     }
     // holders, orientation histogram, counts
     for (int j = tid; j < n; j += RP_T) bt[j] = 0;
@@ -937,7 +946,7 @@ template <typename T> static const T *arena_host(const T *dev) { return (const T
 template <typename T> static T *arena_hostdev(T *dev) { return (T *)(g_ar.hdev + ((uint8_t *)dev - g_ar.base)); }
 #define ORBX_FAST_FALLBACK 1  // positive: not an error, the caller runs the exact legacy kernel
 extern thread_local int t_matchResolver;   // ORBM_OPT_RESOLVER (orbx_match.hip)
-static inline size_t resolve_par_lds(int m, int n) { return sizeof(uint32_t) * ((size_t)QK * m + (size_t)n + (size_t)(n + 31) / 32); }
+static inline size_t resolve_par_lds(int m, int n) { return sizeof(uint32_t) * ((size_t)QK * m + 2 * (size_t)n + (size_t)(n + 31) / 32); }
 static inline bool use_resolve_par(int m, int n) { return t_matchResolver == 0 && m <= RP_T * RP_Q && n <= 30000 && resolve_par_lds(m, n) <= 158 * 1024; }
 #define RESOLVE_PAR_LAUNCH(MODE, M_, ...)                                                                                   \
     do {                                                                                                                  \

@@ -203,11 +203,22 @@ __device__ __forceinline__ int phase2_order_regs(const uint32_t *cnt, int L, uin
 }
 // dispatch on the list length (wave-uniform); false: the caller's LDS network takes the list (longer than 512 nodes - a register budget -, or sizes that need more than 22 bits)
 __device__ __forceinline__ bool phase2_order_in_regs(const uint32_t *cnt, int L, int keyCap, uint16_t *xlist, int lane, int &E) {
-    if (keyCap >= (1 << 22) || L > 512) return false;
+#if OCT_T >= 1024
+    // the 1024-thread build (images with a level of >= 600 FAST cells: budgets of 500-1000 keypoints per level) also takes lists of up to
+    // 1024 nodes in registers, 16 keys per lane (round 5: the LDS network on 1024 keys was ~15 of the 25 us a 1920x1080 level spends in its
+    // passes); the 512-thread build is held to 80 VGPRs and keeps the limit of 512
+    constexpr int LMAX = 1024;
+#else
+    constexpr int LMAX = 512;
+#endif
+    if (keyCap >= (1 << 22) || L > LMAX) return false;
     if (L <= 64) E = phase2_order_regs<1>(cnt, L, xlist, lane);
     else if (L <= 128) E = phase2_order_regs<2>(cnt, L, xlist, lane);
     else if (L <= 256) E = phase2_order_regs<4>(cnt, L, xlist, lane);
-    else E = phase2_order_regs<8>(cnt, L, xlist, lane);
+    else if (L <= 512) E = phase2_order_regs<8>(cnt, L, xlist, lane);
+#if OCT_T >= 1024
+    else E = phase2_order_regs<16>(cnt, L, xlist, lane);
+#endif
     return true;
 }
 
@@ -810,10 +821,17 @@ __global__ __launch_bounds__(OCT_T) OCT_PYR_WAVES void k_octree_pyr(
     const int32_t *__restrict__ candCnt, uint32_t *__restrict__ lvlKp, int lvlKpCap, int32_t *__restrict__ lvlCnt,
     const int32_t *__restrict__ tab, int capMax, int pow2cap, int pyrWords, int32_t *__restrict__ fallback, int dbgStop,
     uint16_t *__restrict__ nodeOf, int scratchInts, int dbgStopExact, unsigned bigMask, int l0, OctSrc src) {
-    const int l = l0 + (int)blockIdx.y, b = blockIdx.x;  // level-major: large levels start first (l0: first level of a group launch)
+    int l = l0 + (int)blockIdx.y, b = blockIdx.x, slice = 0;  // level-major: large levels start first (l0: first level of a group launch)
+    if (src.linear) {   // shared sweeps (OctSrc): linear grid, level-major, then slice, then image
+        const int lin = blockIdx.x;
+        l = 0;
+#pragma unroll
+        for (int i = 1; i < ORBX_MAX_LEVELS; i++) l += (i < nlevels && lin >= src.blkPrefix[i]) ? 1 : 0;
+        const int r = lin - src.blkPrefix[l];
+        slice = r / src.nImages;
+        b = r - slice * src.nImages;
+    }
     if ((bigMask >> l) & 1u) return;             // shared by several workgroups: k_octree_big
-    const int slice = blockIdx.z;                // > 0: one of the extra workgroups of a level whose sweep is shared (OctSrc::nslice)
-    if (slice >= max(1, (int)src.nslice[l])) return;
     // A level is ONE workgroup walking a serial chain: when other kernels share its CU (the pyramid built ahead, the stereo
     // matcher of the previous batch), its waves take the issue slots first - the chain is the critical path, the others are not.
     __builtin_amdgcn_s_setprio(3);

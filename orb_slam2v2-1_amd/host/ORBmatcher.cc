@@ -723,17 +723,16 @@ int ExtractStereoFrameHIP(Frame &F, const cv::Mat &imLeft, const cv::Mat &imRigh
         return -1;
     }
     orbx_extractor_t *h = F.mpORBextractorLeft->handle();
-    const int cap = orbx_max_keypoints(h) + 256;
-    std::vector<orbx_keypoint_t> kl(cap), kr(cap);
-    cv::Mat dl(cap, 32, CV_8U), dr(cap, 32, CV_8U);
-    std::vector<float> ur(cap), dp(cap);
-    int nl = 0, nr = 0, nm = 0;
-    if (orbx_stereo_frame(h, imLeft.ptr(0), imRight.ptr(0), imLeft.cols, imLeft.rows, (int)imLeft.step, F.mbf, F.mb, cap, kl.data(),
-                          dl.ptr(0), &nl, kr.data(), dr.ptr(0), &nr, ur.data(), dp.data(), &nm) != ORBX_OK) {
+    // the latency form (include/orbx.h: orbx_stereo_frame_view): no copy command in either direction - the first kernel reads the images
+    // where they lie (pinned capture buffers from orbx_host_alloc are read over the bus; a pageable cv::Mat is staged by the call) and the
+    // last kernel writes the frame's record into pinned memory of the handle, which `v` points into until the call after the next
+    orbx_stereo_view_t v;
+    if (orbx_stereo_frame_view(h, imLeft.ptr(0), imRight.ptr(0), imLeft.cols, imLeft.rows, (int)imLeft.step, F.mbf, F.mb, &v) != ORBX_OK) {
         std::fprintf(stderr, "ExtractStereoFrame: %s\n", orbx_last_error());
         return -1;
     }
-    auto fill = [](const std::vector<orbx_keypoint_t> &src, const cv::Mat &dsrc, int n, std::vector<cv::KeyPoint> &keys, cv::Mat &desc) {
+    const int nl = v.nl, nr = v.nr, nm = v.nmatch;
+    auto fill = [](const orbx_keypoint_t *src, const uint8_t *dsrc, int n, std::vector<cv::KeyPoint> &keys, cv::Mat &desc) {
         keys.reserve(n);
         for (int i = 0; i < n; i++) {
             const orbx_keypoint_t &s = src[i];
@@ -744,14 +743,14 @@ int ExtractStereoFrameHIP(Frame &F, const cv::Mat &imLeft, const cv::Mat &imRigh
         }
         if (n > 0) {
             desc.create(n, 32, CV_8U);
-            for (int i = 0; i < n; i++) std::memcpy(desc.ptr(i), dsrc.ptr(i), 32);
+            for (int i = 0; i < n; i++) std::memcpy(desc.ptr(i), dsrc + (size_t)32 * i, 32);
         }
     };
-    fill(kl, dl, nl, F.mvKeys, F.mDescriptors);
-    fill(kr, dr, nr, F.mvKeysRight, F.mDescriptorsRight);
+    fill(v.kl, v.dl, nl, F.mvKeys, F.mDescriptors);
+    fill(v.kr, v.dr, nr, F.mvKeysRight, F.mDescriptorsRight);
     F.N = nl;                                         // :86
-    F.mvuRight.assign(ur.begin(), ur.begin() + nl);   // -1 where unmatched, as :483-484 initialise them
-    F.mvDepth.assign(dp.begin(), dp.begin() + nl);
+    F.mvuRight.assign(v.uright, v.uright + nl);       // -1 where unmatched, as :483-484 initialise them
+    F.mvDepth.assign(v.depth, v.depth + nl);
     return nm;
 }
 
