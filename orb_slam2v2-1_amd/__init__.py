@@ -254,7 +254,7 @@ def _check(rc, L=None):
 
 
 def _p(a):
-    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+    return a.ctypes.data if a is not None else None      # (an int: every pointer parameter is declared c_void_p; data_as() costs a microsecond more)
 
 
 def blur_reach_mask():

@@ -1013,11 +1013,14 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
                                 h->keysPerImg, v.candCnt, v.lvlKp, h->lvlKpCap, v.lvlCnt, h->d_tab, h->maxNodeCap,
                                 pow2, h->octPyrWords, v.octFallback, 0, v.nodeOf, scratch, 0, 0u, aSplit, osrc);
             } else {   // no large level (or a phase-stop knob is set): one workgroup per level, one launch
-                // ... except that in a BATCH the sweep of a large level (>= 600 FAST cells) is shared by two or four workgroups
-                // (ORBX_OPT_OCT_SLICES: 0 = by level size, 1 = never): the level-0 workgroup of a 1920x1080 image is otherwise the critical path
+                // ... except that in a BATCH the sweep of a large level (>= 600 FAST cells) MAY be shared by two or four workgroups
+                // (ORBX_OPT_OCT_SLICES = 1; off by default): the level-0 workgroup of a 1920x1080 image is the critical path of the stage
+                // (113 us, 64 of them its sweep), and sharing the sweeps takes the stage ALONE from 120 to 90 us at batch 32 - but the pipelined
+                // step gets slower (0.6105 -> 0.6277 ms at batch 32, 1.186 -> 1.256 ms at batch 64): beside the next pyramid and the previous
+                // matcher the extra 1024-thread workgroups cost more than the shorter critical path gives back
                 OctSrc os = osrc;
                 int kmax = 1;
-                if (fused && !histOct && h->opt[26] == 0 && h->d_octPartBest && h->opt[7] == 0 && h->opt[1] == 0) {
+                if (fused && !histOct && h->opt[26] == 1 && h->d_octPartBest && h->opt[7] == 0 && h->opt[1] == 0) {
                     for (int l = 0; l < nl; l++) {
                         const int k = h->geom[l].ncells >= 1600 ? 4 : h->geom[l].ncells >= 600 ? 2 : 1;
                         os.nslice[l] = (unsigned char)k;

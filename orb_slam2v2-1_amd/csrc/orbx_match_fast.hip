@@ -536,9 +536,9 @@ __global__ __launch_bounds__(64) void k_resolve_windows(const u64 *__restrict__ 
 // Afterwards: holder[j] = the LARGEST committed q with claim j (the loop overwrites), the orientation histogram over all
 // commits (:1435-1469: an entry in a losing bin clears its keypoint even when a later query overwrote the holder), counts.
 // MODE 0: SearchByProjection(F, MPs) (best + second, ratio test); 1: SearchByProjection(cur, last); 2: projected windows.
-#define RP_T 512        // (1024 threads measured ~1 us per barrier: 16 waves; a round is two barriers)
-#define RP_Q 8          // queries per thread: m <= RP_T * RP_Q, larger calls keep the single-wave resolver
-template <int MODE>
+#define RP_T 1024       // (measured: 512 threads x 8 queries 26.8 us, 1024 x 4 18.2 us for 2012 queries - a thread's decisions are chains of dependent LDS reads)
+#define RP_QMAX 4       // queries per thread: 2 (m <= 2048) or 4 (m <= 4096) - template parameter RP_Q; larger calls keep the single-wave resolver
+template <int MODE, int RP_Q>
 __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ keys, const int32_t *__restrict__ ncand,
                                                       const void *__restrict__ meta, const orbx_keypoint_t *__restrict__ kun,
                                                       int m, int n, const int32_t *holder_in, int32_t *holder_out,
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
                                                       int32_t *__restrict__ out, int32_t *__restrict__ out_host) {
     extern __shared__ __align__(16) uint32_t rp_lds[];
     uint32_t *cq = rp_lds;                                   // [m][QK] candidates of every query, best first: dist << 20 | index << 4 | octave (~0: none)
-    uint32_t *bt = rp_lds + (size_t)QK * m;                  // [n] T[j] during the rounds, then the largest committed query + 1
+    uint32_t *bt = rp_lds + (size_t)QK * RP_T * RP_Q;        // [n] T[j] during the rounds, then the largest committed query + 1 (cq has a row for every (thread, r))
     uint32_t *dead = bt + n;                                 // [(n + 31) / 32] bit j: an orientation loser claimed keypoint j
     uint32_t *bt2 = dead + (n + 31) / 32;                    // [n] the blocking times of the NEXT round (double buffer: one barrier less per round)
     __shared__ int sh_flag[3];
@@ -562,6 +562,7 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
     for (int r = 0; r < RP_Q; r++) {
         const int qi = tid + r * RP_T;
         nc[r] = 0; blk[r] = 0; ang[r] = 0.0f; claim[r] = -1;
+        if (qi >= m) { ((uint4 *)(cq + (size_t)QK * qi))[0] = make_uint4(~0u, ~0u, ~0u, ~0u); ((uint4 *)(cq + (size_t)QK * qi))[1] = make_uint4(~0u, ~0u, ~0u, ~0u); }
         if (qi < m) {
             nc[r] = ncand[qi];
             if (MODE == 0) blk[r] = ((const orbm_mappoint_t *)meta)[qi].observations > 0;
@@ -589,17 +590,17 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
     for (int r = 0; r < RP_Q; r++) { const int j = tid + r * RP_T; hin[r] = j < n ? holder_in[j] : -1; }
     bool ranout[RP_Q];
     // the decision of query r of this thread given the blocking times in bt (useBt = false: nothing is blocked)
-    auto decide = [&](int r, const uint32_t *btp) -> int {   // btp: blocking times to decide against (NULL: nothing is blocked)
-        const bool useBt = btp != nullptr;
+    // a decision in two steps, so that a thread's RP_Q decisions of a round overlap their LDS reads: fetch = the query's QK candidates
+    // and their blocking times (btp == NULL: nothing is blocked), pick = the reference's accept rule on them
+    auto fetch = [&](int r, const uint32_t *btp, uint32_t *e8, uint32_t *tb) {
         const uint32_t qi = (uint32_t)(tid + r * RP_T);
-        // the blocking times of all QK candidates are requested at once (independent LDS reads: one latency per decision, not one per
-        // candidate - a round of the iteration is a handful of such latencies and the iteration takes as many rounds as the longest
-        // chain of displaced queries)
         const uint4 c0 = ((const uint4 *)(cq + (size_t)QK * qi))[0], c1 = ((const uint4 *)(cq + (size_t)QK * qi))[1];
-        const uint32_t e8[QK] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        uint32_t tb[QK];
+        e8[0] = c0.x; e8[1] = c0.y; e8[2] = c0.z; e8[3] = c0.w; e8[4] = c1.x; e8[5] = c1.y; e8[6] = c1.z; e8[7] = c1.w;
 #pragma unroll
-        for (int k = 0; k < QK; k++) tb[k] = useBt ? btp[e8[k] == ~0u ? 0u : (e8[k] >> 4) & 0xFFFFu] : 0xFFFFFFFFu;   // (an empty slot looks at entry 0 and ignores it)
+        for (int k = 0; k < QK; k++) tb[k] = btp ? btp[e8[k] == ~0u ? 0u : (e8[k] >> 4) & 0xFFFFu] : 0xFFFFFFFFu;   // (an empty slot looks at entry 0 and ignores it)
+    };
+    auto pick = [&](int r, const uint32_t *e8, const uint32_t *tb) -> int {
+        const uint32_t qi = (uint32_t)(tid + r * RP_T);
         int best = -1, bestDist = 256, bestDist2 = 256, bestLevel = -1, bestLevel2 = -1, found = 0;
 #pragma unroll
         for (int k = 0; k < QK; k++) {
@@ -616,8 +617,24 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
         else accept = best >= 0 && bestDist <= (MODE == 1 ? TH_HIGH : max_dist);
         return accept ? best : -1;
     };
+    auto decide_all = [&](const uint32_t *btp) -> bool {   // every query of this thread; true if a claim changed
+        uint32_t E8[RP_Q][QK], TB[RP_Q][QK];
 #pragma unroll
-    for (int r = 0; r < RP_Q; r++) { ranout[r] = false; if (nc[r] > 0) claim[r] = decide(r, nullptr); }
+        for (int r = 0; r < RP_Q; r++) fetch(r, btp, E8[r], TB[r]);     // (queries past m read slot rows inside the allocation: cq holds RP_T * RP_Q rows)
+        bool changed = false;
+#pragma unroll
+        for (int r = 0; r < RP_Q; r++)
+            if (nc[r] > 0) {
+                const int nw = pick(r, E8[r], TB[r]);
+                changed |= nw != claim[r];
+                claim[r] = nw;
+            }
+        return changed;
+    };
+#pragma unroll
+    for (int r = 0; r < RP_Q; r++) ranout[r] = false;
+    __syncthreads();      // (fetch reads candidate rows of queries >= m too: every row of cq is written - or left alone - before anybody looks)
+    decide_all(nullptr);
     for (int j = tid; j < n; j += RP_T) { bt[j] = 0xFFFFFFFFu; bt2[j] = 0xFFFFFFFFu; }
     if (tid < 3) sh_flag[tid] = 0;
     __syncthreads();
@@ -630,14 +647,7 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
         for (int r = 0; r < RP_Q; r++)
             if (claim[r] >= 0 && blk[r]) atomicMin(&A[claim[r]], (uint32_t)(tid + r * RP_T));
         __syncthreads();
-        bool changed = false;
-#pragma unroll
-        for (int r = 0; r < RP_Q; r++)
-            if (nc[r] > 0) {
-                const int nw = decide(r, A);
-                changed |= nw != claim[r];
-                claim[r] = nw;
-            }
+        const bool changed = decide_all(A);
         for (int j = tid; j < n; j += RP_T) Bn[j] = 0xFFFFFFFFu;     // (last read in the round before this one, behind two barriers)
         if (__ballot(changed) && (tid & 63) == 0) sh_flag[round % 3] = 1;
         __syncthreads();
@@ -772,6 +782,16 @@ __global__ __launch_bounds__(256) void k_queries_frame(const orbm_lastpoint_t *_
         const int hm = cur_mp[i];
         ckp[i] = compact_kp(g, kp[i], hm == -1 ? false : hm == -2 ? (ext_obs && ext_obs[i] > 0) : (last[hm].observations > 0), uright[i]);
     }
+    // my block's 256 records as coalesced dwords -> LDS: `last` may sit in pinned HOST memory, where a wave's seven strided field loads
+    // fetched every 64-byte line seven times over the bus (the kernel ran 10 us for 56 KB)
+    __shared__ uint32_t recs[256 * (sizeof(orbm_lastpoint_t) / 4)];
+    {
+        constexpr int W = sizeof(orbm_lastpoint_t) / 4;
+        const int first = blockIdx.x * 256, cnt = max(0, min(256, nlast - first)) * W;
+        const uint32_t *src = (const uint32_t *)(last + first);
+        for (int k = threadIdx.x; k < cnt; k += 256) recs[k] = src[k];
+    }
+    __syncthreads();
     if (i >= nlast) return;
     // twc = -Rcw^T tcw; tlc = Rlw twc + tlw (:1343-1351): cv::gemm on CV_32F accumulates in double
     float twc[3], tlc2 = 0;
@@ -786,7 +806,7 @@ __global__ __launch_bounds__(256) void k_queries_frame(const orbm_lastpoint_t *_
         tlc2 = (float)(s + (double)Tl[2 * 4 + 3]);
     }
     const bool bForward = tlc2 > cam.mb && !mono, bBackward = -tlc2 > cam.mb && !mono;
-    const orbm_lastpoint_t p = last[i];
+    const orbm_lastpoint_t p = ((const orbm_lastpoint_t *)recs)[threadIdx.x];
     qmeta[i] = make_float2(p.observations > 0 ? 1.0f : 0.0f, p.angle);   // what the resolver needs of the record (`last` may sit in host memory)
     GQuery Q;
     Q.valid = 0; Q.x = Q.y = Q.r = 0; Q.minLevel = Q.maxLevel = -1; Q.ur_c = 0; Q.ur_tol = -1.0f;
@@ -825,8 +845,16 @@ __global__ __launch_bounds__(256) void k_frustum(const orbm_worldpoint_t *__rest
                                                  const float *__restrict__ thr, int nlevels,
                                                  orbm_mappoint_t *__restrict__ out, orbm_mappoint_t *__restrict__ out_host) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint32_t recs[256 * (sizeof(orbm_worldpoint_t) / 4)];   // (the records may sit in pinned host memory: coalesced dwords, see k_queries_frame)
+    {
+        constexpr int W = sizeof(orbm_worldpoint_t) / 4;
+        const int first = blockIdx.x * 256, cnt = max(0, min(256, m - first)) * W;
+        const uint32_t *src = (const uint32_t *)(pts + first);
+        for (int k = threadIdx.x; k < cnt; k += 256) recs[k] = src[k];
+    }
+    __syncthreads();
     if (i >= m) return;
-    const orbm_worldpoint_t p = pts[i];
+    const orbm_worldpoint_t p = ((const orbm_worldpoint_t *)recs)[threadIdx.x];
     orbm_mappoint_t o;
     o.in_view = 0; o.proj_x = 0; o.proj_y = 0; o.proj_xr = 0; o.level = 0; o.view_cos = 0; o.observations = p.observations;
     if (p.valid) {
@@ -946,13 +974,19 @@ template <typename T> static const T *arena_host(const T *dev) { return (const T
 template <typename T> static T *arena_hostdev(T *dev) { return (T *)(g_ar.hdev + ((uint8_t *)dev - g_ar.base)); }
 #define ORBX_FAST_FALLBACK 1  // positive: not an error, the caller runs the exact legacy kernel
 extern thread_local int t_matchResolver;   // ORBM_OPT_RESOLVER (orbx_match.hip)
-static inline size_t resolve_par_lds(int m, int n) { return sizeof(uint32_t) * ((size_t)QK * m + 2 * (size_t)n + (size_t)(n + 31) / 32); }
-static inline bool use_resolve_par(int m, int n) { return t_matchResolver == 0 && m <= RP_T * RP_Q && n <= 30000 && resolve_par_lds(m, n) <= 158 * 1024; }
+static inline int resolve_par_q(int m) { return m <= 2 * RP_T ? 2 : 4; }
+static inline size_t resolve_par_lds(int m, int n) { return sizeof(uint32_t) * ((size_t)QK * RP_T * resolve_par_q(m) + 2 * (size_t)n + (size_t)(n + 31) / 32); }
+static inline bool use_resolve_par(int m, int n) { return t_matchResolver == 0 && m <= RP_T * RP_QMAX && n <= 30000 && resolve_par_lds(m, n) <= 158 * 1024; }
 #define RESOLVE_PAR_LAUNCH(MODE, M_, ...)                                                                                   \
     do {                                                                                                                  \
-        const size_t lds_ = resolve_par_lds((M_), n);                                                                   \
-        if (lds_ > 48 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_resolve_par<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
-        hipLaunchKernelGGL(k_resolve_par<MODE>, dim3(1), dim3(RP_T), lds_, st, __VA_ARGS__);                              \
+        const size_t lds_ = resolve_par_lds((M_), n);                                                                     \
+        if (resolve_par_q(M_) == 2) {                                                                                     \
+            if (lds_ > 48 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_resolve_par<MODE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+            hipLaunchKernelGGL((k_resolve_par<MODE, 2>), dim3(1), dim3(RP_T), lds_, st, __VA_ARGS__);                     \
+        } else {                                                                                                          \
+            if (lds_ > 48 * 1024) ORBX_HIP(hipFuncSetAttribute((const void *)k_resolve_par<MODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+            hipLaunchKernelGGL((k_resolve_par<MODE, 4>), dim3(1), dim3(RP_T), lds_, st, __VA_ARGS__);                     \
+        }                                                                                                                 \
     } while (0)
 
 // Returns ORBX_OK (results written), ORBX_FAST_FALLBACK, or a negative error.

@@ -912,7 +912,7 @@ def test_stereo_frame_view_equals_stereo_frame(pkg, oracle, synth):
 
 
 def test_quadtree_shared_sweep_in_a_batch(pkg, oracle, synth):
-    """ORBX_OPT_OCT_SLICES: in a batch the key sweep of a level with >= 600 FAST cells is shared by two workgroups, >= 1600 by four
+    """ORBX_OPT_OCT_SLICES = 1 (a measured alternative, off by default): in a batch the key sweep of a level with >= 600 FAST cells is shared by two workgroups, >= 1600 by four
     (1920x1080: levels 0-3), each leaving a partial histogram + best keys in global memory for the last one to arrive.  Six images
     of 1920x1080 / 4000 features (more than the four of the small-batch forms) with and without the sharing, 512- and 1024-thread
     builds, three calls each (the arrival counters must be left at zero): keypoints and descriptors of every image == oracle."""
@@ -920,7 +920,7 @@ def test_quadtree_shared_sweep_in_a_batch(pkg, oracle, synth):
     imgs = np.stack([synth.frame(w, h, 4100 + i) for i in range(B)])
     orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
     exp = [orc.extract(im) for im in imgs]
-    for opts in ((), ((26, 1),), ((11, 1),), ((11, 1), (26, 1))):
+    for opts in (((26, 1),), (), ((11, 1), (26, 1)), ((11, 1),)):
         ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
         for k_, v_ in opts:
             ex.set_option(k_, v_)
