@@ -72,29 +72,45 @@ __global__ __launch_bounds__(256) void k_cand(const GQuery *__restrict__ qs, con
         const AreaQuery aq = make_query(g, Q.x, Q.y, Q.r, Q.minLevel, Q.maxLevel);
         if (!aq.empty) {
             const Desc256 da = load_desc(qdesc + (size_t)qi * 32);
-            uint4 rn = ckp[min(lane, n - 1)];   // the next round's records are in flight while this round is tested
-            for (int j0 = 0; j0 < n; j0 += 64) {
-                const int j = j0 + lane;
-                const uint4 r = rn;
-                rn = ckp[min(j + 64, n - 1)];
-                bool ok = false;
-                u64 key = ~0ull;
-                if (j < n) {
-                    const unsigned c = r.z & 0xFFFFu;
-                    const int oct = (int)((r.z >> 16) & 0xFFu);
-                    ok = in_area_xy(aq, c, __uint_as_float(r.x), __uint_as_float(r.y), oct) && !((r.z >> 24) & 1u);
-                    if (ok && Q.ur_tol >= 0.0f) {
-                        const float u = __uint_as_float(r.w);
-                        if (u > 0 && fabsf(Q.ur_c - u) > Q.ur_tol) ok = false;
+            // four rounds of 64 records per trip, all four loads requested before the first test: with ~2 waves per SIMD (one wave per
+            // query, 500 workgroups) the scan is bound by the latency of its loads - one load per round ran 32 round trips per query
+            // (14 us for 2012 x 2012), four in flight run 8
+            for (int j0 = 0; j0 < n; j0 += 256) {
+                uint4 rr[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) rr[u] = ckp[min(j0 + 64 * u + lane, n - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (j0 + 64 * u >= n) break;   // wave-uniform
+                    const int j = j0 + 64 * u + lane;
+                    const uint4 r = rr[u];
+                    bool ok = false;
+                    u64 key = ~0ull;
+                    if (j < n) {
+                        const unsigned c = r.z & 0xFFFFu;
+                        const int oct = (int)((r.z >> 16) & 0xFFu);
+                        ok = in_area_xy(aq, c, __uint_as_float(r.x), __uint_as_float(r.y), oct) && !((r.z >> 24) & 1u);
+                        if (ok && Q.ur_tol >= 0.0f) {
+                            const float uu = __uint_as_float(r.w);
+                            if (uu > 0 && fabsf(Q.ur_c - uu) > Q.ur_tol) ok = false;
+                        }
+                        if (ok) key = fast_key(0, c, j, oct);     // (the distance follows below, for all survivors at once)
                     }
-                    if (ok) key = fast_key(ham(da, load_desc(desc + (size_t)j * 32)), c, j, oct);
+                    const u64 mk = __ballot(ok);
+                    if (ok) {
+                        const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
+                        if (pos < CAND_CAP) L[pos] = key;
+                    }
+                    cnt += __popcll(mk);
                 }
-                const u64 mk = __ballot(ok);
-                if (ok) {
-                    const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
-                    if (pos < CAND_CAP) L[pos] = key;
-                }
-                cnt += __popcll(mk);
+            }
+            // Hamming distances of the survivors, 64 at a time (their descriptor loads all in flight together; inside the scan each
+            // group of 64 records with a survivor waited for a load of its own)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < min(cnt, CAND_CAP); i += 64) {
+                const u64 k0 = L[i];
+                L[i] = k0 | ((u64)ham(da, load_desc(desc + (size_t)KEY_IDX(k0) * 32)) << 32);
             }
         }
     }
@@ -544,6 +560,9 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
                                                       int m, int n, const int32_t *holder_in, int32_t *holder_out,
                                                       int32_t *holder_host, float nnratio, int max_dist, int check_ori,
                                                       int32_t *__restrict__ out, int32_t *__restrict__ out_host) {
+#ifdef ORBX_DEVELOPER
+    const unsigned long long dvT0 = wall_clock64();
+#endif
     extern __shared__ __align__(16) uint32_t rp_lds[];
     uint32_t *cq = rp_lds;                                   // [m][QK] candidates of every query, best first: dist << 20 | index << 4 | octave (~0: none)
     uint32_t *bt = rp_lds + (size_t)QK * RP_T * RP_Q;        // [n] T[j] during the rounds, then the largest committed query + 1 (cq has a row for every (thread, r))
@@ -633,6 +652,9 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
     };
 #pragma unroll
     for (int r = 0; r < RP_Q; r++) ranout[r] = false;
+#ifdef ORBX_DEVELOPER
+    const unsigned long long dvT1 = wall_clock64();
+#endif
     __syncthreads();      // (fetch reads candidate rows of queries >= m too: every row of cq is written - or left alone - before anybody looks)
     decide_all(nullptr);
     for (int j = tid; j < n; j += RP_T) { bt[j] = 0xFFFFFFFFu; bt2[j] = 0xFFFFFFFFu; }
@@ -653,6 +675,9 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
         __syncthreads();
         if (!sh_flag[round % 3]) break;
     }
+#ifdef ORBX_DEVELOPER
+    const unsigned long long dvT2 = wall_clock64();
+#endif
     // holders, orientation histogram, counts
     for (int j = tid; j < n; j += RP_T) bt[j] = 0;
     for (int j = tid; j < (n + 31) / 32; j += RP_T) dead[j] = 0;
@@ -711,6 +736,13 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
     if (tid == 0) {
         out[0] = sh_nm; out[1] = sh_ov; out[2] = rounds;     // [2]: rounds the iteration took (diagnostics)
         if (out_host) { out_host[0] = sh_nm; out_host[1] = sh_ov; out_host[2] = rounds; }
+#ifdef ORBX_DEVELOPER
+        // developer build: [3] = time stamps in 0.1-us units (100-MHz counter): loads << 20 | rounds << 10 | epilogue
+        const unsigned long long dvT3 = wall_clock64();
+        const int stamp = ((int)min((dvT1 - dvT0) / 10ull, 1023ull) << 20) | ((int)min((dvT2 - dvT1) / 10ull, 1023ull) << 10) | (int)min((dvT3 - dvT2) / 10ull, 1023ull);
+        out[3] = stamp;
+        if (out_host) out_host[3] = stamp;
+#endif
     }
 }
 
@@ -788,8 +820,12 @@ __global__ __launch_bounds__(256) void k_queries_frame(const orbm_lastpoint_t *_
     {
         constexpr int W = sizeof(orbm_lastpoint_t) / 4;
         const int first = blockIdx.x * 256, cnt = max(0, min(256, nlast - first)) * W;
-        const uint32_t *src = (const uint32_t *)(last + first);
-        for (int k = threadIdx.x; k < cnt; k += 256) recs[k] = src[k];
+        const uint32_t *src = (const uint32_t *)(last + (cnt > 0 ? first : 0));   // (a block past the records stages nothing; its loads stay inside the array)
+        uint32_t v[W];     // all W loads of a thread are requested before the first is stored: one bus round trip (a rolled loop made it W)
+#pragma unroll
+        for (int j = 0; j < W; j++) { const int k = threadIdx.x + 256 * j; v[j] = src[min(k, max(cnt - 1, 0))]; }
+#pragma unroll
+        for (int j = 0; j < W; j++) { const int k = threadIdx.x + 256 * j; if (k < cnt) recs[k] = v[j]; }
     }
     __syncthreads();
     if (i >= nlast) return;
@@ -849,8 +885,12 @@ __global__ __launch_bounds__(256) void k_frustum(const orbm_worldpoint_t *__rest
     {
         constexpr int W = sizeof(orbm_worldpoint_t) / 4;
         const int first = blockIdx.x * 256, cnt = max(0, min(256, m - first)) * W;
-        const uint32_t *src = (const uint32_t *)(pts + first);
-        for (int k = threadIdx.x; k < cnt; k += 256) recs[k] = src[k];
+        const uint32_t *src = (const uint32_t *)(pts + (cnt > 0 ? first : 0));
+        uint32_t v[W];
+#pragma unroll
+        for (int j = 0; j < W; j++) { const int k = threadIdx.x + 256 * j; v[j] = src[min(k, max(cnt - 1, 0))]; }
+#pragma unroll
+        for (int j = 0; j < W; j++) { const int k = threadIdx.x + 256 * j; if (k < cnt) recs[k] = v[j]; }
     }
     __syncthreads();
     if (i >= m) return;
@@ -1104,7 +1144,7 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
     ORBX_HIP(hipStreamSynchronize(st));
     if (world && proj_out) memcpy(proj_out, arena_host(dmp), sizeof(orbm_mappoint_t) * (size_t)m);
     const int32_t *out = arena_host(dout);
-    if (getenv("ORBX_TRACE_RESOLVE")) fprintf(stderr, "k_resolve_par<mp>: %d queries, %d keypoints, %d rounds\n", m, n, out[2]);
+    if (getenv("ORBX_TRACE_RESOLVE")) fprintf(stderr, "k_resolve_par<mp>: %d queries, %d keypoints, %d rounds; developer build: loads %.1f us, rounds %.1f us, epilogue %.1f us\n", m, n, out[2], (out[3] >> 20) / 10.0, ((out[3] >> 10) & 1023) / 10.0, (out[3] & 1023) / 10.0);
     if (out[1]) return ORBX_FAST_FALLBACK;
     memcpy(frame_mp, arena_host(dfm), sizeof(int32_t) * (size_t)n);
     *nmatches = out[0];
@@ -1158,7 +1198,7 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
     }
     ORBX_HIP(hipStreamSynchronize(st));
     const int32_t *out = arena_host(dout);
-    if (getenv("ORBX_TRACE_RESOLVE")) fprintf(stderr, "k_resolve_par<frame>: %d queries, %d keypoints, %d rounds\n", nlast, n, out[2]);
+    if (getenv("ORBX_TRACE_RESOLVE")) fprintf(stderr, "k_resolve_par<frame>: %d queries, %d keypoints, %d rounds; developer build: loads %.1f us, rounds %.1f us, epilogue %.1f us\n", nlast, n, out[2], (out[3] >> 20) / 10.0, ((out[3] >> 10) & 1023) / 10.0, (out[3] & 1023) / 10.0);
     if (out[1]) return ORBX_FAST_FALLBACK;
     memcpy(cur_mp, arena_host(dcm), sizeof(int32_t) * (size_t)n);
     *nmatches = out[0];
