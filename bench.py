@@ -704,10 +704,22 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
     if world > 1 or force_gather:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+        # RCCL prints a version banner to STDOUT when its communicator is created; stdout carries ONE JSON line, so file descriptor 1 points at
+        # stderr while the process group comes up (a first barrier creates the communicator)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     gather = (world > 1 or force_gather) and not args.no_gather
     # the all-gather is a fixed-shape collective: every rank contributes as many record rows as the LARGEST block holds (a batch that
     # does not divide by the rank count leaves blocks that differ by one frame; the short blocks' last row stays empty)

@@ -811,7 +811,12 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     // decisions of the quad-tree stage that the FAST stage needs to know
     // developer knob 4: 0 default, 1 = the exact form alone, 2 = EVERY level by the multi-workgroup form, 3 = none
     const bool usePyr = h->opt[4] != 1;
-    const bool multiWg = h->opt[4] == 2 || (h->opt[4] != 3 && B <= 4 && h->octBigMask != 0);
+    // (round 5: a batch whose FAST stage histograms its emissions for the quad-tree - at most ORBX_HIST_IMAGES images, every level by
+    // k_fast_cells - needs no shared sweep at all: one 1920x1080 image went through gather 6 + k_octree_big 53 + 15 us)
+    const bool stripsWanted = h->totalStrips > 0 && (h->opt[6] == 0 ? (size_t)h->totalStrips * B >= 4096 : h->opt[6] == 3);
+    const bool histWanted = h->opt[23] == 0 && B <= ORBX_HIST_IMAGES && h->lastChunks == 1 && !stripsWanted && h->opt[0] == 0 && h->opt[18] != 1 &&
+                            h->opt[7] == 0 && h->opt[1] == 0;
+    const bool multiWg = h->opt[4] == 2 || (h->opt[4] != 3 && B <= 4 && h->octBigMask != 0 && !histWanted);
     // Fused: k_octree_pyr reads the FAST stage's cell lists in place (no k_gather launch, no compacted key array: -35 us per
     // 128 images 1241x376, -200 us per 64 images 1920x1080 in the pipelined step).  Not for the multi-workgroup form, the exact
     // form alone and the phase-stop knobs, which sweep the compacted array (developer knob 18 = 1: never fused).
@@ -827,8 +832,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     }
     // ORBX_OPT_OCT_HIST (0 = by batch size, 1 = never): with at most ORBX_HIST_IMAGES images and every level done by k_fast_cells, the FAST
     // stage histograms its emissions for the quad-tree (FastHist) and k_octree_pyr loads the histogram instead of sweeping the keys
-    const bool stripsWanted = h->totalStrips > 0 && (h->opt[6] == 0 ? (size_t)h->totalStrips * B >= 4096 : h->opt[6] == 3);
-    const bool histOct = fused && h->opt[23] == 0 && B <= ORBX_HIST_IMAGES && h->lastChunks == 1 && !stripsWanted && h->opt[0] == 0;
+    const bool histOct = fused && histWanted;
     FastHist fhist = {};
     if (histOct) {
         fhist.cnt = h->d_histCnt; fhist.best = h->d_histBest; fhist.stride = h->histStride; fhist.tab = h->d_tab;

@@ -33,6 +33,14 @@ for it in range(N):
     if not same:
         bad += 1
         print("MISMATCH", it, w, h, nf, sf, nl, mbf, fx, n, on)
+    # round 5: the latency form of the whole stereo frame (orbx_stereo_frame_view: two calls, so that both of the handle's records are used)
+    for rep in range(2):
+        f = exl.stereo_frame_view(l, r, mbf, mb)
+        samev = (f["nmatch"] == on and f["kl"].tobytes() == kl.tobytes() and f["dl"].tobytes() == dl.tobytes() and f["kr"].tobytes() == kr.tobytes() and
+                 f["dr"].tobytes() == dr.tobytes() and f["uright"].tobytes() == our.tobytes() and f["depth"].tobytes() == odp.tobytes())
+        if not samev:
+            bad += 1
+            print("MISMATCH (stereo_frame_view, call %d)" % rep, it, w, h, nf, sf, nl, mbf, fx, f["nmatch"], on)
     exl.close(); exr.close()
 print("stereo stress: %d configs, %d mismatches, %.1f s" % (N, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
