@@ -963,7 +963,8 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             // The multi-workgroup form shortens ONE image's critical path (a 1920x1080 level 0: 195 us alone in its workgroup); a
             // batch already fills the GPU with one workgroup per (image, level), and the extra hand-offs then cost more than they save
             // (batch 32 of 1920x1080: 274 us against 215), so it is taken for small batches only.  Same results either way.
-            const unsigned bigMask = h->opt[4] == 2 ? (1u << nl) - 1u : (h->opt[4] == 3 || B > 4) ? 0u : h->octBigMask;
+            // (only the multi-workgroup form shares levels: it sweeps the COMPACTED keys, which exist only when k_gather ran - i.e. when the call is not fused)
+            const unsigned bigMask = !multiWg ? 0u : h->opt[4] == 2 ? (1u << nl) - 1u : h->octBigMask;
             OctBig big = {};
             // the kernels index this scratch by the chunk-local image: chunks that run side by side on two streams get disjoint slots
             big.part = h->d_octPart + v.octSlot0 * OCT_BIG_K * (size_t)h->octDeepMax; big.leaf = h->d_octLeaf + v.octSlot0 * (size_t)h->octPyrWords;

@@ -13,13 +13,30 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import tracking_chain as tc   # noqa: E402
 
+import time
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+# time spent INSIDE the C ABI (ctypes argument conversion included), per entry point: what is left of a call's wall time is the Python harness
+_ctime = {}
+
+
+def _timed(L, name):
+    f = getattr(L, name)
+
+    def g(*a):
+        t0 = time.perf_counter()
+        r = f(*a)
+        _ctime.setdefault(name, []).append(time.perf_counter() - t0)
+        return r
+    setattr(L, name, g)
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""          # "device": the device-resident chain alone (profiler runs)
 w, h, nf, step = 1241, 376, 2000, 0.04
 synth = importlib.import_module(tc.PKG + ".synth")
 frames, _ = synth.stereo_sequence(w, h, T, k=11, step=step)
 Ts = tc.poses(T, step)
 res = {}
+_pkg = importlib.import_module(tc.PKG)
+for _n in ("orbx_stereo_frame_view", "orbm_search_by_projection_frame_device", "orbm_search_local_points_device"):
+    _timed(_pkg.lib(), _n)
 for B in ((tc.GpuDeviceBackend,) if ONLY == "device" else (tc.GpuViewBackend,) if ONLY == "view" else
           (tc.GpuHostBackend, tc.GpuStereoFrameBackend, tc.GpuDeviceBackend, tc.GpuViewBackend)):
     c = tc.Chain(B(w, h, nf), w, h, nf)
@@ -32,6 +49,8 @@ for B in ((tc.GpuDeviceBackend,) if ONLY == "device" else (tc.GpuViewBackend,) i
     log = c.log[5:]
     ms = lambda key: 1e3 * float(np.median([s[key] for s in log]))
     res[c.be.name] = c.log
+    if c.be.name == "gpu-view":
+        print("           inside the C ABI (median us): " + ", ".join("%s %.1f" % (k, 1e6 * float(np.median(v[5:]))) for k, v in _ctime.items()))
     print("%-10s %dx%d, %d features/camera, %d frames, median per frame: extract L+R + ComputeStereoMatches %.3f ms + "
           "SearchByProjection(cur,last) %.3f ms + SearchLocalPoints %.3f ms = %.3f ms (%.0f frames/s); %d projection / %d local-map matches"
           % (c.be.name, w, h, nf, len(log), ms("t_frame"), ms("t_proj"), ms("t_local"), ms("t_frame") + ms("t_proj") + ms("t_local"),
