@@ -498,6 +498,8 @@ int orbx_get_option(const orbx_extractor_t *h, int key, int *value);
  * (k_resolve_par, the default since round 5).  Identical results whatever the setting; the tests run all three.  Thread-local. */
 #define ORBM_OPT_EXACT_KERNELS 2
 #define ORBM_OPT_RESOLVER 3
+#define ORBM_OPT_STREAM_SYNC 4   /* 1 = a guided search waits for its stream (hipStreamSynchronize); 0 (default) = it polls the completion word its
+                                   * last kernel stores behind the results in pinned memory, with the stream wait as the fall-back after a few ms */
 int orbm_set_thread_option(int key, int value);
 /* The read-only stage hooks the staged parity tests look through (orbx_debug_* / orbm_debug_*) are NOT part of this library: they
  * exist in the developer build only (liborbx_hip_dev.so, -DORBX_DEVELOPER) and are declared in include/orbx_dev.h. */

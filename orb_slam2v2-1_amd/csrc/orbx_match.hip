@@ -19,9 +19,10 @@
 // orbm_set_thread_option (include/orbx.h): like the matchers' scratch, their one option is per host thread - no process-global state
 thread_local int t_matchExact = 0;
 thread_local int t_matchResolver = 0;
+thread_local int t_matchStreamSync = 0;
 extern "C" int orbm_set_thread_option(int key, int value) {
-    if ((key != ORBM_OPT_EXACT_KERNELS && key != ORBM_OPT_RESOLVER) || (value != 0 && value != 1)) { orbx_set_error("orbm_set_thread_option: key %d / value %d", key, value); return ORBX_ERR_ARG; }
-    (key == ORBM_OPT_EXACT_KERNELS ? t_matchExact : t_matchResolver) = value;
+    if ((key != ORBM_OPT_EXACT_KERNELS && key != ORBM_OPT_RESOLVER && key != ORBM_OPT_STREAM_SYNC) || (value != 0 && value != 1)) { orbx_set_error("orbm_set_thread_option: key %d / value %d", key, value); return ORBX_ERR_ARG; }
+    (key == ORBM_OPT_EXACT_KERNELS ? t_matchExact : key == ORBM_OPT_RESOLVER ? t_matchResolver : t_matchStreamSync) = value;
     return ORBX_OK;
 }
 

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
                                                       const void *__restrict__ meta, const orbx_keypoint_t *__restrict__ kun,
                                                       int m, int n, const int32_t *holder_in, int32_t *holder_out,
                                                       int32_t *holder_host, float nnratio, int max_dist, int check_ori,
-                                                      int32_t *__restrict__ out, int32_t *__restrict__ out_host) {
+                                                      int32_t *__restrict__ out, int32_t *__restrict__ out_host, int32_t *doneFlag, int doneSeq) {
 #ifdef ORBX_DEVELOPER
     const unsigned long long dvT0 = wall_clock64();
 #endif
@@ -732,10 +732,14 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
     nm = wave_sum_i32(nm);
     if ((tid & 63) == 0 && nm) atomicAdd(&sh_nm, nm);
     if (__ballot(overflow) && (tid & 63) == 0) sh_ov = 1;
+    if (doneFlag) __threadfence_system();   // my stores into the pinned mirror are visible to the host before the barrier ...
     __syncthreads();
     if (tid == 0) {
         out[0] = sh_nm; out[1] = sh_ov; out[2] = rounds;     // [2]: rounds the iteration took (diagnostics)
         if (out_host) { out_host[0] = sh_nm; out_host[1] = sh_ov; out_host[2] = rounds; }
+        // ... and the call's sequence number behind everything: the host polls this word instead of waiting for the stream (a stream
+        // synchronisation costs 10-15 us of wake-up latency on top of the kernel - a third of a 45-us matcher call)
+        if (doneFlag) { __threadfence_system(); __hip_atomic_store(doneFlag, doneSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 #ifdef ORBX_DEVELOPER
         // developer build: [3] = time stamps in 0.1-us units (100-MHz counter): loads << 20 | rounds << 10 | epilogue
         const unsigned long long dvT3 = wall_clock64();
@@ -946,6 +950,7 @@ static void frustum_pose(const float *T, FrustumPose &P) {   // mRcw, mtcw, mOw 
 // synchronisation (DOWN ... after the sync, copy out).  A call used to issue 8-10 pageable copies and 2 syncs.
 struct Arena {
     uint8_t *base = nullptr, *hbase = nullptr, *hdev = nullptr; size_t cap = 0, off = 0, up_lo = 0, up_hi = 0; int device = -1; hipStream_t st = nullptr;
+    int32_t *hflag = nullptr, *dflag = nullptr; int seq = 0;   // completion word of the last kernel of a call (coherent pinned memory) + the call counter
 };
 static thread_local Arena g_ar;
 static int arena_begin(int device, size_t need) {
@@ -962,6 +967,11 @@ static int arena_begin(int device, size_t need) {
         ORBX_HIP(hipMalloc(&g_ar.base, cap));
         ORBX_HIP(hipHostMalloc((void **)&g_ar.hbase, cap, hipHostMallocDefault));
         ORBX_HIP(hipHostGetDevicePointer((void **)&g_ar.hdev, g_ar.hbase, 0));   // the mirror as the kernels see it (small inputs are read, results written, in place)
+        if (!g_ar.hflag) {
+            ORBX_HIP(hipHostMalloc((void **)&g_ar.hflag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+            *g_ar.hflag = 0;
+            ORBX_HIP(hipHostGetDevicePointer((void **)&g_ar.dflag, g_ar.hflag, 0));
+        }
         g_ar.cap = cap; g_ar.device = device;
     }
     g_ar.off = 0;
@@ -974,6 +984,8 @@ void orbx_internal_release_arena() {
     if (g_ar.st) { hipStreamSynchronize(g_ar.st); hipStreamDestroy(g_ar.st); g_ar.st = nullptr; }
     if (g_ar.base) hipFree(g_ar.base);
     if (g_ar.hbase) hipHostFree(g_ar.hbase);
+    if (g_ar.hflag) hipHostFree(g_ar.hflag);
+    g_ar.hflag = nullptr; g_ar.dflag = nullptr;
     g_ar.base = nullptr; g_ar.hbase = nullptr; g_ar.hdev = nullptr; g_ar.cap = 0; g_ar.device = -1;
 }
 template <typename T> static T *arena_get(size_t count) {
@@ -1014,6 +1026,19 @@ template <typename T> static const T *arena_host(const T *dev) { return (const T
 template <typename T> static T *arena_hostdev(T *dev) { return (T *)(g_ar.hdev + ((uint8_t *)dev - g_ar.base)); }
 #define ORBX_FAST_FALLBACK 1  // positive: not an error, the caller runs the exact legacy kernel
 extern thread_local int t_matchResolver;   // ORBM_OPT_RESOLVER (orbx_match.hip)
+extern thread_local int t_matchStreamSync; // ORBM_OPT_STREAM_SYNC (orbx_match.hip): 1 = always wait for the stream, never poll the completion word
+// Wait for the call's last kernel: poll the completion word it stores behind its results (k_resolve_par), fall back to the stream
+// synchronisation if it does not show up within a few milliseconds (or when the option says so, or the kernel has no such word).
+static int arena_wait(hipStream_t st, int seq) {
+    if (seq > 0 && !t_matchStreamSync) {
+        for (int i = 0; i < 200000; i++) {
+            if (__atomic_load_n(g_ar.hflag, __ATOMIC_ACQUIRE) == seq) return ORBX_OK;
+            __builtin_ia32_pause();
+        }
+    }
+    ORBX_HIP(hipStreamSynchronize(st));
+    return ORBX_OK;
+}
 static inline int resolve_par_q(int m) { return m <= 2 * RP_T ? 2 : 4; }
 static inline size_t resolve_par_lds(int m, int n) { return sizeof(uint32_t) * ((size_t)QK * RP_T * resolve_par_q(m) + 2 * (size_t)n + (size_t)(n + 31) / 32); }
 static inline bool use_resolve_par(int m, int n) { return t_matchResolver == 0 && m <= RP_T * RP_QMAX && n <= 30000 && resolve_par_lds(m, n) <= 158 * 1024; }
@@ -1095,6 +1120,7 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
     const size_t need = (size_t)n * (28 + 32 + 32 + 16) + (size_t)m * (28 + 32 + QK * 8 + 64 + sizeof(orbm_worldpoint_t)) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
+    int waitSeq = 0;   // > 0: the call's last kernel stores this number into the completion word (arena_wait)
     // dev: the frame's keypoints / descriptors / mvuRight are already in HBM (outputs of orbx_extract_batch_device and
     // orbm_stereo_batch_device) and the kernels run on the caller's stream, behind the kernels that produce them
     hipStream_t st = dev ? dev->stream : g_ar.st;
@@ -1133,7 +1159,8 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
     hipLaunchKernelGGL(k_queries_mp, dim3((mx + 255) / 256), dim3(256), 0, st, dmp, m, zsf, th, dq, zfm, zeo, n, dk, du, *g, dckp);
     hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, zmd, m, dckp, dd, n, *g, dkeys, dnc);
     if (use_resolve_par(m, n)) {   // results land in the pinned mirror straight from the kernel
-        RESOLVE_PAR_LAUNCH(0, m, dkeys, dnc, (const void *)dmp, dk, m, n, zfm, zfm, (int32_t *)nullptr, nnratio, 0, 0, dout, arena_hostdev(dout));
+        waitSeq = ++g_ar.seq;
+        RESOLVE_PAR_LAUNCH(0, m, dkeys, dnc, (const void *)dmp, dk, m, n, zfm, zfm, (int32_t *)nullptr, nnratio, 0, 0, dout, arena_hostdev(dout), g_ar.dflag, waitSeq);
         ORBX_HIP(hipGetLastError());
     } else {
         ORBX_HIP(hipMemcpyAsync(dfm, arena_host(dfm), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));   // this resolver works on the device copy
@@ -1141,7 +1168,8 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
         ORBX_HIP(hipGetLastError());
         DOWN(dout, 2); DOWN(dfm, n);
     }
-    ORBX_HIP(hipStreamSynchronize(st));
+    rc = arena_wait(st, waitSeq);
+    if (rc) return rc;
     if (world && proj_out) memcpy(proj_out, arena_host(dmp), sizeof(orbm_mappoint_t) * (size_t)m);
     const int32_t *out = arena_host(dout);
     if (getenv("ORBX_TRACE_RESOLVE")) fprintf(stderr, "k_resolve_par<mp>: %d queries, %d keypoints, %d rounds; developer build: loads %.1f us, rounds %.1f us, epilogue %.1f us\n", m, n, out[2], (out[3] >> 20) / 10.0, ((out[3] >> 10) & 1023) / 10.0, (out[3] & 1023) / 10.0);
@@ -1160,6 +1188,7 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
     const size_t need = (size_t)n * (28 + 32 + 32 + 16) + (size_t)nlast * (28 + 32 + QK * 8 + 64 + 8) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
+    int waitSeq = 0;
     hipStream_t st = dev ? dev->stream : g_ar.st;   // dev: kun / desc / uright / last_desc are device arrays (see fast_search_by_projection_mp)
     orbx_keypoint_t *dk = dev ? const_cast<orbx_keypoint_t *>(kun) : arena_get<orbx_keypoint_t>(n);
     uint8_t *dd = dev ? const_cast<uint8_t *>(desc) : arena_get<uint8_t>((size_t)32 * n);
@@ -1186,7 +1215,8 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
                        mono, dq, zcm, zeo, n, dk, du, dckp, dqm);
     hipLaunchKernelGGL(k_cand<false>, dim3((nlast + 3) / 4), dim3(256), 0, st, dq, dld, nlast, dckp, dd, n, *g, dkeys, dnc);
     if (use_resolve_par(nlast, n)) {
-        RESOLVE_PAR_LAUNCH(1, nlast, dkeys, dnc, (const void *)dqm, dk, nlast, n, zcm, zcm, (int32_t *)nullptr, 0.0f, 0, check_ori, dout, arena_hostdev(dout));
+        waitSeq = ++g_ar.seq;
+        RESOLVE_PAR_LAUNCH(1, nlast, dkeys, dnc, (const void *)dqm, dk, nlast, n, zcm, zcm, (int32_t *)nullptr, 0.0f, 0, check_ori, dout, arena_hostdev(dout), g_ar.dflag, waitSeq);
         ORBX_HIP(hipGetLastError());
     } else {
         ORBX_HIP(hipMemcpyAsync(dcm, arena_host(dcm), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
@@ -1196,7 +1226,8 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
         ORBX_HIP(hipGetLastError());
         DOWN(dout, 2); DOWN(dcm, n);
     }
-    ORBX_HIP(hipStreamSynchronize(st));
+    rc = arena_wait(st, waitSeq);
+    if (rc) return rc;
     const int32_t *out = arena_host(dout);
     if (getenv("ORBX_TRACE_RESOLVE")) fprintf(stderr, "k_resolve_par<frame>: %d queries, %d keypoints, %d rounds; developer build: loads %.1f us, rounds %.1f us, epilogue %.1f us\n", nlast, n, out[2], (out[3] >> 20) / 10.0, ((out[3] >> 10) & 1023) / 10.0, (out[3] & 1023) / 10.0);
     if (out[1]) return ORBX_FAST_FALLBACK;
@@ -1237,7 +1268,7 @@ int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const fl
                        ext_blocks ? deb : (const int32_t *)nullptr, n, dk, du, *ga, dckp);
     hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dqd, m, dckp, dd, n, *g, dkeys, dnc);
     if (use_resolve_par(m, n)) {
-        RESOLVE_PAR_LAUNCH(2, m, dkeys, dnc, (const void *)dw, dk, m, n, dh, dh, arena_hostdev(dh), 0.0f, max_dist, check_ori, dout, arena_hostdev(dout));
+        RESOLVE_PAR_LAUNCH(2, m, dkeys, dnc, (const void *)dw, dk, m, n, dh, dh, arena_hostdev(dh), 0.0f, max_dist, check_ori, dout, arena_hostdev(dout), (int32_t *)nullptr, 0);
         ORBX_HIP(hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_resolve_windows, dim3(1), dim3(64), 2 * (size_t)((n + 15) & ~15), st, dkeys, dnc, dw, dk, m, n, dh, dhi,

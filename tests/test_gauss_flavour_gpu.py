@@ -101,7 +101,7 @@ def test_unknown_flavour_and_options_are_refused(pkg):
     ex.set_option(6, 3)
     assert ex.get_option(6) == 3 and ex.get_option(4) == 0
     assert not hasattr(L, "orbx_debug_set")            # no process-global switch in the product library
-    assert L.orbm_set_thread_option(2, 5) == pkg.ORBX_ERR_ARG and L.orbm_set_thread_option(4, 1) == pkg.ORBX_ERR_ARG and L.orbm_set_thread_option(3, 2) == pkg.ORBX_ERR_ARG
+    assert L.orbm_set_thread_option(2, 5) == pkg.ORBX_ERR_ARG and L.orbm_set_thread_option(5, 1) == pkg.ORBX_ERR_ARG and L.orbm_set_thread_option(3, 2) == pkg.ORBX_ERR_ARG
 
 
 def test_two_threads_two_handles_different_options_and_flavours(pkg, oracle, synth):
