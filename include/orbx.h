@@ -465,6 +465,8 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  *   ORBX_OPT_OCT_SLICES    26  quad-tree of a batch: 1 = the key sweep of a level with >= 600 FAST cells is shared by two workgroups, >= 1600
  *                              by four (partial histograms summed by the last to arrive); 0 = one workgroup per level (default: the
  *                              shared form is faster alone and slower inside the pipelined step)
+ *   ORBX_OPT_STREAM_SYNC   27  orbx_stereo_frame_view: 0 = the host polls the completion word the last kernel stores behind the record (the
+ *                              stream wait as the fall-back), 1 = it waits for the stream
  * Keys 0, 1 and 7 (stop a kernel after phase n: outputs incomplete) exist only in a library built with -DORBX_DEVELOPER
  * (tools/octree_phase_probe.py); the default build refuses them. */
 #define ORBX_OPT_PYR_TILE 3
@@ -489,6 +491,7 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
 #define ORBX_OPT_PAD_FORM 24
 #define ORBX_OPT_PYR_CHAINS 25
 #define ORBX_OPT_OCT_SLICES 26
+#define ORBX_OPT_STREAM_SYNC 27
 #define ORBX_NUM_OPTIONS 32
 int orbx_set_option(orbx_extractor_t *h, int key, int value);
 int orbx_get_option(const orbx_extractor_t *h, int key, int *value);

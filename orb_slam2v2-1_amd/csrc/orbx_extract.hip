@@ -48,7 +48,7 @@ extern "C" int orbx_thread_release_scratch(void) {
 // in a developer build (-DORBX_DEVELOPER).
 extern "C" int orbx_set_option(orbx_extractor_t *h, int key, int value) {
     static const signed char maxv[ORBX_NUM_OPTIONS] = {/*0*/ -1, -1, -2, 64, 3, 4, 3, -1, ORBX_MAX_CHUNKS, 1, 2, 2, 1, 2, 127, ORBX_MAX_LEVELS,
-                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, 2, 1, 2, 1, 1, -2, -2, -2, -2, -2};
+                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, 2, 1, 2, 1, 1, 1, -2, -2, -2, -2};
     if (!h || key < 0 || key >= ORBX_NUM_OPTIONS || maxv[key] == -2) { orbx_set_error("orbx_set_option: unknown key %d", key); return ORBX_ERR_ARG; }
 #ifdef ORBX_DEVELOPER
     if (maxv[key] == -1) { if (value < 0) return ORBX_ERR_ARG; h->opt[key] = value; return ORBX_OK; }
@@ -196,6 +196,7 @@ extern "C" int orbx_destroy(orbx_extractor_t *h) {
     hipFree(h->d_sfr); if (h->h_sfr) hipHostFree(h->h_sfr);
     for (int i = 0; i < 2; i++) { hipFree(h->fv_d[i]); if (h->fv_h[i]) hipHostFree(h->fv_h[i]); }
     if (h->fv_stage) hipHostFree(h->fv_stage);
+    if (h->fv_flag) hipHostFree(h->fv_flag);
     if (h->h_sparseSeen) hipHostFree(h->h_sparseSeen);
     if (h->h_kps) { hipHostFree(h->h_kps); hipHostFree(h->h_desc); hipHostFree(h->h_counts); }
     for (int r = 0; r < ORBX_EV_RING; r++)
@@ -1509,9 +1510,24 @@ extern "C" int orbx_stereo_frame_view(orbx_extractor_t *h, const uint8_t *left, 
     rc = launch_pipeline(h, dl, 2, w, hgt, stride, (size_t)((uintptr_t)dr - (uintptr_t)dl), (orbx_keypoint_t *)rec, rec + 56 * c, (int32_t *)(rec + 128 * c), cap, st);
     h->descHostDelta = 0;
     if (rc) return rc;
-    rc = orbx_internal_stereo_frame_record(h, rec, h->fv_hdev[i], cap, mbf, mb, st, twin != 0);
+    if (!h->fv_flag) {
+        ORBX_HIP(hipHostMalloc((void **)&h->fv_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *h->fv_flag = 0;
+        ORBX_HIP(hipHostGetDevicePointer((void **)&h->fv_flag_dev, h->fv_flag, 0));
+    }
+    int armed = 0;
+    const int seq = ++h->fv_seq;
+    rc = orbx_internal_stereo_frame_record(h, rec, h->fv_hdev[i], cap, mbf, mb, st, twin != 0, h->opt[27] == 0 ? h->fv_flag_dev : nullptr, seq, &armed);
     if (rc) return rc;
-    ORBX_HIP(hipStreamSynchronize(st));
+    // The last kernel stores the call's number into the completion word behind the record; the host polls it (a stream synchronisation
+    // adds 10-15 us of wake-up latency to a 120-us call) and falls back to the stream after a few milliseconds.  ORBX_OPT_STREAM_SYNC = 1: the stream wait.
+    bool done = false;
+    if (armed)
+        for (int spin = 0; spin < 200000 && !done; spin++) {
+            done = __atomic_load_n(h->fv_flag, __ATOMIC_ACQUIRE) == seq;
+            if (!done) __builtin_ia32_pause();
+        }
+    if (!done) ORBX_HIP(hipStreamSynchronize(st));
     const uint8_t *hr = h->fv_h[i];
     const int32_t *tail = (const int32_t *)(hr + 128 * c);
     view->nl = std::min(tail[0], cap); view->nr = std::min(tail[1], cap); view->nmatch = tail[2]; view->cap = cap;

@@ -115,6 +115,7 @@ struct orbx_extractor {
     // orbx_stereo_frame_view: two alternating frame records (HBM + pinned host twin, and the twin as kernels address it), pinned staging for pageable images
     uint8_t *fv_d[2], *fv_h[2], *fv_hdev[2]; int fv_cap, fv_next;
     uint8_t *fv_stage, *fv_stage_dev; size_t fv_stage_bytes;
+    int32_t *fv_flag, *fv_flag_dev; int fv_seq;   // completion word of a latency call (coherent pinned memory): its last kernel stores the call's number, the host polls it
     long long descHostDelta;   // != 0 while a latency call is being issued: k_describe repeats its stores at address + delta (the record's pinned twin)
     uint8_t *d_dbgBlur; int dbgBlurCap;   // test hook: blurred 37x37 blocks of a single-image call (orbx_debug_blur_patches)
     hipStream_t stream;      // own stream
@@ -147,7 +148,8 @@ struct orbx_extractor {
 // extractor internals used by the matcher side
 void orbx_internal_free_stereo_scratch(orbx_extractor *h);   // orbx_match.hip
 // ComputeStereoMatches of the frame in image slots 0 / 1 of h with the record layout of orbx_stereo_frame_view (orbx_match.hip)
-int orbx_internal_stereo_frame_record(orbx_extractor *h, uint8_t *d_rec, uint8_t *rec_hostdev, int cap, float mbf, float mb, hipStream_t st, bool recordsOnHost);
+int orbx_internal_stereo_frame_record(orbx_extractor *h, uint8_t *d_rec, uint8_t *rec_hostdev, int cap, float mbf, float mb, hipStream_t st, bool recordsOnHost,
+                                      int32_t *doneFlag, int doneSeq, int *flagArmed);
 void orbx_internal_release_match_scratch();                  // orbx_match.hip      (thread-local staging pair)
 void orbx_internal_release_arena();                          // orbx_match_fast.hip (thread-local arena)
 void orbx_internal_release_bow_scratch();                    // orbx_bow.hip        (thread-local scratch)

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(SM_T) void k_stereo_median(const int32_t *__restric
 // Record (bytes; cap a multiple of 4): kps L @0 | kps R @28 cap | desc L @56 cap | desc R @88 cap | mvuRight @120 cap | mvDepth @124 cap
 // | @128 cap: int32 nl, nr, nmatch, 0.
 __global__ __launch_bounds__(SF_T) void k_stereo_finish(uint4 *rec, uint4 *__restrict__ rec_host, int cap,
-                                                        const int32_t *__restrict__ sad, int useLds, int uBegin) {
+                                                        const int32_t *__restrict__ sad, int useLds, int uBegin, int32_t *doneFlag, int doneSeq) {
     extern __shared__ int32_t sd_lds[];
     __shared__ int sh_keep;
     const int tid = threadIdx.x;
@@ -491,6 +491,13 @@ __global__ __launch_bounds__(SF_T) void k_stereo_finish(uint4 *rec, uint4 *__res
         } else if (u == total - 1)
             v.z = (uint32_t)sh_keep;
         rec_host[u] = v;
+    }
+    // one workgroup moves the whole tail (the usual latency call): the call's sequence number goes into the handle's completion word behind
+    // everything, and the host polls that word instead of waiting for the stream (see arena_wait, orbx_match_fast.hip)
+    if (doneFlag && gridDim.x == 1) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) { __threadfence_system(); __hip_atomic_store(doneFlag, doneSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
 }
 
@@ -539,7 +546,8 @@ static int stereo_batch_impl(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, 
                              int right_slot0, const orbx_keypoint_t *d_kl, const uint8_t *d_dl, const int32_t *d_nl,
                              const orbx_keypoint_t *d_kr, const uint8_t *d_dr, const int32_t *d_nr,
                              int cap, float mbf, float mb, float *d_uright, float *d_depth,
-                             int32_t *d_nmatch, void *stream, bool prev, uint8_t *finish_rec = nullptr, uint8_t *finish_host = nullptr, bool finish_tail_only = false) {
+                             int32_t *d_nmatch, void *stream, bool prev, uint8_t *finish_rec = nullptr, uint8_t *finish_host = nullptr, bool finish_tail_only = false,
+                             int32_t *doneFlag = nullptr, int doneSeq = 0, int *flagArmed = nullptr) {
     if (!hl || !hr || !d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_uright || !d_depth || B < 1 ||
         cap < 1 || left_slot0 < 0 || right_slot0 < 0 || left_slot0 + B > hl->pB || right_slot0 + B > hr->pB) {
         orbx_set_error("orbm_stereo_batch_device: bad arguments");
@@ -577,8 +585,10 @@ static int stereo_batch_impl(orbx_extractor_t *hl, orbx_extractor_t *hr, int B, 
     if (finish_rec)   // one frame, latency path: median step + the whole record to pinned host memory, one launch
     {
         const int uBegin = finish_tail_only ? (120 * cap) >> 4 : 0;
-        hipLaunchKernelGGL(k_stereo_finish, dim3((8 * cap + 1 - uBegin + SF_T - 1) / SF_T), dim3(SF_T), useLds ? sizeof(int32_t) * cap : 0, st,
-                           (uint4 *)finish_rec, (uint4 *)finish_host, cap, hl->st_sad, useLds, uBegin);
+        const int fgrid = (8 * cap + 1 - uBegin + SF_T - 1) / SF_T;
+        if (flagArmed) *flagArmed = doneFlag != nullptr && fgrid == 1;
+        hipLaunchKernelGGL(k_stereo_finish, dim3(fgrid), dim3(SF_T), useLds ? sizeof(int32_t) * cap : 0, st,
+                           (uint4 *)finish_rec, (uint4 *)finish_host, cap, hl->st_sad, useLds, uBegin, fgrid == 1 ? doneFlag : (int32_t *)nullptr, doneSeq);
     }
     else
         hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(SM_T), useLds ? sizeof(int32_t) * cap : 0, st, d_nl, cap, d_uright,
@@ -597,13 +607,14 @@ extern "C" int orbm_stereo_batch_device(orbx_extractor_t *hl, orbx_extractor_t *
                              d_nmatch, stream, false);
 }
 
-int orbx_internal_stereo_frame_record(orbx_extractor *h, uint8_t *d_rec, uint8_t *rec_hostdev, int cap, float mbf, float mb, hipStream_t st, bool recordsOnHost) {
+int orbx_internal_stereo_frame_record(orbx_extractor *h, uint8_t *d_rec, uint8_t *rec_hostdev, int cap, float mbf, float mb, hipStream_t st, bool recordsOnHost,
+                                      int32_t *doneFlag, int doneSeq, int *flagArmed) {
     const size_t c = (size_t)cap;
     orbx_keypoint_t *kl = (orbx_keypoint_t *)d_rec, *kr = (orbx_keypoint_t *)(d_rec + 28 * c);
     uint8_t *dl = d_rec + 56 * c, *dr = d_rec + 88 * c;
     float *ur = (float *)(d_rec + 120 * c), *dp = (float *)(d_rec + 124 * c);
     int32_t *tail = (int32_t *)(d_rec + 128 * c);
-    return stereo_batch_impl(h, h, 1, 0, 1, kl, dl, tail, kr, dr, tail + 1, cap, mbf, mb, ur, dp, tail + 2, (void *)st, false, d_rec, rec_hostdev, recordsOnHost);
+    return stereo_batch_impl(h, h, 1, 0, 1, kl, dl, tail, kr, dr, tail + 1, cap, mbf, mb, ur, dp, tail + 2, (void *)st, false, d_rec, rec_hostdev, recordsOnHost, doneFlag, doneSeq, flagArmed);
 }
 
 // The same on the pyramids of the extraction call BEFORE the last one (software pipelining: the matcher of batch i-1 issued

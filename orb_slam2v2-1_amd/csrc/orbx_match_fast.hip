@@ -61,62 +61,63 @@ template <bool FULL>
 __global__ __launch_bounds__(256) void k_cand(const GQuery *__restrict__ qs, const uint8_t *__restrict__ qdesc, int m,
                                               const uint4 *__restrict__ ckp, const uint8_t *__restrict__ desc, int n, orbm_grid_geom_t g,
                                               u64 *__restrict__ keys, int32_t *__restrict__ ncand) {
-    __shared__ u64 cl[4][CAND_CAP];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + wave;
-    if (qi >= m) return;
-    u64 *L = cl[wave];
+    // ONE QUERY PER WORKGROUP (round 5; rounds 1-4: one per wave, four per workgroup): the four waves scan a quarter of the frame's records
+    // each and append their survivors to one LDS list; then all 256 lanes fetch the survivors' descriptors, and wave 0 selects.  A query
+    // is a chain of ~1800 dependent-ish instructions; with one wave per query 2000 queries put two waves on a SIMD (nothing to hide the
+    // latencies behind) and ran two rounds of workgroups: 13.7 us for 2012 x 2012.  Same work, four times the waves, a quarter of the chain.
+    __shared__ u64 L[CAND_CAP];
+    __shared__ int sh_cnt;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int qi = blockIdx.x;
+    if (qi >= m) return;   // (workgroup-uniform: a launch for zero queries still starts one workgroup)
     const GQuery Q = qs[qi];
-    int cnt = 0;
+    if (tid == 0) sh_cnt = 0;
+    __syncthreads();
+    bool live = false;
+    Desc256 da = {};
     if (Q.valid) {
         const AreaQuery aq = make_query(g, Q.x, Q.y, Q.r, Q.minLevel, Q.maxLevel);
         if (!aq.empty) {
-            const Desc256 da = load_desc(qdesc + (size_t)qi * 32);
-            // four rounds of 64 records per trip, all four loads requested before the first test: with ~2 waves per SIMD (one wave per
-            // query, 500 workgroups) the scan is bound by the latency of its loads - one load per round ran 32 round trips per query
-            // (14 us for 2012 x 2012), four in flight run 8
-            for (int j0 = 0; j0 < n; j0 += 256) {
-                uint4 rr[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) rr[u] = ckp[min(j0 + 64 * u + lane, n - 1)];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (j0 + 64 * u >= n) break;   // wave-uniform
-                    const int j = j0 + 64 * u + lane;
-                    const uint4 r = rr[u];
-                    bool ok = false;
-                    u64 key = ~0ull;
-                    if (j < n) {
-                        const unsigned c = r.z & 0xFFFFu;
-                        const int oct = (int)((r.z >> 16) & 0xFFu);
-                        ok = in_area_xy(aq, c, __uint_as_float(r.x), __uint_as_float(r.y), oct) && !((r.z >> 24) & 1u);
-                        if (ok && Q.ur_tol >= 0.0f) {
-                            const float uu = __uint_as_float(r.w);
-                            if (uu > 0 && fabsf(Q.ur_c - uu) > Q.ur_tol) ok = false;
-                        }
-                        if (ok) key = fast_key(0, c, j, oct);     // (the distance follows below, for all survivors at once)
+            live = true;
+            da = load_desc(qdesc + (size_t)qi * 32);
+            for (int j0 = 64 * wave; j0 < n; j0 += 256) {
+                const int j = j0 + lane;
+                const uint4 r = ckp[min(j, n - 1)];
+                bool ok = false;
+                u64 key = ~0ull;
+                if (j < n) {
+                    const unsigned c = r.z & 0xFFFFu;
+                    const int oct = (int)((r.z >> 16) & 0xFFu);
+                    ok = in_area_xy(aq, c, __uint_as_float(r.x), __uint_as_float(r.y), oct) && !((r.z >> 24) & 1u);
+                    if (ok && Q.ur_tol >= 0.0f) {
+                        const float uu = __uint_as_float(r.w);
+                        if (uu > 0 && fabsf(Q.ur_c - uu) > Q.ur_tol) ok = false;
                     }
-                    const u64 mk = __ballot(ok);
+                    if (ok) key = fast_key(0, c, j, oct);     // (the distance follows below, for all survivors at once)
+                }
+                const u64 mk = __ballot(ok);
+                if (mk) {   // wave-uniform: one LDS atomic per wave and round reserves the survivors' places
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&sh_cnt, __popcll(mk));
+                    base = __builtin_amdgcn_readfirstlane(base);
                     if (ok) {
-                        const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
+                        const int pos = base + __popcll(mk & ((1ull << lane) - 1ull));
                         if (pos < CAND_CAP) L[pos] = key;
                     }
-                    cnt += __popcll(mk);
                 }
-            }
-            // Hamming distances of the survivors, 64 at a time (their descriptor loads all in flight together; inside the scan each
-            // group of 64 records with a survivor waited for a load of its own)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            for (int i = lane; i < min(cnt, CAND_CAP); i += 64) {
-                const u64 k0 = L[i];
-                L[i] = k0 | ((u64)ham(da, load_desc(desc + (size_t)KEY_IDX(k0) * 32)) << 32);
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    const int cnt = sh_cnt;
     const int nl = min(cnt, CAND_CAP);
+    if (live)   // (workgroup-uniform) Hamming distances of the survivors, their descriptor loads all in flight together
+        for (int i = tid; i < nl; i += 256) {
+            const u64 k0 = L[i];
+            L[i] = k0 | ((u64)ham(da, load_desc(desc + (size_t)KEY_IDX(k0) * 32)) << 32);
+        }
+    __syncthreads();
+    if (wave != 0) return;     // the selection / sort is one wave's job
     if (FULL) {   // bitonic sort of the staged list (wave-synchronous), then copy out
         int P = 1;
         while (P < nl) P <<= 1;
@@ -1074,7 +1075,7 @@ int fast_search_for_initialization(const orbx_keypoint_t *k1, const uint8_t *d1,
     FLUSH_UP();
     hipLaunchKernelGGL(k_compact_kps, dim3((n2 + 255) / 256), dim3(256), 0, st, dk2, n2, *g2, dckp);
     hipLaunchKernelGGL(k_queries_init, dim3((n1 + 255) / 256), dim3(256), 0, st, dk1, dprev, n1, window, dq);
-    hipLaunchKernelGGL(k_cand<true>, dim3((n1 + 3) / 4), dim3(256), 0, st, dq, dd1, n1, dckp, dd2, n2, *g2, dkeys, dnc);
+    hipLaunchKernelGGL(k_cand<true>, dim3(std::max(n1, 1)), dim3(256), 0, st, dq, dd1, n1, dckp, dd2, n2, *g2, dkeys, dnc);
     hipLaunchKernelGGL(k_resolve_init, dim3(1), dim3(64), sizeof(int32_t) * 2 * (size_t)n2 + (size_t)((n2 + 15) & ~15), st, dkeys, dnc, dk1, dk2, n1, n2,
                        dprev, dm12, dbin, nnratio, check_ori, dout);
     ORBX_HIP(hipGetLastError());
@@ -1157,7 +1158,7 @@ int fast_search_by_projection_mp(const orbx_keypoint_t *kun, const uint8_t *desc
     const int mx = std::max(n, m);
     uint4 *dckp = arena_get<uint4>(n);
     hipLaunchKernelGGL(k_queries_mp, dim3((mx + 255) / 256), dim3(256), 0, st, dmp, m, zsf, th, dq, zfm, zeo, n, dk, du, *g, dckp);
-    hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, zmd, m, dckp, dd, n, *g, dkeys, dnc);
+    hipLaunchKernelGGL(k_cand<false>, dim3(std::max(m, 1)), dim3(256), 0, st, dq, zmd, m, dckp, dd, n, *g, dkeys, dnc);
     if (use_resolve_par(m, n)) {   // results land in the pinned mirror straight from the kernel
         waitSeq = ++g_ar.seq;
         RESOLVE_PAR_LAUNCH(0, m, dkeys, dnc, (const void *)dmp, dk, m, n, zfm, zfm, (int32_t *)nullptr, nnratio, 0, 0, dout, arena_hostdev(dout), g_ar.dflag, waitSeq);
@@ -1213,7 +1214,7 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
     uint4 *dckp = arena_get<uint4>(n);
     hipLaunchKernelGGL(k_queries_frame, dim3((mx + 255) / 256), dim3(256), 0, st, zl, nlast, zsf, *cam, *g, zT, zT + 16, th,
                        mono, dq, zcm, zeo, n, dk, du, dckp, dqm);
-    hipLaunchKernelGGL(k_cand<false>, dim3((nlast + 3) / 4), dim3(256), 0, st, dq, dld, nlast, dckp, dd, n, *g, dkeys, dnc);
+    hipLaunchKernelGGL(k_cand<false>, dim3(std::max(nlast, 1)), dim3(256), 0, st, dq, dld, nlast, dckp, dd, n, *g, dkeys, dnc);
     if (use_resolve_par(nlast, n)) {
         waitSeq = ++g_ar.seq;
         RESOLVE_PAR_LAUNCH(1, nlast, dkeys, dnc, (const void *)dqm, dk, nlast, n, zcm, zcm, (int32_t *)nullptr, 0.0f, 0, check_ori, dout, arena_hostdev(dout), g_ar.dflag, waitSeq);
@@ -1266,7 +1267,7 @@ int fast_match_windows(const orbx_keypoint_t *kun, const uint8_t *desc, const fl
     uint4 *dckp = arena_get<uint4>(n);
     hipLaunchKernelGGL(k_queries_windows, dim3((mx + 255) / 256), dim3(256), 0, st, dw, m, dq, dh,
                        ext_blocks ? deb : (const int32_t *)nullptr, n, dk, du, *ga, dckp);
-    hipLaunchKernelGGL(k_cand<false>, dim3((m + 3) / 4), dim3(256), 0, st, dq, dqd, m, dckp, dd, n, *g, dkeys, dnc);
+    hipLaunchKernelGGL(k_cand<false>, dim3(std::max(m, 1)), dim3(256), 0, st, dq, dqd, m, dckp, dd, n, *g, dkeys, dnc);
     if (use_resolve_par(m, n)) {
         RESOLVE_PAR_LAUNCH(2, m, dkeys, dnc, (const void *)dw, dk, m, n, dh, dh, arena_hostdev(dh), 0.0f, max_dist, check_ori, dout, arena_hostdev(dout), (int32_t *)nullptr, 0);
         ORBX_HIP(hipGetLastError());
