@@ -495,7 +495,7 @@ __global__ __launch_bounds__(SF_T) void k_stereo_finish(uint4 *rec, uint4 *__res
     // one workgroup moves the whole tail (the usual latency call): the call's sequence number goes into the handle's completion word behind
     // everything, and the host polls that word instead of waiting for the stream (see arena_wait, orbx_match_fast.hip)
     if (doneFlag && gridDim.x == 1) {
-        __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my stores to the (uncached) host record have been acknowledged; ONE wave fences and signals
         __syncthreads();
         if (tid == 0) { __threadfence_system(); __hip_atomic_store(doneFlag, doneSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }

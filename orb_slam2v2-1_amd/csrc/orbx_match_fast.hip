@@ -18,6 +18,7 @@
 #include "orbx_match_dev.h"
 #include <math.h>
 #include <stdlib.h>
+#include <time.h>
 #include <algorithm>
 
 #define QK 8
@@ -602,7 +603,9 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
             if (nc[r] > CAND_CAP) overflow = true;   // k_cand dropped candidates: its top-QK is not trustworthy
         }
     }
+    __shared__ int hnw[RP_T / 64][32];
     if (tid < HISTO_LENGTH) hn[tid] = 0;
+    for (int i = tid; i < (RP_T / 64) * 32; i += RP_T) (&hnw[0][0])[i] = 0;
     if (tid == 0) { sh_nm = 0; sh_ov = 0; }
     // the holders before the call (they may sit in the pinned mirror: a bus round trip) are requested now, for the write-back at the end
     int32_t hin[RP_Q];
@@ -698,12 +701,19 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
                 int bn = (int)roundf(rot * factor);
                 if (bn == HISTO_LENGTH) bn = 0;
                 bin[r] = bn;
-                atomicAdd(&hn[bn], 1);
+                atomicAdd(&hnw[tid >> 6][bn], 1);   // a histogram per wave (a few hundred commits on 30 bins of ONE histogram serialised the sixteen waves), summed below
             }
         }
     }
     __syncthreads();
     if (MODE != 0 && check_ori) {
+        if (tid < HISTO_LENGTH) {
+            int sum = 0;
+#pragma unroll
+            for (int wv = 0; wv < RP_T / 64; wv++) sum += hnw[wv][tid];
+            hn[tid] = sum;
+        }
+        __syncthreads();
         if (tid == 0) three_maxima(hn, HISTO_LENGTH, ind[0], ind[1], ind[2]);
         __syncthreads();
 #pragma unroll
@@ -733,7 +743,9 @@ __global__ __launch_bounds__(RP_T) void k_resolve_par(const u64 *__restrict__ ke
     nm = wave_sum_i32(nm);
     if ((tid & 63) == 0 && nm) atomicAdd(&sh_nm, nm);
     if (__ballot(overflow) && (tid & 63) == 0) sh_ov = 1;
-    if (doneFlag) __threadfence_system();   // my stores into the pinned mirror are visible to the host before the barrier ...
+    // (a system-scope fence in every wave costs ~0.3 us each and they serialise: +4 us on this kernel.  The results go to UNCACHED host
+    // memory: once a wave's stores are acknowledged - s_waitcnt vmcnt(0) - they are on the host; one wave then fences and signals.)
+    if (doneFlag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my stores into the pinned mirror have arrived before the barrier ...
     __syncthreads();
     if (tid == 0) {
         out[0] = sh_nm; out[1] = sh_ov; out[2] = rounds;     // [2]: rounds the iteration took (diagnostics)
@@ -1186,6 +1198,9 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
                                     const uint8_t *last_desc, int nlast, int32_t *cur_mp, const int32_t *ext_obs,
                                     float th, int mono, int check_ori, int device, int *nmatches, const DevFrame *dev) {
     if (n > 30000) return ORBX_FAST_FALLBACK;
+    static const bool traceHost = getenv("ORBX_TRACE_HOST") != nullptr;   // developer aid: host-side time stamps of this call on stderr
+    timespec ts0, ts1, ts2, ts3;
+    if (traceHost) clock_gettime(CLOCK_MONOTONIC, &ts0);
     const size_t need = (size_t)n * (28 + 32 + 32 + 16) + (size_t)nlast * (28 + 32 + QK * 8 + 64 + 8) + 65536;
     int rc = arena_begin(device, need);
     if (rc) return rc;
@@ -1212,6 +1227,7 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
     const int mx = std::max(n, nlast);
     float2 *dqm = arena_get<float2>(nlast);
     uint4 *dckp = arena_get<uint4>(n);
+    if (traceHost) clock_gettime(CLOCK_MONOTONIC, &ts1);
     hipLaunchKernelGGL(k_queries_frame, dim3((mx + 255) / 256), dim3(256), 0, st, zl, nlast, zsf, *cam, *g, zT, zT + 16, th,
                        mono, dq, zcm, zeo, n, dk, du, dckp, dqm);
     hipLaunchKernelGGL(k_cand<false>, dim3(std::max(nlast, 1)), dim3(256), 0, st, dq, dld, nlast, dckp, dd, n, *g, dkeys, dnc);
@@ -1227,8 +1243,14 @@ int fast_search_by_projection_frame(const orbx_keypoint_t *kun, const uint8_t *d
         ORBX_HIP(hipGetLastError());
         DOWN(dout, 2); DOWN(dcm, n);
     }
+    if (traceHost) clock_gettime(CLOCK_MONOTONIC, &ts2);
     rc = arena_wait(st, waitSeq);
     if (rc) return rc;
+    if (traceHost) {
+        clock_gettime(CLOCK_MONOTONIC, &ts3);
+        auto us = [](const timespec &a, const timespec &b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3; };
+        fprintf(stderr, "search_by_projection_frame host: stage inputs %.1f us, enqueue %.1f us, wait %.1f us\n", us(ts0, ts1), us(ts1, ts2), us(ts2, ts3));
+    }
     const int32_t *out = arena_host(dout);
     if (getenv("ORBX_TRACE_RESOLVE")) fprintf(stderr, "k_resolve_par<frame>: %d queries, %d keypoints, %d rounds; developer build: loads %.1f us, rounds %.1f us, epilogue %.1f us\n", nlast, n, out[2], (out[3] >> 20) / 10.0, ((out[3] >> 10) & 1023) / 10.0, (out[3] & 1023) / 10.0);
     if (out[1]) return ORBX_FAST_FALLBACK;
