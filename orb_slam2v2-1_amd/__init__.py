@@ -423,7 +423,7 @@ class ORBextractor:
         return {"kl": kl[:a].copy(), "dl": dl[:a].copy(), "kr": kr[:b].copy(), "dr": dr[:b].copy(), "uright": ur[:a].copy(),
                 "depth": dp[:a].copy(), "nmatch": nm.value}
 
-    def stereo_frame_view(self, left, right, mbf, mb, shape=None):
+    def stereo_frame_view(self, left, right, mbf, mb, shape=None, stride=None):
         """The latency form of stereo_frame (orbx_stereo_frame_view): no copy commands, results in the handle's pinned record.
         left / right: uint8 numpy arrays [h, w] (pageable: staged by the call), or objects with data_ptr() (torch tensors - pinned
         host or device memory), or raw addresses (then shape = (h, w)).  Returns dict(kl, dl, kr, dr, uright, depth, nmatch, view):
@@ -439,7 +439,7 @@ class ORBextractor:
         la, ra = addr(left), addr(right)
         hgt, w = shape if shape is not None else la[1]
         v = StereoView()
-        self._ck(self._L.orbx_stereo_frame_view(self._h, la[0], ra[0], w, hgt, w, float(mbf), float(mb), C.byref(v)))
+        self._ck(self._L.orbx_stereo_frame_view(self._h, la[0], ra[0], w, hgt, w if stride is None else int(stride), float(mbf), float(mb), C.byref(v)))
         self._shape = (hgt, w)
         a, b = v.nl, v.nr
         view = lambda p, n, dt: np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(p), dt) if n > 0 else np.zeros(0, dt)

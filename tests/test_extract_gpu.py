@@ -932,3 +932,35 @@ def test_quadtree_shared_sweep_in_a_batch(pkg, oracle, synth):
         for l in range(8):
             np.testing.assert_array_equal(ex.debug_level_points(l, 1, b=B - 1), _cands(orc.level_keypoints(l)), err_msg=str((opts, l)))
         ex.close()
+
+
+def test_stereo_frame_view_sizes_strides_and_empty(pkg, oracle, synth):
+    """orbx_stereo_frame_view over the cases a caller can hand it: image sizes that change from call to call on one handle (the plan,
+    the records and the staging buffer are rebuilt), a row stride larger than the width (a cv::Mat ROI; small enough for the LDS-staged
+    level 0, and so large that the call falls back to k_pyr_pad), a byte count that is a multiple of the page size, an empty image."""
+    import torch
+    mbf, mb = 40.0, 0.1
+    ex = pkg.ORBextractor(800, 1.2, 8, 20, 7, developer=False)
+    ref = pkg.ORBextractor(800, 1.2, 8, 20, 7, developer=False)
+    for (w, h, stride, pinned) in ((640, 480, 640, False), (1024, 512, 1024, True), (500, 300, 512, False), (640, 480, 640, True), (333, 257, 20000, False),
+                                   (752, 480, 752, True)):
+        l, r = synth.stereo_pair_blocky(w, h, 9000 + w + stride)
+        want = ref.stereo_frame(l, r, mbf, mb)
+        if stride != w:      # rows padded to `stride` bytes, the padding filled with noise the kernels must not read into the image
+            rng = np.random.default_rng(stride)
+            bl, br = rng.integers(0, 256, (h, stride), dtype=np.uint8), rng.integers(0, 256, (h, stride), dtype=np.uint8)
+            bl[:, :w], br[:, :w] = l, r
+            l2, r2 = bl, br
+        else:
+            l2, r2 = l, r
+        if pinned:
+            tl, tr = torch.from_numpy(np.ascontiguousarray(l2)).pin_memory(), torch.from_numpy(np.ascontiguousarray(r2)).pin_memory()
+            f = ex.stereo_frame_view(tl, tr, mbf, mb, shape=(h, w), stride=stride)
+        else:
+            l2, r2 = np.ascontiguousarray(l2), np.ascontiguousarray(r2)
+            f = ex.stereo_frame_view(l2.ctypes.data, r2.ctypes.data, mbf, mb, shape=(h, w), stride=stride)
+        for key in ("kl", "dl", "kr", "dr", "uright", "depth"):
+            assert f[key].tobytes() == want[key].tobytes(), (w, h, stride, key)
+        assert f["nmatch"] == want["nmatch"]
+    v = pkg.StereoView()
+    assert pkg.lib().orbx_stereo_frame_view(ex._h, None, None, 0, 0, 0, mbf, mb, __import__("ctypes").byref(v)) == 0 and v.nl == 0 and v.nr == 0 and not v.kl
