@@ -704,8 +704,8 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
     if world > 1 or force_gather:
-        # RCCL prints a version banner to STDOUT when its communicator is created; stdout carries ONE JSON line, so file descriptor 1 points at
-        # stderr while the process group comes up (a first barrier creates the communicator)
+        # RCCL prints a version banner to STDOUT when its communicator is created (eagerly, with device_id given); stdout carries ONE JSON
+        # line, so file descriptor 1 points at stderr while the process group comes up
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
@@ -714,8 +714,6 @@ def main():
                 dist.init_process_group("nccl", device_id=dev)
             else:
                 dist.init_process_group("gloo")
-            dist.barrier()
-            torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)

@@ -461,7 +461,8 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  *                              1 = never (k_pyr_pad: unaligned 16-byte chunks), 2 = always
  *   ORBX_OPT_PYR_CHAINS    25  levels >= 1 of batches of up to four images: 0 = in chains of up to four levels per launch (k_pyr_chain:
  *                              a tile's intermediate levels stay in LDS - per-level launches of one or two images are latency-bound),
- *                              1 = one launch per level as in a large batch.  ORBX_OPT_PYRAMID_FORM = 4 forces the chains at any batch size
+ *                              1 = one launch per level as in a large batch, 2 / 3 = chains of up to four / seven levels.  ORBX_OPT_PYRAMID_FORM = 4
+ *                              forces the chains at any batch size
  *   ORBX_OPT_OCT_SLICES    26  quad-tree of a batch: 1 = the key sweep of a level with >= 600 FAST cells is shared by two workgroups, >= 1600
  *                              by four (partial histograms summed by the last to arrive); 0 = one workgroup per level (default: the
  *                              shared form is faster alone and slower inside the pipelined step)

@@ -48,7 +48,7 @@ extern "C" int orbx_thread_release_scratch(void) {
 // in a developer build (-DORBX_DEVELOPER).
 extern "C" int orbx_set_option(orbx_extractor_t *h, int key, int value) {
     static const signed char maxv[ORBX_NUM_OPTIONS] = {/*0*/ -1, -1, -2, 64, 3, 4, 3, -1, ORBX_MAX_CHUNKS, 1, 2, 2, 1, 2, 127, ORBX_MAX_LEVELS,
-                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, 2, 1, 2, 1, 1, 1, -2, -2, -2, -2};
+                                                       /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, 2, 1, 2, 3, 1, 1, -2, -2, -2, -2};
     if (!h || key < 0 || key >= ORBX_NUM_OPTIONS || maxv[key] == -2) { orbx_set_error("orbx_set_option: unknown key %d", key); return ORBX_ERR_ARG; }
 #ifdef ORBX_DEVELOPER
     if (maxv[key] == -1) { if (value < 0) return ORBX_ERR_ARG; h->opt[key] = value; return ORBX_OK; }
@@ -468,19 +468,21 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
         h->pyrLdsBytes = 2 * (size_t)h->pyrBufBytes + (size_t)h->pyrMaxPar * 16 + 16;
         if (h->pyrLdsBytes > 150 * 1024) { orbx_set_error("pyramid tile needs %zu B of LDS", h->pyrLdsBytes); return ORBX_ERR_UNSUPPORTED; }
     }
-    {   // level chains of small batches (ChainPlan, orbx_extract_dev.h): levels 1 .. nlevels-1 in groups of up to PC_MAXL, the first group the short one
-        h->nChains = 0;
+    for (int variant = 0; variant < 2; variant++) {   // level chains of small batches (ChainPlan, orbx_extract_dev.h): levels 1 .. nlevels-1 in groups of up to
+        // CL levels, the first group the short one - planned twice: chains of up to 4 levels (variant 0) and of up to PC_MAXL = 7 (variant 1)
+        const int CL = variant == 0 ? 4 : PC_MAXL;
+        h->nChains[variant] = 0;
         const int nbTotal = h->nlevels - 1;
         if (nbTotal >= 1 && h->scale_factor <= 2.0) {
-            const int nch = (nbTotal + PC_MAXL - 1) / PC_MAXL;
+            const int nch = (nbTotal + CL - 1) / CL;
             int la = 0;
             bool ok = true;
             for (int c = 0; c < nch && ok; c++) {
-                const int nb = c == 0 ? nbTotal - PC_MAXL * (nch - 1) : PC_MAXL, lb = la + nb;
+                const int nb = c == 0 ? nbTotal - CL * (nch - 1) : CL, lb = la + nb;
                 ChainPlan cp;
                 memset(&cp, 0, sizeof(cp));
                 cp.la = la; cp.lb = lb;
-                const int TY = 8;
+                const int TY = nb <= 4 ? 8 : 16;   // (long chains: taller tiles, less of the accumulated row halo per owned row)
                 bool fits = false;
                 for (int TX = 96; TX >= 16 && !fits; TX -= 4) {
                     const size_t mark = tab.size();
@@ -527,10 +529,10 @@ static int ensure_plan(orbx_extractor *h, int w, int hgt, int B) {
                     if (!fits) tab.resize(mark);
                 }
                 ok = fits;
-                if (ok) h->chains[h->nChains++] = cp;
+                if (ok) h->chains[variant][h->nChains[variant]++] = cp;
                 la = lb;
             }
-            if (!ok) h->nChains = 0;
+            if (!ok) h->nChains[variant] = 0;
         }
     }
     if (maxTw > 65 || maxTh > 65) { orbx_set_error("cell window %dx%d exceeds 65", maxTw, maxTh); return ORBX_ERR_UNSUPPORTED; }
@@ -739,9 +741,10 @@ static void launch_pyramid(orbx_extractor *h, const uint8_t *d_imgs, uint8_t *py
         hipLaunchKernelGGL(k_pyr_pad<true>, dim3(((g0.pstride >> 4) * g0.prows + 255) / 256, 1, B), dim3(256), 0, st, d_imgs, stride,
                            img_stride, pyr, h->pyrImgBytes, h->d_geom, 0);
     // ORBX_OPT_PYRAMID_FORM = 4 (and small batches by default, ORBX_OPT_PYR_CHAINS): the levels in chains, one launch per chain
-    if (h->nChains > 0 && !hybrid && (h->opt[5] == 4 || (h->opt[5] == 0 && h->opt[25] != 1 && B <= ORBX_HIST_IMAGES))) {
-        for (int c = 0; c < h->nChains; c++) {
-            const ChainPlan &cp = h->chains[c];
+    const int cv = h->opt[25] == 3 ? 1 : 0;   // ORBX_OPT_PYR_CHAINS: 2 / 3 = chains of up to 4 / 7 levels (0: the default, 1: never)
+    if (h->nChains[cv] > 0 && !hybrid && (h->opt[5] == 4 || (h->opt[5] == 0 && h->opt[25] != 1 && B <= ORBX_HIST_IMAGES))) {
+        for (int c = 0; c < h->nChains[cv]; c++) {
+            const ChainPlan &cp = h->chains[cv][c];
             const size_t lds = 2 * (size_t)cp.bufBytes + (size_t)(cp.lb - cp.la) * cp.maxRows * 8;
             hipLaunchKernelGGL(k_pyr_chain, dim3(cp.tilesX * cp.tilesY, B), dim3(256), lds, st, pyr, h->pyrImgBytes, h->d_geom, h->d_tab, cp);
         }

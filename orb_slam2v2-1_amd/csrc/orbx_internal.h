@@ -59,7 +59,7 @@ struct LevelGeom {
 };
 
 // One launch of k_pyr_chain (orbx_extract_dev.h): up to PC_MAXL consecutive pyramid levels built from the level in front of them
-#define PC_MAXL 4
+#define PC_MAXL 7
 struct ChainPlan {
     int la, lb;                  // source level, last level built (lb - la <= PC_MAXL)
     int tilesX, tilesY;
@@ -93,7 +93,7 @@ struct orbx_extractor {
     uint32_t *d_octPart, *d_octLeaf, *d_octBest; int32_t *d_octState;
     int pyrTilesX, pyrTilesY, pyrXSpanOff, pyrYSpanOff, pyrBufBytes, pyrMaxDim, pyrMaxPar;
     size_t pyrLdsBytes;
-    ChainPlan chains[4]; int nChains;   // level chains of small batches (k_pyr_chain)
+    ChainPlan chains[2][8]; int nChains[2];   // level chains of small batches (k_pyr_chain): [0] up to 4 levels per chain, [1] up to PC_MAXL
     // device buffers
     LevelGeom *d_geom;
     int32_t *d_tab;

@@ -860,7 +860,7 @@ def test_small_batch_forms_agree(pkg, oracle, synth):
             imgs = np.stack([synth.frame(w, h, seed * 10 + i) for i in range(B)])
             orc = oracle.Extractor(nf, 1.2, 8, 20, 7)
             exp = [orc.extract(im) for im in imgs]
-            for opts in ((), ((24, 1),), ((25, 1),), ((23, 1),), ((24, 1), (25, 1), (23, 1)), ((24, 2), (5, 4))):
+            for opts in ((), ((24, 1),), ((25, 1),), ((25, 3),), ((23, 1),), ((24, 1), (25, 1), (23, 1)), ((24, 2), (5, 4)), ((5, 4), (25, 3))):
                 ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7)
                 for k_, v_ in opts:
                     ex.set_option(k_, v_)

@@ -67,7 +67,7 @@ for it in range(N):
                            ("pyramid 16 rows per wave", ((22, 2),)),
                            # round 5: "default" of a single image = level 0 from LDS-staged rows, level chains, quad-tree from the FAST stage's histogram;
                            # here the large-batch forms of those three stages, one by one and together, and the chains / staged rows forced
-                           ("k_pyr_pad instead of staged rows", ((24, 1),)), ("one launch per level instead of chains", ((25, 1),)),
+                           ("k_pyr_pad instead of staged rows", ((24, 1),)), ("one launch per level instead of chains", ((25, 1),)), ("level chains of up to seven levels", ((25, 3),)),
                            ("quad-tree key sweep instead of the FAST histogram", ((23, 1),)), ("large-batch forms", ((23, 1), (24, 1), (25, 1))),
                            ("sse2 flavour", ())):
         e, wk, wd = (ex2, ok2, od2) if variant.startswith("sse2") else (ex, ok, od)

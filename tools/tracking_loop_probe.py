@@ -57,4 +57,13 @@ for B in ((tc.GpuDeviceBackend,) if ONLY == "device" else (tc.GpuViewBackend,) i
              1e3 / (ms("t_frame") + ms("t_proj") + ms("t_local")), int(np.median([s["proj_n"] for s in log])),
              int(np.median([s["local_n"] for s in log]))))
 if not ONLY:
+    # informational: the same latency path when the capture path delivers the images into HBM (device pointers are accepted as they are)
+    import torch
+    c = tc.Chain(tc.GpuViewBackend(w, h, nf), w, h, nf)
+    srcd = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in frames]
+    for t in range(T):
+        c.step(srcd[t][0], srcd[t][1], Ts[t])
+    res["gpu-view-dev"] = c.log
+    print("gpu-view, images already in HBM: extract L+R + ComputeStereoMatches %.3f ms per frame (median); chain identical: %s"
+          % (1e3 * float(np.median([s["t_frame"] for s in c.log[5:]])), tc.first_difference(res["gpu-host"], c.log) is None))
     print("chains identical:", all(tc.first_difference(res["gpu-host"], res[k]) is None for k in ("gpu-device", "gpu-host-1call", "gpu-view")))
