@@ -39,9 +39,10 @@ WORKLOADS = {
     "kitti_stereo_natural_1241x376_1000feat": (1241, 376, 1000, True),
 }
 NATURAL = {"kitti_stereo_natural_1241x376_1000feat"}
-# the other north-star sizes measured (briefly) after the headline: (workload, frames per step)
+# the other north-star sizes measured (briefly) after the headline: (workload, frames per step).  1920x1080: 64 frames = one GPU's share of BASELINE
+# config 4 (a 512-frame batch over 8 GPUs; rounds 1-5 measured 32 here)
 OTHER_WORKLOADS = [("kitti_stereo_1241x376_2000feat", 64), ("euroc_stereo_752x480_1000feat", 64), ("mono_640x480_1000feat", 64),
-                   ("mono_1920x1080_4000feat", 32), ("kitti_stereo_natural_1241x376_1000feat", 64)]
+                   ("mono_1920x1080_4000feat", 64), ("kitti_stereo_natural_1241x376_1000feat", 64)]
 KITTI_FX, KITTI_BF = 718.856, 386.1448  # KITTI-00 calibration (fx, baseline*fx); same constants as pipeline.py
 
 

@@ -203,22 +203,16 @@ __device__ __forceinline__ int phase2_order_regs(const uint32_t *cnt, int L, uin
 }
 // dispatch on the list length (wave-uniform); false: the caller's LDS network takes the list (longer than 512 nodes - a register budget -, or sizes that need more than 22 bits)
 __device__ __forceinline__ bool phase2_order_in_regs(const uint32_t *cnt, int L, int keyCap, uint16_t *xlist, int lane, int &E) {
-#if OCT_T >= 1024
-    // the 1024-thread build (images with a level of >= 600 FAST cells: budgets of 500-1000 keypoints per level) also takes lists of up to
-    // 1024 nodes in registers, 16 keys per lane (round 5: the LDS network on 1024 keys was ~15 of the 25 us a 1920x1080 level spends in its
-    // passes); the 512-thread build is held to 80 VGPRs and keeps the limit of 512
-    constexpr int LMAX = 1024;
-#else
+    // (Round 5 also took lists of up to 1024 nodes in registers in the 1024-thread build, 16 keys per lane: the passes of a 1920x1080 level
+    // did not get shorter - their lists pass 512 nodes only in the last pass - and the kernel went from 101 to 114 VGPRs, i.e. from 416 to
+    // 480 of a SIMD's 512 registers for as long as a workgroup lives: beside it no wave of the descriptor kernel or of the pyramid built
+    // ahead fits any more, and the pipelined step of 64 1920x1080 images got 25 us LONGER (1.159 -> 1.184 ms).  Removed.)
     constexpr int LMAX = 512;
-#endif
     if (keyCap >= (1 << 22) || L > LMAX) return false;
     if (L <= 64) E = phase2_order_regs<1>(cnt, L, xlist, lane);
     else if (L <= 128) E = phase2_order_regs<2>(cnt, L, xlist, lane);
     else if (L <= 256) E = phase2_order_regs<4>(cnt, L, xlist, lane);
-    else if (L <= 512) E = phase2_order_regs<8>(cnt, L, xlist, lane);
-#if OCT_T >= 1024
-    else E = phase2_order_regs<16>(cnt, L, xlist, lane);
-#endif
+    else E = phase2_order_regs<8>(cnt, L, xlist, lane);
     return true;
 }
 
@@ -322,6 +316,8 @@ __device__ __forceinline__ void octree_pyr_body(
             rw = fRaw[cc];
             e = *(const uint4 *)(fSlots + (size_t)cc * capc + 4 * sub);
         };
+        // (Round 5 also kept FOUR rounds of cells in flight instead of one: the sweep of a 1920x1080 level 0 stayed at 63.8 us - it is bound by
+        // the LDS work of its CU, two table reads and up to two atomics per key, not by the memory round trip.)
         uint4 en; uint32_t rwn;
         fetch(cBeg + cgrp, en, rwn);
         for (int c0 = cBeg; c0 < cEnd; c0 += CPR) {
@@ -811,10 +807,21 @@ __device__ __forceinline__ void octree_pyr_body(
 // Registers: three 512-thread workgroups per CU is what the LDS allows (~42 KB each at 1241x376 / 1000 features), i.e. 6 waves per SIMD = 80 VGPRs.
 // Left to itself the compiler takes 84 (round 3; with the register sort of the phase-2 order, 115) and only TWO workgroups fit: the 1024
 // workgroups of a 128-image batch then run in two rounds, 58 us instead of the ~43 us the longest workgroup lives.
+#ifndef OCT_NARROW_WAVES
+#define OCT_NARROW_WAVES 6
+#endif
+// The 1024-thread build (one workgroup per CU: 4 waves per SIMD) would take 102 VGPRs = 416 of a SIMD's 512 for as long as a workgroup lives -
+// ~110 us for level 0 of a 1920x1080 image - and beside it at most one wave of the descriptor kernel or of the pyramid built ahead fits.  Held to
+// 80 (36 B of scratch per lane, in wave 0's pass code) the pipelined step of 64 such images takes 1.145 instead of 1.172 ms; at 96: 1.162,
+// at 64 (96 B of scratch): 1.161; with round 5's short-lived 114-VGPR form (16-key register sort): 1.184.  A kernel that runs BESIDE others is
+// sized by what it leaves them, not by what it could use.
+#ifndef OCT_WIDE_WAVES
+#define OCT_WIDE_WAVES 6
+#endif
 #if OCT_T == 512
-#define OCT_PYR_WAVES __attribute__((amdgpu_waves_per_eu(6, 6)))
+#define OCT_PYR_WAVES __attribute__((amdgpu_waves_per_eu(OCT_NARROW_WAVES, OCT_NARROW_WAVES)))
 #else
-#define OCT_PYR_WAVES
+#define OCT_PYR_WAVES __attribute__((amdgpu_waves_per_eu(OCT_WIDE_WAVES, OCT_WIDE_WAVES)))
 #endif
 __global__ __launch_bounds__(OCT_T) OCT_PYR_WAVES void k_octree_pyr(
     const LevelGeom *__restrict__ geom, int nlevels, const uint32_t *__restrict__ cand, size_t keysPerImg,
