@@ -621,8 +621,8 @@ def main():
                          "the default command are all single-stream (rocprof averages = the reported kernel duration)")
     ap.add_argument("--handle-options", default="", help="k=v[,k=v...]: orbx_set_option(k, v) on every extractor handle of this run (ORBX_OPT_* of "
                     "include/orbx.h: alternative kernels with identical results); recorded in config.handle_options")
-    ap.add_argument("--gauss-flavour", default=os.environ.get("ORBX_TEST_GAUSS_FLAVOUR", "half_up"), choices=["half_up", "sse2"],
-                    help="orbx_flavour_t.gauss_rounding of the handles AND of the oracle that checks them (default: half_up)")
+    ap.add_argument("--gauss-flavour", default=os.environ.get("ORBX_TEST_GAUSS_FLAVOUR", "half_up"),
+                    help="orbx_flavour_t of the handles AND of the oracle that checks them: half_up (default) | sse2 | taps:k0,k1,k2,k3")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N > 1 on a box with fewer GPUs than ranks")
     args = ap.parse_args()

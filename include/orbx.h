@@ -61,13 +61,23 @@ int orbx_destroy(orbx_extractor_t *h);
  *     ORBX_GAUSS_ROUND_HALF_UP  (sum + 2^15) >> 16 on every column: the scalar FixedPtCastEx (builds without SSE2 / NEON column code)
  *     ORBX_GAUSS_ROUND_SSE2     x86 builds (SSE2 is baseline on x86-64): SymmColumnVec_32s8u rounds the columns x < (w & ~3) of a
  *                               level half to EVEN (_mm_cvtps_epi32); the last w % 4 columns take the scalar half-up code.
- *   The two differ at ~1 pixel in 131 072 (sum mod 65536 == 32768 with an even quotient).  Which one a given reference build
- *   follows is reported by the reference-vector consumer (tests/golden/README.md); both are hypotheses until vectors exist. */
+ *   The two differ at ~1 pixel in 131 072 (sum mod 65536 == 32768 with an even quotient).
+ *     ORBX_GAUSS_FIXED_TAPS     OpenCV >= 3.4.1: the bit-exact 8-bit Gaussian (rows in ufixedpoint16, columns in ufixedpoint32, one
+ *                               rounding (sum + 2^15) >> 16, scalar and SIMD code agree) - the arithmetic of HALF_UP on the seven Q8 taps
+ *                               gauss_taps[] = { k0 (centre), k1, k2, k3 } the BUILD uses.  { 55, 49, 34, 18 } = cvRound(256 g_i), sum 257:
+ *                               identical to HALF_UP (3.4.1 up to the error-diffused kernel); later releases spread the rounding error so
+ *                               that the taps add up to 256 - { 56, 48, 34, 18 } by the left-to-right diffusion restated in
+ *                               oracle.refvec.diffused_taps.  When in doubt the taps are FITTED from a reference-vector file's blurred
+ *                               level (oracle.refvec.fit_gauss_taps; tests/golden/README.md).  k0 + 2 (k1 + k2 + k3) <= 257, k0 >= 1.
+ *   Which one a given reference build follows is reported by the reference-vector consumer (tests/golden/README.md); all are
+ *   hypotheses until vectors exist. */
 #define ORBX_GAUSS_ROUND_HALF_UP 0
 #define ORBX_GAUSS_ROUND_SSE2 1
+#define ORBX_GAUSS_FIXED_TAPS 2
 typedef struct {
-    int32_t gauss_rounding;   /* ORBX_GAUSS_ROUND_* */
-    int32_t reserved[7];      /* must be 0 */
+    int32_t gauss_rounding;   /* ORBX_GAUSS_ROUND_* / ORBX_GAUSS_FIXED_TAPS */
+    int32_t gauss_taps[4];    /* ORBX_GAUSS_FIXED_TAPS: Q8 taps, centre first; every other flavour: must be 0 */
+    int32_t reserved[3];      /* must be 0 */
 } orbx_flavour_t;
 int orbx_create_flavoured(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
                           int device, const orbx_flavour_t *flavour, orbx_extractor_t **out);

@@ -106,6 +106,9 @@ def lib():
         L.oracle_gaussian_blur7_flavour.argtypes = [vp, i32, i32, i32, vp, i32, i32]
         L.oracle_set_gauss_flavour.restype = i32
         L.oracle_set_gauss_flavour.argtypes = [vp, i32]
+        L.oracle_set_gauss_taps.restype = i32
+        L.oracle_set_gauss_taps.argtypes = [vp, i32, i32, i32, i32]
+        L.oracle_gaussian_blur7_taps.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(C.c_int)]
         L.oracle_gauss_round_half_even.restype = i32
         L.oracle_gauss_round_half_even.argtypes = [i32]
         L.oracle_gauss_round_sse2_literal.restype = i32
@@ -182,6 +185,21 @@ def _arr(ptr, n, dtype):
 
 
 GAUSS_FLAVOURS = {"half_up": 0, "sse2": 1}
+
+
+def parse_gauss(g):
+    """A Gaussian flavour as the test harness writes it: "half_up" | "sse2" | "taps:k0,k1,k2,k3" (the fixed-point Gaussian of OpenCV >=
+    3.4.1 on the build's Q8 taps, centre first).  Returns (code, taps or None)."""
+    if isinstance(g, str) and g.startswith("taps:"):
+        taps = tuple(int(v) for v in g[5:].split(","))
+        if len(taps) != 4:
+            raise ValueError("bad gauss flavour %r (taps:k0,k1,k2,k3)" % (g,))
+        return 2, taps
+    if g not in GAUSS_FLAVOURS:
+        raise ValueError("bad gauss flavour %r" % (g,))
+    return GAUSS_FLAVOURS[g], None
+
+
 # flavour an Extractor takes when it is not told (tests that run the whole parity suite under the other flavour set this
 # together with the HIP wrapper's default)
 # (ORBX_TEST_GAUSS_FLAVOUR in the environment: the same switch as the HIP wrapper's, inherited by spawned workers)
@@ -192,14 +210,16 @@ class Extractor:
     """CPU oracle of ORBextractor (reference: include/ORBextractor.h:45-111)."""
 
     def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, gauss=None):
-        """gauss: flavour of cv::GaussianBlur's column rounding, "half_up" (scalar FixedPtCastEx, the default) or "sse2"
-        (SymmColumnVec_32s8u: round half to even for the columns x < (w & ~3)); None = default_gauss_flavour."""
+        """gauss: flavour of cv::GaussianBlur on 8U: "half_up" (scalar FixedPtCastEx, the default), "sse2" (SymmColumnVec_32s8u: round
+        half to even for the columns x < (w & ~3)) or "taps:k0,k1,k2,k3" (OpenCV >= 3.4.1's fixed-point Gaussian on the build's Q8 taps,
+        centre first); None = default_gauss_flavour."""
         self.L = lib()
         self.h = self.L.oracle_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
         if not self.h:
             raise ValueError("bad extractor arguments")
         self.gauss = default_gauss_flavour if gauss is None else gauss
-        if self.L.oracle_set_gauss_flavour(self.h, GAUSS_FLAVOURS[self.gauss]):
+        code, taps = parse_gauss(self.gauss)
+        if (self.L.oracle_set_gauss_taps(self.h, *taps) if taps else self.L.oracle_set_gauss_flavour(self.h, code)):
             raise ValueError("bad gauss flavour %r" % (self.gauss,))
         self.nfeatures, self.nlevels = nfeatures, nlevels
 
@@ -321,7 +341,11 @@ def resize_linear(src, dw, dh):
 def gaussian_blur7(src, gauss="half_up"):
     src = np.ascontiguousarray(src, np.uint8)
     dst = np.zeros_like(src)
-    lib().oracle_gaussian_blur7_flavour(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), src.shape[1], GAUSS_FLAVOURS[gauss])
+    code, taps = parse_gauss(gauss)
+    if taps:
+        lib().oracle_gaussian_blur7_taps(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), src.shape[1], (C.c_int * 4)(*taps))
+    else:
+        lib().oracle_gaussian_blur7_flavour(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(dst), src.shape[1], code)
     return dst
 
 

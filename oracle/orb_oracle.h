@@ -78,6 +78,11 @@ void oracle_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_
  * round-half-to-even for the columns x < (w & ~3), scalar for the tail.  Both are hypotheses until reference vectors arrive. */
 #define ORACLE_GAUSS_HALF_UP 0
 #define ORACLE_GAUSS_SSE2 1
+/* FIXED_TAPS = OpenCV >= 3.4.1's bit-exact fixed-point Gaussian: HALF_UP's arithmetic on the Q8 taps of the build (centre first; 55 49 34 18
+ * reproduces HALF_UP; releases that diffuse the rounding error use taps adding up to 256) - oracle_set_gauss_taps / oracle_gaussian_blur7_taps */
+#define ORACLE_GAUSS_FIXED_TAPS 2
+void oracle_gaussian_blur7_taps(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride, const int taps[4]);
+int oracle_set_gauss_taps(orb_oracle_t *o, int k0, int k1, int k2, int k3);
 void oracle_gaussian_blur7_flavour(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride, int flavour);
 int oracle_set_gauss_flavour(orb_oracle_t *o, int flavour);
 int oracle_get_gauss_flavour(const orb_oracle_t *o);

@@ -26,6 +26,7 @@ static const int8_t k_pattern[1024] = {
 struct orb_oracle {
     int nfeatures, nlevels, ini_th, min_th;
     int gauss_flavour;   /* ORACLE_GAUSS_*: column rounding of cv::GaussianBlur (oracle_set_gauss_flavour) */
+    int gauss_taps[4];   /* ORACLE_GAUSS_FIXED_TAPS: the build's Q8 taps, centre first (oracle_set_gauss_taps) */
     double scale_factor; /* member is double: include/ORBextractor.h:98 */
     float sf[MAX_LEVELS], isf[MAX_LEVELS], sig2[MAX_LEVELS], isig2[MAX_LEVELS];
     int32_t nfeat[MAX_LEVELS];
@@ -102,6 +103,18 @@ int oracle_set_gauss_flavour(orb_oracle_t *o, int flavour) {
     return 0;
 }
 int oracle_get_gauss_flavour(const orb_oracle_t *o) { return o->gauss_flavour; }
+/* ORACLE_GAUSS_FIXED_TAPS: the bit-exact 8-bit Gaussian of OpenCV >= 3.4.1 on the taps of the build (see below) */
+static int gauss_taps_ok(const int k[4]) {
+    for (int i = 0; i < 4; i++) if (k[i] < 0 || k[i] > 255) return 0;
+    return k[0] >= 1 && k[0] + 2 * (k[1] + k[2] + k[3]) <= 257;
+}
+int oracle_set_gauss_taps(orb_oracle_t *o, int k0, int k1, int k2, int k3) {
+    const int k[4] = {k0, k1, k2, k3};
+    if (!o || !gauss_taps_ok(k)) return -1;
+    o->gauss_flavour = ORACLE_GAUSS_FIXED_TAPS;
+    memcpy(o->gauss_taps, k, sizeof(k));
+    return 0;
+}
 void oracle_destroy(orb_oracle_t *o) { if (o) { free_frame_state(o); free(o); } }
 
 const float *oracle_scale_factors(const orb_oracle_t *o) { return o->sf; }
@@ -359,9 +372,23 @@ static void gauss_col_sse2_4(const int *tmp, const int k[7], int x, int y, int w
     memcpy(out, &v, 4);
 }
 #endif
+/* ORACLE_GAUSS_FIXED_TAPS (2): OpenCV >= 3.4.1 took 8-bit GaussianBlur out of the filter engine: fixed-point rows (ufixedpoint16: pixel x Q8
+ * tap, exact - 255 * 257 = 65535 still fits), fixed-point columns (ufixedpoint32: Q8.8 row sum x Q8 tap, exact) and ONE rounding
+ * (sum + 2^15) >> 16, the same in its scalar and SIMD code - i.e. the arithmetic of HALF_UP, on the taps that release computes:
+ * cvRound(256 g_i) = 18 34 49 55 .. (sum 257, what <= 3.3 used: then FIXED_TAPS == HALF_UP bit for bit), or, in later releases,
+ * taps with the rounding error diffused so that they add up to 256.  Which taps a build uses is data (oracle.refvec.fit_gauss_taps
+ * recovers them from a blurred level), so they are a parameter.  [external, from memory of smooth.dispatch.cpp: parity unpinned] */
+static void gauss_blur_core(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride, int flavour, const int k[7]);
+void oracle_gaussian_blur7_taps(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride, const int taps[4]) {
+    const int k[7] = {taps[3], taps[2], taps[1], taps[0], taps[1], taps[2], taps[3]};
+    gauss_blur_core(src, w, h, sstride, dst, dstride, ORACLE_GAUSS_HALF_UP, k);
+}
 void oracle_gaussian_blur7_flavour(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride, int flavour) {
     int k[7];
     gauss7_fixed(k);
+    gauss_blur_core(src, w, h, sstride, dst, dstride, flavour, k);
+}
+static void gauss_blur_core(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride, int flavour, const int k[7]) {
     int *tmp = (int *)malloc(sizeof(int) * ((size_t)w * h + 4));
     for (int y = 0; y < h; y++) {
         const uint8_t *s = src + (size_t)y * sstride;
@@ -718,7 +745,8 @@ int oracle_extract(orb_oracle_t *o, const uint8_t *img, int w, int h, int stride
         double tb = now_s(); o->stage_s[3] += tb - ta;
         if (o->nsel[l] == 0) continue;
         o->blur[l] = (uint8_t *)malloc((size_t)lw * lh);
-        oracle_gaussian_blur7_flavour(inner, lw, lh, ps, o->blur[l], lw, o->gauss_flavour);
+        if (o->gauss_flavour == ORACLE_GAUSS_FIXED_TAPS) oracle_gaussian_blur7_taps(inner, lw, lh, ps, o->blur[l], lw, o->gauss_taps);
+        else oracle_gaussian_blur7_flavour(inner, lw, lh, ps, o->blur[l], lw, o->gauss_flavour);
         double tc = now_s(); o->stage_s[4] += tc - tb;
         for (int k = 0; k < o->nsel[l]; k++) {
             oracle_kp_t *kp = &kps[off + k];

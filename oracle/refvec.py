@@ -208,27 +208,88 @@ def compare(ref, got):
     return bad, ncmp, missing
 
 
+def diffused_taps(n=7, sigma=2.0):
+    """Q8 taps of the n-tap Gaussian with the rounding error carried from one tap to the next, left to right, so that they add up to 256
+    (what OpenCV's later bit-exact GaussianBlur does instead of cvRound(256 g_i), whose taps add up to 257; written from memory of
+    smooth.dispatch.cpp - a candidate, not a fact).  Centre first: (56, 48, 34, 18) for n = 7, sigma = 2."""
+    import math
+    g = [math.exp(-0.5 * (i - (n - 1) / 2.0) ** 2 / (sigma * sigma)) for i in range(n)]
+    tot = sum(g)
+    k, err = [], 0.0
+    for v in g:
+        x = v / tot * 256.0 + err
+        q = int(math.floor(x + 0.5))
+        err = x - q
+        k.append(q)
+    return tuple(k[n // 2:])
+
+
+def fit_gauss_taps(level, blurred, samples=768, seed=0):
+    """The Q8 taps (centre first) with which `blurred` is the fixed-point 7x7 Gaussian of `level` - (rows x taps, columns x taps, + 2^15) >>
+    16, saturated -, searched over every symmetric tap set near the sigma-2 Gaussian whose sum is 255..258; interior pixels only (no
+    border rule involved).  -> list of tap tuples that reproduce EVERY interior pixel (normally one; [] = not this family)."""
+    level = np.ascontiguousarray(level, np.uint8).astype(np.int64)
+    blurred = np.ascontiguousarray(blurred, np.uint8)
+    h, w = level.shape
+    if h < 16 or w < 16:
+        return []
+    rng = np.random.default_rng(seed)
+    ys, xs = rng.integers(3, h - 3, samples), rng.integers(3, w - 3, samples)
+    nb = level[(ys[:, None, None] + np.arange(-3, 4)[None, :, None]), (xs[:, None, None] + np.arange(-3, 4)[None, None, :])]   # [S][7 rows][7 columns]
+    want = blurred[ys, xs].astype(np.int64)
+    cands = [(s - 2 * (k1 + k2 + k3), k1, k2, k3) for k3 in range(8, 29) for k2 in range(24, 45) for k1 in range(39, 60) for s in (255, 256, 257, 258)]
+    cands = np.array([c for c in cands if 1 <= c[0] <= 255], np.int64)
+    good = []
+    for i in range(0, len(cands), 2048):
+        c = cands[i:i + 2048]
+        kv = np.stack([c[:, 3], c[:, 2], c[:, 1], c[:, 0], c[:, 1], c[:, 2], c[:, 3]], 1)          # [C][7]
+        rows = np.einsum("syx,cx->scy", nb, kv)                                                     # row sums of the 7 rows
+        out = np.minimum((np.einsum("scy,cy->sc", rows, kv) + 32768) >> 16, 255)
+        ok = (out == want[:, None]).all(0)
+        good += [tuple(int(v) for v in t) for t in c[ok]]
+    import oracle
+    inner = (slice(3, h - 3), slice(3, w - 3))
+    lv8 = level.astype(np.uint8)
+    return [t for t in good if np.array_equal(oracle.gaussian_blur7(lv8, "taps:%d,%d,%d,%d" % t)[inner], blurred[inner])]
+
+
 def identify_flavour(ref, produce):
     """Which flavour of the unpinned OpenCV decisions a reference vector file follows.  produce(flavour) -> the arrays a backend
     (oracle or HIP) gives for the file's case under that flavour.  The flavours differ in the blurred pixels only (per-level
     `crc`[2] / `blur`) and in whatever descriptor bits those pixels decide, so a file whose other stages agree names its flavour by
-    the blur checksums.  -> (flavour whose every compared key agrees or None, {flavour: (bad, ncmp, missing)}, verdict text)."""
+    the blur checksums.  Tried: the two column roundings of OpenCV <= 3.3, the fixed-point Gaussian of >= 3.4.1 with diffused taps
+    (with the plain taps it IS "half_up"), and - when the file carries the pixels of a blurred level - that Gaussian with the taps
+    FITTED to them.  -> (flavour whose every compared key agrees or None, {flavour: (bad, ncmp, missing)}, verdict text)."""
     import oracle
     res = {}
-    for fl in oracle.GAUSS_FLAVOURS:
+    flavours = list(oracle.GAUSS_FLAVOURS) + ["taps:%d,%d,%d,%d" % diffused_taps()]
+    for fl in flavours:
         res[fl] = compare(ref, produce(fl))
     clean = [fl for fl, (bad, _, _) in res.items() if not bad]
     if clean:
         both = len(clean) == len(res)
-        return clean[0], res, ("reference agrees with EVERY flavour (no pixel of this case sits on a rounding tie)" if both else
-                               "reference follows flavour %r of cv::GaussianBlur's column rounding" % clean[0])
+        return clean[0], res, ("reference agrees with EVERY flavour (no pixel of this case decides)" if both else
+                               "reference follows flavour %r of cv::GaussianBlur" % clean[0])
 
     def blur_only(bad):
-        return all(k.rsplit("/", 1)[1] in ("blur", "crc", "descriptors", "descriptors_right") and (k.rsplit("/", 1)[1] != "crc" or "[2]" in d)
+        # (what the blurred pixels decide: the descriptors, and through their distances the stereo matches)
+        return all(k.rsplit("/", 1)[1] in ("blur", "crc", "descriptors", "descriptors_right", "mvuRight", "mvDepth") and (k.rsplit("/", 1)[1] != "crc" or "[2]" in d)
                    for k, _, d in bad)
     hint = [fl for fl, (bad, _, _) in res.items() if blur_only(bad)]
+    if hint:   # only the blur differs: fit the taps of the fixed-point Gaussian to a level the file carries in full
+        name = next(iter(ref)).split("/", 1)[0]
+        for l in range(NLEVELS):
+            if name + "/L%d/pyramid" % l in ref and name + "/L%d/blur" % l in ref:
+                fits = fit_gauss_taps(ref[name + "/L%d/pyramid" % l], ref[name + "/L%d/blur" % l])
+                for t in fits:
+                    fl = "taps:%d,%d,%d,%d" % t
+                    if fl not in res:
+                        res[fl] = compare(ref, produce(fl))
+                    if not res[fl][0]:
+                        return fl, res, "reference follows the fixed-point Gaussian (OpenCV >= 3.4.1) with the FITTED taps %s: create handles with gauss = %r" % (t, fl)
+                break
     return None, res, ("no flavour reproduces the reference" + (
-        "; with %s only the blurred pixels / descriptors differ: a THIRD variant of GaussianBlur (OpenCV >= 3.4.1 bit-exact path, IPP, NEON?)"
+        "; with %s only the blurred pixels / descriptors differ and no tap set of the fixed-point Gaussian fits: a FOURTH variant of GaussianBlur (IPP, NEON?)"
         % " and ".join(repr(h) for h in hint) if hint else "; stages in front of the blur differ too (see the first stage listed)"))
 
 

@@ -92,10 +92,28 @@ def grid_geom(w, h):
 
 class Flavour(C.Structure):
     """orbx_flavour_t: which OpenCV build the handle stands in for (include/orbx.h)."""
-    _fields_ = [("gauss_rounding", C.c_int32), ("reserved", C.c_int32 * 7)]
+    _fields_ = [("gauss_rounding", C.c_int32), ("gauss_taps", C.c_int32 * 4), ("reserved", C.c_int32 * 3)]
 
 
 GAUSS_FLAVOURS = {"half_up": 0, "sse2": 1}
+GAUSS_FIXED_TAPS = 2
+
+
+def parse_gauss(g):
+    """"half_up" | "sse2" | "taps:k0,k1,k2,k3" (ORBX_GAUSS_FIXED_TAPS: the build's Q8 taps, centre first) -> Flavour."""
+    fl = Flavour()
+    if isinstance(g, str) and g.startswith("taps:"):
+        taps = [int(v) for v in g[5:].split(",")]
+        if len(taps) != 4:
+            raise ValueError("bad gauss flavour %r (taps:k0,k1,k2,k3)" % (g,))
+        fl.gauss_rounding = GAUSS_FIXED_TAPS
+        for i, v in enumerate(taps):
+            fl.gauss_taps[i] = v
+    elif g in GAUSS_FLAVOURS:
+        fl.gauss_rounding = GAUSS_FLAVOURS[g]
+    else:
+        raise ValueError("bad gauss flavour %r" % (g,))
+    return fl
 # What an ORBextractor takes when its constructor is not told.  HARNESS state of this Python module (the library itself has no
 # process-global switch: flavour and options are per handle): the parity suite is run under both flavours by changing this and the
 # oracle's default together, and the tests that cover an alternative kernel set a default option around the code under test.
@@ -279,14 +297,13 @@ class ORBextractor:
     """
 
     def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device=0, gauss=None, developer=None):
-        """gauss: "half_up" / "sse2" = orbx_flavour_t.gauss_rounding (include/orbx.h); None = default_gauss_flavour.
+        """gauss: "half_up" / "sse2" / "taps:k0,k1,k2,k3" = orbx_flavour_t (include/orbx.h); None = default_gauss_flavour.
         developer: True = this handle lives in the developer build of the library (stage hooks debug_*); None = default_developer."""
         global _live
         self._L = lib(default_developer if developer is None else developer)
         h = C.c_void_p()
         self.gauss = default_gauss_flavour if gauss is None else gauss
-        fl = Flavour()
-        fl.gauss_rounding = GAUSS_FLAVOURS[self.gauss]
+        fl = parse_gauss(self.gauss)
         self._ck(self._L.orbx_create_flavoured(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST),
                                              int(minThFAST), int(device), C.byref(fl), C.byref(h)))
         self._h = h
@@ -324,6 +341,8 @@ class ORBextractor:
     def flavour(self):
         fl = Flavour()
         self._ck(self._L.orbx_get_flavour(self._h, C.byref(fl)))
+        if fl.gauss_rounding == GAUSS_FIXED_TAPS:
+            return "taps:" + ",".join(str(int(v)) for v in fl.gauss_taps)
         return {v: k for k, v in GAUSS_FLAVOURS.items()}[fl.gauss_rounding]
 
     def close(self):

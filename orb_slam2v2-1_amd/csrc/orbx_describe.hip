@@ -198,7 +198,8 @@ __constant__ const IcTab c_ic = make_ic_tab();
 // ------------------------------------------------------------------------------------
 // K1b: GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) of whole levels (src/ORBextractor.cc:1085-1086), for the levels whose
 // keypoints' 37x37 blocks would add up to more pixels than the level has (k_describe then only gathers).  Same fixed-point
-// arithmetic as the fused form: rows -> sum of taps [18 34 49 55 49 34 18] (<= 65535), columns -> (sum + 2^15) >> 16, saturated.
+// arithmetic as the fused form: rows -> sum of taps [18 34 49 55 49 34 18] (<= 65535; the flavour's own taps for ORBX_GAUSS_FIXED_TAPS),
+// columns -> (sum + 2^15) >> 16, saturated.
 // One wave = a tile of 64 dwords (256 columns) x BLUR_R rows of a level's padded buffer: a lane owns ONE dword column; its left
 // / right neighbours come from the adjacent lanes (DPP wave shifts; lanes 0 and 63 load theirs), the horizontal pass is 10
 // v_dot4_u32_u8 with the taps shifted to each output's byte offset, the vertical pass 4 v_dot2_u32_u16 per output on row pairs
@@ -210,7 +211,7 @@ __device__ __forceinline__ uint32_t dpp_wave_shl1(uint32_t v) { return (uint32_t
 
 __global__ __launch_bounds__(256) void k_blur_levels(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, size_t pyrImgBytes,
                                                      const LevelGeom *__restrict__ geom, int nlevels, int totalTiles, BlurPlan bp,
-                                                     int gaussRounding) {
+                                                     int gaussRounding, uint32_t taps) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int bx, b;
     xcd_block_map(bx, b);
@@ -256,11 +257,13 @@ __global__ __launch_bounds__(256) void k_blur_levels(const uint8_t *__restrict__
         }
     }
     // ---- horizontal pass: output j of the dword = taps over bytes 1+j .. 7+j of (prev | cur | next)
-    constexpr uint32_t T0 = 18, T1 = 34, T2 = 49, T3 = 55;
-    constexpr uint32_t WP0 = (T0 << 8) | (T1 << 16) | (T2 << 24), WC0 = T3 | (T2 << 8) | (T1 << 16) | (T0 << 24);
-    constexpr uint32_t WP1 = (T0 << 16) | (T1 << 24), WC1 = T2 | (T3 << 8) | (T2 << 16) | (T1 << 24), WN1 = T0;
-    constexpr uint32_t WP2 = (T0 << 24), WC2 = T1 | (T2 << 8) | (T3 << 16) | (T2 << 24), WN2 = T1 | (T0 << 8);
-    constexpr uint32_t WC3 = T0 | (T1 << 8) | (T2 << 16) | (T3 << 24), WN3 = T2 | (T1 << 8) | (T0 << 16);
+    // (taps: k3 | k2 << 8 | k1 << 16 | k0 << 24, a kernel argument - the level-wide form is not the default path; ORBX_GAUSS_TAPS_DEFAULT unless
+    // the handle's flavour is ORBX_GAUSS_FIXED_TAPS)
+    const uint32_t T0 = taps & 0xFFu, T1 = (taps >> 8) & 0xFFu, T2 = (taps >> 16) & 0xFFu, T3 = taps >> 24;
+    const uint32_t WP0 = (T0 << 8) | (T1 << 16) | (T2 << 24), WC0 = T3 | (T2 << 8) | (T1 << 16) | (T0 << 24);
+    const uint32_t WP1 = (T0 << 16) | (T1 << 24), WC1 = T2 | (T3 << 8) | (T2 << 16) | (T1 << 24), WN1 = T0;
+    const uint32_t WP2 = (T0 << 24), WC2 = T1 | (T2 << 8) | (T3 << 16) | (T2 << 24), WN2 = T1 | (T0 << 8);
+    const uint32_t WC3 = T0 | (T1 << 8) | (T2 << 16) | (T3 << 24), WN3 = T2 | (T1 << 8) | (T0 << 16);
     uint32_t h01[BLUR_SRC], h23[BLUR_SRC];
 #pragma unroll
     for (int k = 0; k < BLUR_SRC; k++) {
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void k_blur_levels(const uint8_t *__restrict__
         h23[k] = o2 | (o3 << 16);
     }
     // ---- vertical pass: out[r] = (18,34).pair[r] + (49,55).pair[r+2] + (49,34).pair[r+4] + (0,18).pair[r+5] + 2^15, pair[k] = rows (k, k+1)
-    const uint32_t W01 = 18u | (34u << 16), W23 = 49u | (55u << 16), W45 = 49u | (34u << 16), W6 = 18u << 16;
+    const uint32_t W01 = T0 | (T1 << 16), W23 = T2 | (T3 << 16), W45 = T2 | (T1 << 16), W6 = T0 << 16;
     uint32_t pr[BLUR_SRC - 1][4];
 #pragma unroll
     for (int k = 0; k < BLUR_SRC - 1; k++) {
@@ -523,8 +526,10 @@ __global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu
     else {
     uint32_t Wt[4][4];
     {
-        const unsigned __int128 K7 = (unsigned __int128)(18ull | (34ull << 8) | (49ull << 16) | (55ull << 24) | (49ull << 32) |
-                                                         (34ull << 40) | (18ull << 48));
+        // ORBX_GAUSS_FIXED_TAPS: the taps are the handle's (grp.taps, wave-uniform); the other flavours keep their literals
+        const uint32_t tp = GAUSS == ORBX_GAUSS_FIXED_TAPS ? (uint32_t)__builtin_amdgcn_readfirstlane((int)grp.taps) : ORBX_GAUSS_TAPS_DEFAULT;
+        const unsigned long long T0 = tp & 0xFFu, T1 = (tp >> 8) & 0xFFu, T2 = (tp >> 16) & 0xFFu, T3 = tp >> 24;
+        const unsigned __int128 K7 = (unsigned __int128)(T0 | (T1 << 8) | (T2 << 16) | (T3 << 24) | (T2 << 32) | (T1 << 40) | (T0 << 48));
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
             const unsigned __int128 v = K7 << (8 * (sh + jj));
@@ -579,8 +584,10 @@ __global__ __launch_bounds__(64 * DESC_WAVES) __attribute__((amdgpu_waves_per_eu
         // where the rounded byte would pass 255 (the taps add up to 257: a saturated patch reaches 257 * 65535 + 2^15 > 2^24); every
         // term is non-negative, so saturating the partial sums saturates the total.  The result byte is bits 31:24: no v_min.
         constexpr uint32_t A_INIT = GAUSS == ORBX_GAUSS_ROUND_SSE2 ? 0u : 1u << 23;
-        constexpr uint32_t WE[4] = {(18u | (34u << 16)) << 8, (49u | (55u << 16)) << 8, (49u | (34u << 16)) << 8, 18u << 8};
-        constexpr uint32_t WO[4] = {18u << 24, (34u | (49u << 16)) << 8, (55u | (49u << 16)) << 8, (34u | (18u << 16)) << 8};
+        const uint32_t tv = GAUSS == ORBX_GAUSS_FIXED_TAPS ? (uint32_t)__builtin_amdgcn_readfirstlane((int)grp.taps) : ORBX_GAUSS_TAPS_DEFAULT;
+        const uint32_t V0 = tv & 0xFFu, V1 = (tv >> 8) & 0xFFu, V2 = (tv >> 16) & 0xFFu, V3 = tv >> 24;   // (constants unless FIXED_TAPS)
+        const uint32_t WE[4] = {(V0 | (V1 << 16)) << 8, (V2 | (V3 << 16)) << 8, (V2 | (V1 << 16)) << 8, V0 << 8};
+        const uint32_t WO[4] = {V0 << 24, (V1 | (V2 << 16)) << 8, (V3 | (V2 << 16)) << 8, (V1 | (V0 << 16)) << 8};
         uint8_t *out = Bl + r0 * BSTRIDE + 2 * cp;
 #pragma unroll
         for (int i = 0; i < DESC_V_ROWS; i++) {
@@ -659,6 +666,8 @@ ORBX_DESC_INSTANCE(ORBX_GAUSS_ROUND_HALF_UP, false)
 ORBX_DESC_INSTANCE(ORBX_GAUSS_ROUND_HALF_UP, true)
 ORBX_DESC_INSTANCE(ORBX_GAUSS_ROUND_SSE2, false)
 ORBX_DESC_INSTANCE(ORBX_GAUSS_ROUND_SSE2, true)
+ORBX_DESC_INSTANCE(ORBX_GAUSS_FIXED_TAPS, false)
+ORBX_DESC_INSTANCE(ORBX_GAUSS_FIXED_TAPS, true)
 
 #ifdef ORBX_DEVELOPER
 #include "orbx_dev.h"

@@ -89,9 +89,19 @@ extern "C" int orbx_create_flavoured(int nfeatures, float scale_factor, int nlev
     if (!out) { orbx_set_error("orbx_create: out is NULL"); return ORBX_ERR_ARG; }
     *out = nullptr;
     if (flavour) {
-        bool ok = flavour->gauss_rounding == ORBX_GAUSS_ROUND_HALF_UP || flavour->gauss_rounding == ORBX_GAUSS_ROUND_SSE2;
-        for (int i = 0; i < 7; i++) ok = ok && flavour->reserved[i] == 0;
-        if (!ok) { orbx_set_error("orbx_create_flavoured: unknown flavour (gauss_rounding=%d)", flavour->gauss_rounding); return ORBX_ERR_ARG; }
+        bool ok = flavour->gauss_rounding == ORBX_GAUSS_ROUND_HALF_UP || flavour->gauss_rounding == ORBX_GAUSS_ROUND_SSE2 ||
+                  flavour->gauss_rounding == ORBX_GAUSS_FIXED_TAPS;
+        for (int i = 0; i < 3; i++) ok = ok && flavour->reserved[i] == 0;
+        const int32_t *k = flavour->gauss_taps;
+        if (flavour->gauss_rounding == ORBX_GAUSS_FIXED_TAPS) {   // Q8 taps, centre first; a row sum (<= 255 * their sum) must fit 16 bits
+            for (int i = 0; i < 4; i++) ok = ok && k[i] >= 0 && k[i] <= 255;
+            ok = ok && k[0] >= 1 && k[0] + 2 * (k[1] + k[2] + k[3]) <= 257;
+        } else
+            for (int i = 0; i < 4; i++) ok = ok && k[i] == 0;
+        if (!ok) {
+            orbx_set_error("orbx_create_flavoured: unknown flavour (gauss_rounding=%d, gauss_taps=%d %d %d %d)", flavour->gauss_rounding, k[0], k[1], k[2], k[3]);
+            return ORBX_ERR_ARG;
+        }
     }
     if (nfeatures < 1 || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || !(scale_factor > 1.0f) || ini_th < 0 ||
         min_th < 0 || ini_th > 255 || min_th > 255) {
@@ -687,6 +697,12 @@ static unsigned blur_plan(const orbx_extractor *h, BlurPlan &bp, int &totalTiles
     }
     return mask;
 }
+// the Gaussian's taps as the kernels take them: k3 | k2 << 8 | k1 << 16 | k0 << 24 (orbx_flavour_t lists the centre first)
+static uint32_t gauss_taps_packed(const orbx_extractor *h) {
+    if (h->flavour.gauss_rounding != ORBX_GAUSS_FIXED_TAPS) return ORBX_GAUSS_TAPS_DEFAULT;
+    const int32_t *k = h->flavour.gauss_taps;
+    return (uint32_t)k[3] | ((uint32_t)k[2] << 8) | ((uint32_t)k[1] << 16) | ((uint32_t)k[0] << 24);
+}
 static int ensure_blur(orbx_extractor *h, uint8_t **buf, size_t *bytes) {
     const size_t need = h->pyrImgBytes * (size_t)h->pB;
     if (*bytes >= need) return ORBX_OK;
@@ -708,7 +724,7 @@ static int launch_blur(orbx_extractor *h, const uint8_t *pyr, uint8_t **blurBuf,
     if (rc) return rc;
     const size_t off = (size_t)b0 * h->pyrImgBytes;   // images [b0, b0 + B) of both buffers
     hipLaunchKernelGGL(k_blur_levels, dim3((tiles + 3) / 4, B), dim3(256), 0, st, pyr + off, *blurBuf + off, h->pyrImgBytes, h->d_geom, h->nlevels, tiles, bp,
-                       h->flavour.gauss_rounding);
+                       h->flavour.gauss_rounding, gauss_taps_packed(h));
     return ORBX_OK;
 }
 
@@ -1067,8 +1083,10 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
         // ORBX_OPT_DESC_LDS_PAD (KB): unused dynamic LDS per workgroup = fewer resident k_describe workgroups per CU, i.e. wave slots
         // left for the pyramid kernels that run beside it in a pipelined step (tuning only)
         const size_t descPad = (size_t)h->opt[21] * 1024;
-        const auto kDesc = aSplit > 0 ? (sse2 ? k_describe<ORBX_GAUSS_ROUND_SSE2, true> : k_describe<ORBX_GAUSS_ROUND_HALF_UP, true>)
-                                      : (sse2 ? k_describe<ORBX_GAUSS_ROUND_SSE2, false> : k_describe<ORBX_GAUSS_ROUND_HALF_UP, false>);
+        const bool ftaps = h->flavour.gauss_rounding == ORBX_GAUSS_FIXED_TAPS;
+        const uint32_t taps = gauss_taps_packed(h);
+        const auto kDesc = aSplit > 0 ? (ftaps ? k_describe<ORBX_GAUSS_FIXED_TAPS, true> : sse2 ? k_describe<ORBX_GAUSS_ROUND_SSE2, true> : k_describe<ORBX_GAUSS_ROUND_HALF_UP, true>)
+                                      : (ftaps ? k_describe<ORBX_GAUSS_FIXED_TAPS, false> : sse2 ? k_describe<ORBX_GAUSS_ROUND_SSE2, false> : k_describe<ORBX_GAUSS_ROUND_HALF_UP, false>);
         const uint8_t *blurp = h->blurMaskLast ? h->d_blur + (size_t)v.b0 * h->pyrImgBytes : nullptr;
         if (aSplit > 0) {
             int boundA = 0, boundB = 0;
@@ -1077,11 +1095,13 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             orbx_keypoint_t *kB = h->d_kpsB + (size_t)v.b0 * cap;
             uint8_t *dB = h->d_descB + (size_t)v.b0 * cap * 32;
             const int nbB = (maxoB + DESC_WAVES - 1) / DESC_WAVES, nbA = (maxoA + DESC_WAVES - 1) / DESC_WAVES;
-            const DescGroup gB = {aSplit, nl, 0, nbB, nullptr, nullptr};
+            DescGroup gB = {aSplit, nl, 0, nbB, nullptr, nullptr};
+            gB.taps = taps;
             hipLaunchKernelGGL(kDesc, dim3(nbB, B), dim3(64 * DESC_WAVES), descPad, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
                                v.lvlKp, h->lvlKpCap, v.lvlCnt, kB, dB, d_counts, cap, (uint8_t *)nullptr, blurp, h->blurMaskLast, gB);
             ORBX_HIP(hipStreamWaitEvent(st, h->evOctA, 0));
-            const DescGroup gA = {0, aSplit, 1, nbA, kB, dB};
+            DescGroup gA = {0, aSplit, 1, nbA, kB, dB};
+            gA.taps = taps;
             hipLaunchKernelGGL(kDesc, dim3(nbA + (maxoB + DESC_COPY_PER_BLOCK - 1) / DESC_COPY_PER_BLOCK, B), dim3(64 * DESC_WAVES), descPad, st,
                                v.pyr, h->pyrImgBytes, h->d_geom, nl, v.lvlKp, h->lvlKpCap, v.lvlCnt, d_kps, d_desc, d_counts, cap,
                                (uint8_t *)nullptr, blurp, h->blurMaskLast, gA);
@@ -1089,6 +1109,7 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
             const int maxo = std::min(cap, h->max_kp);
             dim3 grid((maxo + DESC_WAVES - 1) / DESC_WAVES, B);
             DescGroup gAll = {0, nl, 1, (int)grid.x, nullptr, nullptr};
+            gAll.taps = taps;
             gAll.hostDelta = h->descHostDelta;   // latency form: records also stored into their pinned host twin
             hipLaunchKernelGGL(kDesc, grid, dim3(64 * DESC_WAVES), descPad, st, v.pyr, h->pyrImgBytes, h->d_geom, nl,
                                v.lvlKp, h->lvlKpCap, v.lvlCnt, d_kps, d_desc, d_counts, cap, h->d_dbgBlur, blurp, h->blurMaskLast, gAll);

@@ -60,6 +60,7 @@ struct DescGroup {
     int copyBlock0;                      // first copy block (grid.x when there is nothing to move)
     const orbx_keypoint_t *kpsScratch;   // records of the levels [lvEnd, nlevels) to move
     const uint8_t *descScratch;
+    uint32_t taps;                       // k_describe<ORBX_GAUSS_FIXED_TAPS, .>: the Gaussian's Q8 taps k3 | k2 << 8 | k1 << 16 | k0 << 24 (k0 = centre)
     long long hostDelta;                 // != 0 (latency form): every keypoint / descriptor / count store is repeated at address + hostDelta - the
                                          // frame record's twin in pinned host memory - so that the last kernel only has mvuRight / mvDepth left to move
 };
@@ -68,7 +69,7 @@ struct DescGroup {
 #define BLUR_SRC (BLUR_R + 6)    // source rows a tile reads
 struct BlurPlan { int tileBase[ORBX_MAX_LEVELS + 1]; int tilesX[ORBX_MAX_LEVELS]; };   // tiles of the levels blurred as a whole (others own none)
 __global__ void k_blur_levels(const uint8_t *pyr, uint8_t *blur, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, int totalTiles,
-                              BlurPlan bp, int gaussRounding);                                                                                        // orbx_describe.hip
+                              BlurPlan bp, int gaussRounding, uint32_t taps);                                                                                        // orbx_describe.hip
 struct CellBases { int v[ORBX_MAX_LEVELS + 1]; };
 __device__ __forceinline__ int level_of_cell(const CellBases &cb, int nlevels, int gc) {
     int l = 0;
@@ -169,7 +170,7 @@ __global__ void k_octree_big_wide(const LevelGeom *geom, int nlevels, const uint
 __global__ void k_octree_wide(const LevelGeom *geom, int nlevels, const uint32_t *cand, uint16_t *nodeOf, size_t keysPerImg,
                               const int32_t *candCnt, uint32_t *lvlKp, int lvlKpCap, int32_t *lvlCnt, const int32_t *tab, int capMax,
                               int pow2cap, int scratchInts, int dbgStop);
-template <int GAUSS, bool SPLIT>   // ORBX_GAUSS_ROUND_*: column rounding of the fused Gaussian (orbx_flavour_t); SPLIT: a launch of a split call (DescGroup)
+template <int GAUSS, bool SPLIT>   // ORBX_GAUSS_ROUND_* / ORBX_GAUSS_FIXED_TAPS: column rounding / taps of the fused Gaussian (orbx_flavour_t); SPLIT: a launch of a split call (DescGroup)
 __global__ void k_describe(const uint8_t *pyr, size_t pyrImgBytes, const LevelGeom *geom, int nlevels, const uint32_t *lvlKp,
                            int lvlKpCap, const int32_t *lvlCnt, orbx_keypoint_t *kps, uint8_t *desc, int32_t *counts,
                            int cap, uint8_t *dbgBlur, const uint8_t *blur, unsigned blurMask, DescGroup grp);                                                                             // orbx_describe.hip

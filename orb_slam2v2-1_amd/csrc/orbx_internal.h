@@ -8,6 +8,8 @@
 #include "orbx.h"
 
 #define ORBX_MAX_LEVELS 16
+// the Gaussian's Q8 taps k3 | k2 << 8 | k1 << 16 | k0 << 24 of every flavour but ORBX_GAUSS_FIXED_TAPS: cvRound(256 g_i) = 18 34 49 55 (sum 257)
+#define ORBX_GAUSS_TAPS_DEFAULT (18u | (34u << 8) | (49u << 16) | (55u << 24))
 #define ORBX_EDGE 19        // EDGE_THRESHOLD            (reference: src/ORBextractor.cc:74)
 #define ORBX_MINB 16        // minBorderX = EDGE-3       (reference: src/ORBextractor.cc:773)
 #define ORBX_HALF_PATCH 15  // HALF_PATCH_SIZE           (reference: src/ORBextractor.cc:73)

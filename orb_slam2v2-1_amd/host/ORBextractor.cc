@@ -22,8 +22,12 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     orbx_flavour_t fl = {};
     if (flavour) fl = *flavour;
     else if (const char *g = std::getenv("ORBX_GAUSS_ROUNDING")) {
+        int k[4];
         if (!std::strcmp(g, "sse2")) fl.gauss_rounding = ORBX_GAUSS_ROUND_SSE2;
-        else if (std::strcmp(g, "half_up")) std::fprintf(stderr, "ORBextractor: ORBX_GAUSS_ROUNDING=%s ignored (half_up | sse2)\n", g);
+        else if (std::sscanf(g, "taps:%d,%d,%d,%d", &k[0], &k[1], &k[2], &k[3]) == 4) {   // OpenCV >= 3.4.1: the build's Q8 taps, centre first
+            fl.gauss_rounding = ORBX_GAUSS_FIXED_TAPS;
+            for (int i = 0; i < 4; i++) fl.gauss_taps[i] = k[i];
+        } else if (std::strcmp(g, "half_up")) std::fprintf(stderr, "ORBextractor: ORBX_GAUSS_ROUNDING=%s ignored (half_up | sse2 | taps:k0,k1,k2,k3)\n", g);
     }
     if (orbx_create_flavoured(nfeatures, _scaleFactor, nlevels, iniThFAST, minThFAST, device, &fl, &mpHandle) != ORBX_OK) {
         std::fprintf(stderr, "ORBextractor: %s\n", orbx_last_error());  // the reference logs with cerr too

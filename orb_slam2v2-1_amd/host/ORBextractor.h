@@ -19,7 +19,7 @@ public:
     // operator() leaves its outputs empty, ok() / lastError() tell why.
     // `flavour`: which OpenCV build this extractor stands in for (orbx_flavour_t, include/orbx.h: the rounding of
     // cv::GaussianBlur's column pass).  The reference's callers (src/Tracking.cc:119-125) pass five arguments; a deployment
-    // selects the flavour of the build it replaces with the environment variable ORBX_GAUSS_ROUNDING = half_up | sse2, read
+    // selects the flavour of the build it replaces with the environment variable ORBX_GAUSS_ROUNDING = half_up | sse2 | taps:k0,k1,k2,k3, read
     // once per constructor (NULL argument); the default is half_up.
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = -1,
                  const orbx_flavour_t *flavour = nullptr);

@@ -1,4 +1,4 @@
-"""GPU: the flavour of cv::GaussianBlur's column rounding (orbx_flavour_t.gauss_rounding) and the per-handle options.
+"""GPU: the flavour of cv::GaussianBlur (orbx_flavour_t: column rounding of OpenCV <= 3.3, fixed-point taps of >= 3.4.1) and the per-handle options.
 
 HIP == oracle in EACH flavour - descriptors, the 37x37 blurred blocks k_describe builds, whole levels by k_blur_levels - on images
 whose levels have every width residue mod 4 (the scalar tail w % 4 of the SSE2 flavour), and the two flavours really differ on the
@@ -13,6 +13,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 FLAVOURS = ["half_up", "sse2"]
+DIFFUSED = "taps:56,48,34,18"     # the fixed-point Gaussian of OpenCV >= 3.4.1 on taps that add up to 256 (oracle.refvec.diffused_taps)
 
 
 @pytest.fixture(autouse=True)
@@ -28,7 +29,7 @@ def _check(gk, gd, ok, od):
     np.testing.assert_array_equal(gd, od)
 
 
-@pytest.mark.parametrize("gauss", FLAVOURS)
+@pytest.mark.parametrize("gauss", FLAVOURS + [DIFFUSED, "taps:60,50,32,16"])
 @pytest.mark.parametrize("w,h,nf,kind", [(1241, 376, 2000, "synth"), (643, 481, 1200, "synth"), (1000, 259, 700, "noise"),
                                          (752, 480, 1000, "quant")])
 def test_hip_equals_oracle_in_each_flavour(pkg, oracle, synth, gauss, w, h, nf, kind):
@@ -87,12 +88,52 @@ def test_flavours_differ_on_the_device(pkg, oracle, synth):
     assert ndiff >= 1
 
 
+def test_fixed_taps_flavour(pkg, oracle, synth):
+    """ORBX_GAUSS_FIXED_TAPS: with the taps cvRound(256 g_i) = 55 49 34 18 the handle IS the half_up handle (records and every blurred
+    level byte for byte, saturated white included: those taps add up to 257); with taps that add up to 256 the keypoints stay, the
+    blurred levels change (by at most one grey level against the same taps' oracle: none) and so do descriptor bits; tap sets whose
+    row sums would not fit 16 bits, a zero centre or taps on another flavour are refused."""
+    import ctypes as C
+    img = synth.frame(1241, 376, k=53)
+    img[40:90, 100:260] = 255            # a saturated block: 257 * 65535 + 2^15 passes 2^24
+    a, b, c = (pkg.ORBextractor(1500, 1.2, 8, 20, 7, gauss=g) for g in ("half_up", "taps:55,49,34,18", DIFFUSED))
+    assert b.flavour() == "taps:55,49,34,18" and c.flavour() == DIFFUSED
+    for e in (a, b, c):
+        e.set_option(13, 2)              # every level blurred as a whole: the hook shows every pixel
+    (ka, da), (kb, db), (kc, dc) = a(img), b(img), c(img)
+    assert ka.tobytes() == kb.tobytes() and da.tobytes() == db.tobytes()
+    assert ka.tobytes() == kc.tobytes() and (da != dc).any()
+    orc = oracle.Extractor(1500, 1.2, 8, 20, 7, gauss=DIFFUSED)
+    ko, do = orc.extract(img)
+    _check(kc, dc, ko, do)
+    for l in range(8):
+        np.testing.assert_array_equal(a.blurred_level(l), b.blurred_level(l))
+        np.testing.assert_array_equal(c.blurred_level(l), orc.blurred_level(l))
+    assert (a.blurred_level(0) != c.blurred_level(0)).any()
+    assert a.blurred_level(0)[50:80, 110:250].min() == 255 and c.blurred_level(0)[50:80, 110:250].min() == 255
+    L = pkg.lib()
+    for rounding, taps in ((2, (0, 49, 34, 18)), (2, (56, 49, 34, 18)), (2, (256, 0, 0, 0)), (2, (55, -1, 34, 18)), (0, (55, 49, 34, 18)), (1, (1, 0, 0, 0))):
+        fl = pkg.Flavour()
+        fl.gauss_rounding = rounding
+        for i, v in enumerate(taps):
+            fl.gauss_taps[i] = v
+        h = C.c_void_p()
+        assert L.orbx_create_flavoured(500, 1.2, 8, 20, 7, 0, C.byref(fl), C.byref(h)) == pkg.ORBX_ERR_ARG and not h.value, (rounding, taps)
+    ident = pkg.ORBextractor(500, 1.2, 8, 20, 7, gauss="taps:1,0,0,0")     # the identity "blur" times 1/256 twice: (p + 2^15) >> 16 = 0
+    ident.set_option(13, 2)
+    ident(img)
+    assert not ident.blurred_level(0).any()
+
+
 def test_unknown_flavour_and_options_are_refused(pkg):
     import ctypes as C
     L = pkg.lib()
     fl = pkg.Flavour()
     fl.gauss_rounding = 7
     h = C.c_void_p()
+    assert L.orbx_create_flavoured(500, 1.2, 8, 20, 7, 0, C.byref(fl), C.byref(h)) == pkg.ORBX_ERR_ARG and not h.value
+    fl.gauss_rounding = 0
+    fl.reserved[2] = 1
     assert L.orbx_create_flavoured(500, 1.2, 8, 20, 7, 0, C.byref(fl), C.byref(h)) == pkg.ORBX_ERR_ARG and not h.value
     ex = pkg.ORBextractor(500, 1.2, 8, 20, 7, developer=False)     # the PRODUCT library refuses the phase-stop keys
     for key, val in ((0, 1), (1, 1), (7, 2), (2, 1), (17, 1), (31, 1), (99, 1), (6, 9), (13, -1)):   # phase stops need -DORBX_DEVELOPER
@@ -150,7 +191,7 @@ def test_matcher_option_is_per_thread(pkg):
     assert L.orbm_set_thread_option(2, 0) == 0
 
 
-@pytest.mark.parametrize("gauss", ["sse2"])
+@pytest.mark.parametrize("gauss", ["sse2", DIFFUSED])
 def test_bench_step_in_the_sse2_flavour(pkg, oracle, synth, gauss, monkeypatch):
     """The timed path of bench.py (pipeline.FrontEnd: batched extraction + ComputeStereoMatches, software-pipelined) with handles
     of the other flavour, frames 0 / 7 / 15 against the oracle of that flavour."""

@@ -98,24 +98,35 @@ def test_consumer_end_to_end_on_oracle_written_vectors(tmp_path, case_name):
 
 
 def test_consumer_names_the_flavour_a_file_follows(tmp_path):
-    """A vector file written under one flavour of the Gaussian's column rounding is reported as following THAT flavour (not as a
-    bare mismatch), from the per-level blur checksums; a third variant is reported as such."""
+    """A vector file written under one flavour of the Gaussian is reported as following THAT flavour (not as a bare mismatch), from
+    the per-level blur checksums - the two column roundings of OpenCV <= 3.3, the fixed-point Gaussian of >= 3.4.1 with diffused taps -;
+    a file with other taps is named by FITTING them to a level it carries in full; anything else is reported as a further variant."""
     rv = _refvec()
     case = next(c for c in rv.CASES if c[0] == "euroc_752x480_1000")
-    vecs = {fl: rv.oracle_vectors(case, gauss=fl) for fl in ("half_up", "sse2")}
+    diffused = "taps:%d,%d,%d,%d" % rv.diffused_taps()
+    vecs = {fl: rv.oracle_vectors(case, gauss=fl) for fl in ("half_up", "sse2", diffused)}
     differ = [k for k in vecs["half_up"] if k.endswith("/crc") and not np.array_equal(vecs["half_up"][k], vecs["sse2"][k])]
     assert differ, "the case must hold at least one rounding tie"
-    for fl in ("half_up", "sse2"):
-        path = str(tmp_path / ("ref_%s.orbvec" % fl))
+    for fl in vecs:
+        path = str(tmp_path / "ref_flavour.orbvec")
         rv.write(path, vecs[fl])
         got, res, verdict = rv.identify_flavour(rv.read(path), lambda g: vecs[g])
         assert got == fl and repr(fl) in verdict, verdict
-        other = "sse2" if fl == "half_up" else "half_up"
-        assert {k.rsplit("/", 1)[1] for k, _, _ in res[other][0]} <= {"crc", "descriptors", "descriptors_right"}
+        for other in vecs:
+            if other != fl:
+                assert {k.rsplit("/", 1)[1] for k, _, _ in res[other][0]} <= {"crc", "descriptors", "descriptors_right", "blur", "mvuRight", "mvDepth"}
     third = dict(vecs["half_up"])
-    a = third[differ[0]].copy(); a[2] += 7; third[differ[0]] = a          # blurred pixels that follow neither flavour
+    a = third[differ[0]].copy(); a[2] += 7; third[differ[0]] = a          # blurred pixels that follow no flavour and no tap set
     got, _, verdict = rv.identify_flavour(third, lambda g: vecs[g])
-    assert got is None and "THIRD variant" in verdict, verdict
+    assert got is None and "FOURTH variant" in verdict, verdict
+    # a build with taps nobody guessed: the consumer fits them to the level the small case carries pixel by pixel
+    tiny = next(c for c in rv.CASES if c[0] == "tiny_320x240_500")
+    odd = "taps:54,49,35,17"
+    path = str(tmp_path / "ref_odd.orbvec")
+    rv.write(path, rv.oracle_vectors(tiny, gauss=odd))
+    cache = {}
+    got, _, verdict = rv.identify_flavour(rv.read(path), lambda g: cache.setdefault(g, rv.oracle_vectors(tiny, gauss=g)))
+    assert got == odd and "FITTED taps (54, 49, 35, 17)" in verdict, verdict
 
 
 def test_reference_vectors_pin_the_oracle():
@@ -179,10 +190,10 @@ def test_consumer_hip_backend_on_oracle_written_vectors(tmp_path, case_name):
     assert ncmp >= 8 * 3 + 5
     # a file written under the OTHER flavour is recognised as such by oracle and HIP path alike (the quantised case has ties)
     if case_name == "tiny_320x240_500":
-        for fl in ("half_up", "sse2"):
+        for fl in ("half_up", "sse2", "taps:56,48,34,18", "taps:54,49,35,17"):
             rv.write(path, rv.oracle_vectors(case, gauss=fl))
             ref = rv.read(path)
             got_fl, _, verdict = rv.identify_flavour(ref, lambda g: be.hip_vectors(case, gauss=g))
-            assert got_fl is not None, verdict
+            assert got_fl is not None and (got_fl == fl or not fl.startswith("taps")), verdict
     # what the HIP path cannot show (primitives it never materialises) is exactly this:
     assert {m.rsplit("/", 1)[1] for m in missing} <= {"fast20", "fast7", "octree_direct"}, missing
