@@ -4,7 +4,7 @@ the default kernel choice of a single image (k_fast_cells, one-workgroup quad-tr
 strips + the multi-workgroup quad-tree on every level (option 4 = 2), strips with the sparse path forced on every level (option
 16 = 2) in its three forms (row skip, strip compaction, cell compaction: option 20), k_gather + compacted keys, k_pyr_level with 16 rows
 per wave on every level (option 22 = 2), and - against the
-oracle of that flavour - a handle of the SSE2 flavour of the Gaussian's column rounding."""
+oracle of that flavour - a handle of the SSE2 flavour of the Gaussian's column rounding and one of the fixed-taps flavour (random taps)."""
 import sys, os, importlib, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -61,6 +61,12 @@ for it in range(N):
     ex = pkg.ORBextractor(nf, sf, nl, ini, mn)
     ok2, od2 = oracle.Extractor(nf, sf, nl, ini, mn, gauss="sse2").extract(img)
     ex2 = pkg.ORBextractor(nf, sf, nl, ini, mn, gauss="sse2")
+    # the fixed-point Gaussian of OpenCV >= 3.4.1 on a random tap set whose sum is 255..257 (the diffused taps every third configuration)
+    k3, k2, k1 = int(rng.integers(8, 28)), int(rng.integers(24, 44)), int(rng.integers(40, 58))
+    k0 = int(rng.integers(255, 258)) - 2 * (k1 + k2 + k3)
+    tf = "taps:56,48,34,18" if it % 3 == 0 or not 1 <= k0 <= 255 else "taps:%d,%d,%d,%d" % (k0, k1, k2, k3)
+    ok3, od3 = oracle.Extractor(nf, sf, nl, ini, mn, gauss=tf).extract(img)
+    ex3 = pkg.ORBextractor(nf, sf, nl, ini, mn, gauss=tf)
     for variant, knobs in (("default", ()), ("strips", ((6, 3),)), ("strips+multi-wg quad-tree", ((6, 3), (4, 2))),
                            ("strips+row skip pre-test", ((6, 3), (16, 2))), ("strips+strip compaction pre-test", ((6, 3), (16, 2), (20, 1))),
                            ("strips+cell compaction pre-test", ((6, 3), (16, 2), (20, 2))), ("k_gather + compacted keys", ((18, 1),)),
@@ -69,8 +75,8 @@ for it in range(N):
                            # here the large-batch forms of those three stages, one by one and together, and the chains / staged rows forced
                            ("k_pyr_pad instead of staged rows", ((24, 1),)), ("one launch per level instead of chains", ((25, 1),)), ("level chains of up to seven levels", ((25, 3),)),
                            ("quad-tree key sweep instead of the FAST histogram", ((23, 1),)), ("large-batch forms", ((23, 1), (24, 1), (25, 1))),
-                           ("sse2 flavour", ())):
-        e, wk, wd = (ex2, ok2, od2) if variant.startswith("sse2") else (ex, ok, od)
+                           ("sse2 flavour", ()), ("fixed-taps flavour", ()), ("fixed-taps flavour, level-wide blur", ((13, 2),))):
+        e, wk, wd = (ex2, ok2, od2) if variant.startswith("sse2") else (ex3, ok3, od3) if variant.startswith("fixed") else (ex, ok, od)
         for k, v in knobs:
             e.set_option(k, v)
         try:
@@ -86,6 +92,7 @@ for it in range(N):
             print("MISMATCH", variant, it, w, h, nf, sf, nl, ini, mn, kind, len(gk), len(ok), flush=True)
     ex.close()
     ex2.close()
+    ex3.close()
     if it % 100 == 99:
         print("  ... %d configs, %d mismatches, %.0f s" % (it + 1, bad, time.time() - t0), flush=True)
 print("stress: %d configs, %d mismatches, %.1f s" % (N, bad, time.time() - t0))
