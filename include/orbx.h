@@ -446,7 +446,9 @@ int orbm_distinctive_descriptors(const uint8_t *desc, const int32_t *offsets, in
  *                              a small batch (default: by batch size)
  *   ORBX_OPT_CHUNKS        8   n >= 2: a batch is cut into n chunks (<= 4) on the handle's side streams (default one)
  *   ORBX_OPT_IGNORE_AHEAD  9   1 = pyramids built ahead are ignored
- *   ORBX_OPT_PREFETCH_GATE 10  where a pyramid built ahead may start: 0 behind FAST, 1 behind the quad-tree, 2 behind the descriptors
+ *   ORBX_OPT_PREFETCH_GATE 10  where a pyramid built ahead may start: 0 behind FAST, 1 behind the quad-tree, 2 behind the descriptors,
+ *                              3 together with FAST (pays when the quad-tree launch fills the GPU more than once and nothing else runs
+ *                              beside FAST: pipeline.FrontEnd picks it for such mono batches)
  *   ORBX_OPT_OCTREE_WIDTH  11  quad-tree kernels in the 1024-thread build never (1) / always (2) (default: by image size)
  *   ORBX_OPT_NO_ORDER_KERNEL 12  1 = no ordering kernel in front of the FAST stage's start event
  *   ORBX_OPT_BLUR_FORM     13  1 = no level blurred as a whole, 2 = every level (orbx_debug_blurred_level); 14 = the rule's threshold

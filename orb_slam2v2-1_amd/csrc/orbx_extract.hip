@@ -47,7 +47,7 @@ extern "C" int orbx_thread_release_scratch(void) {
 // There is no process-global switch.  Keys 0, 1, 7 stop a kernel after phase n (ablation timing; outputs incomplete) and exist only
 // in a developer build (-DORBX_DEVELOPER).
 extern "C" int orbx_set_option(orbx_extractor_t *h, int key, int value) {
-    static const signed char maxv[ORBX_NUM_OPTIONS] = {/*0*/ -1, -1, -2, 64, 3, 4, 3, -1, ORBX_MAX_CHUNKS, 1, 2, 2, 1, 2, 127, ORBX_MAX_LEVELS,
+    static const signed char maxv[ORBX_NUM_OPTIONS] = {/*0*/ -1, -1, -2, 64, 3, 4, 3, -1, ORBX_MAX_CHUNKS, 1, 3, 2, 1, 2, 127, ORBX_MAX_LEVELS,
                                                        /*16*/ 2, -2, 1, ORBX_MAX_LEVELS, 2, 40, 2, 1, 2, 3, 1, 1, -2, -2, -2, -2};
     if (!h || key < 0 || key >= ORBX_NUM_OPTIONS || maxv[key] == -2) { orbx_set_error("orbx_set_option: unknown key %d", key); return ORBX_ERR_ARG; }
 #ifdef ORBX_DEVELOPER
@@ -828,6 +828,8 @@ static int launch_chunk(orbx_extractor *h, const ChunkView &v, int B, int stride
     // (seen as 0.30 instead of 0.27 ms in one run out of four).  An empty kernel orders the stamp behind the wait.
     if (profFast && skipPyr && h->opt[12] == 0) hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, st);
     if (profFast) ORBX_HIP(hipEventRecord(ev[1], st));
+    // (ORBX_OPT_PREFETCH_GATE = 3: a pyramid built ahead may start as soon as THIS call's FAST stage may - it then runs beside it)
+    if (h->pfUsed && evPyrDone == nullptr && h->opt[10] == 3) ORBX_HIP(hipEventRecord(h->evFastDone, st));
     // decisions of the quad-tree stage that the FAST stage needs to know
     // developer knob 4: 0 default, 1 = the exact form alone, 2 = EVERY level by the multi-workgroup form, 3 = none
     const bool usePyr = h->opt[4] != 1;

@@ -17,6 +17,8 @@ import numpy as np
 import torch
 
 from . import KP_DTYPE, ORBextractor, stereo_batch_device
+import sys as _sys
+_pkg = _sys.modules[__package__]
 from .batching import ResultRing
 
 KITTI_FX, KITTI_BF = 718.856, 386.1448  # KITTI-00 calibration (fx, baseline*fx)
@@ -74,6 +76,16 @@ class FrontEnd:
         self.S = max(1, streams)
         self.exs = [ORBextractor(nfeatures, scale_factor, nlevels, ini_th, min_th, device=device_index) for _ in range(self.S)]
         self.ex = self.exs[0]
+        # Where the pyramid built ahead starts (ORBX_OPT_PREFETCH_GATE).  Default: behind FAST(i), beside the quad-tree - a stage of serial
+        # chains that leaves most of the GPU idle, so the pyramid rides free.  When the quad-tree launch holds more workgroups than the GPU takes at
+        # once (1024-thread build: one per CU; 512-thread build: three) nothing rides free there, and for MONO frames nothing else runs beside
+        # FAST (stereo: the matcher of the previous step does): the pyramid then starts with FAST(i).  Measured, 64 images 1920x1080: 1.145 ->
+        # 1.124 ms per step; the same choice at 32 images (quad-tree not saturated) 0.601 -> 0.630, at 640x480 x 64 0.251 -> 0.259, for stereo
+        # workloads +-0.5 % (HISTORY.md, round 5).
+        wide = ((w - 26) // 30) * ((h - 26) // 30) >= 600         # a level of >= 600 FAST cells: the 1024-thread quad-tree kernels
+        cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        if prefetch and not stereo and self.S == 1 and B * nlevels > cus * (1 if wide else 3) and 10 not in _pkg._default_options:      # (an A/B run that sets the option itself keeps its value)
+            self.ex.set_option(10, 3)
         # the matcher of step i-1 is issued after the extraction of step i, on the side stream, behind that extraction's FAST stage;
         # with N > 1 ranks the pack kernel + all-gather of step i-1 follow it on that stream, so N = 1 and N > 1 run the same pipeline
         self.lag = bool(lag_stereo and prefetch and stereo and self.S == 1)

@@ -237,23 +237,56 @@ def test_pyramid_built_ahead_is_used_only_for_the_same_batch():
 
 
 def test_bench_step_mono_full_hd_batch64():
-    """BASELINE config 4's per-GPU share as written (512 frames over 8 GPUs): 64 frames of 1920x1080, 4000 features, ONE
-    batched call, every frame against the oracle."""
+    """BASELINE config 4's per-GPU share as written (512 frames over 8 GPUs): 64 frames of 1920x1080, 4000 features per batched call,
+    five pipelined steps over TWO rotating batches, every frame of the three result sets still resident against the oracle of ITS batch.
+    At this size the quad-tree launch fills the GPU twice, so FrontEnd starts the pyramid built ahead together with FAST
+    (ORBX_OPT_PREFETCH_GATE = 3): a pyramid that overwrote a buffer FAST still reads would show as another batch's pixels."""
     pl, ref = _pipeline(), _ref()
-    w, h, nf, B = 1920, 1080, 4000, 64
-    exp = ref.run_pool(ref.mono_frame, [(w, h, nf, 300 + i) for i in range(B)])
+    w, h, nf, B, nsets, steps = 1920, 1080, 4000, 64, 2, 5
+    exps = [ref.run_pool(ref.mono_frame, [(w, h, nf, 300 + 100 * s + i) for i in range(B)]) for s in range(nsets)]
     fe = pl.FrontEnd(w, h, nf, False, B)
-    fe.upload(np.stack([e["img"] for e in exp]))
-    j = fe.step(0)
+    assert fe.ex.get_option(10) == 3
+    fe.upload(np.stack([e["img"] for e in exps[0]]))
+    fe.upload_more(np.stack([e["img"] for e in exps[1]]))
+    for i in range(steps):
+        fe.step(i)
     fe.drain()
-    imgs, _ = fe.results(j)
     bad = []
-    for b in range(B):
-        m = ref.image_mismatch(imgs[b][0], imgs[b][1], exp[b]["k"], exp[b]["d"])
-        if m:
-            bad.append("frame %d: %s" % (b, m))
+    for i in range(steps - fe.ring.nbuf, steps):
+        imgs, _ = fe.results(i % fe.ring.nbuf)
+        exp = exps[i % nsets]
+        for b in range(B):
+            m = ref.image_mismatch(imgs[b][0], imgs[b][1], exp[b]["k"], exp[b]["d"])
+            if m:
+                bad.append("step %d frame %d: %s" % (i, b, m))
     assert not bad, "\n".join(bad[:20])
-    assert min(len(e["k"]) for e in exp) > 3800
+    assert min(len(e["k"]) for e in exps[0]) > 3800
+
+
+@pytest.mark.parametrize("gate", [0, 1, 2, 3])
+def test_prefetch_gate_does_not_change_results(gate, pkg):
+    """ORBX_OPT_PREFETCH_GATE: the pyramid built ahead behind FAST (default), behind the quad-tree, behind the descriptors or together
+    with FAST - seven pipelined mono steps over three rotating batches, results of the last three against the oracle of their batch."""
+    pl, ref = _pipeline(), _ref()
+    w, h, nf, B, nsets, steps = 752, 480, 800, 12, 3, 7
+    exps = [ref.run_pool(ref.mono_frame, [(w, h, nf, 900 + 40 * s + i) for i in range(B)]) for s in range(nsets)]
+    pkg.set_default_option(10, gate)
+    try:
+        fe = pl.FrontEnd(w, h, nf, False, B)
+        assert fe.ex.get_option(10) == gate
+        fe.upload(np.stack([e["img"] for e in exps[0]]))
+        for s in range(1, nsets):
+            fe.upload_more(np.stack([e["img"] for e in exps[s]]))
+        for i in range(steps):
+            fe.step(i)
+        fe.drain()
+    finally:
+        pkg.set_default_option(10, 0)
+    for i in range(steps - fe.ring.nbuf, steps):
+        imgs, _ = fe.results(i % fe.ring.nbuf)
+        for b in range(B):
+            e = exps[i % nsets][b]
+            assert ref.image_mismatch(imgs[b][0], imgs[b][1], e["k"], e["d"]) is None, (i, b)
 
 
 def test_stereo_scratch_regrows_and_large_cap():
